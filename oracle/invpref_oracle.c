@@ -1,0 +1,378 @@
+/*
+ * oracle/invpref_oracle.c -- CPU restatement of the InvPref hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the checker, never the product: only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The product (invpref_kdd_2022_amd/) never does.
+ *
+ * Parity pin: checked against golden vectors produced by running the reference itself
+ * (tests/golden/gen_goldens.py imports /root/reference/models.py + train.py); see
+ * tests/test_oracle_vs_golden.py.
+ *
+ * It restates, in plain C, what the reference computes with PyTorch ATen ops:
+ *   forward            models.py:307-326 (implicit), :448-467 (explicit), classifier :206-209
+ *   reverse layer      functions.py:4-16
+ *   regularisers       models.py:328-391, classifier :211-217
+ *   loss + backward    train.py:94-167 (BCELoss / MSELoss / NLLLoss, optional re-weighting)
+ *   Adam               train.py:41 (torch.optim.Adam defaults), single-tensor update rule
+ *   E-step             train.py:169-202 (cluster_a_batch), :235-259 (cluster)
+ *   stat_envs          train.py:268-280
+ *
+ * Compiled twice: -DORACLE_F64 gives the double-precision variant (libm exp/log, sequential
+ * sums) used to pin the formulas against the reference's fp64 autograd; the default fp32
+ * variant uses the "canonical arithmetic" of DESIGN.md §3 (16-slot dot product with an xor
+ * butterfly, polynomial exp/log built from fma/mul/add only) so that an independent
+ * implementation of the same definition -- the HIP kernels -- is bit-identical to it.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef ORACLE_F64
+typedef double real;
+#define FN(name) name##_f64
+#else
+typedef float real;
+#define FN(name) name##_f32
+#endif
+
+typedef struct {
+    int64_t U, I, E, D;
+    const real *Pu, *Qi, *Pa, *Qa, *Ev, *W, *b; /* row-major [U,D] [I,D] [U,D] [I,D] [E,D] [E,D] [E] */
+} oracle_tables;
+
+typedef struct {
+    real *Pu, *Qi, *Pa, *Qa, *Ev, *W, *b;
+} oracle_grads;
+
+/* flags */
+#define F_IMPLICIT 1u
+#define F_REWEIGHT_REC 2u /* use_recommend_re_weight  train.py:138-142 */
+#define F_REWEIGHT_CLS 4u /* use_class_re_weight      train.py:120-136 */
+#define F_REG_ONLY_EMBED 8u /* models.py:369 */
+#define F_REG_ENV_EMBED 16u /* models.py:376 */
+
+/* ------------------------------------------------------------------ canonical arithmetic */
+#ifdef ORACLE_F64
+static inline real r_exp(real x) { return exp(x); }
+static inline real r_log(real x) { return log(x); }
+static inline real r_log1p(real x) { return log1p(x); }
+static real dot2(const real *a, const real *b, int64_t D) {
+    real s = 0;
+    for (int64_t i = 0; i < D; i++) s += a[i] * b[i];
+    return s;
+}
+static real dot3(const real *a, const real *b, const real *c, int64_t D) {
+    real s = 0;
+    for (int64_t i = 0; i < D; i++) s += a[i] * b[i] * c[i];
+    return s;
+}
+#else
+static inline float pow2i(int n) { /* 2^n, n in [-126,127] */
+    union { uint32_t u; float f; } c;
+    c.u = (uint32_t)(n + 127) << 23;
+    return c.f;
+}
+static inline float r_exp(float x) {
+    if (x > 88.72283f) return INFINITY;
+    if (x < -87.33654f) return 0.0f;
+    float n = rintf(x * 1.44269504f);
+    float r = fmaf(n, -0.693359375f, x);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = fmaf(p, r2, r);
+    y = y + 1.0f;
+    int ni = (int)n;
+    int h = ni >> 1;
+    return (y * pow2i(h)) * pow2i(ni - h);
+}
+static inline float r_log(float x) {
+    if (x != x) return x;
+    if (x < 0.0f) return NAN;
+    if (x == 0.0f) return -INFINITY;
+    if (x == INFINITY) return x;
+    int eadj = 0;
+    if (x < 1.17549435e-38f) { x = x * 8388608.0f; eadj = -23; }
+    union { uint32_t u; float f; } c;
+    c.f = x;
+    int e = (int)((c.u >> 23) & 0xffu) - 126 + eadj;
+    c.u = (c.u & 0x007fffffu) | 0x3f000000u; /* m in [0.5,1) */
+    float m = c.f;
+    if (m < 0.707106781f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
+    float z = m * m;
+    float p = 7.0376836292e-2f;
+    p = fmaf(p, m, -1.1514610310e-1f);
+    p = fmaf(p, m, 1.1676998740e-1f);
+    p = fmaf(p, m, -1.2420140846e-1f);
+    p = fmaf(p, m, 1.4249322787e-1f);
+    p = fmaf(p, m, -1.6668057665e-1f);
+    p = fmaf(p, m, 2.0000714765e-1f);
+    p = fmaf(p, m, -2.4999993993e-1f);
+    p = fmaf(p, m, 3.3333331174e-1f);
+    float y = (m * z) * p;
+    float fe = (float)e;
+    y = fmaf(fe, -2.12194440e-4f, y);
+    y = fmaf(-0.5f, z, y);
+    float r = m + y;
+    return fmaf(fe, 0.693359375f, r);
+}
+static inline float r_log1p(float x) {
+    float u = 1.0f + x;
+    if (u == 1.0f) return x;
+    return r_log(u) * (x / (u - 1.0f));
+}
+/* 16-slot dot: element i feeds slot (i>>2)&15 by fma in increasing i; slots combined by an
+ * xor butterfly (8,4,2,1).  Matches a 16-lane x float4 row layout on the GPU. */
+static inline float butterfly16(float *s) {
+    for (int m = 8; m >= 1; m >>= 1) {
+        float t[16];
+        for (int k = 0; k < 16; k++) t[k] = s[k] + s[k ^ m];
+        memcpy(s, t, sizeof t);
+    }
+    return s[0];
+}
+static float dot2(const float *a, const float *b, int64_t D) {
+    float s[16] = {0};
+    for (int64_t i = 0; i < D; i++) { int k = (int)((i >> 2) & 15); s[k] = fmaf(a[i], b[i], s[k]); }
+    return butterfly16(s);
+}
+static float dot3(const float *a, const float *b, const float *c, int64_t D) {
+    float s[16] = {0};
+    for (int64_t i = 0; i < D; i++) { int k = (int)((i >> 2) & 15); s[k] = fmaf(a[i] * b[i], c[i], s[k]); }
+    return butterfly16(s);
+}
+#endif
+
+static inline real r_sigmoid(real x) { return (real)1 / ((real)1 + r_exp(-x)); }
+static inline real r_max(real a, real b) { return a > b ? a : b; }
+/* aten binary_cross_entropy: (y-1)*max(log1p(-s),-100) - y*max(log(s),-100) */
+static inline real r_bce(real s, real y) {
+    return (y - (real)1) * r_max(r_log1p(-s), (real)-100) - y * r_max(r_log(s), (real)-100);
+}
+/* aten binary_cross_entropy_backward: (s-y)/max((1-s)*s, 1e-12) */
+static inline real r_dbce(real s, real y) { return (s - y) / r_max(((real)1 - s) * s, (real)1e-12); }
+static inline real r_sign(real x) { return (real)((x > 0) - (x < 0)); }
+
+/* ------------------------------------------------------------------ forward (models.py:307-326) */
+void FN(oracle_forward)(const oracle_tables *t, const int64_t *u, const int64_t *v, const int64_t *e,
+                        int64_t B, uint32_t flags, real *inv, real *envaware, real *envout) {
+    const int64_t D = t->D, E = t->E;
+    real *x = (real *)malloc(sizeof(real) * (size_t)D);
+    real *z = (real *)malloc(sizeof(real) * (size_t)E);
+    for (int64_t i = 0; i < B; i++) {
+        const real *pu = t->Pu + u[i] * D, *qi = t->Qi + v[i] * D;
+        const real *pa = t->Pa + u[i] * D, *qa = t->Qa + v[i] * D, *ev = t->Ev + e[i] * D;
+        real p = dot2(pu, qi, D), q = dot3(pa, qa, ev, D);
+        if (flags & F_IMPLICIT) {
+            real sp = r_sigmoid(p), sq = r_sigmoid(q);
+            inv[i] = sp;
+            envaware[i] = sp * sq;
+        } else {
+            inv[i] = p;
+            envaware[i] = p + q;
+        }
+        for (int64_t d = 0; d < D; d++) x[d] = pu[d] * qi[d];
+        real mx = -INFINITY;
+        for (int64_t c = 0; c < E; c++) {
+            z[c] = dot2(x, t->W + c * D, D) + t->b[c];
+            mx = r_max(mx, z[c]);
+        }
+        real se = 0;
+        for (int64_t c = 0; c < E; c++) se += r_exp(z[c] - mx);
+        real lse = r_log(se);
+        for (int64_t c = 0; c < E; c++) envout[i * E + c] = (z[c] - mx) - lse;
+    }
+    free(x);
+    free(z);
+}
+
+/* ------------------------------------------------------------------ M-step: losses + gradients
+ * train.py:94-157.  coefs = {invariant_coe, env_aware_coe, env_coe, L2_coe, L1_coe, alpha}.
+ * Bnorm is the mean() denominator (the whole minibatch even if this call sees a row slice of
+ * it -- that is how the multi-GPU row sharding is checked).  Gradients are ACCUMULATED into g
+ * (caller zeroes), losses[6] likewise = {inv, env_aware, envs, L2, L1, total}.
+ * include_dense_reg: add the classifier regulariser (a per-step, not per-sample, term). */
+void FN(oracle_mstep)(const oracle_tables *t, const oracle_grads *g, const int64_t *u, const int64_t *v,
+                      const int64_t *e, const real *y, const real *w, int64_t B, int64_t Bnorm,
+                      const double *coefs, uint32_t flags, int include_dense_reg, double *losses) {
+    const int64_t D = t->D, E = t->E;
+    const real ca = (real)coefs[0], cb = (real)coefs[1], cc = (real)coefs[2];
+    const real l2 = (real)coefs[3], l1 = (real)coefs[4], alpha = (real)coefs[5];
+    const real invB = (real)1 / (real)Bnorm;
+    const real r2 = l2 / ((real)Bnorm * (real)D), r1 = l1 / ((real)2 * (real)Bnorm * (real)D);
+    real *x = (real *)malloc(sizeof(real) * (size_t)D);
+    real *gx = (real *)malloc(sizeof(real) * (size_t)D);
+    real *z = (real *)malloc(sizeof(real) * (size_t)E);
+    real *gz = (real *)malloc(sizeof(real) * (size_t)E);
+    double Linv = 0, Lenv = 0, Lcls = 0, L2u = 0, L1u = 0, L2e = 0, L1e = 0;
+    for (int64_t i = 0; i < B; i++) {
+        const int64_t ui = u[i], vi = v[i], ei = e[i];
+        const real *pu = t->Pu + ui * D, *qi = t->Qi + vi * D;
+        const real *pa = t->Pa + ui * D, *qa = t->Qa + vi * D, *ev = t->Ev + ei * D;
+        const real wi = w ? w[i] : (real)1;
+        const real cw_rec = ((flags & F_REWEIGHT_REC) ? wi : (real)1) * invB;
+        const real cw_cls = ((flags & F_REWEIGHT_CLS) ? wi : (real)1) * invB;
+        real p = dot2(pu, qi, D), q = dot3(pa, qa, ev, D);
+        real g_p, g_q, li, le;
+        if (flags & F_IMPLICIT) {
+            real sp = r_sigmoid(p), sq = r_sigmoid(q), se = sp * sq;
+            li = r_bce(sp, y[i]);
+            le = r_bce(se, y[i]);
+            real d_inv = ca * cw_rec * r_dbce(sp, y[i]);
+            real d_env = cb * cw_rec * r_dbce(se, y[i]);
+            g_p = (d_inv + d_env * sq) * (sp * ((real)1 - sp));
+            g_q = d_env * sp * (sq * ((real)1 - sq));
+        } else {
+            real s2 = p + q;
+            li = (p - y[i]) * (p - y[i]);
+            le = (s2 - y[i]) * (s2 - y[i]);
+            real d_env = cb * cw_rec * (real)2 * (s2 - y[i]);
+            g_p = ca * cw_rec * (real)2 * (p - y[i]) + d_env;
+            g_q = d_env;
+        }
+        Linv += (double)(li * ((flags & F_REWEIGHT_REC) ? wi : (real)1));
+        Lenv += (double)(le * ((flags & F_REWEIGHT_REC) ? wi : (real)1));
+        /* classifier on x = Pu*Qi, reversed gradient (functions.py:13-16) */
+        for (int64_t d = 0; d < D; d++) x[d] = pu[d] * qi[d];
+        real mx = -INFINITY;
+        for (int64_t c = 0; c < E; c++) { z[c] = dot2(x, t->W + c * D, D) + t->b[c]; mx = r_max(mx, z[c]); }
+        real se = 0;
+        for (int64_t c = 0; c < E; c++) se += r_exp(z[c] - mx);
+        real lse = r_log(se);
+        Lcls += (double)(-((z[ei] - mx) - lse) * ((flags & F_REWEIGHT_CLS) ? wi : (real)1));
+        for (int64_t d = 0; d < D; d++) gx[d] = 0;
+        for (int64_t c = 0; c < E; c++) {
+            real sm = r_exp((z[c] - mx) - lse);
+            gz[c] = cc * cw_cls * (sm - (real)(c == ei));
+            g->b[c] += gz[c];
+            for (int64_t d = 0; d < D; d++) {
+                g->W[c * D + d] += gz[c] * x[d];
+                gx[d] += gz[c] * t->W[c * D + d];
+            }
+        }
+        for (int64_t d = 0; d < D; d++) {
+            real gip = g_p - alpha * gx[d];
+            g->Pu[ui * D + d] += gip * qi[d] + r2 * pu[d] + r1 * r_sign(pu[d]);
+            g->Qi[vi * D + d] += gip * pu[d] + r2 * qi[d] + r1 * r_sign(qi[d]);
+            g->Pa[ui * D + d] += g_q * (qa[d] * ev[d]) + r2 * pa[d] + r1 * r_sign(pa[d]);
+            g->Qa[vi * D + d] += g_q * (pa[d] * ev[d]) + r2 * qa[d] + r1 * r_sign(qa[d]);
+            real gev = g_q * (pa[d] * qa[d]);
+            if (flags & F_REG_ENV_EMBED) gev += (real)2 * r2 * ev[d] + (real)2 * r1 * r_sign(ev[d]);
+            g->Ev[ei * D + d] += gev;
+            L2u += (double)(pu[d] * pu[d]) + (double)(pa[d] * pa[d]) + (double)(qi[d] * qi[d]) +
+                   (double)(qa[d] * qa[d]);
+            L1u += fabs((double)pu[d]) + fabs((double)pa[d]) + fabs((double)qi[d]) + fabs((double)qa[d]);
+            if (flags & F_REG_ENV_EMBED) { L2e += (double)(ev[d] * ev[d]); L1e += fabs((double)ev[d]); }
+        }
+    }
+    double L2 = L2u / ((double)Bnorm * (double)D * 2.0) + L2e / ((double)Bnorm * (double)D);
+    double L1 = L1u / ((double)Bnorm * (double)D * 2.0) + L1e / ((double)Bnorm * (double)D);
+    if (include_dense_reg && !(flags & F_REG_ONLY_EMBED)) { /* models.py:211-217 */
+        double w2 = 0, w1 = 0, b2 = 0, b1 = 0;
+        const real kw2 = (real)2 * l2 / ((real)D * (real)E), kw1 = l1 / ((real)D * (real)E);
+        const real kb2 = (real)2 * l2 / (real)E, kb1 = l1 / (real)E;
+        for (int64_t k = 0; k < E * D; k++) {
+            w2 += (double)(t->W[k] * t->W[k]);
+            w1 += fabs((double)t->W[k]);
+            g->W[k] += kw2 * t->W[k] + kw1 * r_sign(t->W[k]);
+        }
+        for (int64_t c = 0; c < E; c++) {
+            b2 += (double)(t->b[c] * t->b[c]);
+            b1 += fabs((double)t->b[c]);
+            g->b[c] += kb2 * t->b[c] + kb1 * r_sign(t->b[c]);
+        }
+        L2 += w2 / ((double)D * (double)E) + b2 / (double)E;
+        L1 += w1 / ((double)D * (double)E) + b1 / (double)E;
+    }
+    losses[0] += Linv / (double)Bnorm;
+    losses[1] += Lenv / (double)Bnorm;
+    losses[2] += Lcls / (double)Bnorm;
+    losses[3] += L2;
+    losses[4] += L1;
+    losses[5] = coefs[0] * losses[0] + coefs[1] * losses[1] + coefs[2] * losses[2] + coefs[3] * losses[3] +
+                coefs[4] * losses[4];
+    free(x); free(gx); free(z); free(gz);
+}
+
+/* ------------------------------------------------------------------ Adam (torch.optim.Adam defaults,
+ * single-tensor rule: lerp / addcmul / sqrt / addcdiv; scalars formed in double then narrowed) */
+void FN(oracle_adam)(real *p, const real *g, real *m, real *vv, int64_t n, int64_t step, double lr,
+                     double beta1, double beta2, double eps) {
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const real step_size = (real)(lr / bc1), bc2s = (real)sqrt(bc2);
+    const real w1 = (real)(1.0 - beta1), b2 = (real)beta2, w2 = (real)(1.0 - beta2), epsr = (real)eps;
+    for (int64_t i = 0; i < n; i++) {
+        real gi = g[i];
+        real mi = m[i] + w1 * (gi - m[i]);
+        real vi = vv[i] * b2 + (w2 * gi) * gi;
+        real denom = (real)sqrt((double)vi);
+#ifndef ORACLE_F64
+        denom = sqrtf(vi);
+#endif
+        denom = denom / bc2s + epsr;
+        p[i] = p[i] + ((-step_size) * mi) / denom;
+        m[i] = mi;
+        vv[i] = vi;
+    }
+}
+
+/* ------------------------------------------------------------------ E-step (train.py:169-202, :235-259)
+ * dist_e = BCE(sigma(p)*sigma(q_e), y)  (explicit: (p+q_e-y)^2); argmin, lowest index on ties.
+ * eps_rows (optional, [N,E]) is the random tie-break row already gathered per sample
+ * (train.py:192-196).  dist_out optional [N,E]. */
+void FN(oracle_estep)(const oracle_tables *t, const int64_t *u, const int64_t *v, const real *y, int64_t N,
+                      uint32_t flags, const real *eps_rows, const int64_t *old_envs, int64_t *new_envs,
+                      int64_t *counts, int64_t *diff, real *dist_out) {
+    const int64_t D = t->D, E = t->E;
+    int64_t nd = 0;
+    for (int64_t c = 0; c < E; c++) counts[c] = 0;
+    for (int64_t i = 0; i < N; i++) {
+        const real *pu = t->Pu + u[i] * D, *qi = t->Qi + v[i] * D;
+        const real *pa = t->Pa + u[i] * D, *qa = t->Qa + v[i] * D;
+        real p = dot2(pu, qi, D);
+        real sp = (flags & F_IMPLICIT) ? r_sigmoid(p) : p;
+        real best = 0;
+        int64_t bi = 0;
+        for (int64_t c = 0; c < E; c++) {
+            real q = dot3(pa, qa, t->Ev + c * D, D);
+            real dist;
+            if (flags & F_IMPLICIT) dist = r_bce(sp * r_sigmoid(q), y[i]);
+            else { real r = (p + q) - y[i]; dist = r * r; }
+            if (eps_rows) dist = dist + eps_rows[i * E + c];
+            if (dist_out) dist_out[i * E + c] = dist;
+            if (c == 0 || dist < best) { best = dist; bi = c; }
+        }
+        new_envs[i] = bi;
+        counts[bi]++;
+        if (old_envs && old_envs[i] != bi) nd++;
+    }
+    if (diff) *diff = nd;
+}
+
+/* stat_envs (train.py:268-280): class_w[e] = min(cnt+1, N-1)/N (numpy float64 -> float32) */
+void FN(oracle_stat_envs)(const int64_t *envs, int64_t N, int64_t E, int64_t *counts, real *class_w,
+                          real *sample_w) {
+    for (int64_t c = 0; c < E; c++) counts[c] = 0;
+    for (int64_t i = 0; i < N; i++) counts[envs[i]]++;
+    for (int64_t c = 0; c < E; c++) {
+        double r = (double)(counts[c] + 1 < N - 1 ? counts[c] + 1 : N - 1);
+        class_w[c] = (real)(r / (double)N);
+    }
+    if (sample_w)
+        for (int64_t i = 0; i < N; i++) sample_w[i] = class_w[envs[i]];
+}
+
+#ifndef ORACLE_F64
+/* exported so tests can pin the canonical scalar functions directly */
+float oracle_cexp(float x) { return r_exp(x); }
+float oracle_clog(float x) { return r_log(x); }
+float oracle_clog1p(float x) { return r_log1p(x); }
+float oracle_cdot2(const float *a, const float *b, int64_t D) { return dot2(a, b, D); }
+float oracle_cdot3(const float *a, const float *b, const float *c, int64_t D) { return dot3(a, b, c, D); }
+#endif

@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference, CPU torch).  It imports
+the reference's own ``models.py`` / ``train.py`` (never copied), drives
+``ImplicitTrainManager`` / ``ExplicitTrainManager`` on seeded inputs and stores
+inputs + outputs as small ``.npz`` files.  The GPU box only ever sees the
+``.npz`` data.  Usage:  python tests/golden/gen_goldens.py [g1 g2 g3 g4 g5]
+
+What each fixture pins:
+  g1_*  op level: forward, 6 loss terms, every parameter gradient (fp32+fp64),
+        parameters after one Adam step                    -> §8 a2-a8
+  g2_*  E-step on healthy-margin tables at Yahoo shape    -> §8 a9-a11 (bit exact)
+  g3    Coat-explicit 30-epoch trajectory + first cluster -> §8 a7,a8,a10-a14
+  g4    Yahoo-shaped implicit trajectory, 5 epochs + E-step
+  g5    MIND-shaped single step (E=16, D=256, B=262144)
+"""
+import sys
+import types
+
+sys.dont_write_bytecode = True
+sys.modules.setdefault('seaborn', types.ModuleType('seaborn'))  # utils.py:5 imports it, unused
+sys.path.insert(0, '/root/reference')
+sys.path.insert(0, '/root/repo')
+
+import hashlib
+import os
+
+import numpy as np
+import torch
+
+import models as ref_models  # noqa: E402  (reference)
+import train as ref_train  # noqa: E402  (reference)
+
+from invpref_kdd_2022_amd import synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+CPU = torch.device('cpu')
+
+PARAM_NAMES = [
+    'embed_user_invariant.weight', 'embed_item_invariant.weight',
+    'embed_user_env_aware.weight', 'embed_item_env_aware.weight',
+    'embed_env.weight', 'env_classifier.linear_map.weight', 'env_classifier.linear_map.bias',
+]
+
+
+class StubEvaluator:
+    def evaluate(self):
+        return {'stub': 0.0}
+
+
+def load_tables(model, tabs, dtype=torch.float32):
+    sd = {k: torch.from_numpy(np.asarray(v)).to(dtype) for k, v in tabs.items()}
+    model.load_state_dict(sd)
+
+
+def sd_hash(tabs) -> str:
+    h = hashlib.sha256()
+    for k in PARAM_NAMES:
+        h.update(np.ascontiguousarray(tabs[k], dtype=np.float32).tobytes())
+    return h.hexdigest()
+
+
+def make_manager(kind, model, data, *, batch_size, cfg, cls_w, rec_w, random_sort=False, epochs=1,
+                 cluster_interval=5, no_eps=False):
+    base = ref_train.ImplicitTrainManager if kind == 'implicit' else ref_train.ExplicitTrainManager
+    if no_eps:
+        class Mgr(base):  # 16! permutations cannot be built (train.py:86-92)
+            def _init_eps(self):
+                return torch.zeros(1, self.envs_num)
+        base = Mgr
+    return base(
+        model=model, evaluator=StubEvaluator(), device=CPU, training_data=torch.from_numpy(data),
+        batch_size=batch_size, epochs=epochs, cluster_interval=cluster_interval, evaluate_interval=10 ** 9,
+        lr=cfg['lr'], invariant_coe=cfg['invariant_coe'], env_aware_coe=cfg['env_aware_coe'],
+        env_coe=cfg['env_coe'], L2_coe=cfg['L2_coe'], L1_coe=cfg['L1_coe'], alpha=cfg['alpha'],
+        use_class_re_weight=cls_w, use_recommend_re_weight=rec_w, cluster_use_random_sort=random_sort)
+
+
+COEFS = dict(lr=0.01, invariant_coe=2.050646960185343, env_aware_coe=8.632289952059462,
+             env_coe=5.100067503854663, L2_coe=7.731619515414727, L1_coe=0.0015415961377493945,
+             alpha=1.7379692382330174)
+
+G1_SHAPES = {  # name: (U, I, E, D, B)
+    's16': (50, 30, 4, 16, 256),
+    's30': (40, 35, 3, 30, 200),
+    's40': (30, 20, 2, 40, 100),
+    's128': (20, 25, 8, 128, 64),
+}
+# (reg_only_embed, reg_env_embed, use_class_re_weight, use_recommend_re_weight)
+G1_FLAGS = {'f0': (True, False, True, True), 'f1': (False, True, True, False),
+            'f2': (True, True, False, True), 'f3': (False, False, False, False)}
+
+
+def gen_g1():
+    for kind in ('implicit', 'explicit'):
+        for sname, (U, I, E, D, B) in G1_SHAPES.items():
+            for fname, (roe, ree, cls_w, rec_w) in G1_FLAGS.items():
+                seed = 1000 + hash((kind, sname, fname)) % 1000 if False else \
+                    int(hashlib.md5(f'{kind}{sname}{fname}'.encode()).hexdigest()[:6], 16)
+                rs = np.random.RandomState(seed)
+                tabs = synth.tables(seed, U, I, E, D, std=0.3)
+                u = rs.randint(0, U, B).astype(np.int64)
+                v = rs.randint(0, I, B).astype(np.int64)
+                e = rs.randint(0, E, B).astype(np.int64)
+                y = (rs.randint(0, 2, B) if kind == 'implicit' else rs.randint(1, 6, B)).astype(np.float32)
+                w = rs.uniform(0.05, 1.0, B).astype(np.float32)
+                data = np.stack([u, v, y.astype(np.int64)], axis=1)
+                out = dict(u=u, v=v, e=e, y=y, w=w,
+                           meta=np.array([U, I, E, D, B, int(roe), int(ree), int(cls_w), int(rec_w)]),
+                           coefs=np.array([COEFS[k] for k in ('invariant_coe', 'env_aware_coe', 'env_coe',
+                                                              'L2_coe', 'L1_coe', 'alpha', 'lr')]))
+                for k in PARAM_NAMES:
+                    out['p_' + k] = tabs[k]
+                for dt, tag in ((torch.float32, 'f32'), (torch.float64, 'f64')):
+                    cls = ref_models.InvPrefImplicit if kind == 'implicit' else ref_models.InvPrefExplicit
+                    np.random.seed(0)
+                    model = cls(U, I, E, D, reg_only_embed=roe, reg_env_embed=ree).to(dt)
+                    load_tables(model, tabs, dt)
+                    mgr = make_manager(kind, model, data, batch_size=B, cfg=COEFS, cls_w=cls_w, rec_w=rec_w)
+                    tu, tv, te = map(torch.from_numpy, (u, v, e))
+                    ty, tw = torch.from_numpy(y).to(dt), torch.from_numpy(w).to(dt)
+                    model.train()
+                    inv, envs, envout = model(tu, tv, te, COEFS['alpha'])
+                    out[f'inv_{tag}'] = inv.detach().numpy()
+                    out[f'envaware_{tag}'] = envs.detach().numpy()
+                    out[f'envout_{tag}'] = envout.detach().numpy()
+                    ld = mgr.train_a_batch(tu, tv, ty, te, tw, COEFS['alpha'])
+                    out[f'losses_{tag}'] = np.array(
+                        [ld[k] for k in ('invariant_loss', 'env_aware_loss', 'envs_loss', 'L2_reg', 'L1_reg',
+                                         'loss')], dtype=np.float64)
+                    sd = dict(model.named_parameters())
+                    for k in PARAM_NAMES:
+                        out[f'g_{tag}_' + k] = sd[k].grad.detach().numpy().copy()
+                        out[f'adam1_{tag}_' + k] = sd[k].detach().numpy().copy()
+                    if tag == 'f32':  # two more steps on the same batch: Adam state parity
+                        for _ in range(2):
+                            mgr.train_a_batch(tu, tv, ty, te, tw, COEFS['alpha'])
+                        for k in PARAM_NAMES:
+                            out['adam3_f32_' + k] = sd[k].detach().numpy().copy()
+                    # E-step distances on the (updated) tables would mix concerns; do it on fresh ones
+                    model2 = cls(U, I, E, D, reg_only_embed=roe, reg_env_embed=ree).to(dt)
+                    load_tables(model2, tabs, dt)
+                    mgr2 = make_manager(kind, model2, data, batch_size=B, cfg=COEFS, cls_w=cls_w, rec_w=rec_w)
+                    model2.eval()
+                    dists = []
+                    for env in range(E):
+                        pred = model2.cluster_predict(tu, tv, torch.full((B,), env, dtype=torch.long))
+                        dists.append(mgr2.cluster_distance_func(pred, ty).detach().numpy())
+                    out[f'dist_{tag}'] = np.stack(dists, axis=1)
+                    out[f'newenv_{tag}'] = mgr2.cluster_a_batch(tu, tv, ty).numpy()
+                np.savez_compressed(os.path.join(OUT, f'g1_{kind}_{sname}_{fname}.npz'), **out)
+                print('g1', kind, sname, fname, out['losses_f32'][-1], out['losses_f64'][-1])
+
+
+def pack_envs(envs: np.ndarray) -> np.ndarray:
+    return envs.astype(np.uint8)
+
+
+def gen_g2():
+    U, I, n = synth.YAHOO_SHAPE['user_num'], synth.YAHOO_SHAPE['item_num'], synth.YAHOO_SHAPE['n']
+    E, D = 4, 64
+    for kind in ('implicit', 'explicit'):
+        seed = 2024 if kind == 'implicit' else 2025
+        data = synth.interactions(seed, U, I, n, implicit=(kind == 'implicit'))
+        tabs = synth.tables(seed + 1, U, I, E, D, std=0.3 if kind == 'implicit' else 0.15)
+        cls = ref_models.InvPrefImplicit if kind == 'implicit' else ref_models.InvPrefExplicit
+        model = cls(U, I, E, D, reg_only_embed=True, reg_env_embed=False)
+        load_tables(model, tabs)
+        np.random.seed(seed + 2)
+        mgr = make_manager(kind, model, data, batch_size=8192, cfg=COEFS, cls_w=True, rec_w=True)
+        old = mgr.envs.numpy().copy()
+        # per-row distances for margin statistics
+        model.eval()
+        tu, tv = torch.from_numpy(data[:, 0]), torch.from_numpy(data[:, 1])
+        ty = torch.from_numpy(data[:, 2]).float()
+        with torch.no_grad():
+            dists = []
+            for env in range(E):
+                pred = model.cluster_predict(tu, tv, torch.full((n,), env, dtype=torch.long))
+                dists.append(mgr.cluster_distance_func(pred, ty).numpy())
+            dist = np.stack(dists, axis=1)
+        srt = np.sort(dist, axis=1)
+        margin = (srt[:, 1] - srt[:, 0]) / np.maximum(np.abs(srt[:, 0]), 1e-30)
+        diff = mgr.cluster()
+        cnt = mgr.stat_envs()
+        new = mgr.envs.numpy()
+        assert (new == dist.argmin(1)).all()
+        print('g2', kind, 'diff', diff, 'counts', cnt, 'min rel margin', margin.min(),
+              'rows<1e-5', int((margin < 1e-5).sum()))
+        np.savez_compressed(
+            os.path.join(OUT, f'g2_estep_{kind}.npz'),
+            meta=np.array([U, I, E, D, n, seed]), table_hash=np.array(sd_hash(tabs)),
+            old_envs=pack_envs(old), new_envs=pack_envs(new), diff_num=np.array(diff),
+            counts=np.array([cnt[k] for k in range(E)]), dist_head=dist[:4096].astype(np.float32),
+            rel_margin_min=np.array(margin.min()),
+            low_margin_rows=np.nonzero(margin < 1e-5)[0].astype(np.int64),
+            class_weights=mgr.class_weights.numpy(), sample_weights_head=mgr.sample_weights.numpy()[:4096])
+
+
+COAT_CFG = dict(lr=0.01, invariant_coe=2.050646960185343, env_aware_coe=8.632289952059462,
+                env_coe=5.100067503854663, L2_coe=7.731619515414727, L1_coe=0.0015415961377493945,
+                alpha=1.7379692382330174)
+
+
+def gen_g3():
+    import pandas as pd
+    df = pd.read_csv('/root/reference/dataset/Coat_explicit_all_data/train.csv')
+    data = df[['user_id', 'item_id', 'score']].to_numpy().astype(np.int64)
+    U, I = int(data[:, 0].max()) + 1, int(data[:, 1].max()) + 1
+    E, D = 4, 30
+    seed = 17373331
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    model = ref_models.InvPrefExplicit(U, I, E, D, reg_only_embed=True, reg_env_embed=False)
+    init = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    mgr = make_manager('explicit', model, data, batch_size=1024, cfg=COAT_CFG, cls_w=True, rec_w=True,
+                       random_sort=False, epochs=30, cluster_interval=30)
+    env0 = mgr.envs.numpy().copy()
+    (losses, _), _, (diffs, cnts, _) = mgr.train(silent=True, auto=True)
+    keys = ('invariant_loss', 'env_aware_loss', 'envs_loss', 'L2_reg', 'L1_reg', 'loss')
+    trace = np.array([[d[k] for k in keys] for d in losses], dtype=np.float64)
+    print('g3 coat: loss[0]', trace[0, -1], 'loss[29]', trace[-1, -1], 'diff', diffs, cnts)
+    out = dict(data=data.astype(np.int16), meta=np.array([U, I, E, D, 1024, 30, seed]),
+               env0=pack_envs(env0), env_after=pack_envs(mgr.envs.numpy()), loss_trace=trace,
+               diff_num=np.array(diffs), counts=np.array([[c[k] for k in range(E)] for c in cnts]),
+               coefs=np.array([COAT_CFG[k] for k in ('invariant_coe', 'env_aware_coe', 'env_coe', 'L2_coe',
+                                                     'L1_coe', 'alpha', 'lr')]))
+    for k in PARAM_NAMES:
+        out['init_' + k] = init[k]
+        out['final_' + k] = model.state_dict()[k].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, 'g3_coat_explicit_traj.npz'), **out)
+
+
+YAHOO_CFG = dict(lr=0.005, invariant_coe=3.351991776096847, env_aware_coe=9.988658447411407,
+                 env_coe=9.06447753571379, L2_coe=3.1351402017943117, L1_coe=0.4935216278026648,
+                 alpha=1.9053711444718746)
+
+
+def gen_g4():
+    U, I, n = synth.YAHOO_SHAPE['user_num'], synth.YAHOO_SHAPE['item_num'], synth.YAHOO_SHAPE['n']
+    E, D, seed = 4, 64, 17373331
+    data = synth.yahoo_like(seed)
+    tabs = synth.tables(seed + 7, U, I, E, D, std=0.01)
+    np.random.seed(seed)
+    model = ref_models.InvPrefImplicit(U, I, E, D, reg_only_embed=True, reg_env_embed=False)
+    load_tables(model, tabs)
+    # reference Yahoo flags: class re-weight on, recommend re-weight off (Yahoo_InvPref_Implicit.py:37-38)
+    mgr = make_manager('implicit', model, data, batch_size=8192, cfg=YAHOO_CFG, cls_w=True, rec_w=False,
+                       random_sort=False, epochs=5, cluster_interval=5)
+    env0 = mgr.envs.numpy().copy()
+    torch.set_num_threads(1)  # reference is not thread-count deterministic at this scale
+    (losses, _), _, (diffs, cnts, _) = mgr.train(silent=True, auto=True)
+    keys = ('invariant_loss', 'env_aware_loss', 'envs_loss', 'L2_reg', 'L1_reg', 'loss')
+    trace = np.array([[d[k] for k in keys] for d in losses], dtype=np.float64)
+    print('g4 yahoo-like: losses', trace[:, -1], 'diff', diffs, cnts)
+    fin = model.state_dict()
+    rows = np.random.RandomState(5).randint(0, I, 64)
+    np.savez_compressed(
+        os.path.join(OUT, 'g4_yahoo_like_traj.npz'),
+        meta=np.array([U, I, E, D, 8192, 5, seed]), table_hash=np.array(sd_hash(tabs)),
+        env0=pack_envs(env0), env_after=pack_envs(mgr.envs.numpy()), loss_trace=trace,
+        diff_num=np.array(diffs), counts=np.array([[c[k] for k in range(E)] for c in cnts]),
+        coefs=np.array([YAHOO_CFG[k] for k in ('invariant_coe', 'env_aware_coe', 'env_coe', 'L2_coe', 'L1_coe',
+                                               'alpha', 'lr')]),
+        sample_rows=rows,
+        final_item_inv_rows=fin['embed_item_invariant.weight'].numpy()[rows],
+        final_item_env_rows=fin['embed_item_env_aware.weight'].numpy()[rows],
+        final_env=fin['embed_env.weight'].numpy(), final_W=fin['env_classifier.linear_map.weight'].numpy(),
+        final_b=fin['env_classifier.linear_map.bias'].numpy())
+
+
+def gen_g5():
+    U, I = synth.MIND_SHAPE['user_num'], synth.MIND_SHAPE['item_num']
+    E, D, B, seed = 16, 256, 262144, 99
+    data = synth.interactions(seed, U, I, B, implicit=True, zipf=True)
+    tabs = synth.tables(seed + 1, U, I, E, D, std=0.05)
+    np.random.seed(seed)
+    model = ref_models.InvPrefImplicit(U, I, E, D, reg_only_embed=False, reg_env_embed=True)
+    load_tables(model, tabs)
+    mgr = make_manager('implicit', model, data, batch_size=B, cfg=YAHOO_CFG, cls_w=True, rec_w=True, no_eps=True)
+    env0 = mgr.envs.numpy().copy()
+    mgr.stat_envs()
+    w = mgr.sample_weights.numpy().copy()
+    ld = mgr.train_a_batch(mgr.users_tensor, mgr.items_tensor, mgr.scores_tensor, mgr.envs, mgr.sample_weights,
+                           YAHOO_CFG['alpha'])
+    keys = ('invariant_loss', 'env_aware_loss', 'envs_loss', 'L2_reg', 'L1_reg', 'loss')
+    print('g5 mind-like:', ld)
+    sd = dict(model.named_parameters())
+    rs = np.random.RandomState(3)
+    urows, irows = rs.randint(0, U, 256), rs.randint(0, I, 256)
+    out = dict(meta=np.array([U, I, E, D, B, seed]), table_hash=np.array(sd_hash(tabs)), env0=pack_envs(env0),
+               w_head=w[:1024], losses=np.array([ld[k] for k in keys]), urows=urows, irows=irows,
+               coefs=np.array([YAHOO_CFG[k] for k in ('invariant_coe', 'env_aware_coe', 'env_coe', 'L2_coe',
+                                                      'L1_coe', 'alpha', 'lr')]))
+    for k in PARAM_NAMES:
+        g = sd[k].grad.detach().numpy()
+        out['gnorm_' + k] = np.array(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        if 'user' in k:
+            out['grows_' + k] = g[urows]
+        elif 'item' in k:
+            out['grows_' + k] = g[irows]
+        else:
+            out['g_' + k] = g.copy()
+    np.savez_compressed(os.path.join(OUT, 'g5_mind_like_step.npz'), **out)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5']
+    torch.manual_seed(0)
+    for name in which:
+        globals()['gen_' + name]()

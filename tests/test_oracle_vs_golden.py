@@ -1,0 +1,131 @@
+"""CPU: the oracle (oracle/invpref_oracle.c) against golden vectors produced by the reference
+itself (tests/golden/gen_goldens.py).  This is what pins the oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+G1 = sorted(glob.glob(os.path.join(os.path.dirname(__file__), 'golden', 'g1_*.npz')))
+
+
+def _load(path):
+    z = np.load(path)
+    U, I, E, D, B, roe, ree, cls_w, rec_w = [int(x) for x in z['meta']]
+    kind = 'implicit' if '_implicit_' in path else 'explicit'
+    params = {k: z['p_' + k] for k in O.PARAM_NAMES}
+    flags = O.flags_of(kind == 'implicit', rec_w, cls_w, roe, ree)
+    return z, kind, params, flags, (U, I, E, D, B)
+
+
+def _relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize('path', G1, ids=[os.path.basename(p)[3:-4] for p in G1])
+def test_g1_f64_formulas_exact(path):
+    """fp64 oracle == reference fp64 autograd to ~1e-12: the restated formulas are exact."""
+    z, kind, params, flags, _ = _load(path)
+    tab = O.Tables(params, 'f64')
+    inv, env, out = O.forward(tab, z['u'], z['v'], z['e'], kind == 'implicit')
+    assert _relerr(inv, z['inv_f64']) < 1e-12
+    assert _relerr(env, z['envaware_f64']) < 1e-12
+    assert _relerr(out, z['envout_f64']) < 1e-12
+    grads, losses = O.mstep(tab, z['u'], z['v'], z['e'], z['y'], z['w'], z['coefs'], flags)
+    assert _relerr(losses, z['losses_f64']) < 1e-12
+    for k, g in zip(O.PARAM_NAMES, grads):
+        assert _relerr(g, z['g_f64_' + k]) < 1e-10, k
+    dist = O.estep(tab, z['u'], z['v'], z['y'], kind == 'implicit', want_dist=True)[3]
+    assert _relerr(dist, z['dist_f64']) < 1e-11
+    # one Adam step (in place on the oracle's copy of the tables)
+    for k, p, g in zip(O.PARAM_NAMES, tab.arrs, grads):
+        m, v = np.zeros_like(p), np.zeros_like(p)
+        O.adam(p.reshape(-1), g.reshape(-1), m.reshape(-1), v.reshape(-1), 1, float(z['coefs'][6]), prec='f64')
+        assert _relerr(p, z['adam1_f64_' + k]) < 1e-10, k
+
+
+@pytest.mark.parametrize('path', G1, ids=[os.path.basename(p)[3:-4] for p in G1])
+def test_g1_f32_within_tolerance(path):
+    """fp32 oracle vs reference fp32: losses 1e-5 relative (north_star), grads 2e-5 of max."""
+    z, kind, params, flags, _ = _load(path)
+    tab = O.Tables(params, 'f32')
+    inv, env, out = O.forward(tab, z['u'], z['v'], z['e'], kind == 'implicit')
+    assert _relerr(inv, z['inv_f32']) < 2e-6
+    assert _relerr(env, z['envaware_f32']) < 2e-6
+    assert _relerr(out, z['envout_f32']) < 2e-6
+    grads, losses = O.mstep(tab, z['u'], z['v'], z['e'], z['y'], z['w'], z['coefs'], flags)
+    np.testing.assert_allclose(losses, z['losses_f32'], rtol=1e-5)
+    for k, g in zip(O.PARAM_NAMES, grads):
+        assert _relerr(g, z['g_f32_' + k]) < 2e-5, k
+    dist = O.estep(tab, z['u'], z['v'], z['y'], kind == 'implicit', want_dist=True)
+    assert _relerr(dist[3], z['dist_f32']) < 2e-6
+    # three Adam steps on the same batch (Adam state parity)
+    st = O.Trainer(params, np.stack([z['u'], z['v'], z['y'].astype(np.int64)], 1), z['e'],
+                   implicit=kind == 'implicit', batch_size=len(z['u']), coefs=z['coefs'][:6],
+                   lr=float(z['coefs'][6]), reweight_rec=bool(flags & 2), reweight_cls=bool(flags & 4),
+                   reg_only_embed=bool(flags & 8), reg_env_embed=bool(flags & 16))
+    st.sample_w = z['w'].astype(np.float32)
+    st.train_a_batch(0, len(z['u']))
+    for k, p in zip(O.PARAM_NAMES, st.tab.arrs):
+        # Adam's first step is lr*g/(|g|+eps): an element whose gradient is ~eps-sized amplifies
+        # fp32 rounding; bound those by a fraction of lr and require the bulk to agree tightly
+        d = np.abs(p - z['adam1_f32_' + k])
+        assert d.max() < 0.05 * float(z['coefs'][6]), k
+        assert np.quantile(d, 0.99) < 2e-6 * max(np.abs(z['adam1_f32_' + k]).max(), 1.0), k
+    st.train_a_batch(0, len(z['u']))
+    st.train_a_batch(0, len(z['u']))
+    for k, p in zip(O.PARAM_NAMES, st.tab.arrs):
+        # lr=0.01 steps: a sign flip of a ~0 gradient moves a weight by 2*lr; compare in units of lr
+        assert np.abs(p - z['adam3_f32_' + k]).max() < 0.05 * float(z['coefs'][6]), k
+
+
+def test_g1_newenv_matches_where_margin():
+    """argmin equality on every row whose fp32 top-2 margin is not at rounding level."""
+    bad = 0
+    for path in G1:
+        z, kind, params, flags, _ = _load(path)
+        tab = O.Tables(params, 'f32')
+        new, _, _, dist = O.estep(tab, z['u'], z['v'], z['y'], kind == 'implicit', want_dist=True)
+        ref = z['newenv_f32']
+        srt = np.sort(z['dist_f64'], axis=1)
+        margin = (srt[:, 1] - srt[:, 0]) / np.maximum(srt[:, 0], 1e-30)
+        mism = new != ref
+        assert (margin[mism] < 1e-5).all()
+        bad += int(mism.sum())
+    assert bad <= 2
+
+
+def test_canonical_scalar_functions():
+    L = O.lib()
+    xs = np.concatenate([np.linspace(-87, 88, 20001), np.array([0.0, -0.0, 1e-8, -1e-8, 100.0, -100.0])])
+    got = np.array([L.oracle_cexp(float(np.float32(x))) for x in xs], np.float64)
+    want = np.exp(xs.astype(np.float32).astype(np.float64))
+    want = np.where(xs > 88.72283, np.inf, np.where(xs < -87.33654, 0, want))
+    fin = np.isfinite(want) & (want > 1e-37)
+    assert np.max(np.abs(got[fin] - want[fin]) / want[fin]) < 2.5e-7
+    assert L.oracle_cexp(100.0) == np.inf and L.oracle_cexp(-100.0) == 0.0
+    xs = np.concatenate([np.exp(np.linspace(-80, 80, 20001)), [1.0, 0.5, 2.0, 1e-40]]).astype(np.float32)
+    got = np.array([L.oracle_clog(float(x)) for x in xs], np.float64)
+    want = np.log(xs.astype(np.float64))
+    assert np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-6)) < 3e-7
+    assert L.oracle_clog(0.0) == -np.inf and np.isnan(L.oracle_clog(-1.0)) and L.oracle_clog(1.0) == 0.0
+    xs = -np.concatenate([np.exp(np.linspace(-30, 0, 5001)), [0.0, 1.0]]).astype(np.float32)
+    got = np.array([L.oracle_clog1p(float(x)) for x in xs], np.float64)
+    with np.errstate(divide='ignore'):
+        want = np.log1p(xs.astype(np.float64))
+    ok = np.isfinite(want) & (want != 0)
+    assert np.max(np.abs(got[ok] - want[ok]) / np.abs(want[ok])) < 5e-7
+    assert L.oracle_clog1p(-1.0) == -np.inf and L.oracle_clog1p(0.0) == 0.0
+
+
+def test_stat_envs_rule():
+    envs = np.array([0, 0, 1, 3, 3, 3, 0, 0], np.int64)
+    counts, cw, sw = O.stat_envs(envs, 4)
+    assert counts.tolist() == [4, 1, 0, 3]
+    np.testing.assert_array_equal(cw, (np.array([5, 2, 1, 4], np.float64) / 8).astype(np.float32))
+    np.testing.assert_array_equal(sw, cw[envs])
+    counts, cw, _ = O.stat_envs(np.zeros(8, np.int64), 2)
+    assert cw[0] == np.float32(7 / 8)  # min(cnt+1, N-1)/N   train.py:274

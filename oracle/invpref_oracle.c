@@ -211,6 +211,12 @@ void FN(oracle_mstep)(const oracle_tables *t, const oracle_grads *g, const int64
     real *z = (real *)malloc(sizeof(real) * (size_t)E);
     real *gz = (real *)malloc(sizeof(real) * (size_t)E);
     double Linv = 0, Lenv = 0, Lcls = 0, L2u = 0, L1u = 0, L2e = 0, L1e = 0;
+    /* the three small dense tables receive a contribution from EVERY sample: accumulate them in
+     * double and round once, so the oracle stays a reference at B = 262144 (a sequential fp32 sum
+     * of that many terms is itself ~1e-4 off) */
+    double *aEv = (double *)calloc((size_t)(E * D), sizeof(double));
+    double *aW = (double *)calloc((size_t)(E * D), sizeof(double));
+    double *ab = (double *)calloc((size_t)E, sizeof(double));
     for (int64_t i = 0; i < B; i++) {
         const int64_t ui = u[i], vi = v[i], ei = e[i];
         const real *pu = t->Pu + ui * D, *qi = t->Qi + vi * D;
@@ -250,9 +256,9 @@ void FN(oracle_mstep)(const oracle_tables *t, const oracle_grads *g, const int64
         for (int64_t c = 0; c < E; c++) {
             real sm = r_exp((z[c] - mx) - lse);
             gz[c] = cc * cw_cls * (sm - (real)(c == ei));
-            g->b[c] += gz[c];
+            ab[c] += (double)gz[c];
             for (int64_t d = 0; d < D; d++) {
-                g->W[c * D + d] += gz[c] * x[d];
+                aW[c * D + d] += (double)(gz[c] * x[d]);
                 gx[d] += gz[c] * t->W[c * D + d];
             }
         }
@@ -264,13 +270,16 @@ void FN(oracle_mstep)(const oracle_tables *t, const oracle_grads *g, const int64
             g->Qa[vi * D + d] += g_q * (pa[d] * ev[d]) + r2 * qa[d] + r1 * r_sign(qa[d]);
             real gev = g_q * (pa[d] * qa[d]);
             if (flags & F_REG_ENV_EMBED) gev += (real)2 * r2 * ev[d] + (real)2 * r1 * r_sign(ev[d]);
-            g->Ev[ei * D + d] += gev;
+            aEv[ei * D + d] += (double)gev;
             L2u += (double)(pu[d] * pu[d]) + (double)(pa[d] * pa[d]) + (double)(qi[d] * qi[d]) +
                    (double)(qa[d] * qa[d]);
             L1u += fabs((double)pu[d]) + fabs((double)pa[d]) + fabs((double)qi[d]) + fabs((double)qa[d]);
             if (flags & F_REG_ENV_EMBED) { L2e += (double)(ev[d] * ev[d]); L1e += fabs((double)ev[d]); }
         }
     }
+    for (int64_t k = 0; k < E * D; k++) { g->Ev[k] += (real)aEv[k]; g->W[k] += (real)aW[k]; }
+    for (int64_t c = 0; c < E; c++) g->b[c] += (real)ab[c];
+    free(aEv); free(aW); free(ab);
     double L2 = L2u / ((double)Bnorm * (double)D * 2.0) + L2e / ((double)Bnorm * (double)D);
     double L1 = L1u / ((double)Bnorm * (double)D * 2.0) + L1e / ((double)Bnorm * (double)D);
     if (include_dense_reg && !(flags & F_REG_ONLY_EMBED)) { /* models.py:211-217 */

@@ -1,0 +1,124 @@
+/*
+ * invpref_hip.h -- C ABI of the MI355X-native InvPref hot path (libinvpref_hip.so).
+ *
+ * The reference (AIflowerQ/InvPref_KDD_2022) is pure Python/PyTorch and has no FFI boundary; its
+ * seam for this path is the Python object surface of models.py / train.py.  Each entry point below
+ * names the reference code it replaces (file:line relative to the reference root).  All pointers
+ * are DEVICE pointers unless stated otherwise; the caller owns every buffer; nothing is retained
+ * after a call returns; every launch is enqueued on `stream`
+ * (a hipStream_t passed as void*, NULL = default stream) and no call synchronises the host
+ * unless stated.  Return value: 0 on success, a negative INVPREF_E* code for bad arguments, or a
+ * positive hipError_t passed through.  No exceptions cross this boundary.
+ *
+ * Tables are fp32 row-major; ids are int64 (the reference uses torch.LongTensor, train.py:31-34).
+ * Out-of-range ids are undefined behaviour on the device (the reference raises IndexError).
+ */
+#ifndef INVPREF_HIP_H
+#define INVPREF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INVPREF_ABI_VERSION 1
+
+/* error codes */
+#define INVPREF_OK 0
+#define INVPREF_EINVAL (-1)      /* null pointer / negative size */
+#define INVPREF_EUNSUPPORTED (-2) /* factor_num or env_num outside the compiled range */
+#define INVPREF_EWORKSPACE (-3)  /* workspace too small */
+
+/* limits of the compiled kernels */
+#define INVPREF_MAX_FACTORS 256
+#define INVPREF_MAX_ENVS 16
+
+/* flags (bit set) */
+#define INVPREF_IMPLICIT 1u       /* InvPrefImplicit + BCELoss (models.py:272, train.py:42); else explicit + MSELoss (models.py:414, train.py:719) */
+#define INVPREF_REWEIGHT_REC 2u   /* use_recommend_re_weight  train.py:125-142 */
+#define INVPREF_REWEIGHT_CLS 4u   /* use_class_re_weight      train.py:120-136 */
+#define INVPREF_REG_ONLY_EMBED 8u /* model.reg_only_embed     models.py:369,381 */
+#define INVPREF_REG_ENV_EMBED 16u /* model.reg_env_embed      models.py:376,388 */
+#define INVPREF_DENSE_REG 32u     /* add the classifier regulariser (models.py:211-217) in this call;
+                                     set on exactly one rank when a minibatch is row-sharded */
+
+/* The seven parameter tensors of InvPrefImplicit/InvPrefExplicit (models.py:283-291, :197-201),
+ * in state_dict order.  Also used for gradients and Adam moments (same shapes). */
+typedef struct InvPrefTables {
+    int64_t user_num, item_num, env_num, factor_num;
+    float *embed_user_invariant;   /* [user_num, factor_num] */
+    float *embed_item_invariant;   /* [item_num, factor_num] */
+    float *embed_user_env_aware;   /* [user_num, factor_num] */
+    float *embed_item_env_aware;   /* [item_num, factor_num] */
+    float *embed_env;              /* [env_num,  factor_num] */
+    float *classifier_weight;      /* [env_num,  factor_num]  env_classifier.linear_map.weight */
+    float *classifier_bias;        /* [env_num]               env_classifier.linear_map.bias   */
+} InvPrefTables;
+
+/* loss coefficients of ImplicitTrainManager/ExplicitTrainManager (train.py:22, :45-49) + the
+ * gradient-reversal alpha handed to forward() (train.py:108, functions.py:7-16) */
+typedef struct InvPrefCoefs {
+    float invariant_coe, env_aware_coe, env_coe, L2_coe, L1_coe, alpha;
+} InvPrefCoefs;
+
+int invpref_abi_version(void);
+/* name of the device the library would launch on (host buffer), for bench/logging */
+int invpref_device_name(char *buf, size_t len);
+
+/* ---- forward: replaces InvPref{Implicit,Explicit}.forward (models.py:307-326, :448-467).
+ * out: invariant_score[B], env_aware_score[B], env_outputs[B, env_num] (log-softmax). */
+int invpref_forward_hip(const InvPrefTables *tables, const int64_t *users, const int64_t *items,
+                        const int64_t *envs, int64_t B, uint32_t flags, float *invariant_score,
+                        float *env_aware_score, float *env_outputs, void *stream);
+
+/* ---- M-step gradient: replaces the forward + 3 losses + 2 regularisers + loss.backward() of
+ * train_a_batch (train.py:94-156; models.py:307-391; functions.py:4-16).
+ * Gradients are ADDED into `grads` (zero it first: invpref_adam_hip(..., zero_grad=1) leaves it
+ * zeroed).  `batch_norm` is the mean() denominator -- the length of the whole minibatch, which is
+ * larger than B when the minibatch is row-sharded over several GPUs.  losses6 (device, fp32[6]) is
+ * ADDED to: {invariant_loss, env_aware_loss, envs_loss, L2_reg, L1_reg, loss} as in train.py:159-166
+ * (zero it first; `loss` is the coefficient-weighted sum of this call's five partial terms, so it
+ * is additive across shards as well).  sample_weights may be NULL when no re-weight flag is set.
+ * workspace: device scratch of at least invpref_mstep_workspace_bytes() bytes. */
+size_t invpref_mstep_workspace_bytes(const InvPrefTables *tables, int64_t B);
+int invpref_mstep_grad_hip(const InvPrefTables *tables, const InvPrefTables *grads, const int64_t *users,
+                           const int64_t *items, const int64_t *envs, const float *scores,
+                           const float *sample_weights, int64_t B, int64_t batch_norm,
+                           const InvPrefCoefs *coefs, uint32_t flags, float *losses6, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
+/* ---- dense Adam: replaces optimizer.zero_grad() + optimizer.step() of torch.optim.Adam with
+ * default betas/eps (train.py:41, :155-157) over one flat fp32 buffer of n parameters.
+ * step is 1-based.  zero_grad != 0 also clears grad (the next step's zero_grad()). */
+int invpref_adam_hip(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step,
+                     double lr, double beta1, double beta2, double eps, int zero_grad, void *stream);
+
+/* ---- E-step: replaces cluster() / cluster_a_batch() / cluster_predict() (train.py:235-259,
+ * :169-202; models.py:409-411) over all N interactions, followed by stat_envs() (train.py:268-280).
+ * eps_rows: optional [N, env_num] tie-break rows already gathered per sample (train.py:192-196), or NULL.
+ * old_envs may alias new_envs.  Outputs: new_envs[N]; counts[env_num] (int64); diff[1] (int64, number of
+ * changed assignments, train.py:256-257); class_weights[env_num] and sample_weights[N] (train.py:274-278),
+ * either may be NULL.  workspace as above. */
+size_t invpref_estep_workspace_bytes(const InvPrefTables *tables, int64_t N);
+int invpref_estep_hip(const InvPrefTables *tables, const int64_t *users, const int64_t *items,
+                      const float *scores, int64_t N, uint32_t flags, const float *eps_rows,
+                      const int64_t *old_envs, int64_t *new_envs, int64_t *counts, int64_t *diff,
+                      float *class_weights, float *sample_weights, void *workspace, size_t workspace_bytes,
+                      void *stream);
+
+/* ---- stat_envs alone (train.py:268-280), e.g. before the first epoch (train.py:297). */
+int invpref_stat_envs_hip(const int64_t *envs, int64_t N, int64_t env_num, int64_t *counts, float *class_weights,
+                          float *sample_weights, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- the weight half of stat_envs (train.py:274-278) from counts that are already global
+ * (row-sharded runs all-reduce the per-rank counts first): class_weights[e] = min(counts[e]+1,
+ * N_total-1)/N_total, sample_weights[i] = class_weights[envs[i]] for the N_local local rows. */
+int invpref_sample_weights_hip(const int64_t *envs, int64_t N_local, const int64_t *counts, int64_t N_total,
+                               int64_t env_num, float *class_weights, float *sample_weights, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INVPREF_HIP_H */

@@ -1,0 +1,119 @@
+"""ctypes binding of libinvpref_hip.so (include/invpref_hip.h).
+
+torch is plumbing here: tensors provide device memory (``data_ptr()``) and the current HIP
+stream; every computation happens inside the library's kernels.  There is no fallback: if the
+library is missing or a call fails this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, 'libinvpref_hip.so')
+
+IMPLICIT, REWEIGHT_REC, REWEIGHT_CLS, REG_ONLY_EMBED, REG_ENV_EMBED, DENSE_REG = 1, 2, 4, 8, 16, 32
+
+EXPORTS = [
+    'invpref_abi_version', 'invpref_device_name', 'invpref_forward_hip', 'invpref_mstep_workspace_bytes',
+    'invpref_mstep_grad_hip', 'invpref_adam_hip', 'invpref_estep_workspace_bytes', 'invpref_estep_hip',
+    'invpref_stat_envs_hip', 'invpref_sample_weights_hip',
+]
+
+
+class InvPrefError(RuntimeError):
+    pass
+
+
+class Tables(C.Structure):
+    """struct InvPrefTables"""
+    _fields_ = [('user_num', C.c_int64), ('item_num', C.c_int64), ('env_num', C.c_int64), ('factor_num', C.c_int64),
+                ('embed_user_invariant', C.c_void_p), ('embed_item_invariant', C.c_void_p),
+                ('embed_user_env_aware', C.c_void_p), ('embed_item_env_aware', C.c_void_p),
+                ('embed_env', C.c_void_p), ('classifier_weight', C.c_void_p), ('classifier_bias', C.c_void_p)]
+
+
+class Coefs(C.Structure):
+    """struct InvPrefCoefs"""
+    _fields_ = [(n, C.c_float) for n in ('invariant_coe', 'env_aware_coe', 'env_coe', 'L2_coe', 'L1_coe', 'alpha')]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; fail loudly when it is absent (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise InvPrefError(
+                f'{LIB_PATH} is missing: build it with `python -m invpref_kdd_2022_amd.build` '
+                '(or __graft_entry__.build()); the InvPref hot path has no fallback implementation')
+        L = C.CDLL(LIB_PATH)
+        L.invpref_mstep_workspace_bytes.restype = C.c_size_t
+        L.invpref_estep_workspace_bytes.restype = C.c_size_t
+        L.invpref_mstep_workspace_bytes.argtypes = [C.POINTER(Tables), C.c_int64]
+        L.invpref_estep_workspace_bytes.argtypes = [C.POINTER(Tables), C.c_int64]
+        vp, i64, u32, f64 = C.c_void_p, C.c_int64, C.c_uint32, C.c_double
+        L.invpref_forward_hip.argtypes = [C.POINTER(Tables), vp, vp, vp, i64, u32, vp, vp, vp, vp]
+        L.invpref_mstep_grad_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), vp, vp, vp, vp, vp, i64, i64,
+                                             C.POINTER(Coefs), u32, vp, vp, C.c_size_t, vp]
+        L.invpref_adam_hip.argtypes = [vp, vp, vp, vp, i64, i64, f64, f64, f64, f64, C.c_int, vp]
+        L.invpref_estep_hip.argtypes = [C.POINTER(Tables), vp, vp, vp, i64, u32, vp, vp, vp, vp, vp, vp, vp, vp,
+                                        C.c_size_t, vp]
+        L.invpref_stat_envs_hip.argtypes = [vp, i64, i64, vp, vp, vp, vp, C.c_size_t, vp]
+        L.invpref_sample_weights_hip.argtypes = [vp, i64, vp, i64, i64, vp, vp, vp]
+        L.invpref_device_name.argtypes = [C.c_char_p, C.c_size_t]
+        if L.invpref_abi_version() != 1:
+            raise InvPrefError('libinvpref_hip.so ABI version mismatch')
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: 'invalid argument', -2: 'unsupported factor_num/env_num', -3: 'workspace too small'}.get(
+            rc, f'hipError_t {rc}' if rc > 0 else f'error {rc}')
+        raise InvPrefError(f'{what} failed: {kind}')
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise InvPrefError(f'{name} must live on the GPU (got {t.device}); the HIP path has no CPU fallback')
+    if t.dtype != dtype:
+        raise InvPrefError(f'{name} must be {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise InvPrefError(f'{name} must be contiguous')
+
+
+def make_tables(tensors) -> Tables:
+    """tensors: the 7 parameter (or gradient) tensors in state_dict order."""
+    pu, qi, pa, qa, ev, w, b = tensors
+    for n, t in zip(('Pu', 'Qi', 'Pa', 'Qa', 'Ev', 'W', 'b'), tensors):
+        _req(t, torch.float32, n)
+    U, D = pu.shape
+    I = qi.shape[0]
+    E = ev.shape[0]
+    if pa.shape != (U, D) or qa.shape != (I, D) or ev.shape != (E, D) or w.shape != (E, D) or b.shape != (E,):
+        raise InvPrefError('inconsistent table shapes')
+    return Tables(U, I, E, D, *[t.data_ptr() for t in tensors])
+
+
+def device_name() -> str:
+    buf = C.create_string_buffer(256)
+    check(lib().invpref_device_name(buf, 256), 'invpref_device_name')
+    return buf.value.decode()

@@ -1,0 +1,44 @@
+"""Builds libinvpref_hip.so (hand-written gfx950 kernels + the C ABI of include/invpref_hip.h)
+in-tree with hipcc.  hipcc cross-compiles without a GPU, so this also runs in CI containers."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, 'csrc')
+LIB = os.path.join(PKG, 'libinvpref_hip.so')
+SOURCES = ['invpref_kernels.hip']
+HEADERS = ['canon_math.hpp', os.path.join('..', '..', 'include', 'invpref_hip.h')]
+# -ffp-contract=off: every fma of the canonical arithmetic is written explicitly
+FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
+         '-fno-fast-math', '-Wall', '-Wno-unused-function']
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError('hipcc not found: the InvPref HIP library cannot be built')
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if force or needs_build():
+        cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force=True, verbose=True))

@@ -1,0 +1,798 @@
+// invpref_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the InvPref hot path and their
+// C-ABI launchers (include/invpref_hip.h).  No torch types, no CPU fallback.
+//
+// Work layout shared by every per-interaction kernel: one interaction is owned by a 16-lane row
+// of a wavefront (4 interactions per wave64).  Lane l of the row holds the float4 chunks
+// l, l+16, l+32, ... of each gathered embedding row, so a row of D=64 floats is ONE coalesced
+// 256-byte global_load_dwordx4 across the 16 lanes, dot products are a per-lane fma chain plus a
+// 4-step DPP butterfly (canon_math.hpp), and no LDS is needed for the reductions.  The E x D
+// environment table and classifier live in LDS for the whole workgroup.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/invpref_hip.h"
+#include "canon_math.hpp"
+
+using namespace invpref;
+
+namespace {
+
+constexpr int kRow = 16;          // lanes per interaction
+constexpr int kLossSlots = 8;     // 5 used
+
+struct DevTables {
+    const float *Pu, *Qi, *Pa, *Qa, *Ev, *W, *b;
+    int U, I, E, D;
+};
+struct DevGrads {
+    float *Pu, *Qi, *Pa, *Qa, *Ev, *W, *b;
+};
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+
+// gather one embedding row into the lane's NC chunks (zero beyond D)
+template <int NC, bool VEC>
+__device__ __forceinline__ void load_row(const float *__restrict__ base, int64_t row, int D, int l16, float4 (&r)[NC]) {
+    const float *p = base + row * (int64_t)D;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int i0 = (l16 + kRow * c) * 4;
+        if (VEC) {
+            r[c] = (i0 < D) ? *reinterpret_cast<const float4 *>(p + i0) : f4zero();
+        } else {
+            r[c].x = (i0 + 0 < D) ? p[i0 + 0] : 0.f;
+            r[c].y = (i0 + 1 < D) ? p[i0 + 1] : 0.f;
+            r[c].z = (i0 + 2 < D) ? p[i0 + 2] : 0.f;
+            r[c].w = (i0 + 3 < D) ? p[i0 + 3] : 0.f;
+        }
+    }
+}
+// a row of an LDS-resident [E][DP] table (DP = NC*64, zero padded)
+template <int NC>
+__device__ __forceinline__ void lds_row(const float *tab, int e, int l16, float4 (&r)[NC]) {
+#pragma unroll
+    for (int c = 0; c < NC; c++) r[c] = *reinterpret_cast<const float4 *>(tab + e * (NC * 64) + (l16 + kRow * c) * 4);
+}
+
+template <int NC>
+__device__ __forceinline__ float dot2(const float4 (&a)[NC], const float4 (&b)[NC]) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        s = __builtin_fmaf(a[c].x, b[c].x, s);
+        s = __builtin_fmaf(a[c].y, b[c].y, s);
+        s = __builtin_fmaf(a[c].z, b[c].z, s);
+        s = __builtin_fmaf(a[c].w, b[c].w, s);
+    }
+    return row16_sum(s);
+}
+template <int NC>
+__device__ __forceinline__ float dot3(const float4 (&a)[NC], const float4 (&b)[NC], const float4 (&cc)[NC]) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        s = __builtin_fmaf(a[c].x * b[c].x, cc[c].x, s);
+        s = __builtin_fmaf(a[c].y * b[c].y, cc[c].y, s);
+        s = __builtin_fmaf(a[c].z * b[c].z, cc[c].z, s);
+        s = __builtin_fmaf(a[c].w * b[c].w, cc[c].w, s);
+    }
+    return row16_sum(s);
+}
+
+// stage a small [E][D] table into LDS as [E][DP] zero padded
+__device__ __forceinline__ void stage_table(float *dst, const float *__restrict__ src, int E, int D, int DP) {
+    for (int i = threadIdx.x; i < E * DP; i += blockDim.x) {
+        const int e = i / DP, d = i - e * DP;
+        dst[i] = (d < D) ? src[e * D + d] : 0.f;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+    return x;
+}
+
+__device__ __forceinline__ void atomic_add_f4(float *p, float4 v, int i0, int D, bool vec) {
+    if (vec || i0 + 3 < D) {
+        atomicAdd(p + i0 + 0, v.x);
+        atomicAdd(p + i0 + 1, v.y);
+        atomicAdd(p + i0 + 2, v.z);
+        atomicAdd(p + i0 + 3, v.w);
+    } else {
+        if (i0 + 0 < D) atomicAdd(p + i0 + 0, v.x);
+        if (i0 + 1 < D) atomicAdd(p + i0 + 1, v.y);
+        if (i0 + 2 < D) atomicAdd(p + i0 + 2, v.z);
+    }
+}
+
+// =====================================================================================
+// forward  (models.py:307-326 / :448-467)
+// =====================================================================================
+template <int NC, bool VEC, int EMAX>
+__global__ __launch_bounds__(256) void forward_kernel(DevTables t, const int64_t *__restrict__ users,
+                                                      const int64_t *__restrict__ items,
+                                                      const int64_t *__restrict__ envs, int64_t B, uint32_t flags,
+                                                      float *__restrict__ inv, float *__restrict__ envaware,
+                                                      float *__restrict__ envout) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int DP = NC * 64;
+    float *sEv = lds, *sW = lds + t.E * DP, *sb = sW + t.E * DP;
+    stage_table(sEv, t.Ev, t.E, t.D, DP);
+    stage_table(sW, t.W, t.E, t.D, DP);
+    for (int i = threadIdx.x; i < t.E; i += blockDim.x) sb[i] = t.b[i];
+    __syncthreads();
+    const int l16 = threadIdx.x & 15;
+    const int64_t rows_per_block = blockDim.x / kRow;
+    const bool implicit = flags & INVPREF_IMPLICIT;
+    for (int64_t s = blockIdx.x * rows_per_block + (threadIdx.x >> 4); s < B; s += gridDim.x * rows_per_block) {
+        const int64_t u = users[s], v = items[s];
+        const int e = (int)envs[s];
+        float4 pu[NC], qi[NC], pa[NC], qa[NC], ev[NC];
+        load_row<NC, VEC>(t.Pu, u, t.D, l16, pu);
+        load_row<NC, VEC>(t.Qi, v, t.D, l16, qi);
+        load_row<NC, VEC>(t.Pa, u, t.D, l16, pa);
+        load_row<NC, VEC>(t.Qa, v, t.D, l16, qa);
+        lds_row<NC>(sEv, e, l16, ev);
+        const float p = dot2<NC>(pu, qi), q = dot3<NC>(pa, qa, ev);
+        float s_inv, s_env;
+        if (implicit) { const float sp = c_sigmoid(p); s_inv = sp; s_env = sp * c_sigmoid(q); }
+        else { s_inv = p; s_env = p + q; }
+        float4 x[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) x[c] = f4mul(pu[c], qi[c]);
+        float z[EMAX], mx = -__builtin_inff();
+#pragma unroll
+        for (int c = 0; c < EMAX; c++) {
+            if (c < t.E) {
+                float4 w[NC];
+                lds_row<NC>(sW, c, l16, w);
+                z[c] = dot2<NC>(x, w) + sb[c];
+                mx = z[c] > mx ? z[c] : mx;
+            }
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < EMAX; c++) if (c < t.E) se += c_exp(z[c] - mx);
+        const float lse = c_log(se);
+        if (l16 == 0) { inv[s] = s_inv; envaware[s] = s_env; }
+#pragma unroll
+        for (int c = 0; c < EMAX; c++) if (c < t.E && l16 == (c & 15)) envout[s * t.E + c] = (z[c] - mx) - lse;
+    }
+}
+
+// =====================================================================================
+// M-step gradient, scatter-add by global float atomics (works on any minibatch, no plan)
+//   train.py:94-156; analytic backward of SURVEY.md §8 a7'
+// Per workgroup: gEv/gW/gb and the five loss sums are accumulated in LDS and written as one
+// partial slab; mstep_finish_kernel folds the slabs (no same-address global atomics).
+// =====================================================================================
+struct StepScalars {
+    float ca, cb, cc, alpha, invB, r2, r1;
+};
+
+template <int NC, bool VEC, int EMAX>
+__global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads g, const int64_t *__restrict__ users,
+                                                           const int64_t *__restrict__ items,
+                                                           const int64_t *__restrict__ envs,
+                                                           const float *__restrict__ scores,
+                                                           const float *__restrict__ weights, int64_t B,
+                                                           StepScalars k, uint32_t flags, float *__restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int DP = NC * 64;
+    const int EDP = t.E * DP;
+    float *sEv = lds, *sW = sEv + EDP, *aEv = sW + EDP, *aW = aEv + EDP;
+    float *sb = aW + EDP, *ab = sb + EMAX, *aL = ab + EMAX;  // aL[kLossSlots]
+    const int slab_len = 2 * EDP + EMAX + kLossSlots;
+    stage_table(sEv, t.Ev, t.E, t.D, DP);
+    stage_table(sW, t.W, t.E, t.D, DP);
+    for (int i = threadIdx.x; i < 2 * EDP; i += blockDim.x) aEv[i] = 0.f;  // aEv and aW are adjacent
+    for (int i = threadIdx.x; i < EMAX; i += blockDim.x) { sb[i] = (i < t.E) ? t.b[i] : 0.f; ab[i] = 0.f; }
+    if (threadIdx.x < kLossSlots) aL[threadIdx.x] = 0.f;
+    __syncthreads();
+
+    const int l16 = threadIdx.x & 15;
+    const int64_t rows_per_block = blockDim.x / kRow;
+    const bool implicit = flags & INVPREF_IMPLICIT;
+    const bool rw_rec = flags & INVPREF_REWEIGHT_REC, rw_cls = flags & INVPREF_REWEIGHT_CLS;
+    const bool reg_env = flags & INVPREF_REG_ENV_EMBED;
+    float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
+
+    for (int64_t s = blockIdx.x * rows_per_block + (threadIdx.x >> 4); s < B; s += gridDim.x * rows_per_block) {
+        const int64_t u = users[s], v = items[s];
+        const int e = (int)envs[s];
+        const float y = scores[s];
+        const float w = (rw_rec || rw_cls) ? weights[s] : 1.f;
+        const float w_rec = rw_rec ? w : 1.f, w_cls = rw_cls ? w : 1.f;
+        const float cw_rec = w_rec * k.invB, cw_cls = w_cls * k.invB;
+        float4 pu[NC], qi[NC], pa[NC], qa[NC], ev[NC];
+        load_row<NC, VEC>(t.Pu, u, t.D, l16, pu);
+        load_row<NC, VEC>(t.Qi, v, t.D, l16, qi);
+        load_row<NC, VEC>(t.Pa, u, t.D, l16, pa);
+        load_row<NC, VEC>(t.Qa, v, t.D, l16, qa);
+        lds_row<NC>(sEv, e, l16, ev);
+        const float p = dot2<NC>(pu, qi), q = dot3<NC>(pa, qa, ev);
+        float g_p, g_q, li, le;
+        if (implicit) {
+            const float sp = c_sigmoid(p), sq = c_sigmoid(q), sv = sp * sq;
+            li = c_bce(sp, y);
+            le = c_bce(sv, y);
+            const float d_inv = k.ca * cw_rec * c_dbce(sp, y);
+            const float d_env = k.cb * cw_rec * c_dbce(sv, y);
+            g_p = (d_inv + d_env * sq) * (sp * (1.f - sp));
+            g_q = d_env * sp * (sq * (1.f - sq));
+        } else {
+            const float s2 = p + q;
+            li = (p - y) * (p - y);
+            le = (s2 - y) * (s2 - y);
+            const float d_env = k.cb * cw_rec * 2.f * (s2 - y);
+            g_p = k.ca * cw_rec * 2.f * (p - y) + d_env;
+            g_q = d_env;
+        }
+        // classifier on x = Pu*Qi
+        float4 x[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) x[c] = f4mul(pu[c], qi[c]);
+        float z[EMAX], mx = -__builtin_inff();
+#pragma unroll
+        for (int c = 0; c < EMAX; c++) {
+            z[c] = -__builtin_inff();
+            if (c < t.E) {
+                float4 wr[NC];
+                lds_row<NC>(sW, c, l16, wr);
+                z[c] = dot2<NC>(x, wr) + sb[c];
+                mx = z[c] > mx ? z[c] : mx;
+            }
+        }
+        float se = 0.f, ze = 0.f;
+#pragma unroll
+        for (int c = 0; c < EMAX; c++) {
+            if (c < t.E) { z[c] = c_exp(z[c] - mx) ; se += z[c]; }
+        }
+        // z[c] now holds exp(z-mx); log-prob of the true env: log(ex_e/se)
+#pragma unroll
+        for (int c = 0; c < EMAX; c++) ze = (c == e) ? z[c] : ze;
+        const float lcls = -c_log(ze / se);
+        const float rse = 1.f / se;
+        float4 gx[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) gx[c] = f4zero();
+#pragma unroll
+        for (int c = 0; c < EMAX; c++) {
+            if (c < t.E) {
+                const float gz = k.cc * cw_cls * (z[c] * rse - (c == e ? 1.f : 0.f));
+                float4 wr[NC];
+                lds_row<NC>(sW, c, l16, wr);
+#pragma unroll
+                for (int j = 0; j < NC; j++) {
+                    gx[j].x = __builtin_fmaf(gz, wr[j].x, gx[j].x);
+                    gx[j].y = __builtin_fmaf(gz, wr[j].y, gx[j].y);
+                    gx[j].z = __builtin_fmaf(gz, wr[j].z, gx[j].z);
+                    gx[j].w = __builtin_fmaf(gz, wr[j].w, gx[j].w);
+                    float *dst = aW + c * DP + (l16 + kRow * j) * 4;
+                    atomicAdd(dst + 0, gz * x[j].x);
+                    atomicAdd(dst + 1, gz * x[j].y);
+                    atomicAdd(dst + 2, gz * x[j].z);
+                    atomicAdd(dst + 3, gz * x[j].w);
+                }
+                if (l16 == 0) atomicAdd(ab + c, gz);
+            }
+        }
+        // scatter-add the four embedding-row gradients (+ per-occurrence L2/L1 terms)
+        float *gpu = g.Pu + u * (int64_t)t.D, *gqi = g.Qi + v * (int64_t)t.D;
+        float *gpa = g.Pa + u * (int64_t)t.D, *gqa = g.Qa + v * (int64_t)t.D;
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+            const int i0 = (l16 + kRow * j) * 4;
+            if (i0 < t.D) {
+                float4 gip, o;
+                gip.x = g_p - k.alpha * gx[j].x; gip.y = g_p - k.alpha * gx[j].y;
+                gip.z = g_p - k.alpha * gx[j].z; gip.w = g_p - k.alpha * gx[j].w;
+#define REG(a) (k.r2 * (a) + k.r1 * c_sign(a))
+                o = make_float4(gip.x * qi[j].x + REG(pu[j].x), gip.y * qi[j].y + REG(pu[j].y),
+                                gip.z * qi[j].z + REG(pu[j].z), gip.w * qi[j].w + REG(pu[j].w));
+                atomic_add_f4(gpu, o, i0, t.D, VEC);
+                o = make_float4(gip.x * pu[j].x + REG(qi[j].x), gip.y * pu[j].y + REG(qi[j].y),
+                                gip.z * pu[j].z + REG(qi[j].z), gip.w * pu[j].w + REG(qi[j].w));
+                atomic_add_f4(gqi, o, i0, t.D, VEC);
+                o = make_float4(g_q * (qa[j].x * ev[j].x) + REG(pa[j].x), g_q * (qa[j].y * ev[j].y) + REG(pa[j].y),
+                                g_q * (qa[j].z * ev[j].z) + REG(pa[j].z), g_q * (qa[j].w * ev[j].w) + REG(pa[j].w));
+                atomic_add_f4(gpa, o, i0, t.D, VEC);
+                o = make_float4(g_q * (pa[j].x * ev[j].x) + REG(qa[j].x), g_q * (pa[j].y * ev[j].y) + REG(qa[j].y),
+                                g_q * (pa[j].z * ev[j].z) + REG(qa[j].z), g_q * (pa[j].w * ev[j].w) + REG(qa[j].w));
+                atomic_add_f4(gqa, o, i0, t.D, VEC);
+#undef REG
+                o = make_float4(g_q * (pa[j].x * qa[j].x), g_q * (pa[j].y * qa[j].y), g_q * (pa[j].z * qa[j].z),
+                                g_q * (pa[j].w * qa[j].w));
+                if (reg_env) {
+                    o.x += 2.f * k.r2 * ev[j].x + 2.f * k.r1 * c_sign(ev[j].x);
+                    o.y += 2.f * k.r2 * ev[j].y + 2.f * k.r1 * c_sign(ev[j].y);
+                    o.z += 2.f * k.r2 * ev[j].z + 2.f * k.r1 * c_sign(ev[j].z);
+                    o.w += 2.f * k.r2 * ev[j].w + 2.f * k.r1 * c_sign(ev[j].w);
+                }
+                float *dst = aEv + e * DP + i0;
+                atomicAdd(dst + 0, o.x); atomicAdd(dst + 1, o.y); atomicAdd(dst + 2, o.z); atomicAdd(dst + 3, o.w);
+            }
+            // regulariser REPORTS: users+items weigh 1/(2BD), env rows 1/(BD) -> count env terms twice
+            float s2 = pu[j].x * pu[j].x + pu[j].y * pu[j].y + pu[j].z * pu[j].z + pu[j].w * pu[j].w;
+            s2 += pa[j].x * pa[j].x + pa[j].y * pa[j].y + pa[j].z * pa[j].z + pa[j].w * pa[j].w;
+            s2 += qi[j].x * qi[j].x + qi[j].y * qi[j].y + qi[j].z * qi[j].z + qi[j].w * qi[j].w;
+            s2 += qa[j].x * qa[j].x + qa[j].y * qa[j].y + qa[j].z * qa[j].z + qa[j].w * qa[j].w;
+            float s1 = fabsf(pu[j].x) + fabsf(pu[j].y) + fabsf(pu[j].z) + fabsf(pu[j].w);
+            s1 += fabsf(pa[j].x) + fabsf(pa[j].y) + fabsf(pa[j].z) + fabsf(pa[j].w);
+            s1 += fabsf(qi[j].x) + fabsf(qi[j].y) + fabsf(qi[j].z) + fabsf(qi[j].w);
+            s1 += fabsf(qa[j].x) + fabsf(qa[j].y) + fabsf(qa[j].z) + fabsf(qa[j].w);
+            if (reg_env) {
+                s2 += 2.f * (ev[j].x * ev[j].x + ev[j].y * ev[j].y + ev[j].z * ev[j].z + ev[j].w * ev[j].w);
+                s1 += 2.f * (fabsf(ev[j].x) + fabsf(ev[j].y) + fabsf(ev[j].z) + fabsf(ev[j].w));
+            }
+            accL2 += s2;
+            accL1 += s1;
+        }
+        if (l16 == 0) { accLi += li * w_rec; accLe += le * w_rec; accLc += lcls * w_cls; }
+    }
+    // workgroup reduction of the loss sums
+    accLi = wave_sum(accLi); accLe = wave_sum(accLe); accLc = wave_sum(accLc);
+    accL2 = wave_sum(accL2); accL1 = wave_sum(accL1);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(aL + 0, accLi); atomicAdd(aL + 1, accLe); atomicAdd(aL + 2, accLc);
+        atomicAdd(aL + 3, accL2); atomicAdd(aL + 4, accL1);
+    }
+    __syncthreads();
+    float *slab = slabs + (int64_t)blockIdx.x * slab_len;
+    for (int i = threadIdx.x; i < 2 * EDP; i += blockDim.x) slab[i] = aEv[i];
+    for (int i = threadIdx.x; i < EMAX + kLossSlots; i += blockDim.x) slab[2 * EDP + i] = ab[i];  // ab then aL
+}
+
+// folds the per-workgroup slabs into grads.Ev / W / b and the six loss outputs, adds the
+// classifier regulariser (models.py:211-217) when INVPREF_DENSE_REG is set.
+// grid: ceil(slab_len/64) blocks of 1024 threads: 64 slab elements x 16 slab-subsets per block.
+template <int DUMMY>
+__global__ __launch_bounds__(1024) void mstep_finish_kernel(DevTables t, DevGrads g, const float *__restrict__ slabs,
+                                                            int nslabs, int DP, int EMAX, StepScalars k,
+                                                            float l2, float l1, int64_t Bnorm, uint32_t flags,
+                                                            float *__restrict__ losses6) {
+    __shared__ double part[16][64];
+    __shared__ double sloss[kLossSlots];
+    __shared__ double sreg[2];
+    const int EDP = t.E * DP, slab_len = 2 * EDP + EMAX + kLossSlots;
+    const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + col;
+    double acc = 0.0;
+    if (idx < slab_len)
+        for (int s = sub; s < nslabs; s += 16) acc += (double)slabs[(int64_t)s * slab_len + idx];
+    part[sub][col] = acc;
+    if (threadIdx.x < 2) sreg[threadIdx.x] = 0.0;
+    __syncthreads();
+    const bool dense = (flags & INVPREF_DENSE_REG) && !(flags & INVPREF_REG_ONLY_EMBED);
+    const bool last_block = blockIdx.x == gridDim.x - 1;  // owns the bias + loss tail (asserted by the launcher)
+    if (sub == 0 && idx < slab_len) {
+        double v = 0.0;
+        for (int s = 0; s < 16; s++) v += part[s][col];
+        if (idx < 2 * EDP) {
+            const bool isW = idx >= EDP;
+            const int r = isW ? idx - EDP : idx;
+            const int e = r / DP, d = r - e * DP;
+            if (d < t.D) {
+                float add = (float)v;
+                if (isW && dense) {
+                    const float wv = t.W[e * t.D + d];
+                    add += 2.f * l2 / ((float)t.D * (float)t.E) * wv + l1 / ((float)t.D * (float)t.E) * c_sign(wv);
+                }
+                float *dst = (isW ? g.W : g.Ev) + e * t.D + d;
+                *dst += add;
+            }
+        } else if (idx < 2 * EDP + EMAX) {
+            const int e = idx - 2 * EDP;
+            if (e < t.E) {
+                float add = (float)v;
+                if (dense) { const float bv = t.b[e]; add += 2.f * l2 / (float)t.E * bv + l1 / (float)t.E * c_sign(bv); }
+                g.b[e] += add;
+            }
+        } else {
+            sloss[idx - 2 * EDP - EMAX] = v;
+        }
+    }
+    __syncthreads();
+    if (last_block) {
+        // classifier regulariser report (tiny: E*D + E terms), by the first wave
+        if (dense && threadIdx.x < 64) {
+            double w2 = 0, w1 = 0, b2 = 0, b1 = 0;
+            for (int i = threadIdx.x; i < t.E * t.D; i += 64) { const double x = t.W[i]; w2 += x * x; w1 += fabs(x); }
+            for (int i = threadIdx.x; i < t.E; i += 64) { const double x = t.b[i]; b2 += x * x; b1 += fabs(x); }
+            double r2v = w2 / ((double)t.D * t.E) + b2 / (double)t.E, r1v = w1 / ((double)t.D * t.E) + b1 / (double)t.E;
+            for (int m = 32; m >= 1; m >>= 1) { r2v += __shfl_xor(r2v, m, 64); r1v += __shfl_xor(r1v, m, 64); }
+            if (threadIdx.x == 0) { sreg[0] = r2v; sreg[1] = r1v; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double Bn = (double)Bnorm, BD2 = Bn * (double)t.D * 2.0;
+            const double Li = sloss[0] / Bn, Le = sloss[1] / Bn, Lc = sloss[2] / Bn;
+            const double L2 = sloss[3] / BD2 + sreg[0], L1 = sloss[4] / BD2 + sreg[1];
+            losses6[0] += (float)Li; losses6[1] += (float)Le; losses6[2] += (float)Lc;
+            losses6[3] += (float)L2; losses6[4] += (float)L1;
+            losses6[5] += (float)((double)k.ca * Li + (double)k.cb * Le + (double)k.cc * Lc + (double)l2 * L2 + (double)l1 * L1);
+        }
+    }
+}
+
+// =====================================================================================
+// dense Adam over a flat buffer (torch.optim.Adam single-tensor rule; train.py:41,155-157)
+// =====================================================================================
+struct AdamScalars {
+    float step_size, bc2_sqrt, w1, b2, w2, eps;
+};
+__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, const AdamScalars &a) {
+    m = m + a.w1 * (g - m);
+    v = v * a.b2 + (a.w2 * g) * g;
+    const float denom = __builtin_sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p + ((-a.step_size) * m) / denom;
+}
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, int64_t n, AdamScalars a, int zero_grad) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4 *>(p)[i], gg = reinterpret_cast<float4 *>(g)[i];
+        float4 mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+        adam1(pp.x, gg.x, mm.x, vv.x, a); adam1(pp.y, gg.y, mm.y, vv.y, a);
+        adam1(pp.z, gg.z, mm.z, vv.z, a); adam1(pp.w, gg.w, mm.w, vv.w, a);
+        reinterpret_cast<float4 *>(p)[i] = pp; reinterpret_cast<float4 *>(m)[i] = mm;
+        reinterpret_cast<float4 *>(v)[i] = vv;
+        if (zero_grad) reinterpret_cast<float4 *>(g)[i] = f4zero();
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam1(pp, g[i], mm, vv, a);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+        if (zero_grad) g[i] = 0.f;
+    }
+}
+
+// =====================================================================================
+// E-step  (train.py:169-202, :235-259): argmin_e dist_e, lowest index on ties
+// =====================================================================================
+template <int NC, bool VEC>
+__global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const int64_t *__restrict__ users,
+                                                           const int64_t *__restrict__ items,
+                                                           const float *__restrict__ scores, int64_t N, uint32_t flags,
+                                                           const float *__restrict__ eps_rows,
+                                                           const int64_t *__restrict__ old_envs,
+                                                           int64_t *__restrict__ new_envs, int *__restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int DP = NC * 64;
+    float *sEv = lds;
+    int *cnt = reinterpret_cast<int *>(lds + t.E * DP);  // [E + 1]
+    stage_table(sEv, t.Ev, t.E, t.D, DP);
+    for (int i = threadIdx.x; i <= t.E; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    const int l16 = threadIdx.x & 15;
+    const int64_t rows_per_block = blockDim.x / kRow;
+    const bool implicit = flags & INVPREF_IMPLICIT;
+    for (int64_t s = blockIdx.x * rows_per_block + (threadIdx.x >> 4); s < N; s += gridDim.x * rows_per_block) {
+        const int64_t u = users[s], v = items[s];
+        const float y = scores[s];
+        float4 pu[NC], qi[NC], pa[NC], qa[NC];
+        load_row<NC, VEC>(t.Pu, u, t.D, l16, pu);
+        load_row<NC, VEC>(t.Qi, v, t.D, l16, qi);
+        load_row<NC, VEC>(t.Pa, u, t.D, l16, pa);
+        load_row<NC, VEC>(t.Qa, v, t.D, l16, qa);
+        const float p = dot2<NC>(pu, qi);
+        const float sp = implicit ? c_sigmoid(p) : p;
+        float best = 0.f;
+        int bi = 0;
+        for (int c = 0; c < t.E; c++) {
+            float4 ev[NC];
+            lds_row<NC>(sEv, c, l16, ev);
+            const float q = dot3<NC>(pa, qa, ev);
+            float dist;
+            if (implicit) dist = c_bce(sp * c_sigmoid(q), y);
+            else { const float r = (p + q) - y; dist = r * r; }
+            if (eps_rows) dist = dist + eps_rows[s * t.E + c];
+            if (c == 0 || dist < best) { best = dist; bi = c; }
+        }
+        if (l16 == 0) {
+            const bool changed = old_envs ? (old_envs[s] != (int64_t)bi) : false;
+            new_envs[s] = bi;
+            atomicAdd(cnt + bi, 1);
+            if (changed) atomicAdd(cnt + t.E, 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= t.E; i += blockDim.x) slabs[(int64_t)blockIdx.x * (t.E + 1) + i] = cnt[i];
+}
+
+// per-workgroup env histogram (for stat_envs alone)
+__global__ __launch_bounds__(256) void env_hist_kernel(const int64_t *__restrict__ envs, int64_t N, int E,
+                                                       int *__restrict__ slabs) {
+    __shared__ int cnt[INVPREF_MAX_ENVS + 1];
+    for (int i = threadIdx.x; i <= E; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < N; s += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(cnt + (int)envs[s], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i <= E; i += blockDim.x) slabs[(int64_t)blockIdx.x * (E + 1) + i] = cnt[i];
+}
+
+// stat_envs (train.py:268-280): every workgroup folds the count slabs (tiny), forms
+// class_w[e] = min(cnt+1, N-1)/N and then gathers sample_weights for its share of the rows.
+__global__ __launch_bounds__(256) void stat_envs_kernel(const int64_t *__restrict__ envs, int64_t N, int E,
+                                                        const int *__restrict__ slabs, int nslabs,
+                                                        int64_t *__restrict__ counts, int64_t *__restrict__ diff,
+                                                        float *__restrict__ class_w, float *__restrict__ sample_w) {
+    __shared__ long long tot[INVPREF_MAX_ENVS + 1];
+    __shared__ float cw[INVPREF_MAX_ENVS];
+    for (int i = threadIdx.x; i <= E; i += blockDim.x) tot[i] = 0;
+    __syncthreads();
+    for (int c = 0; c <= E; c++) {
+        long long a = 0;
+        for (int s = threadIdx.x; s < nslabs; s += blockDim.x) a += slabs[(int64_t)s * (E + 1) + c];
+        for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&tot[c], (unsigned long long)a);
+    }
+    __syncthreads();
+    if (threadIdx.x < E) {
+        const long long c = tot[threadIdx.x];
+        const long long r = (c + 1 < N - 1) ? c + 1 : N - 1;
+        const float w = (float)((double)r / (double)N);
+        cw[threadIdx.x] = w;
+        if (blockIdx.x == 0) {
+            counts[threadIdx.x] = c;
+            if (class_w) class_w[threadIdx.x] = w;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && diff) *diff = tot[E];
+    __syncthreads();
+    if (sample_w)
+        for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < N; s += (int64_t)gridDim.x * blockDim.x)
+            sample_w[s] = cw[(int)envs[s]];
+}
+
+// class/sample weights from already-global counts (multi-GPU: counts were all-reduced)
+__global__ __launch_bounds__(256) void sample_weights_kernel(const int64_t *__restrict__ envs, int64_t N_local,
+                                                             const int64_t *__restrict__ counts, int64_t N_total, int E,
+                                                             float *__restrict__ class_w, float *__restrict__ sample_w) {
+    __shared__ float cw[INVPREF_MAX_ENVS];
+    if (threadIdx.x < E) {
+        const long long c = counts[threadIdx.x];
+        const long long r = (c + 1 < N_total - 1) ? c + 1 : N_total - 1;
+        const float w = (float)((double)r / (double)N_total);
+        cw[threadIdx.x] = w;
+        if (blockIdx.x == 0 && class_w) class_w[threadIdx.x] = w;
+    }
+    __syncthreads();
+    if (sample_w)
+        for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < N_local; s += (int64_t)gridDim.x * blockDim.x)
+            sample_w[s] = cw[(int)envs[s]];
+}
+
+// ------------------------------------------------------------------ host helpers
+inline int check_tables(const InvPrefTables *t) {
+    if (!t) return INVPREF_EINVAL;
+    if (t->user_num <= 0 || t->item_num <= 0 || t->env_num <= 0 || t->factor_num <= 0) return INVPREF_EINVAL;
+    if (t->factor_num > INVPREF_MAX_FACTORS || t->env_num > INVPREF_MAX_ENVS) return INVPREF_EUNSUPPORTED;
+    if (!t->embed_user_invariant || !t->embed_item_invariant || !t->embed_user_env_aware || !t->embed_item_env_aware ||
+        !t->embed_env || !t->classifier_weight || !t->classifier_bias)
+        return INVPREF_EINVAL;
+    return 0;
+}
+inline DevTables dev_tables(const InvPrefTables *t) {
+    return DevTables{t->embed_user_invariant, t->embed_item_invariant, t->embed_user_env_aware, t->embed_item_env_aware,
+                     t->embed_env, t->classifier_weight, t->classifier_bias,
+                     (int)t->user_num, (int)t->item_num, (int)t->env_num, (int)t->factor_num};
+}
+inline DevGrads dev_grads(const InvPrefTables *t) {
+    return DevGrads{t->embed_user_invariant, t->embed_item_invariant, t->embed_user_env_aware, t->embed_item_env_aware,
+                    t->embed_env, t->classifier_weight, t->classifier_bias};
+}
+inline int nc_of(int D) { return D <= 64 ? 1 : (D <= 128 ? 2 : 4); }
+inline int emax_of(int E) { return E <= 4 ? 4 : (E <= 8 ? 8 : 16); }
+inline bool vec_ok(const InvPrefTables *t) {
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    return (t->factor_num % 4 == 0) && al(t->embed_user_invariant) && al(t->embed_item_invariant) &&
+           al(t->embed_user_env_aware) && al(t->embed_item_env_aware);
+}
+constexpr int kMstepThreads = 512, kMstepMaxBlocks = 512;
+constexpr int kEstepThreads = 256, kEstepMaxBlocks = 2048;
+inline int mstep_blocks(int64_t B) {
+    int64_t nb = (B + (kMstepThreads / kRow) - 1) / (kMstepThreads / kRow);
+    return (int)(nb < 1 ? 1 : (nb > kMstepMaxBlocks ? kMstepMaxBlocks : nb));
+}
+inline int estep_blocks(int64_t N) {
+    int64_t nb = (N + (kEstepThreads / kRow) - 1) / (kEstepThreads / kRow);
+    return (int)(nb < 1 ? 1 : (nb > kEstepMaxBlocks ? kEstepMaxBlocks : nb));
+}
+
+// dispatch over (NC, VEC, EMAX): VEC=false only exists at NC=4 (any D <= 256)
+#define DISPATCH_NVE(NCV, VECV, EMAXV, CALL)                                             \
+    do {                                                                                  \
+        if (!(VECV)) {                                                                    \
+            if ((EMAXV) == 4) { CALL(4, false, 4); } else if ((EMAXV) == 8) { CALL(4, false, 8); } else { CALL(4, false, 16); } \
+        } else if ((NCV) == 1) {                                                          \
+            if ((EMAXV) == 4) { CALL(1, true, 4); } else if ((EMAXV) == 8) { CALL(1, true, 8); } else { CALL(1, true, 16); } \
+        } else if ((NCV) == 2) {                                                          \
+            if ((EMAXV) == 4) { CALL(2, true, 4); } else if ((EMAXV) == 8) { CALL(2, true, 8); } else { CALL(2, true, 16); } \
+        } else {                                                                          \
+            if ((EMAXV) == 4) { CALL(4, true, 4); } else if ((EMAXV) == 8) { CALL(4, true, 8); } else { CALL(4, true, 16); } \
+        }                                                                                 \
+    } while (0)
+
+}  // namespace
+
+// ===================================================================================== C ABI
+extern "C" {
+
+int invpref_abi_version(void) { return INVPREF_ABI_VERSION; }
+
+int invpref_device_name(char *buf, size_t len) {
+    if (!buf || len == 0) return INVPREF_EINVAL;
+    int dev = 0;
+    hipError_t err = hipGetDevice(&dev);
+    if (err != hipSuccess) return (int)err;
+    hipDeviceProp_t prop;
+    err = hipGetDeviceProperties(&prop, dev);
+    if (err != hipSuccess) return (int)err;
+    snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+
+int invpref_forward_hip(const InvPrefTables *tables, const int64_t *users, const int64_t *items, const int64_t *envs,
+                        int64_t B, uint32_t flags, float *invariant_score, float *env_aware_score, float *env_outputs,
+                        void *stream) {
+    int rc = check_tables(tables);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!users || !items || !envs || !invariant_score || !env_aware_score || !env_outputs)))
+        return INVPREF_EINVAL;
+    if (B == 0) return 0;
+    const DevTables t = dev_tables(tables);
+    const bool vec = vec_ok(tables);
+    const int nc = vec ? nc_of(t.D) : 4, emax = emax_of(t.E);
+    const int nb = estep_blocks(B);
+    const size_t lds = sizeof(float) * (2 * (size_t)t.E * nc * 64 + t.E);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(NCV, VECV, EMAXV)                                                                               \
+    hipLaunchKernelGGL((forward_kernel<NCV, VECV, EMAXV>), dim3(nb), dim3(256), lds, st, t, users, items, envs, B, \
+                       flags, invariant_score, env_aware_score, env_outputs)
+    DISPATCH_NVE(nc, vec, emax, CALL);
+#undef CALL
+    return (int)hipGetLastError();
+}
+
+size_t invpref_mstep_workspace_bytes(const InvPrefTables *tables, int64_t B) {
+    if (check_tables(tables)) return 0;
+    const int nc = 4;  // upper bound independent of alignment
+    const size_t slab_len = 2 * (size_t)tables->env_num * nc * 64 + 16 + kLossSlots;
+    (void)B;
+    return sizeof(float) * slab_len * kMstepMaxBlocks;
+}
+
+int invpref_mstep_grad_hip(const InvPrefTables *tables, const InvPrefTables *grads, const int64_t *users,
+                           const int64_t *items, const int64_t *envs, const float *scores, const float *sample_weights,
+                           int64_t B, int64_t batch_norm, const InvPrefCoefs *coefs, uint32_t flags, float *losses6,
+                           void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = check_tables(tables);
+    if (rc) return rc;
+    rc = check_tables(grads);
+    if (rc) return rc;
+    if (!coefs || !losses6 || !workspace || B < 0 || batch_norm < B || batch_norm <= 0) return INVPREF_EINVAL;
+    if (B > 0 && (!users || !items || !envs || !scores)) return INVPREF_EINVAL;
+    if ((flags & (INVPREF_REWEIGHT_REC | INVPREF_REWEIGHT_CLS)) && B > 0 && !sample_weights) return INVPREF_EINVAL;
+    if (workspace_bytes < invpref_mstep_workspace_bytes(tables, B)) return INVPREF_EWORKSPACE;
+    const DevTables t = dev_tables(tables);
+    const DevGrads g = dev_grads(grads);
+    const bool vec = vec_ok(tables) && vec_ok(grads);
+    const int nc = vec ? nc_of(t.D) : 4, emax = emax_of(t.E);
+    const int DP = nc * 64, EDP = t.E * DP;
+    const int nb = mstep_blocks(B);
+    StepScalars k;
+    k.ca = coefs->invariant_coe; k.cb = coefs->env_aware_coe; k.cc = coefs->env_coe; k.alpha = coefs->alpha;
+    k.invB = 1.0f / (float)batch_norm;
+    k.r2 = coefs->L2_coe / ((float)batch_norm * (float)t.D);
+    k.r1 = coefs->L1_coe / (2.0f * (float)batch_norm * (float)t.D);
+    const size_t lds = sizeof(float) * (4 * (size_t)EDP + 2 * emax + kLossSlots);
+    hipStream_t st = (hipStream_t)stream;
+    float *slabs = (float *)workspace;
+#define CALL(NCV, VECV, EMAXV)                                                                                       \
+    hipLaunchKernelGGL((mstep_atomic_kernel<NCV, VECV, EMAXV>), dim3(nb), dim3(kMstepThreads), lds, st, t, g, users, \
+                       items, envs, scores, sample_weights, B, k, flags, slabs)
+    DISPATCH_NVE(nc, vec, emax, CALL);
+#undef CALL
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return (int)err;
+    const int slab_len = 2 * EDP + emax + kLossSlots;
+    // the loss tail (kLossSlots) must sit entirely inside the last 64-column block
+    const int nfb = (slab_len + 63) / 64;
+    if ((nfb - 1) * 64 > 2 * EDP + emax) return INVPREF_EUNSUPPORTED;
+    hipLaunchKernelGGL((mstep_finish_kernel<0>), dim3(nfb), dim3(1024), 0, st, t, g, slabs, nb, DP, emax, k,
+                       coefs->L2_coe, coefs->L1_coe, batch_norm, flags, losses6);
+    return (int)hipGetLastError();
+}
+
+int invpref_adam_hip(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step, double lr,
+                     double beta1, double beta2, double eps, int zero_grad, void *stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return INVPREF_EINVAL;
+    if (n == 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15u)
+        return INVPREF_EINVAL;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    AdamScalars a;
+    a.step_size = (float)(lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.w1 = (float)(1.0 - beta1);
+    a.b2 = (float)beta2;
+    a.w2 = (float)(1.0 - beta2);
+    a.eps = (float)eps;
+    int64_t nb = ((n >> 2) + 255) / 256;
+    if (nb < 1) nb = 1;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, a, zero_grad);
+    return (int)hipGetLastError();
+}
+
+size_t invpref_estep_workspace_bytes(const InvPrefTables *tables, int64_t N) {
+    (void)N;
+    const int64_t E = tables ? tables->env_num : INVPREF_MAX_ENVS;
+    return sizeof(int) * (size_t)(E + 1) * kEstepMaxBlocks;
+}
+
+int invpref_stat_envs_hip(const int64_t *envs, int64_t N, int64_t env_num, int64_t *counts, float *class_weights,
+                          float *sample_weights, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!envs || !counts || !workspace || N <= 0 || env_num <= 0) return INVPREF_EINVAL;
+    if (env_num > INVPREF_MAX_ENVS) return INVPREF_EUNSUPPORTED;
+    if (workspace_bytes < sizeof(int) * (size_t)(env_num + 1) * kEstepMaxBlocks) return INVPREF_EWORKSPACE;
+    int64_t nb = (N + 255) / 256;
+    if (nb > kEstepMaxBlocks) nb = kEstepMaxBlocks;
+    hipStream_t st = (hipStream_t)stream;
+    int *slabs = (int *)workspace;
+    hipLaunchKernelGGL(env_hist_kernel, dim3((unsigned)nb), dim3(256), 0, st, envs, N, (int)env_num, slabs);
+    hipLaunchKernelGGL(stat_envs_kernel, dim3((unsigned)nb), dim3(256), 0, st, envs, N, (int)env_num, slabs, (int)nb,
+                       counts, (int64_t *)nullptr, class_weights, sample_weights);
+    return (int)hipGetLastError();
+}
+
+int invpref_sample_weights_hip(const int64_t *envs, int64_t N_local, const int64_t *counts, int64_t N_total,
+                               int64_t env_num, float *class_weights, float *sample_weights, void *stream) {
+    if (!counts || N_local < 0 || N_total <= 0 || env_num <= 0 || (N_local > 0 && sample_weights && !envs))
+        return INVPREF_EINVAL;
+    if (env_num > INVPREF_MAX_ENVS) return INVPREF_EUNSUPPORTED;
+    int64_t nb = (N_local + 255) / 256;
+    if (nb < 1) nb = 1;
+    if (nb > kEstepMaxBlocks) nb = kEstepMaxBlocks;
+    hipLaunchKernelGGL(sample_weights_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, envs, N_local, counts,
+                       N_total, (int)env_num, class_weights, sample_weights);
+    return (int)hipGetLastError();
+}
+
+int invpref_estep_hip(const InvPrefTables *tables, const int64_t *users, const int64_t *items, const float *scores,
+                      int64_t N, uint32_t flags, const float *eps_rows, const int64_t *old_envs, int64_t *new_envs,
+                      int64_t *counts, int64_t *diff, float *class_weights, float *sample_weights, void *workspace,
+                      size_t workspace_bytes, void *stream) {
+    int rc = check_tables(tables);
+    if (rc) return rc;
+    if (N <= 0 || !users || !items || !scores || !new_envs || !counts || !diff || !workspace) return INVPREF_EINVAL;
+    if (workspace_bytes < invpref_estep_workspace_bytes(tables, N)) return INVPREF_EWORKSPACE;
+    const DevTables t = dev_tables(tables);
+    const bool vec = vec_ok(tables);
+    const int nc = vec ? nc_of(t.D) : 4;
+    const int nb = estep_blocks(N);
+    const size_t lds = sizeof(float) * ((size_t)t.E * nc * 64) + sizeof(int) * (t.E + 1);
+    hipStream_t st = (hipStream_t)stream;
+    int *slabs = (int *)workspace;
+#define ECALL(NCV, VECV)                                                                                          \
+    hipLaunchKernelGGL((estep_assign_kernel<NCV, VECV>), dim3(nb), dim3(kEstepThreads), lds, st, t, users, items, \
+                       scores, N, flags, eps_rows, old_envs, new_envs, slabs)
+    if (!vec) { ECALL(4, false); } else if (nc == 1) { ECALL(1, true); } else if (nc == 2) { ECALL(2, true); } else { ECALL(4, true); }
+#undef ECALL
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return (int)err;
+    int64_t nb2 = (N + 255) / 256;
+    if (nb2 > kEstepMaxBlocks) nb2 = kEstepMaxBlocks;
+    hipLaunchKernelGGL(stat_envs_kernel, dim3((unsigned)nb2), dim3(256), 0, st, new_envs, N, t.E, slabs, nb, counts, diff,
+                       class_weights, sample_weights);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,332 @@
+"""Drop-in ``ImplicitTrainManager`` / ``ExplicitTrainManager`` (reference train.py:16-342, :693-1019).
+
+Same constructor signature, public attributes, method names and return shapes as the reference;
+the work inside is re-designed for MI355X:
+
+* the seven parameter tensors are re-homed as views of ONE flat fp32 buffer (with flat gradient
+  and Adam-moment twins), so the optimiser is a single fused HIP launch and multi-GPU needs a
+  single RCCL all-reduce per step;
+* ``train_a_batch`` = fused M-step HIP kernel (forward + 3 losses + 2 regularisers + analytic
+  backward + scatter-add) -> [all-reduce] -> fused zero_grad+Adam kernel;
+* ``cluster`` + ``stat_envs`` = one E-step launch over all local interactions + one finish launch;
+* no per-batch host syncs: ``train_a_epoch`` reads the loss terms back once per epoch.
+
+Row sharding: with ``world_size`` G > 1 every minibatch ``[kB,(k+1)B)`` is cut
+into G contiguous row slices; rank r keeps only its slices of users/items/scores/envs/weights.
+Every mean() keeps the GLOBAL batch length as denominator, so summing the per-rank gradient
+buffers reproduces the single-GPU gradient.
+"""
+from __future__ import annotations
+
+import itertools
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .parallel import RowShard, all_reduce_sum_
+
+LOSS_KEYS = ('invariant_loss', 'env_aware_loss', 'envs_loss', 'L2_reg', 'L1_reg', 'loss')
+_ALIGN = 64  # floats; every table starts on a 256-byte boundary of the flat buffer
+
+
+def transfer_loss_dict_to_line_str(d: dict) -> str:
+    return ' '.join(f'{k}: {v}' for k, v in d.items())
+
+
+class FlatState:
+    """params / grads / exp_avg / exp_avg_sq as four flat buffers + per-table views."""
+
+    def __init__(self, model, device):
+        tabs = model.tables()
+        self.shapes = [tuple(p.shape) for p in tabs]
+        self.offsets = []
+        off = 0
+        for p in tabs:
+            self.offsets.append(off)
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.n = off
+        self.param = torch.zeros(self.n, dtype=torch.float32, device=device)
+        # +8: the six loss partials ride at the tail of the gradient buffer so that ONE all-reduce
+        # carries everything
+        self.grad_ext = torch.zeros(self.n + 8, dtype=torch.float32, device=device)
+        self.grad = self.grad_ext[:self.n]
+        self.losses6 = self.grad_ext[self.n:self.n + 6]
+        self.exp_avg = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.p_views = self._views(self.param)
+        self.g_views = self._views(self.grad)
+        with torch.no_grad():
+            for p, view in zip(tabs, self.p_views):
+                view.copy_(p.detach().to(device=device, dtype=torch.float32))
+                p.data = view  # the module's parameters now alias the flat buffer
+        self.step = 0
+
+    def _views(self, flat):
+        return [flat[o:o + int(np.prod(s))].view(s) for o, s in zip(self.offsets, self.shapes)]
+
+
+class _InvPrefTrainManager:
+    implicit = True
+
+    def __init__(
+            self, model, evaluator, device: torch.device, training_data: torch.Tensor, batch_size: int,
+            epochs: int, cluster_interval: int, evaluate_interval: int, lr: float,
+            invariant_coe: float, env_aware_coe: float, env_coe: float, L2_coe: float, L1_coe: float,
+            alpha: float = None, use_class_re_weight: bool = False, test_begin_epoch: int = 0,
+            begin_cluster_epoch: int = None, stop_cluster_epoch: int = None, cluster_use_random_sort: bool = True,
+            use_recommend_re_weight: bool = True, *, rank: Optional[int] = None, world_size: Optional[int] = None,
+            process_group=None,
+    ):
+        if model.implicit != self.implicit:
+            raise TypeError(f'{type(self).__name__} needs an {"implicit" if self.implicit else "explicit"} model')
+        self.model = model
+        self.evaluator = evaluator
+        self.envs_num: int = model.env_num
+        self.device = torch.device(device)
+        self.process_group = process_group
+        if world_size is None:
+            import torch.distributed as dist
+            world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+            rank = dist.get_rank(process_group) if world_size > 1 else 0
+        self.rank, self.world_size = int(rank or 0), int(world_size)
+
+        n_total = training_data.shape[0]
+        self.n_total = n_total
+        self.batch_size = batch_size
+        self.batch_num = math.ceil(n_total / batch_size)
+        self.shard = RowShard(n_total, batch_size, self.rank, self.world_size)
+        rows = self.shard.local_rows().to(training_data.device)
+        td = training_data.index_select(0, rows) if self.world_size > 1 else training_data
+        # full tensors keep the reference attribute names; *_local are what the kernels read
+        self.users_tensor = td[:, 0].contiguous().to(self.device)
+        self.items_tensor = td[:, 1].contiguous().to(self.device)
+        self.scores_tensor = td[:, 2].float().contiguous().to(self.device)
+        # initial environments: one numpy draw over ALL rows, like the reference (train.py:34),
+        # then this rank keeps its rows -> identical to the single-GPU run for any world size
+        envs_all = torch.from_numpy(np.random.randint(0, self.envs_num, n_total).astype(np.int64))
+        self.envs = (envs_all.index_select(0, rows.cpu()) if self.world_size > 1 else envs_all).to(self.device)
+
+        self.cluster_interval, self.evaluate_interval, self.epochs = cluster_interval, evaluate_interval, epochs
+        self.lr = lr
+        self.invariant_coe, self.env_aware_coe, self.env_coe = invariant_coe, env_aware_coe, env_coe
+        self.L2_coe, self.L1_coe = L2_coe, L1_coe
+        self.epoch_cnt = 0
+        self.each_env_count = dict()
+        if alpha is None:
+            self.alpha, self.update_alpha = 0., True
+        else:
+            self.alpha, self.update_alpha = alpha, False
+        self.use_class_re_weight = use_class_re_weight
+        self.use_recommend_re_weight = use_recommend_re_weight
+        self.sample_weights = torch.zeros(self.users_tensor.shape[0], dtype=torch.float32, device=self.device)
+        self.class_weights = torch.zeros(self.envs_num, dtype=torch.float32, device=self.device)
+        self.test_begin_epoch = test_begin_epoch
+        self.begin_cluster_epoch, self.stop_cluster_epoch = begin_cluster_epoch, stop_cluster_epoch
+        self.cluster_use_random_sort = cluster_use_random_sort
+        self._eps_base = np.array([1e-10 * (1e-1 ** i) for i in range(self.envs_num)], dtype=np.float32)
+        self._eps_rows_cnt = math.factorial(self.envs_num)
+
+        self.model.to(self.device)
+        self.state = FlatState(model, self.device)
+        self.workspace = ops.Workspace(self.device)
+        self._flags = ops.flags_of(self.implicit, use_recommend_re_weight, use_class_re_weight,
+                                   model.reg_only_embed, model.reg_env_embed, dense_reg=(self.rank == 0))
+
+    # ------------------------------------------------------------------ M-step
+    def _coefs(self, alpha):
+        return (self.invariant_coe, self.env_aware_coe, self.env_coe, self.L2_coe, self.L1_coe, alpha)
+
+    def _step(self, users, items, scores, envs, weights, alpha, batch_norm: int):
+        """one optimiser step; leaves the six loss terms of this step in state.losses6 (device)."""
+        st = self.state
+        st.losses6.zero_()
+        ops.mstep_grad(st.p_views, st.g_views, users, items, envs, scores, weights, batch_norm, self._coefs(alpha),
+                       self._flags, st.losses6, self.workspace)
+        if self.world_size > 1:
+            all_reduce_sum_(st.grad_ext, self.process_group)
+        st.step += 1
+        ops.adam_(st.param, st.grad, st.exp_avg, st.exp_avg_sq, st.step, self.lr, zero_grad=True)
+
+    def train_a_batch(self, batch_users_tensor, batch_items_tensor, batch_scores_tensor, batch_envs_tensor,
+                      batch_sample_weights, alpha) -> dict:
+        """train.py:94-167.  In a row-sharded run the arguments are this rank's slice of the batch."""
+        assert batch_users_tensor.shape == batch_items_tensor.shape == batch_scores_tensor.shape \
+            == batch_envs_tensor.shape
+        bn = batch_users_tensor.shape[0]
+        if self.world_size > 1:
+            t = torch.tensor([bn], dtype=torch.int64, device=self.device)
+            all_reduce_sum_(t, self.process_group)
+            bn = int(t.item())
+        self._step(batch_users_tensor.contiguous(), batch_items_tensor.contiguous(),
+                   batch_scores_tensor.float().contiguous(), batch_envs_tensor.contiguous(),
+                   batch_sample_weights.contiguous(), alpha, bn)
+        vals = self.state.losses6.tolist()
+        return dict(zip(LOSS_KEYS, vals))
+
+    def train_a_epoch(self) -> dict:
+        """train.py:204-233, without the per-batch host syncs."""
+        self.model.train()
+        acc = torch.zeros(6, dtype=torch.float32, device=self.device)
+        for k in range(self.batch_num):
+            lo, hi = self.shard.local_batch_bounds(k)
+            if self.update_alpha:  # train.py:214-217
+                p = float(k + (self.epoch_cnt + 1) * self.batch_num) / float((self.epoch_cnt + 1) * self.batch_num)
+                self.alpha = 2. / (1. + np.exp(-10. * p)) - 1.
+            self._step(self.users_tensor[lo:hi], self.items_tensor[lo:hi], self.scores_tensor[lo:hi],
+                       self.envs[lo:hi], self.sample_weights[lo:hi], self.alpha, self.shard.global_batch_len(k))
+            acc += self.state.losses6
+        self.epoch_cnt += 1
+        vals = (acc / self.batch_num).tolist()
+        return dict(zip(LOSS_KEYS, vals))
+
+    # ------------------------------------------------------------------ E-step
+    def _eps_rows(self, n_rows: int) -> torch.Tensor:
+        """train.py:86-92,192-196: per batch, np.random.randint picks a permutation of the eps vector
+        per row.  The E! x E table is not materialised: row r is unranked on the fly."""
+        out = np.empty((n_rows, self.envs_num), np.float32)
+        done = 0
+        if self._eps_rows_cnt <= 40320:
+            table = np.array(list(itertools.permutations(self._eps_base)), dtype=np.float32)
+        for k in range(self.batch_num):
+            glen = self.shard.global_batch_len(k)
+            idx = np.random.randint(0, self._eps_rows_cnt, glen)  # same numpy stream as the reference
+            a, b = self.shard.slice_in_batch(k)
+            idx = idx[a:b]
+            if self._eps_rows_cnt <= 40320:
+                out[done:done + len(idx)] = table[idx]
+            else:
+                out[done:done + len(idx)] = _unrank_permutations(idx, self._eps_base)
+            done += len(idx)
+        return torch.from_numpy(out).to(self.device)
+
+    def cluster(self) -> int:
+        """train.py:235-259 (+ the stat_envs that always follows it is fused in: train.py:330)."""
+        self.model.eval()
+        eps = self._eps_rows(self.users_tensor.shape[0]) if self.cluster_use_random_sort else None
+        new, counts, diff, cw, sw = ops.estep(self.state.p_views, self.users_tensor, self.items_tensor,
+                                              self.scores_tensor, self.implicit, self.envs, self.workspace,
+                                              eps_rows=eps, want_weights=(self.world_size == 1))
+        self.envs = new
+        if self.world_size > 1:
+            cd = torch.cat([counts, diff])
+            all_reduce_sum_(cd, self.process_group)
+            counts, diff = cd[:-1].contiguous(), cd[-1:]
+            cw, sw = ops.sample_weights(self.envs, counts, self.n_total, self.envs_num)
+        self._pending_stat = (counts, cw, sw)
+        return int(diff.item())
+
+    def cluster_a_batch(self, batch_users_tensor, batch_items_tensor, batch_scores_tensor) -> torch.Tensor:
+        """train.py:169-202 for one batch (single-rank semantics)."""
+        eps = None
+        if self.cluster_use_random_sort:
+            idx = np.random.randint(0, self._eps_rows_cnt, batch_users_tensor.shape[0])
+            eps = torch.from_numpy(_unrank_permutations(idx, self._eps_base)).to(self.device)
+        new, _, _, _, _ = ops.estep(self.state.p_views, batch_users_tensor.contiguous(),
+                                    batch_items_tensor.contiguous(), batch_scores_tensor.float().contiguous(),
+                                    self.implicit, None, self.workspace, eps_rows=eps, want_weights=False)
+        return new
+
+    def stat_envs(self) -> dict:
+        """train.py:268-280."""
+        pend = getattr(self, '_pending_stat', None)
+        if pend is not None:
+            counts, cw, sw = pend
+            self._pending_stat = None
+        elif self.world_size == 1:
+            counts, cw, sw = ops.stat_envs(self.envs, self.envs_num, self.workspace)
+        else:
+            counts, _, _ = ops.stat_envs(self.envs, self.envs_num, self.workspace, want_sample_weights=False)
+            all_reduce_sum_(counts, self.process_group)
+            cw, sw = ops.sample_weights(self.envs, counts, self.n_total, self.envs_num)
+        self.class_weights, self.sample_weights = cw, sw
+        return {env: int(c) for env, c in enumerate(counts.tolist())}
+
+    def update_each_env_count(self):  # train.py:261-266
+        counts, _, _ = ops.stat_envs(self.envs, self.envs_num, self.workspace, want_sample_weights=False)
+        if self.world_size > 1:
+            all_reduce_sum_(counts, self.process_group)
+        self.each_env_count.update({e: c for e, c in enumerate(counts)})
+
+    # ------------------------------------------------------------------ outer loop (train.py:282-342)
+    def train(self, silent: bool = False, auto: bool = False):
+        test_result_list, test_epoch_list = [], []
+        cluster_diff_num_list, cluster_epoch_list, envs_cnt_list = [], [], []
+        loss_result_list, train_epoch_index_list = [], []
+
+        temp_eval_result = self.evaluator.evaluate()
+        test_result_list.append(temp_eval_result)
+        test_epoch_list.append(self.epoch_cnt)
+        self.stat_envs()
+        if not silent and not auto:
+            print('test at epoch:', self.epoch_cnt)
+            print(transfer_loss_dict_to_line_str(temp_eval_result))
+
+        while self.epoch_cnt < self.epochs:
+            temp_loss_dict = self.train_a_epoch()
+            train_epoch_index_list.append(self.epoch_cnt)
+            loss_result_list.append(temp_loss_dict)
+            if not silent and not auto:
+                print('train epoch:', self.epoch_cnt)
+                print(transfer_loss_dict_to_line_str(temp_loss_dict))
+
+            if (self.epoch_cnt % self.evaluate_interval) == 0 and self.epoch_cnt >= self.test_begin_epoch:
+                temp_eval_result = self.evaluator.evaluate()
+                test_result_list.append(temp_eval_result)
+                test_epoch_list.append(self.epoch_cnt)
+                if not silent and not auto:
+                    print('test at epoch:', self.epoch_cnt)
+                    print(transfer_loss_dict_to_line_str(temp_eval_result))
+
+            if (self.epoch_cnt % self.cluster_interval) == 0:
+                if (self.begin_cluster_epoch is None or self.begin_cluster_epoch <= self.epoch_cnt) \
+                        and (self.stop_cluster_epoch is None or self.stop_cluster_epoch > self.epoch_cnt):
+                    diff_num = self.cluster()
+                else:
+                    diff_num = 0
+                cluster_diff_num_list.append(diff_num)
+                envs_cnt = self.stat_envs()
+                cluster_epoch_list.append(self.epoch_cnt)
+                envs_cnt_list.append(envs_cnt)
+                if not silent and not auto:
+                    print('cluster at epoch:', self.epoch_cnt)
+                    print('diff num:', diff_num)
+                    print(transfer_loss_dict_to_line_str(envs_cnt))
+
+        return (loss_result_list, train_epoch_index_list), \
+               (test_result_list, test_epoch_list), \
+               (cluster_diff_num_list, envs_cnt_list, cluster_epoch_list)
+
+
+def _unrank_permutations(idx: np.ndarray, base: np.ndarray) -> np.ndarray:
+    """Row idx[i] of ``list(itertools.permutations(base))`` (lexicographic in positions), without
+    building the E! table (the reference builds it eagerly, train.py:86-92, and cannot be
+    constructed for E >= 11)."""
+    E = len(base)
+    idx = np.asarray(idx, dtype=np.int64).copy()
+    n = len(idx)
+    out = np.empty((n, E), np.float32)
+    avail = np.tile(np.arange(E, dtype=np.int64), (n, 1))
+    for pos in range(E):
+        f = math.factorial(E - 1 - pos)
+        d = idx // f
+        idx = idx % f
+        pick = avail[np.arange(n), d]
+        out[:, pos] = base[pick]
+        # remove the picked element from each row's availability list
+        keep = np.ones_like(avail, dtype=bool)
+        keep[np.arange(n), d] = False
+        avail = avail[keep].reshape(n, -1)
+    return out
+
+
+class ImplicitTrainManager(_InvPrefTrainManager):
+    """reference train.py:16-342 (BCELoss)."""
+    implicit = True
+
+
+class ExplicitTrainManager(_InvPrefTrainManager):
+    """reference train.py:693-1019 (MSELoss)."""
+    implicit = False

@@ -128,9 +128,10 @@ static inline float r_log1p(float x) {
     return r_log(u) * (x / (u - 1.0f));
 }
 /* 16-slot dot: element i feeds slot (i>>2)&15 by fma in increasing i; slots combined by an
- * xor butterfly (8,4,2,1).  Matches a 16-lane x float4 row layout on the GPU. */
+ * xor butterfly in the order 1,2,4,8 (a 16-lane x float4 row layout; low-to-high so that
+ * quad-perm / half-mirror / mirror lane exchanges realise it exactly). */
 static inline float butterfly16(float *s) {
-    for (int m = 8; m >= 1; m >>= 1) {
+    for (int m = 1; m <= 8; m <<= 1) {
         float t[16];
         for (int k = 0; k < 16; k++) t[k] = s[k] + s[k ^ m];
         memcpy(s, t, sizeof t);

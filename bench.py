@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- training interactions/sec of the InvPref hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): Yahoo!R3-implicit-shaped synthetic data,
+U=15 400, I=1 000, 250 154 interactions PER GPU, E=4, D=64, minibatch 8 192 rows PER GPU (weak
+scaling: the global minibatch is 8 192*N rows, row-sharded, one RCCL all-reduce of the flat gradient
+buffer per step), reference Yahoo hyper-parameters (Yahoo_InvPref_Implicit.py:17-41).
+
+A "step" is one optimiser step of the M-step (fused gradient kernel + dense Adam) on one minibatch;
+every 155 steps (= cluster_interval 5 epochs x 31 minibatches) the E-step (+ stat_envs) over all
+interactions runs inside the timed region, as in the reference loop.  Inputs are resident in HBM
+before the timed region.  value = interactions processed by all ranks / max-over-ranks time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+U, I, E, D, N_PER_GPU, B_PER_GPU = 15400, 1000, 4, 64, 250154, 8192
+SEED = 17373331
+YAHOO = dict(lr=0.005, invariant_coe=3.351991776096847, env_aware_coe=9.988658447411407,
+             env_coe=9.06447753571379, L2_coe=3.1351402017943117, L1_coe=0.4935216278026648,
+             alpha=1.9053711444718746)
+ESTEP_EVERY = 155
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+class StubEvaluator:
+    def evaluate(self):
+        return {}
+
+
+def cpu_baseline(seconds_budget: float = 12.0):
+    """The oracle (C port, one thread) on the same Yahoo-shaped workload, bounded sample."""
+    from invpref_kdd_2022_amd import synth
+    from oracle import oracle as O
+    data = synth.interactions(SEED, U, I, N_PER_GPU, implicit=True)
+    tabs = synth.tables(SEED + 7, U, I, E, D)
+    env0 = np.random.RandomState(SEED).randint(0, E, N_PER_GPU)
+    cf = [YAHOO[k] for k in ('invariant_coe', 'env_aware_coe', 'env_coe', 'L2_coe', 'L1_coe', 'alpha')]
+    tr = O.Trainer(tabs, data, env0, implicit=True, batch_size=B_PER_GPU, coefs=cf, lr=YAHOO['lr'],
+                   reweight_rec=False, reweight_cls=True, reg_only_embed=True, reg_env_embed=False)
+    tr.stat_envs()
+    nb = (N_PER_GPU + B_PER_GPU - 1) // B_PER_GPU
+    done, t0 = 0, time.perf_counter()
+    k = 0
+    while True:
+        lo = (k % nb) * B_PER_GPU
+        hi = min(lo + B_PER_GPU, N_PER_GPU)
+        tr.train_a_batch(lo, hi)
+        done += hi - lo
+        k += 1
+        if time.perf_counter() - t0 > seconds_budget and k % nb == 0:
+            break
+    t_m = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    tr.cluster()
+    t_e = time.perf_counter() - t1
+    return {'value': done / t_m, 'unit': 'interactions/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{k} M-step minibatches ({done} interactions, {t_m:.1f} s) of the same Yahoo-shaped workload '
+                      f'through oracle/invpref_oracle.c, single thread; E-step alone {N_PER_GPU / t_e:.0f} interactions/s',
+            'estep_value': N_PER_GPU / t_e}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=620)
+    ap.add_argument('--warmup', type=int, default=62)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from invpref_kdd_2022_amd import parallel, synth
+    from invpref_kdd_2022_amd.models import InvPrefImplicit
+    from invpref_kdd_2022_amd.train import ImplicitTrainManager
+
+    rank, local, world = parallel.init_from_env('nccl')
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    data = synth.interactions(SEED, U, I, N_PER_GPU * world, implicit=True)
+    tabs = synth.tables(SEED + 7, U, I, E, D)
+    model = InvPrefImplicit(U, I, E, D, reg_only_embed=True, reg_env_embed=False)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in tabs.items()})
+    np.random.seed(SEED)
+    mgr = ImplicitTrainManager(
+        model=model, evaluator=StubEvaluator(), device=dev, training_data=torch.from_numpy(data).to(dev),
+        batch_size=B_PER_GPU * world, epochs=10 ** 9, cluster_interval=5, evaluate_interval=10 ** 9,
+        use_class_re_weight=True, use_recommend_re_weight=False, cluster_use_random_sort=False,
+        rank=rank, world_size=world, **YAHOO)
+    mgr.stat_envs()
+    mgr._raw_setup()
+    nb = mgr.batch_num
+    stream = torch.cuda.current_stream().cuda_stream
+
+    ev = {'m0': [], 'm1': [], 'a1': []}
+
+    def run(n_steps, start, timed):
+        for s in range(start, start + n_steps):
+            k = s % nb
+            if getattr(mgr, '_raw_ptrs', None) is None or mgr._raw_ptrs[4] != mgr.sample_weights.data_ptr():
+                mgr._raw_setup()
+            if timed:
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
+            # ---- one optimiser step (the same two C-ABI calls train_a_epoch issues)
+            if timed:
+                mgr._raw_step(k, mgr.alpha, stream, mid_event=e1)
+                e2.record()
+                ev['m0'].append(e0); ev['m1'].append(e1); ev['a1'].append(e2)
+            else:
+                mgr._raw_step(k, mgr.alpha, stream)
+            if (s + 1) % ESTEP_EVERY == 0:
+                mgr.cluster()
+                mgr.stat_envs()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    run(args.warmup, 0, False)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup, True)
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    inter = args.steps * B_PER_GPU * world
+    value = inter / dt
+    # per-op device time from HIP events recorded on the launch stream inside the timed region
+    ms_m = float(np.mean([a.elapsed_time(b) for a, b in zip(ev['m0'], ev['m1'])]))
+    ms_a = float(np.mean([a.elapsed_time(b) for a, b in zip(ev['m1'], ev['a1'])]))
+    P = mgr.state.n
+    bytes_m = B_PER_GPU * (32 + 32 * D)       # ids/labels + 4 row reads + 4 grad-row adds
+    bytes_a = 32 * P                           # 28 B/param Adam + 4 B/param zeroing
+    if ms_a >= ms_m:
+        roof = {'kernel': 'adam_kernel', 'achieved': bytes_a / (ms_a * 1e-3) / 1e9, 'bytes_per_launch': bytes_a,
+                'avg_ms': ms_a}
+    else:
+        roof = {'kernel': 'mstep_atomic_kernel(+finish)', 'achieved': bytes_m / (ms_m * 1e-3) / 1e9,
+                'bytes_per_launch': bytes_m, 'avg_ms': ms_m}
+    roofline = {'bound': 'hbm', 'achieved': roof['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': roof['achieved'] / HBM_PEAK_GBS, 'traffic': None, 'kernel': roof['kernel'],
+                'avg_launch_ms': roof['avg_ms'], 'algorithmic_bytes_per_launch': roof['bytes_per_launch'],
+                'other': {'mstep_ms': ms_m, 'mstep_GBs': bytes_m / (ms_m * 1e-3) / 1e9, 'adam_ms': ms_a,
+                          'adam_GBs': bytes_a / (ms_a * 1e-3) / 1e9}}
+    out = {
+        'metric': 'training interactions/sec, Yahoo-implicit InvPref', 'value': value, 'unit': 'interactions/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'yahoo_r3_implicit_shaped', 'users': U, 'items': I, 'envs': E, 'factor_num': D,
+                   'interactions_per_gpu': N_PER_GPU, 'batch_per_gpu': B_PER_GPU, 'global_batch': B_PER_GPU * world,
+                   'estep_every_steps': ESTEP_EVERY, 'parallelism': f'row-shard x{world}, 1 all-reduce/step'},
+        'roofline': roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -44,6 +44,8 @@ extern "C" {
 #define INVPREF_DENSE_REG 32u     /* add the classifier regulariser (models.py:211-217) in this call;
                                      set on exactly one rank when a minibatch is row-sharded */
 
+#define INVPREF_NO_GRAD 64u       /* invpref_mstep_grad_hip: report the loss terms only, write no gradient */
+
 /* The seven parameter tensors of InvPrefImplicit/InvPrefExplicit (models.py:283-291, :197-201),
  * in state_dict order.  Also used for gradients and Adam moments (same shapes). */
 typedef struct InvPrefTables {
@@ -88,6 +90,20 @@ int invpref_mstep_grad_hip(const InvPrefTables *tables, const InvPrefTables *gra
                            const float *sample_weights, int64_t B, int64_t batch_norm,
                            const InvPrefCoefs *coefs, uint32_t flags, float *losses6, void *workspace,
                            size_t workspace_bytes, void *stream);
+
+/* ---- backward of forward(): replaces autograd through InvPref*.forward + ReverseLayerF
+ * (models.py:307-326 / :448-467, functions.py:7-16) for callers that build their own loss on the
+ * unfused outputs (e.g. the reference's untouched train.py).  Upstream gradients d_* have the shapes
+ * of the forward outputs; any of them may be NULL (zeros).  ADDS into `grads`. */
+int invpref_backward_hip(const InvPrefTables *tables, const InvPrefTables *grads, const int64_t *users,
+                         const int64_t *items, const int64_t *envs, int64_t B, uint32_t flags, float alpha,
+                         const float *d_invariant_score, const float *d_env_aware_score, const float *d_env_outputs,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- predict: replaces InvPrefImplicit.predict (models.py:393-407): out[n_users, item_num] =
+ * sigmoid(user_table[users] . item_table^T) (apply_sigmoid=0: raw dot products). */
+int invpref_predict_hip(const float *user_table, const float *item_table, const int64_t *users, int64_t n_users,
+                        int64_t item_num, int64_t factor_num, int apply_sigmoid, float *out, void *stream);
 
 /* ---- dense Adam: replaces optimizer.zero_grad() + optimizer.step() of torch.optim.Adam with
  * default betas/eps (train.py:41, :155-157) over one flat fp32 buffer of n parameters.

@@ -14,12 +14,12 @@ import torch
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, 'libinvpref_hip.so')
 
-IMPLICIT, REWEIGHT_REC, REWEIGHT_CLS, REG_ONLY_EMBED, REG_ENV_EMBED, DENSE_REG = 1, 2, 4, 8, 16, 32
+IMPLICIT, REWEIGHT_REC, REWEIGHT_CLS, REG_ONLY_EMBED, REG_ENV_EMBED, DENSE_REG, NO_GRAD = 1, 2, 4, 8, 16, 32, 64
 
 EXPORTS = [
     'invpref_abi_version', 'invpref_device_name', 'invpref_forward_hip', 'invpref_mstep_workspace_bytes',
     'invpref_mstep_grad_hip', 'invpref_adam_hip', 'invpref_estep_workspace_bytes', 'invpref_estep_hip',
-    'invpref_stat_envs_hip', 'invpref_sample_weights_hip',
+    'invpref_stat_envs_hip', 'invpref_sample_weights_hip', 'invpref_backward_hip', 'invpref_predict_hip',
 ]
 
 
@@ -65,6 +65,9 @@ def lib():
                                         C.c_size_t, vp]
         L.invpref_stat_envs_hip.argtypes = [vp, i64, i64, vp, vp, vp, vp, C.c_size_t, vp]
         L.invpref_sample_weights_hip.argtypes = [vp, i64, vp, i64, i64, vp, vp, vp]
+        L.invpref_backward_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), vp, vp, vp, i64, u32, C.c_float, vp,
+                                           vp, vp, vp, C.c_size_t, vp]
+        L.invpref_predict_hip.argtypes = [vp, vp, vp, i64, i64, i64, C.c_int, vp, vp]
         L.invpref_device_name.argtypes = [C.c_char_p, C.c_size_t]
         if L.invpref_abi_version() != 1:
             raise InvPrefError('libinvpref_hip.so ABI version mismatch')

@@ -172,13 +172,20 @@ struct StepScalars {
     float ca, cb, cc, alpha, invB, r2, r1;
 };
 
-template <int NC, bool VEC, int EMAX>
+// UPSTREAM = true turns the same kernel into the plain backward of forward(): the per-sample
+// upstream gradients (d invariant_score, d env_aware_score, d env_outputs) come from memory instead
+// of from the fused losses, and no regulariser / loss sums are formed.
+struct Upstream {
+    const float *d_inv, *d_env, *d_out;  // [B], [B], [B,E]; any may be null (= zeros)
+};
+template <int NC, bool VEC, int EMAX, bool UPSTREAM>
 __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads g, const int64_t *__restrict__ users,
                                                            const int64_t *__restrict__ items,
                                                            const int64_t *__restrict__ envs,
                                                            const float *__restrict__ scores,
                                                            const float *__restrict__ weights, int64_t B,
-                                                           StepScalars k, uint32_t flags, float *__restrict__ slabs) {
+                                                           StepScalars k, uint32_t flags, float *__restrict__ slabs,
+                                                           Upstream up) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int DP = NC * 64;
     const int EDP = t.E * DP;
@@ -197,13 +204,14 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
     const bool implicit = flags & INVPREF_IMPLICIT;
     const bool rw_rec = flags & INVPREF_REWEIGHT_REC, rw_cls = flags & INVPREF_REWEIGHT_CLS;
     const bool reg_env = flags & INVPREF_REG_ENV_EMBED;
+    const bool no_grad = flags & INVPREF_NO_GRAD;
     float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
 
     for (int64_t s = blockIdx.x * rows_per_block + (threadIdx.x >> 4); s < B; s += gridDim.x * rows_per_block) {
         const int64_t u = users[s], v = items[s];
         const int e = (int)envs[s];
-        const float y = scores[s];
-        const float w = (rw_rec || rw_cls) ? weights[s] : 1.f;
+        const float y = UPSTREAM ? 0.f : scores[s];
+        const float w = (!UPSTREAM && (rw_rec || rw_cls)) ? weights[s] : 1.f;
         const float w_rec = rw_rec ? w : 1.f, w_cls = rw_cls ? w : 1.f;
         const float cw_rec = w_rec * k.invB, cw_cls = w_cls * k.invB;
         float4 pu[NC], qi[NC], pa[NC], qa[NC], ev[NC];
@@ -213,8 +221,18 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
         load_row<NC, VEC>(t.Qa, v, t.D, l16, qa);
         lds_row<NC>(sEv, e, l16, ev);
         const float p = dot2<NC>(pu, qi), q = dot3<NC>(pa, qa, ev);
-        float g_p, g_q, li, le;
-        if (implicit) {
+        float g_p, g_q, li = 0.f, le = 0.f;
+        if (UPSTREAM) {
+            const float ui = up.d_inv ? up.d_inv[s] : 0.f, ue = up.d_env ? up.d_env[s] : 0.f;
+            if (implicit) {
+                const float sp = c_sigmoid(p), sq = c_sigmoid(q);
+                g_p = (ui + ue * sq) * (sp * (1.f - sp));
+                g_q = ue * sp * (sq * (1.f - sq));
+            } else {
+                g_p = ui + ue;
+                g_q = ue;
+            }
+        } else if (implicit) {
             const float sp = c_sigmoid(p), sq = c_sigmoid(q), sv = sp * sq;
             li = c_bce(sp, y);
             le = c_bce(sv, y);
@@ -253,15 +271,22 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
         // z[c] now holds exp(z-mx); log-prob of the true env: log(ex_e/se)
 #pragma unroll
         for (int c = 0; c < EMAX; c++) ze = (c == e) ? z[c] : ze;
-        const float lcls = -c_log(ze / se);
+        const float lcls = UPSTREAM ? 0.f : -c_log(ze / se);
         const float rse = 1.f / se;
+        float usum = 0.f;  // sum_c d_out[c]  (log_softmax backward: dz = d_out - softmax * sum d_out)
+        if (UPSTREAM && up.d_out) {
+#pragma unroll
+            for (int c = 0; c < EMAX; c++) if (c < t.E) usum += up.d_out[s * t.E + c];
+        }
         float4 gx[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++) gx[c] = f4zero();
 #pragma unroll
         for (int c = 0; c < EMAX; c++) {
             if (c < t.E) {
-                const float gz = k.cc * cw_cls * (z[c] * rse - (c == e ? 1.f : 0.f));
+                float gz;
+                if (UPSTREAM) gz = up.d_out ? (up.d_out[s * t.E + c] - (z[c] * rse) * usum) : 0.f;
+                else gz = k.cc * cw_cls * (z[c] * rse - (c == e ? 1.f : 0.f));
                 float4 wr[NC];
                 lds_row<NC>(sW, c, l16, wr);
 #pragma unroll
@@ -270,13 +295,15 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
                     gx[j].y = __builtin_fmaf(gz, wr[j].y, gx[j].y);
                     gx[j].z = __builtin_fmaf(gz, wr[j].z, gx[j].z);
                     gx[j].w = __builtin_fmaf(gz, wr[j].w, gx[j].w);
-                    float *dst = aW + c * DP + (l16 + kRow * j) * 4;
-                    atomicAdd(dst + 0, gz * x[j].x);
-                    atomicAdd(dst + 1, gz * x[j].y);
-                    atomicAdd(dst + 2, gz * x[j].z);
-                    atomicAdd(dst + 3, gz * x[j].w);
+                    if (!no_grad) {
+                        float *dst = aW + c * DP + (l16 + kRow * j) * 4;
+                        atomicAdd(dst + 0, gz * x[j].x);
+                        atomicAdd(dst + 1, gz * x[j].y);
+                        atomicAdd(dst + 2, gz * x[j].z);
+                        atomicAdd(dst + 3, gz * x[j].w);
+                    }
                 }
-                if (l16 == 0) atomicAdd(ab + c, gz);
+                if (l16 == 0 && !no_grad) atomicAdd(ab + c, gz);
             }
         }
         // scatter-add the four embedding-row gradients (+ per-occurrence L2/L1 terms)
@@ -285,7 +312,7 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
 #pragma unroll
         for (int j = 0; j < NC; j++) {
             const int i0 = (l16 + kRow * j) * 4;
-            if (i0 < t.D) {
+            if (i0 < t.D && !no_grad) {
                 float4 gip, o;
                 gip.x = g_p - k.alpha * gx[j].x; gip.y = g_p - k.alpha * gx[j].y;
                 gip.z = g_p - k.alpha * gx[j].z; gip.w = g_p - k.alpha * gx[j].w;
@@ -314,6 +341,7 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
                 float *dst = aEv + e * DP + i0;
                 atomicAdd(dst + 0, o.x); atomicAdd(dst + 1, o.y); atomicAdd(dst + 2, o.z); atomicAdd(dst + 3, o.w);
             }
+            if (UPSTREAM) continue;
             // regulariser REPORTS: users+items weigh 1/(2BD), env rows 1/(BD) -> count env terms twice
             float s2 = pu[j].x * pu[j].x + pu[j].y * pu[j].y + pu[j].z * pu[j].z + pu[j].w * pu[j].w;
             s2 += pa[j].x * pa[j].x + pa[j].y * pa[j].y + pa[j].z * pa[j].z + pa[j].w * pa[j].w;
@@ -366,6 +394,7 @@ __global__ __launch_bounds__(1024) void mstep_finish_kernel(DevTables t, DevGrad
     if (threadIdx.x < 2) sreg[threadIdx.x] = 0.0;
     __syncthreads();
     const bool dense = (flags & INVPREF_DENSE_REG) && !(flags & INVPREF_REG_ONLY_EMBED);
+    const bool no_grad = flags & INVPREF_NO_GRAD;
     const bool last_block = blockIdx.x == gridDim.x - 1;  // owns the bias + loss tail (asserted by the launcher)
     if (sub == 0 && idx < slab_len) {
         double v = 0.0;
@@ -374,7 +403,7 @@ __global__ __launch_bounds__(1024) void mstep_finish_kernel(DevTables t, DevGrad
             const bool isW = idx >= EDP;
             const int r = isW ? idx - EDP : idx;
             const int e = r / DP, d = r - e * DP;
-            if (d < t.D) {
+            if (d < t.D && !no_grad) {
                 float add = (float)v;
                 if (isW && dense) {
                     const float wv = t.W[e * t.D + d];
@@ -385,7 +414,7 @@ __global__ __launch_bounds__(1024) void mstep_finish_kernel(DevTables t, DevGrad
             }
         } else if (idx < 2 * EDP + EMAX) {
             const int e = idx - 2 * EDP;
-            if (e < t.E) {
+            if (e < t.E && !no_grad) {
                 float add = (float)v;
                 if (dense) { const float bv = t.b[e]; add += 2.f * l2 / (float)t.E * bv + l1 / (float)t.E * c_sign(bv); }
                 g.b[e] += add;
@@ -395,7 +424,7 @@ __global__ __launch_bounds__(1024) void mstep_finish_kernel(DevTables t, DevGrad
         }
     }
     __syncthreads();
-    if (last_block) {
+    if (last_block && losses6) {
         // classifier regulariser report (tiny: E*D + E terms), by the first wave
         if (dense && threadIdx.x < 64) {
             double w2 = 0, w1 = 0, b2 = 0, b1 = 0;
@@ -549,6 +578,42 @@ __global__ __launch_bounds__(256) void stat_envs_kernel(const int64_t *__restric
             sample_w[s] = cw[(int)envs[s]];
 }
 
+// =====================================================================================
+// predict (models.py:393-407): scores[n, I] = f(Pu[users[n]] . Qi[i]) for ALL items, f = sigmoid
+// (implicit) or identity.  One 16-lane row keeps its user row in registers and sweeps the item
+// table (L2/Infinity-Cache resident); 16 results are collected across the row and stored as one
+// 64-byte segment.
+// =====================================================================================
+template <int NC, bool VEC>
+__global__ __launch_bounds__(256) void predict_kernel(const float *__restrict__ Pu, const float *__restrict__ Qi,
+                                                      const int64_t *__restrict__ users, int64_t n, int I, int D,
+                                                      int apply_sigmoid, float *__restrict__ out) {
+    const int l16 = threadIdx.x & 15;
+    const int64_t row = blockIdx.x * (int64_t)(blockDim.x / kRow) + (threadIdx.x >> 4);
+    if (row >= n) return;
+    float4 pu[NC];
+    load_row<NC, VEC>(Pu, users[row], D, l16, pu);
+    float *o = out + row * (int64_t)I;
+    const int i_lo = blockIdx.y * (int)((I + gridDim.y - 1) / gridDim.y);
+    int i_hi = i_lo + (int)((I + gridDim.y - 1) / gridDim.y);
+    i_hi = i_hi < I ? i_hi : I;
+    for (int i0 = i_lo; i0 < i_hi; i0 += 16) {
+        float res = 0.f;
+#pragma unroll 4
+        for (int j = 0; j < 16; j++) {
+            const int i = i0 + j;
+            if (i < i_hi) {
+                float4 qi[NC];
+                load_row<NC, VEC>(Qi, i, D, l16, qi);
+                float p = dot2<NC>(pu, qi);
+                if (apply_sigmoid) p = c_sigmoid(p);
+                res = (j == l16) ? p : res;
+            }
+        }
+        if (i0 + l16 < i_hi) o[i0 + l16] = res;
+    }
+}
+
 // class/sample weights from already-global counts (multi-GPU: counts were all-reduced)
 __global__ __launch_bounds__(256) void sample_weights_kernel(const int64_t *__restrict__ envs, int64_t N_local,
                                                              const int64_t *__restrict__ counts, int64_t N_total, int E,
@@ -694,8 +759,8 @@ int invpref_mstep_grad_hip(const InvPrefTables *tables, const InvPrefTables *gra
     hipStream_t st = (hipStream_t)stream;
     float *slabs = (float *)workspace;
 #define CALL(NCV, VECV, EMAXV)                                                                                       \
-    hipLaunchKernelGGL((mstep_atomic_kernel<NCV, VECV, EMAXV>), dim3(nb), dim3(kMstepThreads), lds, st, t, g, users, \
-                       items, envs, scores, sample_weights, B, k, flags, slabs)
+    hipLaunchKernelGGL((mstep_atomic_kernel<NCV, VECV, EMAXV, false>), dim3(nb), dim3(kMstepThreads), lds, st, t, g, users, \
+                       items, envs, scores, sample_weights, B, k, flags, slabs, Upstream{nullptr, nullptr, nullptr})
     DISPATCH_NVE(nc, vec, emax, CALL);
 #undef CALL
     hipError_t err = hipGetLastError();
@@ -706,6 +771,69 @@ int invpref_mstep_grad_hip(const InvPrefTables *tables, const InvPrefTables *gra
     if ((nfb - 1) * 64 > 2 * EDP + emax) return INVPREF_EUNSUPPORTED;
     hipLaunchKernelGGL((mstep_finish_kernel<0>), dim3(nfb), dim3(1024), 0, st, t, g, slabs, nb, DP, emax, k,
                        coefs->L2_coe, coefs->L1_coe, batch_norm, flags, losses6);
+    return (int)hipGetLastError();
+}
+
+int invpref_backward_hip(const InvPrefTables *tables, const InvPrefTables *grads, const int64_t *users,
+                         const int64_t *items, const int64_t *envs, int64_t B, uint32_t flags, float alpha,
+                         const float *d_invariant_score, const float *d_env_aware_score, const float *d_env_outputs,
+                         void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = check_tables(tables);
+    if (rc) return rc;
+    rc = check_tables(grads);
+    if (rc) return rc;
+    if (!workspace || B < 0 || (B > 0 && (!users || !items || !envs))) return INVPREF_EINVAL;
+    if (workspace_bytes < invpref_mstep_workspace_bytes(tables, B)) return INVPREF_EWORKSPACE;
+    if (B == 0) return 0;
+    const DevTables t = dev_tables(tables);
+    const DevGrads g = dev_grads(grads);
+    const bool vec = vec_ok(tables) && vec_ok(grads);
+    const int nc = vec ? nc_of(t.D) : 4, emax = emax_of(t.E);
+    const int DP = nc * 64, EDP = t.E * DP;
+    const int nb = mstep_blocks(B);
+    StepScalars k{};
+    k.alpha = alpha;
+    k.invB = 1.f;
+    const uint32_t fl = flags & INVPREF_IMPLICIT;
+    const size_t lds = sizeof(float) * (4 * (size_t)EDP + 2 * emax + kLossSlots);
+    hipStream_t st = (hipStream_t)stream;
+    float *slabs = (float *)workspace;
+    const Upstream up{d_invariant_score, d_env_aware_score, d_env_outputs};
+#define CALL(NCV, VECV, EMAXV)                                                                                            \
+    hipLaunchKernelGGL((mstep_atomic_kernel<NCV, VECV, EMAXV, true>), dim3(nb), dim3(kMstepThreads), lds, st, t, g, users, \
+                       items, envs, (const float *)nullptr, (const float *)nullptr, B, k, fl, slabs, up)
+    DISPATCH_NVE(nc, vec, emax, CALL);
+#undef CALL
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return (int)err;
+    const int slab_len = 2 * EDP + emax + kLossSlots;
+    const int nfb = (slab_len + 63) / 64;
+    hipLaunchKernelGGL((mstep_finish_kernel<0>), dim3(nfb), dim3(1024), 0, st, t, g, slabs, nb, DP, emax, k, 0.f, 0.f,
+                       (int64_t)1, fl, (float *)nullptr);
+    return (int)hipGetLastError();
+}
+
+int invpref_predict_hip(const float *user_table, const float *item_table, const int64_t *users, int64_t n_users,
+                        int64_t item_num, int64_t factor_num, int apply_sigmoid, float *out, void *stream) {
+    if (!user_table || !item_table || !out || n_users < 0 || item_num <= 0 || factor_num <= 0) return INVPREF_EINVAL;
+    if (factor_num > INVPREF_MAX_FACTORS) return INVPREF_EUNSUPPORTED;
+    if (n_users == 0) return 0;
+    if (!users) return INVPREF_EINVAL;
+    const bool vec = (factor_num % 4 == 0) && !((reinterpret_cast<uintptr_t>(user_table) | reinterpret_cast<uintptr_t>(item_table)) & 15u);
+    const int nc = vec ? nc_of((int)factor_num) : 4;
+    const int64_t rows_per_block = 256 / kRow;
+    const unsigned gx = (unsigned)((n_users + rows_per_block - 1) / rows_per_block);
+    unsigned gy = 1;  // split the item sweep when there are few users, to fill the chip
+    while ((int64_t)gx * gy < 1024 && gy * 64 < (unsigned)item_num) gy *= 2;
+    // item slices must start on multiples of 16 for the 64-byte result segments: enforced by rounding
+    const int per = (int)((item_num + gy - 1) / gy);
+    if (per % 16 != 0) gy = 1;
+    hipStream_t st = (hipStream_t)stream;
+#define PCALL(NCV, VECV)                                                                                   \
+    hipLaunchKernelGGL((predict_kernel<NCV, VECV>), dim3(gx, gy), dim3(256), 0, st, user_table, item_table, users, \
+                       n_users, (int)item_num, (int)factor_num, apply_sigmoid, out)
+    if (!vec) { PCALL(4, false); } else if (nc == 1) { PCALL(1, true); } else if (nc == 2) { PCALL(2, true); } else { PCALL(4, true); }
+#undef PCALL
     return (int)hipGetLastError();
 }
 

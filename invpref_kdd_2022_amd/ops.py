@@ -142,3 +142,28 @@ def sample_weights(envs: torch.Tensor, counts: torch.Tensor, n_total: int, env_n
     check(lib().invpref_sample_weights_hip(ptr(_ids(envs, 'envs')), N, ptr(counts), int(n_total), env_num, ptr(cw),
                                            ptr(sw), stream_ptr()), 'invpref_sample_weights_hip')
     return cw, sw
+
+
+def backward(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], users, items, envs, implicit: bool,
+             alpha: float, d_inv, d_env, d_out, workspace: Workspace) -> None:
+    """Backward of forward() incl. the gradient-reversal layer (functions.py:7-16): ADDS into grads."""
+    t, g = make_tables(params), make_tables(grads)
+    B = users.numel()
+    for n, x in (('d_inv', d_inv), ('d_env', d_env), ('d_out', d_out)):
+        _capi._req(x, torch.float32, n)
+    ws = workspace.get(lib().invpref_mstep_workspace_bytes(C.byref(t), B))
+    check(lib().invpref_backward_hip(C.byref(t), C.byref(g), ptr(_ids(users, 'users')), ptr(_ids(items, 'items')),
+                                     ptr(_ids(envs, 'envs')), B, IMPLICIT if implicit else 0, float(alpha), ptr(d_inv),
+                                     ptr(d_env), ptr(d_out), ptr(ws), ws.numel(), stream_ptr()),
+          'invpref_backward_hip')
+
+
+def predict(user_table: torch.Tensor, item_table: torch.Tensor, users: torch.Tensor, sigmoid: bool) -> torch.Tensor:
+    """InvPrefImplicit.predict (models.py:393-407): [n_users, item_num] scores."""
+    _capi._req(user_table, torch.float32, 'user_table')
+    _capi._req(item_table, torch.float32, 'item_table')
+    n, (I, D) = users.numel(), item_table.shape
+    out = torch.empty(n, I, dtype=torch.float32, device=users.device)
+    check(lib().invpref_predict_hip(ptr(user_table), ptr(item_table), ptr(_ids(users, 'users')), n, I, D,
+                                    int(bool(sigmoid)), ptr(out), stream_ptr()), 'invpref_predict_hip')
+    return out

@@ -25,7 +25,9 @@ from typing import Optional
 import numpy as np
 import torch
 
-from . import ops
+import ctypes as C
+
+from . import _capi, ops
 from .parallel import RowShard, all_reduce_sum_
 
 LOSS_KEYS = ('invariant_loss', 'env_aware_loss', 'envs_loss', 'L2_reg', 'L1_reg', 'loss')
@@ -139,12 +141,15 @@ class _InvPrefTrainManager:
     def _coefs(self, alpha):
         return (self.invariant_coe, self.env_aware_coe, self.env_coe, self.L2_coe, self.L1_coe, alpha)
 
-    def _step(self, users, items, scores, envs, weights, alpha, batch_norm: int):
-        """one optimiser step; leaves the six loss terms of this step in state.losses6 (device)."""
+    def _step(self, users, items, scores, envs, weights, alpha, batch_norm: int, losses6=None):
+        """one optimiser step on explicit tensors; the six loss terms of this step are ADDED into
+        `losses6` (default: state.losses6, zeroed first)."""
         st = self.state
-        st.losses6.zero_()
+        if losses6 is None:
+            losses6 = st.losses6
+            losses6.zero_()
         ops.mstep_grad(st.p_views, st.g_views, users, items, envs, scores, weights, batch_norm, self._coefs(alpha),
-                       self._flags, st.losses6, self.workspace)
+                       self._flags, losses6, self.workspace)
         if self.world_size > 1:
             all_reduce_sum_(st.grad_ext, self.process_group)
         st.step += 1
@@ -166,20 +171,68 @@ class _InvPrefTrainManager:
         vals = self.state.losses6.tolist()
         return dict(zip(LOSS_KEYS, vals))
 
-    def train_a_epoch(self) -> dict:
-        """train.py:204-233, without the per-batch host syncs."""
-        self.model.train()
-        acc = torch.zeros(6, dtype=torch.float32, device=self.device)
+    # ---- the epoch loop issues raw C-ABI calls with every argument prepared once: per step the host
+    #      does two (three with a collective) foreign calls and nothing else
+    def _raw_setup(self):
+        st = self.state
+        L = _capi.lib()
+        self._raw_t = _capi.make_tables(st.p_views)
+        self._raw_g = _capi.make_tables(st.g_views)
+        self._raw_ws = self.workspace.get(L.invpref_mstep_workspace_bytes(C.byref(self._raw_t), self.batch_size))
+        self._epoch_losses = torch.zeros(self.batch_num, 6, dtype=torch.float32, device=self.device)
+        self._raw_ptrs = (self.users_tensor.data_ptr(), self.items_tensor.data_ptr(), self.envs.data_ptr(),
+                          self.scores_tensor.data_ptr(), self.sample_weights.data_ptr())
+        self._raw_batches = []
         for k in range(self.batch_num):
             lo, hi = self.shard.local_batch_bounds(k)
-            if self.update_alpha:  # train.py:214-217
-                p = float(k + (self.epoch_cnt + 1) * self.batch_num) / float((self.epoch_cnt + 1) * self.batch_num)
-                self.alpha = 2. / (1. + np.exp(-10. * p)) - 1.
-            self._step(self.users_tensor[lo:hi], self.items_tensor[lo:hi], self.scores_tensor[lo:hi],
-                       self.envs[lo:hi], self.sample_weights[lo:hi], self.alpha, self.shard.global_batch_len(k))
-            acc += self.state.losses6
+            self._raw_batches.append((lo, hi - lo, self.shard.global_batch_len(k)))
+        self._raw_mstep, self._raw_adam = L.invpref_mstep_grad_hip, L.invpref_adam_hip
+
+    def _raw_step(self, k: int, alpha: float, stream, mid_event=None):
+        st = self.state
+        lo, n, bn = self._raw_batches[k]
+        pu, pi, pe, py, pw = self._raw_ptrs
+        cf = _capi.Coefs(self.invariant_coe, self.env_aware_coe, self.env_coe, self.L2_coe, self.L1_coe, alpha)
+        multi = self.world_size > 1
+        if multi:
+            st.losses6.zero_()
+            lp = st.losses6.data_ptr()
+        else:
+            lp = self._epoch_losses.data_ptr() + 24 * k
+        rc = self._raw_mstep(C.byref(self._raw_t), C.byref(self._raw_g), pu + 8 * lo, pi + 8 * lo, pe + 8 * lo,
+                             py + 4 * lo, pw + 4 * lo, n, bn, C.byref(cf), self._flags, lp,
+                             self._raw_ws.data_ptr(), self._raw_ws.numel(), stream)
+        if rc:
+            _capi.check(rc, 'invpref_mstep_grad_hip')
+        if multi:
+            all_reduce_sum_(st.grad_ext, self.process_group)
+            self._epoch_losses[k] += st.losses6
+        if mid_event is not None:
+            mid_event.record()
+        st.step += 1
+        rc = self._raw_adam(st.param.data_ptr(), st.grad.data_ptr(), st.exp_avg.data_ptr(), st.exp_avg_sq.data_ptr(),
+                            st.n, st.step, self.lr, 0.9, 0.999, 1e-8, 1, stream)
+        if rc:
+            _capi.check(rc, 'invpref_adam_hip')
+
+    def _alpha_for(self, k: int) -> float:
+        if self.update_alpha:  # train.py:214-217
+            p = float(k + (self.epoch_cnt + 1) * self.batch_num) / float((self.epoch_cnt + 1) * self.batch_num)
+            self.alpha = 2. / (1. + np.exp(-10. * p)) - 1.
+        return self.alpha
+
+    def train_a_epoch(self) -> dict:
+        """train.py:204-233, without the per-batch host syncs (one read-back per epoch)."""
+        self.model.train()
+        if getattr(self, '_raw_ptrs', None) is None or self._raw_ptrs[2] != self.envs.data_ptr() \
+                or self._raw_ptrs[4] != self.sample_weights.data_ptr():
+            self._raw_setup()
+        self._epoch_losses.zero_()
+        stream = torch.cuda.current_stream().cuda_stream
+        for k in range(self.batch_num):
+            self._raw_step(k, self._alpha_for(k), stream)
         self.epoch_cnt += 1
-        vals = (acc / self.batch_num).tolist()
+        vals = self._epoch_losses.mean(dim=0).tolist()
         return dict(zip(LOSS_KEYS, vals))
 
     # ------------------------------------------------------------------ E-step
@@ -206,10 +259,11 @@ class _InvPrefTrainManager:
         """train.py:235-259 (+ the stat_envs that always follows it is fused in: train.py:330)."""
         self.model.eval()
         eps = self._eps_rows(self.users_tensor.shape[0]) if self.cluster_use_random_sort else None
+        # new assignments overwrite self.envs in place (the kernel reads old_envs[i] before writing i)
         new, counts, diff, cw, sw = ops.estep(self.state.p_views, self.users_tensor, self.items_tensor,
                                               self.scores_tensor, self.implicit, self.envs, self.workspace,
-                                              eps_rows=eps, want_weights=(self.world_size == 1))
-        self.envs = new
+                                              eps_rows=eps, new_envs=self.envs,
+                                              want_weights=(self.world_size == 1))
         if self.world_size > 1:
             cd = torch.cat([counts, diff])
             all_reduce_sum_(cd, self.process_group)

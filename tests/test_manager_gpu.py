@@ -1,0 +1,152 @@
+"""GPU: the drop-in modules / train managers end to end against trajectories recorded from the
+reference managers, and the unfused autograd surface against the reference's gradients."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from invpref_kdd_2022_amd import ops, synth
+from invpref_kdd_2022_amd.models import InvPrefExplicit, InvPrefImplicit
+from invpref_kdd_2022_amd.train import LOSS_KEYS, ExplicitTrainManager, ImplicitTrainManager
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+G1 = sorted(glob.glob(os.path.join(G, 'g1_*.npz')))
+DEV = torch.device('cuda:0')
+
+
+class StubEvaluator:
+    def evaluate(self):
+        return {'stub': 0.0}
+
+
+def _mgr(cls, model, data, z, **kw):
+    cf = z['coefs']
+    return cls(model=model, evaluator=StubEvaluator(), device=DEV, training_data=torch.from_numpy(data).to(DEV),
+               batch_size=int(z['meta'][4]), epochs=int(z['meta'][5]), cluster_interval=int(z['meta'][5]),
+               evaluate_interval=10 ** 9, lr=float(cf[6]), invariant_coe=float(cf[0]), env_aware_coe=float(cf[1]),
+               env_coe=float(cf[2]), L2_coe=float(cf[3]), L1_coe=float(cf[4]), alpha=float(cf[5]),
+               cluster_use_random_sort=False, **kw)
+
+
+def test_g3_coat_explicit_trajectory_through_manager():
+    z = np.load(os.path.join(G, 'g3_coat_explicit_traj.npz'))
+    U, I, E, D, bs, epochs, seed = [int(x) for x in z['meta']]
+    data = z['data'].astype(np.int64)
+    model = InvPrefExplicit(U, I, E, D, reg_only_embed=True, reg_env_embed=False)
+    model.load_state_dict({k: torch.from_numpy(z['init_' + k]) for k in O.PARAM_NAMES})
+    np.random.seed(seed)
+    mgr = _mgr(ExplicitTrainManager, model, data, z, use_class_re_weight=True, use_recommend_re_weight=True)
+    np.testing.assert_array_equal(mgr.envs.cpu().numpy(), z['env0'].astype(np.int64))
+    (losses, ep), (tests, _), (diffs, cnts, cep) = mgr.train(silent=True, auto=True)
+    trace = np.array([[d[k] for k in LOSS_KEYS] for d in losses])
+    np.testing.assert_allclose(trace, z['loss_trace'], rtol=1e-5)
+    assert ep == list(range(1, 31)) and cep == [30] and len(tests) == 1
+    mism = int((mgr.envs.cpu().numpy() != z['env_after'].astype(np.int64)).sum())
+    assert mism <= 3
+    assert abs(diffs[0] - int(z['diff_num'][0])) <= mism
+    assert np.abs(np.array([cnts[0][k] for k in range(E)]) - z['counts'][0]).sum() <= 2 * mism
+    sd = model.state_dict()
+    for k in O.PARAM_NAMES:
+        assert np.abs(sd[k].cpu().numpy() - z['final_' + k]).max() < 2e-4, k
+
+
+def test_g4_yahoo_like_trajectory_through_manager():
+    z = np.load(os.path.join(G, 'g4_yahoo_like_traj.npz'))
+    U, I, E, D, bs, epochs, seed = [int(x) for x in z['meta']]
+    data = synth.yahoo_like(seed)
+    tabs = synth.tables(seed + 7, U, I, E, D, std=0.01)
+    model = InvPrefImplicit(U, I, E, D, reg_only_embed=True, reg_env_embed=False)
+    model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+    np.random.seed(seed)
+    mgr = _mgr(ImplicitTrainManager, model, data, z, use_class_re_weight=True, use_recommend_re_weight=False)
+    np.testing.assert_array_equal(mgr.envs.cpu().numpy(), z['env0'].astype(np.int64))
+    (losses, _), _, (diffs, cnts, _) = mgr.train(silent=True, auto=True)
+    trace = np.array([[d[k] for k in LOSS_KEYS] for d in losses])
+    np.testing.assert_allclose(trace[:, [0, 1, 2, 5]], z['loss_trace'][:, [0, 1, 2, 5]], rtol=1e-5)
+    np.testing.assert_allclose(trace[:, [3, 4]], z['loss_trace'][:, [3, 4]], rtol=5e-5)  # see oracle test
+    # E-step in the tie-heavy regime: HIP == oracle bit-exact on the SAME tables; vs the reference every
+    # disagreeing row has a relative distance gap < 2e-5
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    tab = O.Tables(sd)
+    # the manager's envs are post-cluster; recompute the oracle E-step on the final tables
+    on, oc, _, dist = O.estep(tab, data[:, 0], data[:, 1], data[:, 2], True, want_dist=True)
+    got = mgr.envs.cpu().numpy()
+    np.testing.assert_array_equal(got, on)
+    ref = z['env_after'].astype(np.int64)
+    mm = np.nonzero(got != ref)[0]
+    gap = (dist[mm, ref[mm]] - dist[mm, got[mm]]) / dist[mm, got[mm]]
+    assert gap.max() < 2e-5
+    assert sum(cnts[0].values()) == len(data)
+
+
+@pytest.mark.parametrize('path', G1[::3], ids=[os.path.basename(p)[3:-4] for p in G1[::3]])
+def test_unfused_autograd_surface_matches_reference_grads(path):
+    """Build the loss with torch ops exactly like the reference's train_a_batch does, on top of the
+    module's HIP-backed forward / get_L*_reg, and compare .grad with the recorded reference grads."""
+    z = np.load(path)
+    U, I, E, D, B, roe, ree, cls_w, rec_w = [int(x) for x in z['meta']]
+    implicit = '_implicit_' in path
+    cls = InvPrefImplicit if implicit else InvPrefExplicit
+    model = cls(U, I, E, D, reg_only_embed=bool(roe), reg_env_embed=bool(ree)).to(DEV)
+    model.load_state_dict({k: torch.from_numpy(z['p_' + k]) for k in O.PARAM_NAMES})
+    u, v, e = (torch.from_numpy(z[k]).to(DEV) for k in 'uve')
+    y, w = torch.from_numpy(z['y']).to(DEV), torch.from_numpy(z['w']).to(DEV)
+    ca, cb, cc, l2, l1, alpha, lr = [float(x) for x in z['coefs']]
+    inv, env, out = model(u, v, e, alpha)
+    assert np.abs(inv.detach().cpu().numpy() - z['inv_f32']).max() < 2e-6 * max(1, np.abs(z['inv_f32']).max())
+    rec = torch.nn.BCELoss if implicit else torch.nn.MSELoss
+    li = rec(reduction='none')(inv, y) if rec_w else rec()(inv, y)
+    le = rec(reduction='none')(env, y) if rec_w else rec()(env, y)
+    lc = torch.nn.NLLLoss(reduction='none')(out, e) if cls_w else torch.nn.NLLLoss()(out, e)
+    if cls_w:
+        lc = torch.mean(lc * w)
+    if rec_w:
+        li, le = torch.mean(li * w), torch.mean(le * w)
+    L2, L1 = model.get_L2_reg(u, v, e), model.get_L1_reg(u, v, e)
+    loss = li * ca + le * cb + lc * cc + L2 * l2 + L1 * l1
+    loss.backward()
+    got = np.array([float(li), float(le), float(lc), float(L2), float(L1), float(loss)])
+    np.testing.assert_allclose(got, z['losses_f32'], rtol=1e-5)
+    sd = dict(model.named_parameters())
+    for k in O.PARAM_NAMES:
+        ref = z['g_f32_' + k]
+        assert np.abs(sd[k].grad.cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max() + 1e-9, k
+
+
+def test_predict_matches_forward_bit_exact():
+    U, I, E, D = 300, 1000, 4, 64
+    tabs = synth.tables(11, U, I, E, D, std=0.3)
+    model = InvPrefImplicit(U, I, E, D).to(DEV)
+    model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+    users = torch.from_numpy(np.random.RandomState(1).randint(0, U, 77).astype(np.int64)).to(DEV)
+    scores = model.predict(users)
+    assert scores.shape == (77, I)
+    uu = users.cpu().numpy().repeat(I)
+    ii = np.tile(np.arange(I, dtype=np.int64), 77)
+    inv, _, _ = O.forward(O.Tables(tabs), uu, ii, np.zeros_like(uu), True)
+    np.testing.assert_array_equal(scores.cpu().numpy().reshape(-1), inv)
+    m2 = InvPrefExplicit(U, I, E, D).to(DEV)
+    m2.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+    p = m2.predict(users, users % I)
+    inv, _, _ = O.forward(O.Tables(tabs), users.cpu().numpy(), (users % I).cpu().numpy(), np.zeros(77, np.int64), False)
+    np.testing.assert_array_equal(p.cpu().numpy(), inv)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from invpref_kdd_2022_amd import _capi
+    monkeypatch.setattr(_capi, '_lib', None)
+    monkeypatch.setattr(_capi, 'LIB_PATH', '/nonexistent/libinvpref_hip.so')
+    with pytest.raises(_capi.InvPrefError):
+        _capi.lib()
+
+
+def test_cpu_tensors_are_rejected():
+    tabs = synth.tables(3, 10, 10, 2, 16)
+    P = [torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES]
+    ids = torch.zeros(4, dtype=torch.int64)
+    with pytest.raises(ops.InvPrefError):
+        ops.forward(P, ids, ids, ids, True)

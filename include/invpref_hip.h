@@ -91,6 +91,55 @@ int invpref_mstep_grad_hip(const InvPrefTables *tables, const InvPrefTables *gra
                            const InvPrefCoefs *coefs, uint32_t flags, float *losses6, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* ---- planned, atomic-free M-step ("row jobs").  utils.mini_batch (utils.py:12-19) yields the same
+ * contiguous, unshuffled slices every epoch, so the scatter pattern of a minibatch is inverted once
+ * into a plan (built on the host, invpref_kdd_2022_amd/plan.py).  All arrays are device memory and
+ * are only read.
+ *   job   = one row of the user tables (side 0) or of the item tables (side 1) + the minibatch's
+ *           interactions that touch it, cut into 1, 2, 4, 8 or 16 equal slices;
+ *   round = the 16 group slots (16 lanes each) of one workgroup; all jobs of a round have the same
+ *           slice count; slices of a job sit in adjacent slots, the first one is the leader;
+ *   workgroup b runs rounds [b*rounds_per_task, (b+1)*rounds_per_task); rounds [0, n_item_rounds)
+ *           are item-side (n_item_rounds is a multiple of rounds_per_task), the rest user-side.
+ * desc[round][slot] is 8 int32:
+ *   {row (-1: idle slot), meta, a, b, c, d, e, f}
+ *   meta = leader | slices << 1 | mode << 6 | row_count << 8     (idle slots carry slices too)
+ *   mode 0: no interaction; 1 / 2: one / two interactions inline as (partner_row, position, label
+ *   bits) = (a, b, c) and (d, e, f); 3: interactions [a, b) of the side's sorted arrays below.
+ * Every row of every table must appear in exactly one job (rows the minibatch does not touch as
+ * jobs with mode 0).  other_*[j] / pos_*[j]: for the j-th interaction in that side's order (sorted by
+ * own row), its row in the OTHER side's tables and its position inside the minibatch (index into the
+ * envs / scores / sample_weights minibatch slices). */
+typedef struct InvPrefRowPlan {
+    int32_t n_rounds, n_item_rounds, rounds_per_task, n;   /* n = interactions of the minibatch (shard) */
+    const int32_t *desc;                      /* [n_rounds][16][8] */
+    const int32_t *other_user, *pos_user;     /* [n] */
+    const int32_t *other_item, *pos_item;     /* [n] */
+} InvPrefRowPlan;
+
+/* The rows-path workspace must be ZERO-FILLED before its first use; every call leaves it zero-filled. */
+size_t invpref_rows_workspace_bytes(const InvPrefTables *tables);
+
+/* same contract as invpref_mstep_grad_hip, except that EVERY row of every table of `grads` is
+ * OVERWRITTEN (rows the minibatch does not touch get zeros): no zeroing pass is needed.  The four big
+ * tables' gradients are bitwise reproducible run to run (register accumulation, fixed-order sums);
+ * embed_env / classifier gradients and the loss sums go through a few float atomics. */
+int invpref_mstep_rows_grad_hip(const InvPrefTables *tables, const InvPrefTables *grads, const InvPrefRowPlan *plan,
+                                const int64_t *envs, const float *scores, const float *sample_weights,
+                                int64_t batch_norm, const InvPrefCoefs *coefs, uint32_t flags, float *losses6,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
+/* M-step + optimizer.step() in one pass (train.py:94-157 entire): reads `tables`, writes the updated
+ * parameters into `new_tables` (a second buffer: other workgroups still gather the old rows) and
+ * updates exp_avg / exp_avg_sq in place; the gradient is never stored.  Same Adam rule as
+ * invpref_adam_hip.  Single-GPU path (a row-sharded run must all-reduce the gradient first). */
+int invpref_mstep_rows_adam_hip(const InvPrefTables *tables, const InvPrefTables *new_tables,
+                                const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
+                                const InvPrefRowPlan *plan, const int64_t *envs, const float *scores,
+                                const float *sample_weights, int64_t batch_norm, const InvPrefCoefs *coefs,
+                                uint32_t flags, float *losses6, int64_t step, double lr, double beta1, double beta2,
+                                double eps, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- backward of forward(): replaces autograd through InvPref*.forward + ReverseLayerF
  * (models.py:307-326 / :448-467, functions.py:7-16) for callers that build their own loss on the
  * unfused outputs (e.g. the reference's untouched train.py).  Upstream gradients d_* have the shapes

@@ -20,6 +20,7 @@ EXPORTS = [
     'invpref_abi_version', 'invpref_device_name', 'invpref_forward_hip', 'invpref_mstep_workspace_bytes',
     'invpref_mstep_grad_hip', 'invpref_adam_hip', 'invpref_estep_workspace_bytes', 'invpref_estep_hip',
     'invpref_stat_envs_hip', 'invpref_sample_weights_hip', 'invpref_backward_hip', 'invpref_predict_hip',
+    'invpref_rows_workspace_bytes', 'invpref_mstep_rows_grad_hip', 'invpref_mstep_rows_adam_hip',
 ]
 
 
@@ -68,6 +69,13 @@ def lib():
         L.invpref_backward_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), vp, vp, vp, i64, u32, C.c_float, vp,
                                            vp, vp, vp, C.c_size_t, vp]
         L.invpref_predict_hip.argtypes = [vp, vp, vp, i64, i64, i64, C.c_int, vp, vp]
+        L.invpref_rows_workspace_bytes.restype = C.c_size_t
+        L.invpref_rows_workspace_bytes.argtypes = [C.POINTER(Tables)]
+        L.invpref_mstep_rows_grad_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), vp, vp, vp, vp, i64,
+                                                   C.POINTER(Coefs), u32, vp, vp, C.c_size_t, vp]
+        L.invpref_mstep_rows_adam_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), C.POINTER(Tables),
+                                                   C.POINTER(Tables), vp, vp, vp, vp, i64, C.POINTER(Coefs), u32, vp,
+                                                   i64, f64, f64, f64, f64, vp, C.c_size_t, vp]
         L.invpref_device_name.argtypes = [C.c_char_p, C.c_size_t]
         if L.invpref_abi_version() != 1:
             raise InvPrefError('libinvpref_hip.so ABI version mismatch')

@@ -9,10 +9,11 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libinvpref_hip.so')
-SOURCES = ['invpref_kernels.hip']
-HEADERS = ['canon_math.hpp', os.path.join('..', '..', 'include', 'invpref_hip.h')]
+OBJDIR = os.path.join(PKG, 'build')
+SOURCES = ['invpref_kernels.hip', 'invpref_rows.hip']
+HEADERS = ['canon_math.hpp', 'kernel_common.hpp', os.path.join('..', '..', 'include', 'invpref_hip.h')]
 # -ffp-contract=off: every fma of the canonical arithmetic is written explicitly
-FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
+FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-ffp-contract=off',
          '-fno-fast-math', '-Wall', '-Wno-unused-function']
 
 
@@ -33,7 +34,20 @@ def needs_build() -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
-        cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
+        os.makedirs(OBJDIR, exist_ok=True)
+        extra = os.environ.get('INVPREF_HIPCC_EXTRA', '').split()
+        procs, objs = [], []
+        for src in SOURCES:  # one hipcc per translation unit, in parallel
+            obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + '.o')
+            cmd = [_hipcc()] + FLAGS + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
+            if verbose:
+                print(' '.join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+            objs.append(obj)
+        for cmd, p in procs:
+            if p.wait() != 0:
+                raise subprocess.CalledProcessError(p.returncode, cmd)
+        cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)

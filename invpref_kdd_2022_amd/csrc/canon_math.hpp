@@ -102,6 +102,28 @@ __device__ __forceinline__ float c_dbce(float s, float y) {
 
 __device__ __forceinline__ float c_sign(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
 
+// ---- M-step arithmetic: hardware transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp).
+// The M-step is held to 1e-5 relative on the losses (north_star), not to bit equality -- float sums
+// over a minibatch reorder anyway -- so it does not pay for the canonical polynomials: a sigmoid is
+// 4 instructions here against ~40.  (The E-step and forward() keep the canonical forms.)
+__device__ __forceinline__ float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float f_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504f); }
+__device__ __forceinline__ float f_log(float x) { return __builtin_amdgcn_logf(x) * 0.693147181f; }
+__device__ __forceinline__ float f_sigmoid(float x) { return f_rcp(1.0f + f_exp(-x)); }
+// -log(s) and -log(1-s) with the reference's clamp at 100 (aten binary_cross_entropy)
+__device__ __forceinline__ float f_bce(float s, float y) {
+    float a = f_log(1.0f - s);
+    a = a > -100.0f ? a : -100.0f;
+    float b = f_log(s);
+    b = b > -100.0f ? b : -100.0f;
+    return (y - 1.0f) * a - y * b;
+}
+__device__ __forceinline__ float f_dbce(float s, float y) {
+    float d = (1.0f - s) * s;
+    d = d > 1e-12f ? d : 1e-12f;
+    return (s - y) * f_rcp(d);
+}
+
 // ---- lane exchanges inside a 16-lane row (DPP; a "row" of the DPP unit is exactly 16 lanes)
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {

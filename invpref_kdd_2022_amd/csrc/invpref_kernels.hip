@@ -7,105 +7,11 @@
 // 256-byte global_load_dwordx4 across the 16 lanes, dot products are a per-lane fma chain plus a
 // 4-step DPP butterfly (canon_math.hpp), and no LDS is needed for the reductions.  The E x D
 // environment table and classifier live in LDS for the whole workgroup.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#include "../../include/invpref_hip.h"
-#include "canon_math.hpp"
+#include "kernel_common.hpp"
 
 using namespace invpref;
 
 namespace {
-
-constexpr int kRow = 16;          // lanes per interaction
-constexpr int kLossSlots = 8;     // 5 used
-
-struct DevTables {
-    const float *Pu, *Qi, *Pa, *Qa, *Ev, *W, *b;
-    int U, I, E, D;
-};
-struct DevGrads {
-    float *Pu, *Qi, *Pa, *Qa, *Ev, *W, *b;
-};
-
-__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-__device__ __forceinline__ float4 f4mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-
-// gather one embedding row into the lane's NC chunks (zero beyond D)
-template <int NC, bool VEC>
-__device__ __forceinline__ void load_row(const float *__restrict__ base, int64_t row, int D, int l16, float4 (&r)[NC]) {
-    const float *p = base + row * (int64_t)D;
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        const int i0 = (l16 + kRow * c) * 4;
-        if (VEC) {
-            r[c] = (i0 < D) ? *reinterpret_cast<const float4 *>(p + i0) : f4zero();
-        } else {
-            r[c].x = (i0 + 0 < D) ? p[i0 + 0] : 0.f;
-            r[c].y = (i0 + 1 < D) ? p[i0 + 1] : 0.f;
-            r[c].z = (i0 + 2 < D) ? p[i0 + 2] : 0.f;
-            r[c].w = (i0 + 3 < D) ? p[i0 + 3] : 0.f;
-        }
-    }
-}
-// a row of an LDS-resident [E][DP] table (DP = NC*64, zero padded)
-template <int NC>
-__device__ __forceinline__ void lds_row(const float *tab, int e, int l16, float4 (&r)[NC]) {
-#pragma unroll
-    for (int c = 0; c < NC; c++) r[c] = *reinterpret_cast<const float4 *>(tab + e * (NC * 64) + (l16 + kRow * c) * 4);
-}
-
-template <int NC>
-__device__ __forceinline__ float dot2(const float4 (&a)[NC], const float4 (&b)[NC]) {
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        s = __builtin_fmaf(a[c].x, b[c].x, s);
-        s = __builtin_fmaf(a[c].y, b[c].y, s);
-        s = __builtin_fmaf(a[c].z, b[c].z, s);
-        s = __builtin_fmaf(a[c].w, b[c].w, s);
-    }
-    return row16_sum(s);
-}
-template <int NC>
-__device__ __forceinline__ float dot3(const float4 (&a)[NC], const float4 (&b)[NC], const float4 (&cc)[NC]) {
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        s = __builtin_fmaf(a[c].x * b[c].x, cc[c].x, s);
-        s = __builtin_fmaf(a[c].y * b[c].y, cc[c].y, s);
-        s = __builtin_fmaf(a[c].z * b[c].z, cc[c].z, s);
-        s = __builtin_fmaf(a[c].w * b[c].w, cc[c].w, s);
-    }
-    return row16_sum(s);
-}
-
-// stage a small [E][D] table into LDS as [E][DP] zero padded
-__device__ __forceinline__ void stage_table(float *dst, const float *__restrict__ src, int E, int D, int DP) {
-    for (int i = threadIdx.x; i < E * DP; i += blockDim.x) {
-        const int e = i / DP, d = i - e * DP;
-        dst[i] = (d < D) ? src[e * D + d] : 0.f;
-    }
-}
-
-__device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
-    return x;
-}
-
-__device__ __forceinline__ void atomic_add_f4(float *p, float4 v, int i0, int D, bool vec) {
-    if (vec || i0 + 3 < D) {
-        atomicAdd(p + i0 + 0, v.x);
-        atomicAdd(p + i0 + 1, v.y);
-        atomicAdd(p + i0 + 2, v.z);
-        atomicAdd(p + i0 + 3, v.w);
-    } else {
-        if (i0 + 0 < D) atomicAdd(p + i0 + 0, v.x);
-        if (i0 + 1 < D) atomicAdd(p + i0 + 1, v.y);
-        if (i0 + 2 < D) atomicAdd(p + i0 + 2, v.z);
-    }
-}
 
 // =====================================================================================
 // forward  (models.py:307-326 / :448-467)
@@ -168,9 +74,6 @@ __global__ __launch_bounds__(256) void forward_kernel(DevTables t, const int64_t
 // Per workgroup: gEv/gW/gb and the five loss sums are accumulated in LDS and written as one
 // partial slab; mstep_finish_kernel folds the slabs (no same-address global atomics).
 // =====================================================================================
-struct StepScalars {
-    float ca, cb, cc, alpha, invB, r2, r1;
-};
 
 // UPSTREAM = true turns the same kernel into the plain backward of forward(): the per-sample
 // upstream gradients (d invariant_score, d env_aware_score, d env_outputs) come from memory instead
@@ -449,15 +352,6 @@ __global__ __launch_bounds__(1024) void mstep_finish_kernel(DevTables t, DevGrad
 // =====================================================================================
 // dense Adam over a flat buffer (torch.optim.Adam single-tensor rule; train.py:41,155-157)
 // =====================================================================================
-struct AdamScalars {
-    float step_size, bc2_sqrt, w1, b2, w2, eps;
-};
-__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, const AdamScalars &a) {
-    m = m + a.w1 * (g - m);
-    v = v * a.b2 + (a.w2 * g) * g;
-    const float denom = __builtin_sqrtf(v) / a.bc2_sqrt + a.eps;
-    p = p + ((-a.step_size) * m) / denom;
-}
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                    float *__restrict__ v, int64_t n, AdamScalars a, int zero_grad) {
     const int64_t n4 = n >> 2;
@@ -633,31 +527,6 @@ __global__ __launch_bounds__(256) void sample_weights_kernel(const int64_t *__re
 }
 
 // ------------------------------------------------------------------ host helpers
-inline int check_tables(const InvPrefTables *t) {
-    if (!t) return INVPREF_EINVAL;
-    if (t->user_num <= 0 || t->item_num <= 0 || t->env_num <= 0 || t->factor_num <= 0) return INVPREF_EINVAL;
-    if (t->factor_num > INVPREF_MAX_FACTORS || t->env_num > INVPREF_MAX_ENVS) return INVPREF_EUNSUPPORTED;
-    if (!t->embed_user_invariant || !t->embed_item_invariant || !t->embed_user_env_aware || !t->embed_item_env_aware ||
-        !t->embed_env || !t->classifier_weight || !t->classifier_bias)
-        return INVPREF_EINVAL;
-    return 0;
-}
-inline DevTables dev_tables(const InvPrefTables *t) {
-    return DevTables{t->embed_user_invariant, t->embed_item_invariant, t->embed_user_env_aware, t->embed_item_env_aware,
-                     t->embed_env, t->classifier_weight, t->classifier_bias,
-                     (int)t->user_num, (int)t->item_num, (int)t->env_num, (int)t->factor_num};
-}
-inline DevGrads dev_grads(const InvPrefTables *t) {
-    return DevGrads{t->embed_user_invariant, t->embed_item_invariant, t->embed_user_env_aware, t->embed_item_env_aware,
-                    t->embed_env, t->classifier_weight, t->classifier_bias};
-}
-inline int nc_of(int D) { return D <= 64 ? 1 : (D <= 128 ? 2 : 4); }
-inline int emax_of(int E) { return E <= 4 ? 4 : (E <= 8 ? 8 : 16); }
-inline bool vec_ok(const InvPrefTables *t) {
-    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-    return (t->factor_num % 4 == 0) && al(t->embed_user_invariant) && al(t->embed_item_invariant) &&
-           al(t->embed_user_env_aware) && al(t->embed_item_env_aware);
-}
 constexpr int kMstepThreads = 512, kMstepMaxBlocks = 512;
 constexpr int kEstepThreads = 256, kEstepMaxBlocks = 2048;
 inline int mstep_blocks(int64_t B) {

@@ -1,0 +1,705 @@
+// invpref_rows.hip -- the planned, atomic-free M-step ("row jobs") and its fused Adam.
+//
+// Why a plan: global float atomics run at ~1.3 TB/s chip-wide on MI355X whatever the schedule and
+// LDS float atomics retire about one lane per clock (measured here: an LDS-accumulating variant of
+// this kernel spent half its time in ds_add_f32).  The reference's minibatches are static --
+// utils.mini_batch (utils.py:12-19) yields the same contiguous, unshuffled slices every epoch -- so
+// the scatter pattern of each minibatch is inverted ONCE on the host (plan.py) into row jobs:
+//
+//   job   = one row of the user tables (or of the item tables) + the minibatch's interactions
+//           that touch it, cut into 1, 2, 4, 8 or 16 equal slices, one slice per 16-lane group;
+//   round = 16 group slots of one workgroup filled with jobs of one slice count;
+//   task  = a few consecutive rounds of one side, run by one 256-thread workgroup.
+//
+// A group keeps its row's two gradient rows (invariant / env-aware table) in REGISTERS while it
+// walks its slice (forward + analytic backward per interaction, partner rows gathered as coalesced
+// float4 from L2 / Infinity Cache).  Slices of one row meet through LDS with plain stores and a
+// fixed-order sum by the job's leader group, so the big-table gradients are bitwise reproducible.
+// The leader then finishes the row: gradient = sum + count * (L2/L1 term), and EITHER stores the
+// gradient row (multi-GPU path: all-reduce, then the stand-alone Adam kernel) OR applies Adam on the
+// spot and writes p', m', v' (single-GPU path: the gradient never reaches memory).
+// Every table row is a job, touched or not (dense-Adam semantics of torch.optim.Adam over
+// nn.Embedding(sparse=False), train.py:41: momentum keeps moving untouched rows), so nothing needs
+// zeroing.  Parameters are double-buffered (read old, write new): other workgroups still gather
+// the old rows.  Each interaction is evaluated twice (once for its user row, once for its item
+// row).  The E x D tables (embed_env, classifier) and the loss sums come from the user-side jobs:
+// per-group register partials -> workgroup reduction -> float atomics into a few replica slabs
+// (~2 KB per workgroup, 256-byte contiguous instructions) folded by rows_finish_kernel.
+#include <stdlib.h>
+
+#include "kernel_common.hpp"
+
+using namespace invpref;
+
+namespace {
+
+#ifndef ROWS_MIN_WAVES
+#define ROWS_MIN_WAVES 3  // workgroups per CU the register allocator must leave room for (4 spills)
+#endif
+
+constexpr int kReplicas = 64;   // replica slabs for the E x D gradients / loss sums
+constexpr int kGroups = 16;     // 16-lane groups per 256-thread workgroup
+
+struct RowsArgs {
+    const int4 *desc;             // [n_rounds][16][2]: see InvPrefRowPlan in include/invpref_hip.h
+    int n_rounds, n_item_rounds, rounds_per_task;
+    const int *oth[2], *pos[2];   // per side, in that side's sorted order: partner row, position in the minibatch
+    const int64_t *envs;          // minibatch base pointers, indexed by pos
+    const float *scores, *weights;
+    StepScalars k;
+    uint32_t flags;
+    float *slabs;
+    int fused;                    // 0: store gradient rows to g; 1: Adam on the spot -> np / m / v
+    float *g[4];                  // Pu, Qi, Pa, Qa gradient tables   (fused == 0)
+    float *np[4];                 // new parameter tables              (fused == 1)
+    float *m[4], *v[4];           // Adam moments                      (fused == 1)
+    AdamScalars ad;
+    unsigned long long *stamps;   // diagnostic builds only (INVPREF_STAMPS): [n_tasks][8] s_memrealtime ticks
+};
+
+// diagnostic phase stamp: drains the wave's outstanding memory operations first, so the latency of
+// a phase is charged to that phase.  Never executed unless a stamp buffer is passed.
+#define STAMP(i)                                                                  \
+    do {                                                                          \
+        if (a.stamps) {                                                           \
+            __builtin_amdgcn_s_waitcnt(0);                                        \
+            if (threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                         \
+    } while (0)
+
+template <int NC, bool VEC>
+__device__ __forceinline__ void store_row(float *__restrict__ base, int64_t row, int D, int l16, const float4 (&r)[NC]) {
+    float *p = base + row * (int64_t)D;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int i0 = (l16 + kRow * c) * 4;
+        if (VEC) {
+            if (i0 < D) *reinterpret_cast<float4 *>(p + i0) = r[c];
+        } else {
+            if (i0 + 0 < D) p[i0 + 0] = r[c].x;
+            if (i0 + 1 < D) p[i0 + 1] = r[c].y;
+            if (i0 + 2 < D) p[i0 + 2] = r[c].z;
+            if (i0 + 3 < D) p[i0 + 3] = r[c].w;
+        }
+    }
+}
+
+__device__ __forceinline__ void f4fma(float4 &acc, float s, float4 a) {
+    acc.x = __builtin_fmaf(s, a.x, acc.x); acc.y = __builtin_fmaf(s, a.y, acc.y);
+    acc.z = __builtin_fmaf(s, a.z, acc.z); acc.w = __builtin_fmaf(s, a.w, acc.w);
+}
+__device__ __forceinline__ void f4add(float4 &acc, float4 a) { acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+__device__ __forceinline__ float4 f4sel(bool c, float4 a) { return c ? a : f4zero(); }
+__device__ __forceinline__ float4 f4xor_lanes(float4 v, int m) {
+    return make_float4(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64), __shfl_xor(v.z, m, 64), __shfl_xor(v.w, m, 64));
+}
+
+// DREG ("dense areas"): the E x D partials (classifier weight / env table gradients) of the user-side
+// jobs are kept in LDS, one private area per WAVE, updated with plain read-modify-write; the four
+// groups of a wave take turns (wave-level fence between turns), so no atomics and no VGPRs are
+// spent.  For large E*D (four areas would not fit comfortably) the workgroup shares one area through
+// LDS atomics instead (slower, still correct).
+struct Sample {
+    int oth, ps;
+    float y;
+};
+
+template <int NC, bool VEC, int EMAX, bool DREG, bool USER>
+__device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a, const int4 task, float *lds) {
+    constexpr int DP = NC * 64;
+    constexpr int side = USER ? 0 : 1;
+    constexpr bool user_side = USER;
+    const int EDP = t.E * DP;
+    float *slots = lds;                                  // [16][2][DP] slice partials
+    float *sEv = slots + kGroups * 2 * DP, *sW = sEv + EDP, *sb = sW + EDP;   // staged small tables
+    float *red = sb + EMAX;                              // DREG: [4 waves][2*EDP]; else one shared [2*EDP]
+    float *ab = red + (DREG ? 4 : 1) * 2 * EDP, *aL = ab + EMAX;             // [EMAX], [kLossSlots]
+    // Adam moments of the rows being finished, prefetched by LDS-DMA (no VGPRs held across the
+    // interaction loop): [4 waves][m_inv, v_inv, m_env, v_env][NC chunks][64 lanes] float4
+    float4 *mv = reinterpret_cast<float4 *>(aL + kLossSlots);
+
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+    const bool dma = VEC && a.fused;
+    float4 *mv_wave = mv + wave * 4 * NC * 64;
+    const bool implicit = a.flags & INVPREF_IMPLICIT;
+    const bool rw_rec = a.flags & INVPREF_REWEIGHT_REC, rw_cls = a.flags & INVPREF_REWEIGHT_CLS;
+    const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
+    const StepScalars k = a.k;
+    const int *oth_ids = a.oth[side], *pos = a.pos[side];
+    const float *T_own_inv = user_side ? t.Pu : t.Qi, *T_own_env = user_side ? t.Pa : t.Qa;
+    const float *T_oth_inv = user_side ? t.Qi : t.Pu, *T_oth_env = user_side ? t.Qa : t.Pa;
+
+    STAMP(0);
+    // the first round's descriptor goes out before anything else: every gather below hangs on it
+    int4 d = a.desc[(task.y * kGroups + grp) * 2], d1 = a.desc[(task.y * kGroups + grp) * 2 + 1];
+    stage_table(sEv, t.Ev, t.E, t.D, DP);
+    stage_table(sW, t.W, t.E, t.D, DP);
+    for (int i = threadIdx.x; i < EMAX; i += blockDim.x) { sb[i] = (i < t.E) ? t.b[i] : 0.f; ab[i] = 0.f; }
+    if (threadIdx.x < kLossSlots) aL[threadIdx.x] = 0.f;
+    if (user_side) {
+        if (DREG) {  // each wave clears its own area (only that wave ever touches it)
+            float *area = red + wave * 2 * EDP;
+            for (int i = (threadIdx.x & 63) * 4; i < 2 * EDP; i += 256) *reinterpret_cast<float4 *>(area + i) = f4zero();
+        } else {
+            for (int i = threadIdx.x; i < 2 * EDP; i += blockDim.x) red[i] = 0.f;
+        }
+    }
+    float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
+    float *area = red + (DREG ? wave * 2 * EDP : 0);  // [EDP] env-table part, [EDP] classifier part
+    STAMP(1);
+
+    for (int r = task.y; r < task.y + task.z; r++) {
+        // one 32-byte descriptor per group slot; slices of up to two interactions carry them inline
+        // (partner row, position, label), so the gathers below depend on this single load only
+        if (r != task.y) { d = a.desc[(r * kGroups + grp) * 2]; d1 = a.desc[(r * kGroups + grp) * 2 + 1]; }
+        const int row = d.x, meta = d.y;
+        const bool active = row >= 0, leader = meta & 1;
+        const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 3;
+        const int nsmp = mode == 3 ? d.w - d.z : mode;
+        if (r == task.y) STAMP(2);
+        auto sample_at = [&](int sidx) {
+            Sample sm;
+            if (mode == 3) { sm.oth = oth_ids[d.z + sidx]; sm.ps = pos[d.z + sidx]; sm.y = a.scores[sm.ps]; }
+            else if (sidx == 0) { sm.oth = d.z; sm.ps = d.w; sm.y = __builtin_bit_cast(float, d1.x); }
+            else { sm.oth = d1.y; sm.ps = d1.z; sm.y = __builtin_bit_cast(float, d1.w); }
+            return sm;
+        };
+        // everything that depends only on the descriptor is requested together: own rows, the Adam
+        // moments of the row (needed last) and the first interaction's partner rows / env / weight
+        float4 oi[NC], oe[NC], gi[NC], ge[NC], pi[NC], pe[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) oi[c] = oe[c] = gi[c] = ge[c] = pi[c] = pe[c] = f4zero();
+        Sample cur{0, 0, 0.f};
+        int e = 0;
+        float w = 1.f;
+        if (active) {
+            load_row<NC, VEC>(T_own_inv, row, t.D, l16, oi);
+            load_row<NC, VEC>(T_own_env, row, t.D, l16, oe);
+            if (nsmp > 0) {
+                cur = sample_at(0);
+                load_row<NC, VEC>(T_oth_inv, cur.oth, t.D, l16, pi);
+                load_row<NC, VEC>(T_oth_env, cur.oth, t.D, l16, pe);
+                e = (int)a.envs[cur.ps];
+                if (rw_rec || rw_cls) w = a.weights[cur.ps];
+            }
+        }
+        if (dma) {
+            // each lane sends its 16-byte piece of the row's four moment rows straight to LDS; the
+            // destination of a wave instruction is one contiguous 1 KiB block, lane-major
+            const bool mine = active && leader;
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) {
+                const float *src_tab = (tn & 1) ? a.v[(tn >> 1) * 2 + side] : a.m[(tn >> 1) * 2 + side];
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const int i0 = (l16 + kRow * c) * 4;
+                    if (mine && i0 < t.D)
+                        __builtin_amdgcn_global_load_lds(
+                            (const __attribute__((address_space(1))) void *)(src_tab + (int64_t)row * t.D + i0),
+                            (__attribute__((address_space(3))) void *)(mv_wave + (tn * NC + c) * 64), 16, 0, 0);
+                }
+            }
+        }
+        if (r == task.y) { __syncthreads(); STAMP(3); }  // staged tables visible (the gathers above are in flight)
+        for (int sidx = 0; sidx < nsmp; sidx++) {
+            // request the next interaction before working on this one
+            float4 pin[NC], pen[NC];
+            Sample nxt{0, 0, 0.f};
+            int en = 0;
+            float wn = 1.f;
+            if (sidx + 1 < nsmp) {
+                nxt = sample_at(sidx + 1);
+                load_row<NC, VEC>(T_oth_inv, nxt.oth, t.D, l16, pin);
+                load_row<NC, VEC>(T_oth_env, nxt.oth, t.D, l16, pen);
+                en = (int)a.envs[nxt.ps];
+                if (rw_rec || rw_cls) wn = a.weights[nxt.ps];
+            }
+            const float y = cur.y;
+            const float w_rec = rw_rec ? w : 1.f, w_cls = rw_cls ? w : 1.f;
+            const float cw_rec = w_rec * k.invB, cw_cls = w_cls * k.invB;
+            float4 ev[NC];
+            lds_row<NC>(sEv, e, l16, ev);
+            const float p = user_side ? dot2<NC>(oi, pi) : dot2<NC>(pi, oi);
+            const float q = user_side ? dot3<NC>(oe, pe, ev) : dot3<NC>(pe, oe, ev);
+            float g_p, g_q, li, le;
+            if (implicit) {
+                const float sp = f_sigmoid(p), sq = f_sigmoid(q), sv = sp * sq;
+                li = f_bce(sp, y);
+                le = f_bce(sv, y);
+                const float d_inv = k.ca * cw_rec * f_dbce(sp, y);
+                const float d_env = k.cb * cw_rec * f_dbce(sv, y);
+                g_p = (d_inv + d_env * sq) * (sp * (1.f - sp));
+                g_q = d_env * sp * (sq * (1.f - sq));
+            } else {
+                const float s2 = p + q;
+                li = (p - y) * (p - y);
+                le = (s2 - y) * (s2 - y);
+                const float d_env = k.cb * cw_rec * 2.f * (s2 - y);
+                g_p = k.ca * cw_rec * 2.f * (p - y) + d_env;
+                g_q = d_env;
+            }
+            float4 x[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) x[c] = user_side ? f4mul(oi[c], pi[c]) : f4mul(pi[c], oi[c]);
+            float z[EMAX], mx = -__builtin_inff();
+#pragma unroll
+            for (int c = 0; c < EMAX; c++) {
+                z[c] = -__builtin_inff();
+                if (c < t.E) {
+                    float4 wr[NC];
+                    lds_row<NC>(sW, c, l16, wr);
+                    z[c] = dot2<NC>(x, wr) + sb[c];
+                    mx = z[c] > mx ? z[c] : mx;
+                }
+            }
+            float se = 0.f, ze = 0.f;
+#pragma unroll
+            for (int c = 0; c < EMAX; c++)
+                if (c < t.E) { z[c] = f_exp(z[c] - mx); se += z[c]; }
+#pragma unroll
+            for (int c = 0; c < EMAX; c++) ze = (c == e) ? z[c] : ze;
+            const float rse = f_rcp(se);
+            float gz[EMAX];
+            float4 gx[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) gx[c] = f4zero();
+#pragma unroll
+            for (int c = 0; c < EMAX; c++) {
+                gz[c] = 0.f;
+                if (c < t.E) {
+                    gz[c] = k.cc * cw_cls * (z[c] * rse - (c == e ? 1.f : 0.f));
+                    float4 wr[NC];
+                    lds_row<NC>(sW, c, l16, wr);
+#pragma unroll
+                    for (int jj = 0; jj < NC; jj++) f4fma(gx[jj], gz[c], wr[jj]);
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < NC; jj++) {
+                float4 gip;
+                gip.x = g_p - k.alpha * gx[jj].x; gip.y = g_p - k.alpha * gx[jj].y;
+                gip.z = g_p - k.alpha * gx[jj].z; gip.w = g_p - k.alpha * gx[jj].w;
+                f4add(gi[jj], f4mul(gip, pi[jj]));
+                f4fma(ge[jj], g_q, f4mul(pe[jj], ev[jj]));
+            }
+            if (user_side) {
+                // ---- E x D partials: env-table row e gets g_q * Pa*Qa (+ its regulariser), classifier row c gets gz_c * x
+                float4 o[NC];
+#pragma unroll
+                for (int jj = 0; jj < NC; jj++) {
+                    o[jj] = f4mul(oe[jj], pe[jj]);
+                    o[jj].x *= g_q; o[jj].y *= g_q; o[jj].z *= g_q; o[jj].w *= g_q;
+                    if (reg_env) {
+                        o[jj].x += 2.f * k.r2 * ev[jj].x + 2.f * k.r1 * c_sign(ev[jj].x);
+                        o[jj].y += 2.f * k.r2 * ev[jj].y + 2.f * k.r1 * c_sign(ev[jj].y);
+                        o[jj].z += 2.f * k.r2 * ev[jj].z + 2.f * k.r1 * c_sign(ev[jj].z);
+                        o[jj].w += 2.f * k.r2 * ev[jj].w + 2.f * k.r1 * c_sign(ev[jj].w);
+                    }
+                }
+                if (DREG) {
+#pragma unroll
+                    for (int turn = 0; turn < 4; turn++) {  // the wave's four groups, one after the other
+                        if ((grp & 3) == turn) {
+#pragma unroll
+                            for (int jj = 0; jj < NC; jj++) {
+                                float4 *dst = reinterpret_cast<float4 *>(area + e * DP + (l16 + kRow * jj) * 4);
+                                float4 cv = *dst;
+                                f4add(cv, o[jj]);
+                                *dst = cv;
+#pragma unroll
+                                for (int c = 0; c < EMAX; c++) {
+                                    if (c < t.E) {
+                                        float4 *dw = reinterpret_cast<float4 *>(area + EDP + c * DP + (l16 + kRow * jj) * 4);
+                                        float4 cw = *dw;
+                                        f4fma(cw, gz[c], x[jj]);
+                                        *dw = cw;
+                                    }
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                } else {
+#pragma unroll
+                    for (int jj = 0; jj < NC; jj++) {
+                        float *dst = area + e * DP + (l16 + kRow * jj) * 4;
+                        atomicAdd(dst + 0, o[jj].x); atomicAdd(dst + 1, o[jj].y); atomicAdd(dst + 2, o[jj].z); atomicAdd(dst + 3, o[jj].w);
+#pragma unroll
+                        for (int c = 0; c < EMAX; c++) {
+                            if (c < t.E) {
+                                float *dw = area + EDP + c * DP + (l16 + kRow * jj) * 4;
+                                atomicAdd(dw + 0, gz[c] * x[jj].x); atomicAdd(dw + 1, gz[c] * x[jj].y);
+                                atomicAdd(dw + 2, gz[c] * x[jj].z); atomicAdd(dw + 3, gz[c] * x[jj].w);
+                            }
+                        }
+                    }
+                }
+                if (l16 == 0) {
+#pragma unroll
+                    for (int c = 0; c < EMAX; c++) if (c < t.E) atomicAdd(ab + c, gz[c]);
+                }
+                // regulariser REPORTS over the four rows of the interaction (env rows weigh double)
+#pragma unroll
+                for (int jj = 0; jj < NC; jj++) {
+                    float s2 = oi[jj].x * oi[jj].x + oi[jj].y * oi[jj].y + oi[jj].z * oi[jj].z + oi[jj].w * oi[jj].w;
+                    s2 += oe[jj].x * oe[jj].x + oe[jj].y * oe[jj].y + oe[jj].z * oe[jj].z + oe[jj].w * oe[jj].w;
+                    s2 += pi[jj].x * pi[jj].x + pi[jj].y * pi[jj].y + pi[jj].z * pi[jj].z + pi[jj].w * pi[jj].w;
+                    s2 += pe[jj].x * pe[jj].x + pe[jj].y * pe[jj].y + pe[jj].z * pe[jj].z + pe[jj].w * pe[jj].w;
+                    float s1 = fabsf(oi[jj].x) + fabsf(oi[jj].y) + fabsf(oi[jj].z) + fabsf(oi[jj].w);
+                    s1 += fabsf(oe[jj].x) + fabsf(oe[jj].y) + fabsf(oe[jj].z) + fabsf(oe[jj].w);
+                    s1 += fabsf(pi[jj].x) + fabsf(pi[jj].y) + fabsf(pi[jj].z) + fabsf(pi[jj].w);
+                    s1 += fabsf(pe[jj].x) + fabsf(pe[jj].y) + fabsf(pe[jj].z) + fabsf(pe[jj].w);
+                    if (reg_env) {
+                        s2 += 2.f * (ev[jj].x * ev[jj].x + ev[jj].y * ev[jj].y + ev[jj].z * ev[jj].z + ev[jj].w * ev[jj].w);
+                        s1 += 2.f * (fabsf(ev[jj].x) + fabsf(ev[jj].y) + fabsf(ev[jj].z) + fabsf(ev[jj].w));
+                    }
+                    accL2 += s2;
+                    accL1 += s1;
+                }
+                if (l16 == 0) { accLi += li * w_rec; accLe += le * w_rec; accLc += -f_log(ze * rse) * w_cls; }
+            }
+            // rotate in the prefetched interaction
+            cur = nxt; e = en; w = wn;
+#pragma unroll
+            for (int c = 0; c < NC; c++) { pi[c] = pin[c]; pe[c] = pen[c]; }
+        }
+        if (r == task.y) STAMP(4);
+        // ---- slices of one row meet through LDS: plain stores, fixed-order sum by the leader
+        if (slices > 1) {  // same for every slot of a round, idle slots included
+            float *mine = slots + grp * 2 * DP;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                *reinterpret_cast<float4 *>(mine + (l16 + kRow * c) * 4) = gi[c];
+                *reinterpret_cast<float4 *>(mine + DP + (l16 + kRow * c) * 4) = ge[c];
+            }
+            __syncthreads();
+            if (active && leader) {
+                for (int s = 1; s < slices; s++) {
+                    const float *oth_slot = slots + (grp + s) * 2 * DP;
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        f4add(gi[c], *reinterpret_cast<const float4 *>(oth_slot + (l16 + kRow * c) * 4));
+                        f4add(ge[c], *reinterpret_cast<const float4 *>(oth_slot + DP + (l16 + kRow * c) * 4));
+                    }
+                }
+            }
+            if (r + 1 < task.y + task.z) __syncthreads();  // the slots are rewritten by the next round
+        }
+        if (r == task.y) STAMP(5);
+        // ---- the leader finishes the row
+        if (active && leader) {
+            const float cnt = (float)(meta >> 8);
+            if (cnt != 0.f) {  // an untouched row has a zero gradient; Adam still moves it (dense semantics)
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    gi[c].x += cnt * (k.r2 * oi[c].x + k.r1 * c_sign(oi[c].x)); gi[c].y += cnt * (k.r2 * oi[c].y + k.r1 * c_sign(oi[c].y));
+                    gi[c].z += cnt * (k.r2 * oi[c].z + k.r1 * c_sign(oi[c].z)); gi[c].w += cnt * (k.r2 * oi[c].w + k.r1 * c_sign(oi[c].w));
+                    ge[c].x += cnt * (k.r2 * oe[c].x + k.r1 * c_sign(oe[c].x)); ge[c].y += cnt * (k.r2 * oe[c].y + k.r1 * c_sign(oe[c].y));
+                    ge[c].z += cnt * (k.r2 * oe[c].z + k.r1 * c_sign(oe[c].z)); ge[c].w += cnt * (k.r2 * oe[c].w + k.r1 * c_sign(oe[c].w));
+                }
+            }
+            if (!a.fused) {
+                store_row<NC, VEC>(a.g[side], row, t.D, l16, gi);
+                store_row<NC, VEC>(a.g[2 + side], row, t.D, l16, ge);
+            } else {
+                float4 mi[NC], vi[NC], me[NC], ve[NC];
+                if (dma) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA pieces have landed
+                    const int lane = threadIdx.x & 63;
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        mi[c] = mv_wave[(0 * NC + c) * 64 + lane]; vi[c] = mv_wave[(1 * NC + c) * 64 + lane];
+                        me[c] = mv_wave[(2 * NC + c) * 64 + lane]; ve[c] = mv_wave[(3 * NC + c) * 64 + lane];
+                    }
+                } else {
+                    load_row<NC, VEC>(a.m[side], row, t.D, l16, mi);
+                    load_row<NC, VEC>(a.v[side], row, t.D, l16, vi);
+                    load_row<NC, VEC>(a.m[2 + side], row, t.D, l16, me);
+                    load_row<NC, VEC>(a.v[2 + side], row, t.D, l16, ve);
+                }
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    adam1f(oi[c].x, gi[c].x, mi[c].x, vi[c].x, a.ad); adam1f(oi[c].y, gi[c].y, mi[c].y, vi[c].y, a.ad);
+                    adam1f(oi[c].z, gi[c].z, mi[c].z, vi[c].z, a.ad); adam1f(oi[c].w, gi[c].w, mi[c].w, vi[c].w, a.ad);
+                    adam1f(oe[c].x, ge[c].x, me[c].x, ve[c].x, a.ad); adam1f(oe[c].y, ge[c].y, me[c].y, ve[c].y, a.ad);
+                    adam1f(oe[c].z, ge[c].z, me[c].z, ve[c].z, a.ad); adam1f(oe[c].w, ge[c].w, me[c].w, ve[c].w, a.ad);
+                }
+                store_row<NC, VEC>(a.np[side], row, t.D, l16, oi);
+                store_row<NC, VEC>(a.m[side], row, t.D, l16, mi);
+                store_row<NC, VEC>(a.v[side], row, t.D, l16, vi);
+                store_row<NC, VEC>(a.np[2 + side], row, t.D, l16, oe);
+                store_row<NC, VEC>(a.m[2 + side], row, t.D, l16, me);
+                store_row<NC, VEC>(a.v[2 + side], row, t.D, l16, ve);
+            }
+        }
+    }
+
+    STAMP(6);
+    if (!user_side) return;
+    // ---- dense partials of this workgroup -> replica slab
+    accLi = wave_sum(accLi); accLe = wave_sum(accLe); accLc = wave_sum(accLc);
+    accL2 = wave_sum(accL2); accL1 = wave_sum(accL1);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(aL + 0, accLi); atomicAdd(aL + 1, accLe); atomicAdd(aL + 2, accLc);
+        atomicAdd(aL + 3, accL2); atomicAdd(aL + 4, accL1);
+    }
+    __syncthreads();
+    const int slab_len = 2 * EDP + EMAX + kLossSlots;
+    float *slab = a.slabs + (int64_t)(blockIdx.x % kReplicas) * slab_len;
+    for (int i = threadIdx.x * 4; i < 2 * EDP; i += blockDim.x * 4) {
+        float4 x = *reinterpret_cast<const float4 *>(red + i);
+        if (DREG) {
+#pragma unroll
+            for (int wq = 1; wq < 4; wq++) f4add(x, *reinterpret_cast<const float4 *>(red + wq * 2 * EDP + i));
+        }
+        if (x.x != 0.f) atomicAdd(slab + i + 0, x.x);
+        if (x.y != 0.f) atomicAdd(slab + i + 1, x.y);
+        if (x.z != 0.f) atomicAdd(slab + i + 2, x.z);
+        if (x.w != 0.f) atomicAdd(slab + i + 3, x.w);
+    }
+    for (int i = threadIdx.x; i < EMAX + kLossSlots; i += blockDim.x) {
+        const float x = ab[i];  // ab then aL are adjacent
+        if (x != 0.f) atomicAdd(slab + 2 * EDP + i, x);
+    }
+    STAMP(7);
+}
+
+template <int NC, bool VEC, int EMAX, bool DREG>
+__global__ __launch_bounds__(256, ROWS_MIN_WAVES) void mstep_rows_kernel(DevTables t, RowsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // workgroup b runs rounds [b*rpt, (b+1)*rpt); the item-side rounds come first (they hold the longest
+    // jobs) and are padded to a multiple of rpt, so a workgroup never mixes sides.  One code path per
+    // side: the item side carries no loss / dense-gradient work.
+    const int r0 = blockIdx.x * a.rounds_per_task;
+    const int nr = min(a.rounds_per_task, a.n_rounds - r0);
+    const int4 task = make_int4(r0 < a.n_item_rounds ? 1 : 0, r0, nr, 0);
+    if (task.x == 0) rows_task<NC, VEC, EMAX, DREG, true>(t, a, task, lds);
+    else rows_task<NC, VEC, EMAX, DREG, false>(t, a, task, lds);
+}
+
+// folds (and re-zeroes) the replica slabs: gradients of embed_env / classifier (+ classifier
+// regulariser, models.py:211-217), the six loss outputs; then either stores those gradients
+// (fused == 0) or applies Adam to the three small tables (fused == 1).
+struct SmallTables {
+    float *gEv, *gW, *gb;        // fused == 0
+    float *nEv, *nW, *nb;        // fused == 1: new parameters
+    float *mEv, *mW, *mb, *vEv, *vW, *vb;
+};
+__global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTables o, float *__restrict__ slabs,
+                                                           int nslabs, int DP, int EMAX, StepScalars k, float l2,
+                                                           float l1, int64_t Bnorm, uint32_t flags, int fused,
+                                                           AdamScalars ad, float *__restrict__ losses6) {
+    __shared__ double part[16][64];
+    __shared__ double sloss[kLossSlots];
+    __shared__ double sreg[2];
+    const int EDP = t.E * DP, slab_len = 2 * EDP + EMAX + kLossSlots;
+    const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + col;
+    double acc = 0.0;
+    if (idx < slab_len)
+        for (int s = sub; s < nslabs; s += 16) {
+            float *q = slabs + (int64_t)s * slab_len + idx;
+            acc += (double)__builtin_nontemporal_load(q);
+            *q = 0.f;  // leave the replicas zeroed for the next step
+        }
+    part[sub][col] = acc;
+    if (threadIdx.x < 2) sreg[threadIdx.x] = 0.0;
+    __syncthreads();
+    const bool dense = (flags & INVPREF_DENSE_REG) && !(flags & INVPREF_REG_ONLY_EMBED);
+    const bool last_block = blockIdx.x == gridDim.x - 1;
+    if (sub == 0 && idx < slab_len) {
+        double v = 0.0;
+        for (int s = 0; s < 16; s++) v += part[s][col];
+        if (idx < 2 * EDP) {
+            const bool isW = idx >= EDP;
+            const int r = isW ? idx - EDP : idx;
+            const int e = r / DP, d = r - e * DP;
+            if (d < t.D) {
+                const int off = e * t.D + d;
+                float gv = (float)v;
+                float pv = isW ? t.W[off] : t.Ev[off];
+                if (isW && dense) gv += 2.f * l2 / ((float)t.D * (float)t.E) * pv + l1 / ((float)t.D * (float)t.E) * c_sign(pv);
+                if (!fused) {
+                    (isW ? o.gW : o.gEv)[off] = gv;
+                } else {
+                    float *mp = (isW ? o.mW : o.mEv) + off, *vp = (isW ? o.vW : o.vEv) + off;
+                    float mm = *mp, vv = *vp;
+                    adam1(pv, gv, mm, vv, ad);
+                    (isW ? o.nW : o.nEv)[off] = pv; *mp = mm; *vp = vv;
+                }
+            }
+        } else if (idx < 2 * EDP + EMAX) {
+            const int e = idx - 2 * EDP;
+            if (e < t.E) {
+                float gv = (float)v, pv = t.b[e];
+                if (dense) gv += 2.f * l2 / (float)t.E * pv + l1 / (float)t.E * c_sign(pv);
+                if (!fused) {
+                    o.gb[e] = gv;
+                } else {
+                    float mm = o.mb[e], vv = o.vb[e];
+                    adam1(pv, gv, mm, vv, ad);
+                    o.nb[e] = pv; o.mb[e] = mm; o.vb[e] = vv;
+                }
+            }
+        } else {
+            sloss[idx - 2 * EDP - EMAX] = v;
+        }
+    }
+    __syncthreads();
+    if (last_block && losses6) {
+        if (dense && threadIdx.x < 64) {
+            double w2 = 0, w1 = 0, b2 = 0, b1 = 0;
+            for (int i = threadIdx.x; i < t.E * t.D; i += 64) { const double x = t.W[i]; w2 += x * x; w1 += fabs(x); }
+            for (int i = threadIdx.x; i < t.E; i += 64) { const double x = t.b[i]; b2 += x * x; b1 += fabs(x); }
+            double r2v = w2 / ((double)t.D * t.E) + b2 / (double)t.E, r1v = w1 / ((double)t.D * t.E) + b1 / (double)t.E;
+            for (int m = 32; m >= 1; m >>= 1) { r2v += __shfl_xor(r2v, m, 64); r1v += __shfl_xor(r1v, m, 64); }
+            if (threadIdx.x == 0) { sreg[0] = r2v; sreg[1] = r1v; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double Bn = (double)Bnorm, BD2 = Bn * (double)t.D * 2.0;
+            const double Li = sloss[0] / Bn, Le = sloss[1] / Bn, Lc = sloss[2] / Bn;
+            const double L2 = sloss[3] / BD2 + sreg[0], L1 = sloss[4] / BD2 + sreg[1];
+            losses6[0] += (float)Li; losses6[1] += (float)Le; losses6[2] += (float)Lc;
+            losses6[3] += (float)L2; losses6[4] += (float)L1;
+            losses6[5] += (float)((double)k.ca * Li + (double)k.cb * Le + (double)k.cc * Lc + (double)l2 * L2 + (double)l1 * L1);
+        }
+    }
+}
+
+inline bool dreg_of(int nc, int emax) { return nc * emax <= 4; }
+
+size_t rows_lds_bytes(int E, int nc, int emax) {
+    const size_t DP = (size_t)nc * 64, EDP = (size_t)E * DP;
+    const size_t red = (dreg_of(nc, emax) ? 4 : 1) * 2 * EDP;
+    return sizeof(float) * (kGroups * 2 * DP + 2 * EDP + emax + red + emax + kLossSlots) + 16 * (size_t)(4 * 4 * nc * 64);
+}
+
+template <typename K>
+int ensure_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const int64_t *envs, const float *scores,
+                const float *weights, int64_t batch_norm, const InvPrefCoefs *coefs, uint32_t flags, float *losses6,
+                void *workspace, size_t workspace_bytes, hipStream_t st, int fused, const InvPrefTables *grads,
+                const InvPrefTables *new_tables, const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
+                const AdamScalars &ad) {
+    int rc = check_tables(tables);
+    if (rc) return rc;
+    if (!plan || !coefs || !losses6 || !workspace || !envs || !scores || batch_norm <= 0) return INVPREF_EINVAL;
+    if (plan->n_rounds <= 0 || plan->rounds_per_task <= 0 || plan->n_item_rounds < 0 ||
+        plan->n_item_rounds > plan->n_rounds || plan->n_item_rounds % plan->rounds_per_task != 0 || !plan->desc ||
+        !plan->other_user || !plan->pos_user || !plan->other_item || !plan->pos_item)
+        return INVPREF_EINVAL;
+    if ((flags & (INVPREF_REWEIGHT_REC | INVPREF_REWEIGHT_CLS)) && !weights) return INVPREF_EINVAL;
+    const DevTables t = dev_tables(tables);
+    bool vec = vec_ok(tables);
+    RowsArgs a{};
+    if (!fused) {
+        if ((rc = check_tables(grads))) return rc;
+        vec = vec && vec_ok(grads);
+        a.g[0] = grads->embed_user_invariant; a.g[1] = grads->embed_item_invariant;
+        a.g[2] = grads->embed_user_env_aware; a.g[3] = grads->embed_item_env_aware;
+    } else {
+        if ((rc = check_tables(new_tables)) || (rc = check_tables(exp_avg)) || (rc = check_tables(exp_avg_sq))) return rc;
+        vec = vec && vec_ok(new_tables) && vec_ok(exp_avg) && vec_ok(exp_avg_sq);
+        const InvPrefTables *src[3] = {new_tables, exp_avg, exp_avg_sq};
+        float **dst[3] = {a.np, a.m, a.v};
+        for (int i = 0; i < 3; i++) {
+            dst[i][0] = src[i]->embed_user_invariant; dst[i][1] = src[i]->embed_item_invariant;
+            dst[i][2] = src[i]->embed_user_env_aware; dst[i][3] = src[i]->embed_item_env_aware;
+        }
+    }
+    const int nc = vec ? nc_of(t.D) : 4, emax = emax_of(t.E);
+    const int DP = nc * 64, EDP = t.E * DP;
+    const int slab_len = 2 * EDP + emax + kLossSlots;
+    if (workspace_bytes < sizeof(float) * (size_t)slab_len * kReplicas) return INVPREF_EWORKSPACE;
+    StepScalars k;
+    k.ca = coefs->invariant_coe; k.cb = coefs->env_aware_coe; k.cc = coefs->env_coe; k.alpha = coefs->alpha;
+    k.invB = 1.0f / (float)batch_norm;
+    k.r2 = coefs->L2_coe / ((float)batch_norm * (float)t.D);
+    k.r1 = coefs->L1_coe / (2.0f * (float)batch_norm * (float)t.D);
+    a.desc = reinterpret_cast<const int4 *>(plan->desc);
+    a.n_rounds = plan->n_rounds; a.n_item_rounds = plan->n_item_rounds; a.rounds_per_task = plan->rounds_per_task;
+    const int n_tasks = (plan->n_rounds + plan->rounds_per_task - 1) / plan->rounds_per_task;
+    a.oth[0] = plan->other_user; a.pos[0] = plan->pos_user;
+    a.oth[1] = plan->other_item; a.pos[1] = plan->pos_item;
+    a.envs = envs; a.scores = scores; a.weights = weights;
+    a.k = k; a.flags = flags; a.slabs = (float *)workspace; a.fused = fused; a.ad = ad;
+    // diagnostics: INVPREF_STAMPS=<device pointer, hex> makes the kernel write phase time stamps there
+    static const char *stamp_env = getenv("INVPREF_STAMPS");
+    a.stamps = stamp_env ? reinterpret_cast<unsigned long long *>(strtoull(stamp_env, nullptr, 16)) : nullptr;
+    const size_t lds = rows_lds_bytes(t.E, nc, emax);
+    if (lds > 160 * 1024) return INVPREF_EUNSUPPORTED;
+#define CALL(NCV, VECV, EMAXV, DREGV)                                                                 \
+    do {                                                                                              \
+        if ((rc = ensure_lds(mstep_rows_kernel<NCV, VECV, EMAXV, DREGV>, lds))) return rc;            \
+        hipLaunchKernelGGL((mstep_rows_kernel<NCV, VECV, EMAXV, DREGV>), dim3(n_tasks), dim3(256), lds, st, t, a); \
+    } while (0)
+    if (!vec) {
+        if (emax == 4) CALL(4, false, 4, false); else if (emax == 8) CALL(4, false, 8, false); else CALL(4, false, 16, false);
+    } else if (nc == 1) {
+        if (emax == 4) CALL(1, true, 4, true); else if (emax == 8) CALL(1, true, 8, false); else CALL(1, true, 16, false);
+    } else if (nc == 2) {
+        if (emax == 4) CALL(2, true, 4, false); else if (emax == 8) CALL(2, true, 8, false); else CALL(2, true, 16, false);
+    } else {
+        if (emax == 4) CALL(4, true, 4, false); else if (emax == 8) CALL(4, true, 8, false); else CALL(4, true, 16, false);
+    }
+#undef CALL
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return (int)err;
+    SmallTables o{};
+    if (!fused) {
+        o.gEv = grads->embed_env; o.gW = grads->classifier_weight; o.gb = grads->classifier_bias;
+    } else {
+        o.nEv = new_tables->embed_env; o.nW = new_tables->classifier_weight; o.nb = new_tables->classifier_bias;
+        o.mEv = exp_avg->embed_env; o.mW = exp_avg->classifier_weight; o.mb = exp_avg->classifier_bias;
+        o.vEv = exp_avg_sq->embed_env; o.vW = exp_avg_sq->classifier_weight; o.vb = exp_avg_sq->classifier_bias;
+    }
+    const int nfb = (slab_len + 63) / 64;
+    hipLaunchKernelGGL(rows_finish_kernel, dim3(nfb), dim3(1024), 0, st, t, o, (float *)workspace, kReplicas, DP, emax, k,
+                       coefs->L2_coe, coefs->L1_coe, batch_norm, flags, fused, ad, losses6);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t invpref_rows_workspace_bytes(const InvPrefTables *tables) {
+    if (check_tables(tables)) return 0;
+    const size_t slab_len = 2 * (size_t)tables->env_num * 256 + 16 + kLossSlots;
+    return sizeof(float) * slab_len * kReplicas;
+}
+
+int invpref_mstep_rows_grad_hip(const InvPrefTables *tables, const InvPrefTables *grads, const InvPrefRowPlan *plan,
+                                const int64_t *envs, const float *scores, const float *sample_weights,
+                                int64_t batch_norm, const InvPrefCoefs *coefs, uint32_t flags, float *losses6,
+                                void *workspace, size_t workspace_bytes, void *stream) {
+    return launch_rows(tables, plan, envs, scores, sample_weights, batch_norm, coefs, flags, losses6, workspace,
+                       workspace_bytes, (hipStream_t)stream, 0, grads, nullptr, nullptr, nullptr, AdamScalars{});
+}
+
+int invpref_mstep_rows_adam_hip(const InvPrefTables *tables, const InvPrefTables *new_tables,
+                                const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
+                                const InvPrefRowPlan *plan, const int64_t *envs, const float *scores,
+                                const float *sample_weights, int64_t batch_norm, const InvPrefCoefs *coefs,
+                                uint32_t flags, float *losses6, int64_t step, double lr, double beta1, double beta2,
+                                double eps, void *workspace, size_t workspace_bytes, void *stream) {
+    if (step < 1) return INVPREF_EINVAL;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    AdamScalars ad;
+    ad.step_size = (float)(lr / bc1);
+    ad.bc2_sqrt = (float)sqrt(bc2);
+    ad.w1 = (float)(1.0 - beta1);
+    ad.b2 = (float)beta2;
+    ad.w2 = (float)(1.0 - beta2);
+    ad.eps = (float)eps;
+    return launch_rows(tables, plan, envs, scores, sample_weights, batch_norm, coefs, flags, losses6, workspace,
+                       workspace_bytes, (hipStream_t)stream, 1, nullptr, new_tables, exp_avg, exp_avg_sq, ad);
+}
+
+}  // extern "C"

@@ -46,6 +46,13 @@ class Workspace:
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self.buf
 
+    def get_zeroed(self, nbytes: int) -> torch.Tensor:
+        """the owner path's replica slabs: zero-filled before first use, left zeroed by every call"""
+        z = getattr(self, 'zbuf', None)
+        if z is None or z.numel() < nbytes:
+            self.zbuf = z = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        return z
+
 
 def forward(params: Sequence[torch.Tensor], users, items, envs, implicit: bool):
     """InvPref{Implicit,Explicit}.forward (models.py:307-326 / :448-467), values only."""
@@ -167,3 +174,34 @@ def predict(user_table: torch.Tensor, item_table: torch.Tensor, users: torch.Ten
     check(lib().invpref_predict_hip(ptr(user_table), ptr(item_table), ptr(_ids(users, 'users')), n, I, D,
                                     int(bool(sigmoid)), ptr(out), stream_ptr()), 'invpref_predict_hip')
     return out
+
+
+def mstep_rows_grad(params, grads, dplan, envs, scores, sample_weights, batch_norm: int, coefs, flags: int,
+                     losses6: torch.Tensor, workspace: Workspace) -> None:
+    """Planned, atomic-free M-step gradient of one minibatch (plan.py): OVERWRITES every row of grads."""
+    t, g = make_tables(params), make_tables(grads)
+    _capi._req(scores, torch.float32, 'scores')
+    _capi._req(sample_weights, torch.float32, 'sample_weights')
+    cf = Coefs(*[float(c) for c in coefs[:6]])
+    ws = workspace.get_zeroed(lib().invpref_rows_workspace_bytes(C.byref(t)))
+    check(lib().invpref_mstep_rows_grad_hip(C.byref(t), C.byref(g), C.byref(dplan.struct), ptr(_ids(envs, 'envs')),
+                                             ptr(scores), ptr(sample_weights), int(batch_norm), C.byref(cf), flags,
+                                             ptr(losses6), ptr(ws), ws.numel(), stream_ptr()),
+          'invpref_mstep_rows_grad_hip')
+
+
+def mstep_rows_adam(params, new_params, exp_avg, exp_avg_sq, dplan, envs, scores, sample_weights, batch_norm: int,
+                     coefs, flags: int, losses6: torch.Tensor, step: int, lr: float, workspace: Workspace,
+                     beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:
+    """M-step + Adam in one pass: reads params, writes new_params, updates the moments in place."""
+    t, tn = make_tables(params), make_tables(new_params)
+    tm, tv = make_tables(exp_avg), make_tables(exp_avg_sq)
+    _capi._req(scores, torch.float32, 'scores')
+    _capi._req(sample_weights, torch.float32, 'sample_weights')
+    cf = Coefs(*[float(c) for c in coefs[:6]])
+    ws = workspace.get_zeroed(lib().invpref_rows_workspace_bytes(C.byref(t)))
+    check(lib().invpref_mstep_rows_adam_hip(C.byref(t), C.byref(tn), C.byref(tm), C.byref(tv), C.byref(dplan.struct),
+                                             ptr(_ids(envs, 'envs')), ptr(scores), ptr(sample_weights),
+                                             int(batch_norm), C.byref(cf), flags, ptr(losses6), int(step), float(lr),
+                                             float(beta1), float(beta2), float(eps), ptr(ws), ws.numel(),
+                                             stream_ptr()), 'invpref_mstep_rows_adam_hip')

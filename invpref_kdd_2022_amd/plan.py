@@ -1,0 +1,124 @@
+"""Row plans for the planned, atomic-free M-step (include/invpref_hip.h: InvPrefRowPlan).
+
+Built once per training run: the reference's minibatches are static (utils.mini_batch,
+utils.py:12-19: contiguous, unshuffled slices), so each minibatch's scatter pattern is inverted
+ahead of time.  Host side, numpy, vectorised; the result is a few int32 device arrays per minibatch.
+
+    job   = one table row + the minibatch's interactions that touch it, cut into 1/2/4/8/16 slices
+    round = 16 group slots of a workgroup, filled with jobs of one slice count (heaviest first)
+    task  = `rounds_per_task` consecutive rounds of one side, run by one workgroup
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+GROUPS = 16
+
+
+class RowPlanStruct(C.Structure):
+    """struct InvPrefRowPlan"""
+    _fields_ = [('n_rounds', C.c_int32), ('n_item_rounds', C.c_int32), ('rounds_per_task', C.c_int32),
+                ('n', C.c_int32), ('desc', C.c_void_p), ('other_user', C.c_void_p), ('pos_user', C.c_void_p),
+                ('other_item', C.c_void_p), ('pos_item', C.c_void_p)]
+
+
+def _side_rounds(own, oth, pos, y, n_rows: int, per_slice: int, pad_to: int):
+    """desc [n_rounds,16,8] int32 for one side.  own / oth / pos / y are in the side's sorted order."""
+    cnt = np.bincount(own, minlength=n_rows).astype(np.int64)
+    ptr = np.concatenate([[0], np.cumsum(cnt)])
+    ybits = np.ascontiguousarray(y, np.float32).view(np.int32)
+    # slices needed at `per_slice` interactions each, rounded up to a power of two, at most 16;
+    # rows hotter than 16*per_slice get longer slices instead
+    need = np.maximum(1, -(-cnt // per_slice))
+    slices = np.minimum(GROUPS, 1 << np.ceil(np.log2(need)).astype(np.int64))
+    sl_len = np.maximum(-(-cnt // slices), 1)
+    descs = []
+    for g in (16, 8, 4, 2, 1):
+        rows = np.flatnonzero(slices == g)
+        if len(rows) == 0:
+            continue
+        rows = rows[np.argsort(-cnt[rows], kind='stable')]  # heaviest first
+        per_round = GROUPS // g
+        n_rounds = -(-len(rows) // per_round)
+        d = np.zeros((n_rounds, GROUPS, 8), np.int32)
+        d[:, :, 0] = -1
+        d[:, :, 1] = g << 1            # idle slots still tell the round's slice count (sync decision)
+        i = np.arange(len(rows))
+        rnd, first = i // per_round, (i % per_round) * g
+        for k in range(g):
+            j0 = np.minimum(ptr[rows] + k * sl_len[rows], ptr[rows + 1])
+            j1 = np.minimum(j0 + sl_len[rows], ptr[rows + 1])
+            m = j1 - j0
+            mode = np.where(m <= 2, m, 3)
+            meta = (1 if k == 0 else 0) | (g << 1) | (mode << 6) | (cnt[rows] << 8)
+            slot = d[rnd, first + k]
+            slot[:, 0], slot[:, 1] = rows, meta
+            j0c, j1c = np.minimum(j0, max(len(oth) - 1, 0)), np.minimum(j0 + 1, max(len(oth) - 1, 0))
+            if len(oth):
+                inl = mode <= 2
+                slot[:, 2] = np.where(inl, np.where(m >= 1, oth[j0c], 0), j0)
+                slot[:, 3] = np.where(inl, np.where(m >= 1, pos[j0c], 0), j1)
+                slot[:, 4] = np.where(inl & (m >= 1), ybits[j0c], 0)
+                slot[:, 5] = np.where(inl & (m >= 2), oth[j1c], 0)
+                slot[:, 6] = np.where(inl & (m >= 2), pos[j1c], 0)
+                slot[:, 7] = np.where(inl & (m >= 2), ybits[j1c], 0)
+            d[rnd, first + k] = slot
+        descs.append(d)
+    d = np.concatenate(descs)
+    pad = (-len(d)) % pad_to
+    if pad:
+        idle = np.zeros((pad, GROUPS, 8), np.int32)
+        idle[:, :, 0] = -1
+        idle[:, :, 1] = 1 << 1
+        d = np.concatenate([d, idle])
+    return d
+
+
+def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, user_num: int, item_num: int,
+                   per_slice: int | None = None, rounds_per_task: int | None = None) -> dict:
+    """users/items/scores: ONE minibatch (or this rank's slice of it); scores as the fp32 labels."""
+    users = np.asarray(users, dtype=np.int64)
+    items = np.asarray(items, dtype=np.int64)
+    scores = np.asarray(scores, dtype=np.float32)
+    if per_slice is None:
+        per_slice = int(os.environ.get('INVPREF_PLAN_PER_SLICE', '1'))
+    if rounds_per_task is None:
+        rounds_per_task = int(os.environ.get('INVPREF_PLAN_ROUNDS', '1'))
+    n = len(users)
+    if n and (cnt_max := max(np.bincount(users).max(), np.bincount(items).max())) >= (1 << 23):
+        raise ValueError(f'a row with {cnt_max} interactions in one minibatch overflows the job descriptor')
+    pu = np.argsort(users, kind='stable')
+    pi = np.argsort(items, kind='stable')
+    # item rounds first (they hold the longest jobs; padded to whole workgroups), user rounds after
+    di = _side_rounds(items[pi], users[pi], pi, scores[pi], item_num, per_slice, rounds_per_task)
+    du = _side_rounds(users[pu], items[pu], pu, scores[pu], user_num, per_slice, 1)
+    return dict(n=n, n_item_rounds=len(di), rounds_per_task=rounds_per_task, desc=np.concatenate([di, du]),
+                other_user=items[pu].astype(np.int32), pos_user=pu.astype(np.int32),
+                other_item=users[pi].astype(np.int32), pos_item=pi.astype(np.int32))
+
+
+@dataclass
+class DevicePlan:
+    struct: RowPlanStruct
+    arrays: list  # keeps the device tensors alive
+    n_tasks: int
+    n_rounds: int
+
+
+def upload(plan: dict, device) -> DevicePlan:
+    keys = ('desc', 'other_user', 'pos_user', 'other_item', 'pos_item')
+    flat = np.concatenate([np.ascontiguousarray(plan[k], np.int32).reshape(-1) for k in keys])
+    buf = torch.from_numpy(flat).to(device)
+    ptrs, off = {}, 0
+    for k in keys:
+        ptrs[k] = buf.data_ptr() + 4 * off
+        off += int(np.asarray(plan[k]).size)
+    nr, rpt = len(plan['desc']), plan['rounds_per_task']
+    st = RowPlanStruct(nr, plan['n_item_rounds'], rpt, plan['n'], ptrs['desc'], ptrs['other_user'],
+                       ptrs['pos_user'], ptrs['other_item'], ptrs['pos_item'])
+    return DevicePlan(st, [buf], -(-nr // rpt), nr)

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import itertools
 import math
+import os
 from typing import Optional
 
 import numpy as np
@@ -28,6 +29,7 @@ import torch
 import ctypes as C
 
 from . import _capi, ops
+from . import plan as planlib
 from .parallel import RowShard, all_reduce_sum_
 
 LOSS_KEYS = ('invariant_loss', 'env_aware_loss', 'envs_loss', 'L2_reg', 'L1_reg', 'loss')
@@ -58,13 +60,27 @@ class FlatState:
         self.losses6 = self.grad_ext[self.n:self.n + 6]
         self.exp_avg = torch.zeros(self.n, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(self.n, dtype=torch.float32, device=device)
+        # double buffer for the fused M-step+Adam pass (reads old rows, writes new rows)
+        self.param_alt = torch.zeros(self.n, dtype=torch.float32, device=device)
         self.p_views = self._views(self.param)
+        self.p_views_alt = self._views(self.param_alt)
         self.g_views = self._views(self.grad)
+        self.m_views = self._views(self.exp_avg)
+        self.v_views = self._views(self.exp_avg_sq)
+        self._tabs = tabs
         with torch.no_grad():
             for p, view in zip(tabs, self.p_views):
                 view.copy_(p.detach().to(device=device, dtype=torch.float32))
                 p.data = view  # the module's parameters now alias the flat buffer
         self.step = 0
+
+    def swap(self):
+        """the fused pass wrote the new parameters into the alternate buffer: make it current and
+        re-point the module's parameters at it (metadata only, no copy)."""
+        self.param, self.param_alt = self.param_alt, self.param
+        self.p_views, self.p_views_alt = self.p_views_alt, self.p_views
+        for p, view in zip(self._tabs, self.p_views):
+            p.data = view
 
     def _views(self, flat):
         return [flat[o:o + int(np.prod(s))].view(s) for o, s in zip(self.offsets, self.shapes)]
@@ -136,6 +152,9 @@ class _InvPrefTrainManager:
         self.workspace = ops.Workspace(self.device)
         self._flags = ops.flags_of(self.implicit, use_recommend_re_weight, use_class_re_weight,
                                    model.reg_only_embed, model.reg_env_embed, dense_reg=(self.rank == 0))
+        # atomic-free planned M-step (plan.py) unless INVPREF_NO_PLAN=1 (then: float-atomic scatter-add)
+        self.use_plan = os.environ.get('INVPREF_NO_PLAN', '0') != '1'
+        self._plans = None
 
     # ------------------------------------------------------------------ M-step
     def _coefs(self, alpha):
@@ -187,6 +206,20 @@ class _InvPrefTrainManager:
             lo, hi = self.shard.local_batch_bounds(k)
             self._raw_batches.append((lo, hi - lo, self.shard.global_batch_len(k)))
         self._raw_mstep, self._raw_adam = L.invpref_mstep_grad_hip, L.invpref_adam_hip
+        self._raw_owner_grad, self._raw_owner_adam = L.invpref_mstep_rows_grad_hip, L.invpref_mstep_rows_adam_hip
+        if self.use_plan and self._plans is None:
+            u, v = self.users_tensor.cpu().numpy(), self.items_tensor.cpu().numpy()
+            y = self.scores_tensor.cpu().numpy()
+            self._plans = []
+            for lo, n, _ in self._raw_batches:
+                pl = planlib.build_row_plan(u[lo:lo + n], v[lo:lo + n], y[lo:lo + n], self.model.user_num,
+                                            self.model.item_num)
+                self._plans.append(planlib.upload(pl, self.device))
+        if self.use_plan:
+            self._raw_ows = self.workspace.get_zeroed(L.invpref_rows_workspace_bytes(C.byref(self._raw_t)))
+        # ctypes views of both parameter buffers / moments for the fused pass
+        self._raw_tabs = {id(st.p_views): _capi.make_tables(st.p_views), id(st.p_views_alt): _capi.make_tables(st.p_views_alt)}
+        self._raw_m, self._raw_v = _capi.make_tables(st.m_views), _capi.make_tables(st.v_views)
 
     def _raw_step(self, k: int, alpha: float, stream, mid_event=None):
         st = self.state
@@ -199,19 +232,40 @@ class _InvPrefTrainManager:
             lp = st.losses6.data_ptr()
         else:
             lp = self._epoch_losses.data_ptr() + 24 * k
-        rc = self._raw_mstep(C.byref(self._raw_t), C.byref(self._raw_g), pu + 8 * lo, pi + 8 * lo, pe + 8 * lo,
-                             py + 4 * lo, pw + 4 * lo, n, bn, C.byref(cf), self._flags, lp,
-                             self._raw_ws.data_ptr(), self._raw_ws.numel(), stream)
+        t_cur = self._raw_tabs[id(st.p_views)]
+        if self.use_plan and not multi:
+            # fused M-step + Adam: one pass, gradient never stored, parameters ping-pong
+            st.step += 1
+            rc = self._raw_owner_adam(C.byref(t_cur), C.byref(self._raw_tabs[id(st.p_views_alt)]),
+                                      C.byref(self._raw_m), C.byref(self._raw_v), C.byref(self._plans[k].struct),
+                                      pe + 8 * lo, py + 4 * lo, pw + 4 * lo, bn, C.byref(cf), self._flags, lp,
+                                      st.step, self.lr, 0.9, 0.999, 1e-8, self._raw_ows.data_ptr(),
+                                      self._raw_ows.numel(), stream)
+            if rc:
+                _capi.check(rc, 'invpref_mstep_rows_adam_hip')
+            st.swap()
+            if mid_event is not None:
+                mid_event.record()
+            return
+        if self.use_plan:
+            rc = self._raw_owner_grad(C.byref(t_cur), C.byref(self._raw_g), C.byref(self._plans[k].struct),
+                                      pe + 8 * lo, py + 4 * lo, pw + 4 * lo, bn, C.byref(cf), self._flags, lp,
+                                      self._raw_ows.data_ptr(), self._raw_ows.numel(), stream)
+        else:
+            rc = self._raw_mstep(C.byref(t_cur), C.byref(self._raw_g), pu + 8 * lo, pi + 8 * lo, pe + 8 * lo,
+                                 py + 4 * lo, pw + 4 * lo, n, bn, C.byref(cf), self._flags, lp,
+                                 self._raw_ws.data_ptr(), self._raw_ws.numel(), stream)
         if rc:
-            _capi.check(rc, 'invpref_mstep_grad_hip')
+            _capi.check(rc, 'invpref_mstep_(owner_)grad_hip')
         if multi:
             all_reduce_sum_(st.grad_ext, self.process_group)
             self._epoch_losses[k] += st.losses6
         if mid_event is not None:
             mid_event.record()
         st.step += 1
+        # the planned gradient pass overwrites every row, so the gradient buffer needs no zeroing
         rc = self._raw_adam(st.param.data_ptr(), st.grad.data_ptr(), st.exp_avg.data_ptr(), st.exp_avg_sq.data_ptr(),
-                            st.n, st.step, self.lr, 0.9, 0.999, 1e-8, 1, stream)
+                            st.n, st.step, self.lr, 0.9, 0.999, 1e-8, 0 if self.use_plan else 1, stream)
         if rc:
             _capi.check(rc, 'invpref_adam_hip')
 

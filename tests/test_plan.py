@@ -1,0 +1,68 @@
+"""CPU: invariants of the host-side row plan (plan.py) that the planned M-step kernel relies on."""
+import numpy as np
+import pytest
+
+from invpref_kdd_2022_amd import plan as planlib, synth
+
+
+def check_plan(users, items, U, I, **kw):
+    y = (np.arange(len(users)) % 5).astype(np.float32)
+    p = planlib.build_row_plan(users, items, y, U, I, **kw)
+    desc, rpt, nir = p['desc'], p['rounds_per_task'], p['n_item_rounds']
+    n = len(users)
+    assert desc.shape[1:] == (16, 8) and nir % rpt == 0 and 0 < nir < len(desc)
+    for side, (own, oth, R, o_key, p_key, rounds) in enumerate((
+            (users, items, U, 'other_user', 'pos_user', desc[nir:]),
+            (items, users, I, 'other_item', 'pos_item', desc[:nir]))):
+        pos = p[p_key]
+        assert sorted(pos.tolist()) == list(range(n))                 # a permutation of the minibatch
+        assert (np.diff(own[pos]) >= 0).all()                         # sorted by own row
+        np.testing.assert_array_equal(p[o_key], oth[pos])
+        d = rounds.reshape(-1, 8)
+        act = d[d[:, 0] >= 0]
+        leaders = act[(act[:, 1] & 1) == 1]
+        assert sorted(leaders[:, 0].tolist()) == list(range(R))      # every table row is exactly one job
+        cnt = np.bincount(own, minlength=R)
+        np.testing.assert_array_equal(leaders[:, 1] >> 8, cnt[leaders[:, 0]])
+        seen = np.zeros(n, np.int32)
+        for row, meta, a, b, c, dd, e, f in act:
+            mode = (meta >> 6) & 3
+            if mode == 3:
+                assert a < b
+                js = pos[a:b]
+                assert (own[js] == row).all() and b - a > 2
+                seen[js] += 1
+            else:
+                for (o_, p_, y_) in ((a, b, c), (dd, e, f))[:mode]:
+                    assert own[p_] == row and oth[p_] == o_           # inline copy of the interaction
+                    assert np.int32(y_).view(np.float32) == y[p_]
+                    seen[p_] += 1
+        assert (seen == 1).all()                                      # every interaction in exactly one slice
+        for rd in rounds:                                             # slot layout inside a round
+            g = (rd[0, 1] >> 1) & 31
+            assert g in (1, 2, 4, 8, 16) and (((rd[:, 1] >> 1) & 31) == g).all()
+            for s0 in range(0, 16, g):
+                if rd[s0, 0] < 0:
+                    assert (rd[s0:s0 + g, 0] < 0).all()
+                    continue
+                assert rd[s0, 1] & 1 and (rd[s0:s0 + g, 0] == rd[s0, 0]).all() and ((rd[s0 + 1:s0 + g, 1] & 1) == 0).all()
+    return p
+
+
+def test_plan_yahoo_like_batch():
+    d = synth.yahoo_like()[:8192]
+    p = check_plan(d[:, 0], d[:, 1], 15400, 1000)
+    assert len(p['desc']) < 4000
+
+
+@pytest.mark.parametrize('per_slice,rpt', [(1, 1), (2, 3), (4, 2), (64, 5)])
+def test_plan_parameters(per_slice, rpt):
+    rs = np.random.RandomState(per_slice)
+    u, v = rs.randint(0, 37, 500), rs.randint(0, 5, 500)  # item rows with ~100 interactions each
+    check_plan(u, v, 40, 7, per_slice=per_slice, rounds_per_task=rpt)
+
+
+def test_plan_empty_and_single():
+    check_plan(np.zeros(0, np.int64), np.zeros(0, np.int64), 5, 3)
+    check_plan(np.array([2]), np.array([0]), 5, 3)
+    check_plan(np.full(300, 1), np.full(300, 2), 4, 4)   # one hot row on both sides: 16 slices of 19

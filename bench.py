@@ -33,7 +33,7 @@ SEED = 17373331
 YAHOO = dict(lr=0.005, invariant_coe=3.351991776096847, env_aware_coe=9.988658447411407,
              env_coe=9.06447753571379, L2_coe=3.1351402017943117, L1_coe=0.4935216278026648,
              alpha=1.9053711444718746)
-ESTEP_EVERY = 155
+ESTEP_EVERY = 155  # cluster_interval (5 epochs) x 31 minibatches
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -104,28 +104,27 @@ def main():
         use_class_re_weight=True, use_recommend_re_weight=False, cluster_use_random_sort=False,
         rank=rank, world_size=world, **YAHOO)
     mgr.stat_envs()
-    mgr._raw_setup()
     nb = mgr.batch_num
-    stream = torch.cuda.current_stream().cuda_stream
+    state = {'pos': 0, 'done': 0}
 
-    ev = {'m0': [], 'm1': [], 'a1': []}
-
-    def run(n_steps, start, timed):
-        for s in range(start, start + n_steps):
-            k = s % nb
-            if getattr(mgr, '_raw_ptrs', None) is None or mgr._raw_ptrs[4] != mgr.sample_weights.data_ptr():
-                mgr._raw_setup()
-            if timed:
-                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-                e0.record()
-            # ---- one optimiser step (the same two C-ABI calls train_a_epoch issues)
-            if timed:
-                mgr._raw_step(k, mgr.alpha, stream, mid_event=e1)
-                e2.record()
-                ev['m0'].append(e0); ev['m1'].append(e1); ev['a1'].append(e2)
+    def run(n_steps):
+        """n_steps optimiser steps of the training loop: whole epochs go through train_a_epoch() (one HIP
+        graph launch per epoch on a single GPU), a partial epoch through the same per-step calls issued
+        eagerly; the E-step + stat_envs run every ESTEP_EVERY steps as in the reference loop."""
+        left = n_steps
+        while left > 0:
+            if state['pos'] == 0 and left >= nb:
+                mgr.train_a_epoch()
+                left -= nb
+                state['done'] += nb
             else:
-                mgr._raw_step(k, mgr.alpha, stream)
-            if (s + 1) % ESTEP_EVERY == 0:
+                if getattr(mgr, '_raw_ptrs', None) is None:
+                    mgr._raw_setup()
+                mgr._raw_step(state['pos'], mgr.alpha, torch.cuda.current_stream().cuda_stream)
+                state['pos'] = (state['pos'] + 1) % nb
+                left -= 1
+                state['done'] += 1
+            if state['done'] % ESTEP_EVERY == 0 and state['pos'] == 0:
                 mgr.cluster()
                 mgr.stat_envs()
 
@@ -133,10 +132,10 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
-    run(args.warmup, 0, False)
+    run(args.warmup)
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.steps, args.warmup, True)
+    run(args.steps)
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -144,11 +143,25 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    # per-launch device time of the step's kernels: HIP events on the launch stream around the same
+    # calls issued eagerly (events cannot be read back from inside a replayed graph), one epoch's worth
+    if getattr(mgr, '_raw_ptrs', None) is None:
+        mgr._raw_setup()
+    ev = {'m0': [], 'm1': [], 'a1': []}
+    stream = torch.cuda.current_stream().cuda_stream
+    for k in range(nb):
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        mgr._raw_step(k, mgr.alpha, stream, mid_event=e1)
+        e2.record()
+        ev['m0'].append(e0); ev['m1'].append(e1); ev['a1'].append(e2)
+    torch.cuda.synchronize()
+
     inter = args.steps * B_PER_GPU * world
     value = inter / dt
     # per-op device time from HIP events recorded on the launch stream inside the timed region
-    ms_m = float(np.mean([a.elapsed_time(b) for a, b in zip(ev['m0'], ev['m1'])]))
-    ms_a = float(np.mean([a.elapsed_time(b) for a, b in zip(ev['m1'], ev['a1'])]))
+    ms_m = float(np.median([a.elapsed_time(b) for a, b in zip(ev['m0'], ev['m1'])]))
+    ms_a = float(np.median([a.elapsed_time(b) for a, b in zip(ev['m1'], ev['a1'])]))
     P = mgr.state.n
     # Algorithmic bytes.  SURVEY §8(d) prices the un-fused pair: M-step B*(32+32D) (ids/labels,
     # 4 row reads, 4 gradient-row adds) + Adam 32P (28 B/param + 4 B zeroing).  The fused owner pass never
@@ -157,7 +170,7 @@ def main():
     fused = mgr.use_plan and world == 1
     if fused:
         nbytes = B_PER_GPU * (32 + 16 * D) + 24 * P
-        roof = {'kernel': 'mstep_owner_kernel (+owner_finish_kernel), Adam fused', 'bytes': nbytes, 'ms': ms_m}
+        roof = {'kernel': 'mstep_rows_kernel (+rows_finish_kernel), Adam fused', 'bytes': nbytes, 'ms': ms_m}
         other = {'step_ms_events': ms_m, 'GBs_at_survey_unfused_pricing': (bytes_m_survey + bytes_a_survey) / (ms_m * 1e-3) / 1e9}
     else:
         bytes_m = bytes_m_survey
@@ -177,7 +190,8 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'yahoo_r3_implicit_shaped', 'users': U, 'items': I, 'envs': E, 'factor_num': D,
                    'interactions_per_gpu': N_PER_GPU, 'batch_per_gpu': B_PER_GPU, 'global_batch': B_PER_GPU * world,
-                   'estep_every_steps': ESTEP_EVERY, 'parallelism': f'row-shard x{world}, 1 all-reduce/step'},
+                   'estep_every_steps': ESTEP_EVERY, 'parallelism': f'row-shard x{world}, 1 all-reduce/step',
+                   'hip_graph_epochs': bool(mgr._graphs)},
         'roofline': roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -140,6 +140,26 @@ int invpref_mstep_rows_adam_hip(const InvPrefTables *tables, const InvPrefTables
                                 uint32_t flags, float *losses6, int64_t step, double lr, double beta1, double beta2,
                                 double eps, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- the same pass for HIP-graph replay.  A captured launch freezes its kernel arguments, so the
+ * per-step Adam scalars cannot be passed by value: they are looked up on the device as
+ * table[state[0] - state[1]], and the pass advances state[0] when it is done.
+ *   state: device int32[4] = {next step (1-based), step that table[0] belongs to, 0, 0}
+ *   table: device float[n][6], filled on the host by invpref_adam_schedule_fill() and uploaded.
+ * The caller keeps state[0] - state[1] inside [0, n) (refill + rebase between replays). */
+typedef struct InvPrefAdamSchedule {
+    int32_t *state;
+    const float *table;
+    int32_t n;
+} InvPrefAdamSchedule;
+int invpref_adam_schedule_fill(float *host_table, int64_t first_step, int64_t n, double lr, double beta1, double beta2,
+                               double eps);
+int invpref_mstep_rows_adam_sched_hip(const InvPrefTables *tables, const InvPrefTables *new_tables,
+                                      const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
+                                      const InvPrefRowPlan *plan, const int64_t *envs, const float *scores,
+                                      const float *sample_weights, int64_t batch_norm, const InvPrefCoefs *coefs,
+                                      uint32_t flags, float *losses6, const InvPrefAdamSchedule *sched,
+                                      void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- backward of forward(): replaces autograd through InvPref*.forward + ReverseLayerF
  * (models.py:307-326 / :448-467, functions.py:7-16) for callers that build their own loss on the
  * unfused outputs (e.g. the reference's untouched train.py).  Upstream gradients d_* have the shapes

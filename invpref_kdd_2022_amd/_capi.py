@@ -21,6 +21,7 @@ EXPORTS = [
     'invpref_mstep_grad_hip', 'invpref_adam_hip', 'invpref_estep_workspace_bytes', 'invpref_estep_hip',
     'invpref_stat_envs_hip', 'invpref_sample_weights_hip', 'invpref_backward_hip', 'invpref_predict_hip',
     'invpref_rows_workspace_bytes', 'invpref_mstep_rows_grad_hip', 'invpref_mstep_rows_adam_hip',
+    'invpref_adam_schedule_fill', 'invpref_mstep_rows_adam_sched_hip',
 ]
 
 
@@ -39,6 +40,11 @@ class Tables(C.Structure):
 class Coefs(C.Structure):
     """struct InvPrefCoefs"""
     _fields_ = [(n, C.c_float) for n in ('invariant_coe', 'env_aware_coe', 'env_coe', 'L2_coe', 'L1_coe', 'alpha')]
+
+
+class AdamSchedule(C.Structure):
+    """struct InvPrefAdamSchedule"""
+    _fields_ = [('state', C.c_void_p), ('table', C.c_void_p), ('n', C.c_int32)]
 
 
 _lib = None
@@ -76,6 +82,10 @@ def lib():
         L.invpref_mstep_rows_adam_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), C.POINTER(Tables),
                                                    C.POINTER(Tables), vp, vp, vp, vp, i64, C.POINTER(Coefs), u32, vp,
                                                    i64, f64, f64, f64, f64, vp, C.c_size_t, vp]
+        L.invpref_adam_schedule_fill.argtypes = [vp, i64, i64, f64, f64, f64, f64]
+        L.invpref_mstep_rows_adam_sched_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), C.POINTER(Tables),
+                                                        C.POINTER(Tables), vp, vp, vp, vp, i64, C.POINTER(Coefs), u32,
+                                                        vp, C.POINTER(AdamSchedule), vp, C.c_size_t, vp]
         L.invpref_device_name.argtypes = [C.c_char_p, C.c_size_t]
         if L.invpref_abi_version() != 1:
             raise InvPrefError('libinvpref_hip.so ABI version mismatch')

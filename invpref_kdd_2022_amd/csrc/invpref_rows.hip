@@ -54,6 +54,8 @@ struct RowsArgs {
     float *np[4];                 // new parameter tables              (fused == 1)
     float *m[4], *v[4];           // Adam moments                      (fused == 1)
     AdamScalars ad;
+    int *sched_state;             // optional device int32[4] = {step (1-based), first step of sched_table, ticket, 0}
+    const AdamScalars *sched_table;  // optional device table of per-step Adam scalars (graph replay)
     unsigned long long *stamps;   // diagnostic builds only (INVPREF_STAMPS): [n_tasks][8] s_memrealtime ticks
 };
 
@@ -128,6 +130,9 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
     const int *oth_ids = a.oth[side], *pos = a.pos[side];
     const float *T_own_inv = user_side ? t.Pu : t.Qi, *T_own_env = user_side ? t.Pa : t.Qa;
     const float *T_oth_inv = user_side ? t.Qi : t.Pu, *T_oth_env = user_side ? t.Qa : t.Pa;
+    // Adam scalars of this step: by value, or (graph replay: kernel arguments are frozen) looked up
+    // by the device-side step counter that rows_finish_kernel advances
+    const AdamScalars ad = a.sched_state ? a.sched_table[a.sched_state[0] - a.sched_state[1]] : a.ad;
 
     STAMP(0);
     // the first round's descriptor goes out before anything else: every gather below hangs on it
@@ -420,10 +425,10 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
                 }
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
-                    adam1f(oi[c].x, gi[c].x, mi[c].x, vi[c].x, a.ad); adam1f(oi[c].y, gi[c].y, mi[c].y, vi[c].y, a.ad);
-                    adam1f(oi[c].z, gi[c].z, mi[c].z, vi[c].z, a.ad); adam1f(oi[c].w, gi[c].w, mi[c].w, vi[c].w, a.ad);
-                    adam1f(oe[c].x, ge[c].x, me[c].x, ve[c].x, a.ad); adam1f(oe[c].y, ge[c].y, me[c].y, ve[c].y, a.ad);
-                    adam1f(oe[c].z, ge[c].z, me[c].z, ve[c].z, a.ad); adam1f(oe[c].w, ge[c].w, me[c].w, ve[c].w, a.ad);
+                    adam1f(oi[c].x, gi[c].x, mi[c].x, vi[c].x, ad); adam1f(oi[c].y, gi[c].y, mi[c].y, vi[c].y, ad);
+                    adam1f(oi[c].z, gi[c].z, mi[c].z, vi[c].z, ad); adam1f(oi[c].w, gi[c].w, mi[c].w, vi[c].w, ad);
+                    adam1f(oe[c].x, ge[c].x, me[c].x, ve[c].x, ad); adam1f(oe[c].y, ge[c].y, me[c].y, ve[c].y, ad);
+                    adam1f(oe[c].z, ge[c].z, me[c].z, ve[c].z, ad); adam1f(oe[c].w, ge[c].w, me[c].w, ve[c].w, ad);
                 }
                 store_row<NC, VEC>(a.np[side], row, t.D, l16, oi);
                 store_row<NC, VEC>(a.m[side], row, t.D, l16, mi);
@@ -489,7 +494,10 @@ struct SmallTables {
 __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTables o, float *__restrict__ slabs,
                                                            int nslabs, int DP, int EMAX, StepScalars k, float l2,
                                                            float l1, int64_t Bnorm, uint32_t flags, int fused,
-                                                           AdamScalars ad, float *__restrict__ losses6) {
+                                                           AdamScalars ad_in, int *sched_state,
+                                                           const AdamScalars *sched_table,
+                                                           float *__restrict__ losses6) {
+    const AdamScalars ad = sched_state ? sched_table[sched_state[0] - sched_state[1]] : ad_in;
     __shared__ double part[16][64];
     __shared__ double sloss[kLossSlots];
     __shared__ double sreg[2];
@@ -566,6 +574,16 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
             losses6[5] += (float)((double)k.ca * Li + (double)k.cb * Le + (double)k.cc * Lc + (double)l2 * L2 + (double)l1 * L1);
         }
     }
+    // the step is over: the block that finishes LAST (ticket) advances the device-side step counter;
+    // every block read the counter before taking its ticket, so no block can see the new value
+    if (sched_state && threadIdx.x == 0) {
+        __threadfence();
+        const int ticket = atomicAdd(sched_state + 2, 1);
+        if (ticket == (int)gridDim.x - 1) {
+            sched_state[2] = 0;
+            sched_state[0] = sched_state[0] + 1;
+        }
+    }
 }
 
 inline bool dreg_of(int nc, int emax) { return nc * emax <= 4; }
@@ -586,8 +604,9 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
                 const float *weights, int64_t batch_norm, const InvPrefCoefs *coefs, uint32_t flags, float *losses6,
                 void *workspace, size_t workspace_bytes, hipStream_t st, int fused, const InvPrefTables *grads,
                 const InvPrefTables *new_tables, const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
-                const AdamScalars &ad) {
+                const AdamScalars &ad, const InvPrefAdamSchedule *sched = nullptr) {
     int rc = check_tables(tables);
+    if (sched && (!sched->state || !sched->table || sched->n <= 0)) return INVPREF_EINVAL;
     if (rc) return rc;
     if (!plan || !coefs || !losses6 || !workspace || !envs || !scores || batch_norm <= 0) return INVPREF_EINVAL;
     if (plan->n_rounds <= 0 || plan->rounds_per_task <= 0 || plan->n_item_rounds < 0 ||
@@ -629,6 +648,8 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a.oth[1] = plan->other_item; a.pos[1] = plan->pos_item;
     a.envs = envs; a.scores = scores; a.weights = weights;
     a.k = k; a.flags = flags; a.slabs = (float *)workspace; a.fused = fused; a.ad = ad;
+    a.sched_state = sched ? sched->state : nullptr;
+    a.sched_table = sched ? reinterpret_cast<const AdamScalars *>(sched->table) : nullptr;
     // diagnostics: INVPREF_STAMPS=<device pointer, hex> makes the kernel write phase time stamps there
     static const char *stamp_env = getenv("INVPREF_STAMPS");
     a.stamps = stamp_env ? reinterpret_cast<unsigned long long *>(strtoull(stamp_env, nullptr, 16)) : nullptr;
@@ -661,7 +682,7 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     }
     const int nfb = (slab_len + 63) / 64;
     hipLaunchKernelGGL(rows_finish_kernel, dim3(nfb), dim3(1024), 0, st, t, o, (float *)workspace, kReplicas, DP, emax, k,
-                       coefs->L2_coe, coefs->L1_coe, batch_norm, flags, fused, ad, losses6);
+                       coefs->L2_coe, coefs->L1_coe, batch_norm, flags, fused, ad, a.sched_state, a.sched_table, losses6);
     return (int)hipGetLastError();
 }
 
@@ -700,6 +721,37 @@ int invpref_mstep_rows_adam_hip(const InvPrefTables *tables, const InvPrefTables
     ad.eps = (float)eps;
     return launch_rows(tables, plan, envs, scores, sample_weights, batch_norm, coefs, flags, losses6, workspace,
                        workspace_bytes, (hipStream_t)stream, 1, nullptr, new_tables, exp_avg, exp_avg_sq, ad);
+}
+
+/* host helper: the per-step Adam scalars exactly as invpref_adam_hip / invpref_mstep_rows_adam_hip form
+ * them from (step, lr, betas, eps); table[i] belongs to step first_step + i. */
+int invpref_adam_schedule_fill(float *host_table, int64_t first_step, int64_t n, double lr, double beta1, double beta2,
+                               double eps) {
+    if (!host_table || first_step < 1 || n < 0) return INVPREF_EINVAL;
+    for (int64_t i = 0; i < n; i++) {
+        const double step = (double)(first_step + i);
+        const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+        float *r = host_table + 6 * i;
+        r[0] = (float)(lr / bc1);
+        r[1] = (float)sqrt(bc2);
+        r[2] = (float)(1.0 - beta1);
+        r[3] = (float)beta2;
+        r[4] = (float)(1.0 - beta2);
+        r[5] = (float)eps;
+    }
+    return 0;
+}
+
+int invpref_mstep_rows_adam_sched_hip(const InvPrefTables *tables, const InvPrefTables *new_tables,
+                                      const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
+                                      const InvPrefRowPlan *plan, const int64_t *envs, const float *scores,
+                                      const float *sample_weights, int64_t batch_norm, const InvPrefCoefs *coefs,
+                                      uint32_t flags, float *losses6, const InvPrefAdamSchedule *sched,
+                                      void *workspace, size_t workspace_bytes, void *stream) {
+    if (!sched) return INVPREF_EINVAL;
+    return launch_rows(tables, plan, envs, scores, sample_weights, batch_norm, coefs, flags, losses6, workspace,
+                       workspace_bytes, (hipStream_t)stream, 1, nullptr, new_tables, exp_avg, exp_avg_sq, AdamScalars{},
+                       sched);
 }
 
 }  // extern "C"

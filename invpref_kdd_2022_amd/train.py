@@ -155,6 +155,11 @@ class _InvPrefTrainManager:
         # atomic-free planned M-step (plan.py) unless INVPREF_NO_PLAN=1 (then: float-atomic scatter-add)
         self.use_plan = os.environ.get('INVPREF_NO_PLAN', '0') != '1'
         self._plans = None
+        # whole epochs as one HIP graph launch (single GPU, planned path, fixed alpha); INVPREF_NO_GRAPH=1 disables
+        self.use_graph = os.environ.get('INVPREF_NO_GRAPH', '0') != '1'
+        self._graphs, self._graph_warm = {}, False
+        self._sched = None
+        self._sched_synced = False
 
     # ------------------------------------------------------------------ M-step
     def _coefs(self, alpha):
@@ -172,6 +177,7 @@ class _InvPrefTrainManager:
         if self.world_size > 1:
             all_reduce_sum_(st.grad_ext, self.process_group)
         st.step += 1
+        self._sched_synced = False
         ops.adam_(st.param, st.grad, st.exp_avg, st.exp_avg_sq, st.step, self.lr, zero_grad=True)
 
     def train_a_batch(self, batch_users_tensor, batch_items_tensor, batch_scores_tensor, batch_envs_tensor,
@@ -207,6 +213,7 @@ class _InvPrefTrainManager:
             self._raw_batches.append((lo, hi - lo, self.shard.global_batch_len(k)))
         self._raw_mstep, self._raw_adam = L.invpref_mstep_grad_hip, L.invpref_adam_hip
         self._raw_owner_grad, self._raw_owner_adam = L.invpref_mstep_rows_grad_hip, L.invpref_mstep_rows_adam_hip
+        self._raw_owner_adam_sched = L.invpref_mstep_rows_adam_sched_hip
         if self.use_plan and self._plans is None:
             u, v = self.users_tensor.cpu().numpy(), self.items_tensor.cpu().numpy()
             y = self.scores_tensor.cpu().numpy()
@@ -221,8 +228,10 @@ class _InvPrefTrainManager:
         self._raw_tabs = {id(st.p_views): _capi.make_tables(st.p_views), id(st.p_views_alt): _capi.make_tables(st.p_views_alt)}
         self._raw_m, self._raw_v = _capi.make_tables(st.m_views), _capi.make_tables(st.v_views)
 
-    def _raw_step(self, k: int, alpha: float, stream, mid_event=None):
+    def _raw_step(self, k: int, alpha: float, stream, mid_event=None, sched=False):
         st = self.state
+        if not sched:
+            self._sched_synced = False
         lo, n, bn = self._raw_batches[k]
         pu, pi, pe, py, pw = self._raw_ptrs
         cf = _capi.Coefs(self.invariant_coe, self.env_aware_coe, self.env_coe, self.L2_coe, self.L1_coe, alpha)
@@ -236,11 +245,18 @@ class _InvPrefTrainManager:
         if self.use_plan and not multi:
             # fused M-step + Adam: one pass, gradient never stored, parameters ping-pong
             st.step += 1
-            rc = self._raw_owner_adam(C.byref(t_cur), C.byref(self._raw_tabs[id(st.p_views_alt)]),
-                                      C.byref(self._raw_m), C.byref(self._raw_v), C.byref(self._plans[k].struct),
-                                      pe + 8 * lo, py + 4 * lo, pw + 4 * lo, bn, C.byref(cf), self._flags, lp,
-                                      st.step, self.lr, 0.9, 0.999, 1e-8, self._raw_ows.data_ptr(),
-                                      self._raw_ows.numel(), stream)
+            if sched:  # graph capture: Adam scalars come from the device-side schedule
+                rc = self._raw_owner_adam_sched(
+                    C.byref(t_cur), C.byref(self._raw_tabs[id(st.p_views_alt)]), C.byref(self._raw_m),
+                    C.byref(self._raw_v), C.byref(self._plans[k].struct), pe + 8 * lo, py + 4 * lo, pw + 4 * lo, bn,
+                    C.byref(cf), self._flags, lp, C.byref(self._sched['struct']), self._raw_ows.data_ptr(),
+                    self._raw_ows.numel(), stream)
+            else:
+                rc = self._raw_owner_adam(
+                    C.byref(t_cur), C.byref(self._raw_tabs[id(st.p_views_alt)]), C.byref(self._raw_m),
+                    C.byref(self._raw_v), C.byref(self._plans[k].struct), pe + 8 * lo, py + 4 * lo, pw + 4 * lo, bn,
+                    C.byref(cf), self._flags, lp, st.step, self.lr, 0.9, 0.999, 1e-8, self._raw_ows.data_ptr(),
+                    self._raw_ows.numel(), stream)
             if rc:
                 _capi.check(rc, 'invpref_mstep_rows_adam_hip')
             st.swap()
@@ -275,16 +291,67 @@ class _InvPrefTrainManager:
             self.alpha = 2. / (1. + np.exp(-10. * p)) - 1.
         return self.alpha
 
+    # ---- device-side Adam schedule for graph replay (include/invpref_hip.h: InvPrefAdamSchedule)
+    _SCHED_N = 8192
+
+    def _sched_prepare(self, steps_ahead: int):
+        st, L = self.state, _capi.lib()
+        if self._sched is None:
+            table = torch.zeros(self._SCHED_N, 6, dtype=torch.float32, device=self.device)
+            state = torch.zeros(4, dtype=torch.int32, device=self.device)
+            self._sched = dict(table=table, state=state, base=-(10 ** 9),
+                               struct=_capi.AdamSchedule(state.data_ptr(), table.data_ptr(), self._SCHED_N))
+        sc = self._sched
+        first = st.step + 1
+        if first < sc['base'] or first + steps_ahead > sc['base'] + self._SCHED_N:
+            host = np.zeros((self._SCHED_N, 6), np.float32)
+            _capi.check(L.invpref_adam_schedule_fill(host.ctypes.data, first, self._SCHED_N, self.lr, 0.9, 0.999, 1e-8),
+                        'invpref_adam_schedule_fill')
+            sc['table'].copy_(torch.from_numpy(host))
+            sc['base'] = first
+            self._sched_synced = False
+        if not self._sched_synced:  # the device counter follows the host's after eager steps / refills
+            sc['state'].copy_(torch.tensor([first, sc['base'], 0, 0], dtype=torch.int32))
+            self._sched_synced = True
+
+    def _issue_epoch(self, stream, sched: bool):
+        self._epoch_losses.zero_()
+        for k in range(self.batch_num):
+            self._raw_step(k, self._alpha_for(k), stream, sched=sched)
+
     def train_a_epoch(self) -> dict:
-        """train.py:204-233, without the per-batch host syncs (one read-back per epoch)."""
+        """train.py:204-233, without the per-batch host syncs (one read-back per epoch).  On one GPU
+        with a fixed alpha the whole epoch (batch_num fused steps) is captured once per parameter-buffer
+        parity into a HIP graph and replayed: one launch per epoch instead of 2*batch_num."""
         self.model.train()
         if getattr(self, '_raw_ptrs', None) is None or self._raw_ptrs[2] != self.envs.data_ptr() \
                 or self._raw_ptrs[4] != self.sample_weights.data_ptr():
             self._raw_setup()
-        self._epoch_losses.zero_()
-        stream = torch.cuda.current_stream().cuda_stream
-        for k in range(self.batch_num):
-            self._raw_step(k, self._alpha_for(k), stream)
+            self._graphs.clear()
+        st = self.state
+        graph_ok = self.use_graph and self.use_plan and self.world_size == 1 and not self.update_alpha
+        if graph_ok and self._graph_warm:
+            self._sched_prepare(self.batch_num)
+            key = id(st.p_views)
+            g = self._graphs.get(key)
+            if g is None:
+                step0, views0 = st.step, st.p_views
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._issue_epoch(torch.cuda.current_stream().cuda_stream, sched=True)
+                # capture records, it does not run: put the host-side bookkeeping back
+                st.step = step0
+                if st.p_views is not views0:
+                    st.swap()
+                self._graphs[key] = g
+            g.replay()
+            st.step += self.batch_num
+            if self.batch_num % 2:
+                st.swap()
+        else:
+            self._issue_epoch(torch.cuda.current_stream().cuda_stream, sched=False)
+            self._graph_warm = True
+            self._sched_synced = False
         self.epoch_cnt += 1
         vals = self._epoch_losses.mean(dim=0).tolist()
         return dict(zip(LOSS_KEYS, vals))
@@ -349,7 +416,9 @@ class _InvPrefTrainManager:
             counts, _, _ = ops.stat_envs(self.envs, self.envs_num, self.workspace, want_sample_weights=False)
             all_reduce_sum_(counts, self.process_group)
             cw, sw = ops.sample_weights(self.envs, counts, self.n_total, self.envs_num)
-        self.class_weights, self.sample_weights = cw, sw
+        # in place: the epoch loop (and a captured HIP graph of it) holds pointers into these buffers
+        self.class_weights.copy_(cw)
+        self.sample_weights.copy_(sw)
         return {env: int(c) for env, c in enumerate(counts.tolist())}
 
     def update_each_env_count(self):  # train.py:261-266

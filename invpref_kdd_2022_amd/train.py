@@ -157,6 +157,10 @@ class _InvPrefTrainManager:
         self._plans = None
         # whole epochs as one HIP graph launch (single GPU, planned path, fixed alpha); INVPREF_NO_GRAPH=1 disables
         self.use_graph = os.environ.get('INVPREF_NO_GRAPH', '0') != '1'
+        # testing aid: run the multi-GPU step sequence (gradient pass -> all-reduce -> stand-alone Adam) on one rank
+        self._force_sharded_path = os.environ.get('INVPREF_FORCE_SHARDED_PATH', '0') == '1'
+        import torch.distributed as _dist
+        self._collective_ok = _dist.is_available() and _dist.is_initialized()
         self._graphs, self._graph_warm = {}, False
         self._sched = None
         self._sched_synced = False
@@ -235,7 +239,7 @@ class _InvPrefTrainManager:
         lo, n, bn = self._raw_batches[k]
         pu, pi, pe, py, pw = self._raw_ptrs
         cf = _capi.Coefs(self.invariant_coe, self.env_aware_coe, self.env_coe, self.L2_coe, self.L1_coe, alpha)
-        multi = self.world_size > 1
+        multi = self.world_size > 1 or self._force_sharded_path
         if multi:
             st.losses6.zero_()
             lp = st.losses6.data_ptr()
@@ -274,7 +278,8 @@ class _InvPrefTrainManager:
         if rc:
             _capi.check(rc, 'invpref_mstep_(owner_)grad_hip')
         if multi:
-            all_reduce_sum_(st.grad_ext, self.process_group)
+            if self.world_size > 1 or self._collective_ok:
+                all_reduce_sum_(st.grad_ext, self.process_group)
             self._epoch_losses[k] += st.losses6
         if mid_event is not None:
             mid_event.record()
@@ -329,7 +334,8 @@ class _InvPrefTrainManager:
             self._raw_setup()
             self._graphs.clear()
         st = self.state
-        graph_ok = self.use_graph and self.use_plan and self.world_size == 1 and not self.update_alpha
+        graph_ok = self.use_graph and self.use_plan and self.world_size == 1 and not self.update_alpha \
+            and not self._force_sharded_path
         if graph_ok and self._graph_warm:
             self._sched_prepare(self.batch_num)
             key = id(st.p_views)

@@ -1,0 +1,176 @@
+"""CPU, world_size 2 over gloo: the row-sharded training path (parallel.RowShard, FlatState layout,
+one all-reduce of the flat gradient buffer with the loss tail, sharded E-step counts) run through the
+REAL manager code with the HIP ops swapped for the CPU oracle (test infrastructure), against the
+single-process oracle trajectory."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from invpref_kdd_2022_amd import ops, synth
+from invpref_kdd_2022_amd.parallel import RowShard
+from oracle import oracle as O
+
+U, I, E, D, N, B = 60, 40, 3, 16, 1000, 256
+COEFS = dict(invariant_coe=2.0, env_aware_coe=8.6, env_coe=5.1, L2_coe=7.7, L1_coe=0.0015, alpha=1.7)
+LR = 0.01
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _oracle_ops(monkey_target):
+    """CPU stand-ins with the signatures of ops.mstep_grad / ops.adam_ / ops.estep / ops.stat_envs /
+    ops.sample_weights, backed by the oracle."""
+
+    def tables_of(params):
+        return O.Tables({k: p.detach().numpy() for k, p in zip(O.PARAM_NAMES, params)})
+
+    def mstep_grad(params, grads, users, items, envs, scores, weights, batch_norm, coefs, flags, losses6, ws):
+        dense = bool(flags & 32)
+        g, l = O.mstep(tables_of(params), users.numpy(), items.numpy(), envs.numpy(), scores.numpy(),
+                       None if weights is None else weights.numpy(), np.asarray(coefs, np.float64), flags & 31,
+                       bnorm=batch_norm, include_dense_reg=dense)
+        for dst, src in zip(grads, g):
+            dst += torch.from_numpy(src)
+        losses6 += torch.from_numpy(l.astype(np.float32))
+
+    def adam_(param, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, zero_grad=True):
+        n = param.numel()
+        O.adam(param.numpy(), grad[:n].numpy().copy(), m.numpy(), v.numpy(), step, lr)
+        if zero_grad:
+            grad.zero_()
+
+    def estep(params, users, items, scores, implicit, old_envs, ws, eps_rows=None, new_envs=None, want_weights=True):
+        new, counts, diff, _ = O.estep(tables_of(params), users.numpy(), items.numpy(), scores.numpy(), implicit,
+                                       old_envs=None if old_envs is None else old_envs.numpy())
+        if new_envs is not None:
+            new_envs.copy_(torch.from_numpy(new))
+        return (new_envs if new_envs is not None else torch.from_numpy(new), torch.from_numpy(counts),
+                torch.tensor([diff]), None, None)
+
+    def stat_envs(envs, env_num, ws, want_sample_weights=True):
+        c, cw, sw = O.stat_envs(envs.numpy(), env_num)
+        return torch.from_numpy(c), torch.from_numpy(cw), torch.from_numpy(sw)
+
+    def sample_weights(envs, counts, n_total, env_num):
+        c = counts.numpy()
+        cw = (np.minimum(c + 1, n_total - 1) / n_total).astype(np.float32)
+        return torch.from_numpy(cw), torch.from_numpy(cw[envs.numpy()])
+
+    for name, fn in dict(mstep_grad=mstep_grad, adam_=adam_, estep=estep, stat_envs=stat_envs,
+                         sample_weights=sample_weights).items():
+        setattr(monkey_target, name, fn)
+
+
+def _make_manager(rank, world, data, tabs):
+    from invpref_kdd_2022_amd.models import InvPrefExplicit
+    from invpref_kdd_2022_amd.train import ExplicitTrainManager
+
+    class Stub:
+        def evaluate(self):
+            return {}
+
+    os.environ['INVPREF_NO_PLAN'] = '1'  # the planned path is HIP-only; the sharding logic is the same
+    model = InvPrefExplicit(U, I, E, D, reg_only_embed=False, reg_env_embed=True)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in tabs.items()})
+    np.random.seed(5)
+    return ExplicitTrainManager(model=model, evaluator=Stub(), device=torch.device('cpu'),
+                                training_data=torch.from_numpy(data), batch_size=B, epochs=2, cluster_interval=1,
+                                evaluate_interval=10 ** 9, lr=LR, use_class_re_weight=True,
+                                use_recommend_re_weight=True, cluster_use_random_sort=False, rank=rank,
+                                world_size=world, **COEFS)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        _oracle_ops(ops)
+        data = synth.interactions(3, U, I, N, implicit=False, zipf=False)
+        tabs = synth.tables(4, U, I, E, D, std=0.2)
+        mgr = _make_manager(rank, world, data, tabs)
+        # this rank holds exactly its row slices of every minibatch, in order
+        rows = RowShard(N, B, rank, world).local_rows().numpy()
+        np.testing.assert_array_equal(mgr.users_tensor.numpy(), data[rows, 0])
+        mgr.stat_envs()
+        losses = []
+        for _ in range(2):
+            for k in range(mgr.batch_num):
+                lo, hi = mgr.shard.local_batch_bounds(k)
+                losses.append(mgr.train_a_batch(mgr.users_tensor[lo:hi], mgr.items_tensor[lo:hi],
+                                                mgr.scores_tensor[lo:hi], mgr.envs[lo:hi],
+                                                mgr.sample_weights[lo:hi], mgr.alpha))
+            diff = mgr.cluster()
+            cnt = mgr.stat_envs()
+        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), param=mgr.state.param.numpy(),
+                 losses=np.array([[d[k] for k in d] for d in losses]), diff=diff,
+                 counts=np.array([cnt[e] for e in range(E)]), envs=mgr.envs.numpy(), rows=rows)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_row_sharded_training_matches_single_process(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f'rank{i}.npz') for i in range(world)]
+    # replicas stay identical
+    np.testing.assert_array_equal(r[0]['param'], r[1]['param'])
+    np.testing.assert_array_equal(r[0]['losses'], r[1]['losses'])
+    assert int(r[0]['diff']) == int(r[1]['diff'])
+    np.testing.assert_array_equal(r[0]['counts'], r[1]['counts'])
+    # single-process reference: the oracle's own loop on the whole data
+    data = synth.interactions(3, U, I, N, implicit=False, zipf=False)
+    tabs = synth.tables(4, U, I, E, D, std=0.2)
+    np.random.seed(5)
+    env0 = np.random.randint(0, E, N)
+    cf = [COEFS[k] for k in ('invariant_coe', 'env_aware_coe', 'env_coe', 'L2_coe', 'L1_coe', 'alpha')]
+    tr = O.Trainer(tabs, data, env0, implicit=False, batch_size=B, coefs=cf, lr=LR, reweight_rec=True,
+                   reweight_cls=True, reg_only_embed=False, reg_env_embed=True)
+    tr.stat_envs()
+    ref_losses = []
+    for _ in range(2):
+        for lo in range(0, N, B):
+            ref_losses.append(tr.train_a_batch(lo, min(lo + B, N)))
+        diff = tr.cluster()
+        cnt = tr.stat_envs()
+    np.testing.assert_allclose(r[0]['losses'], np.array(ref_losses), rtol=2e-5)
+    # sharded parameters == single-process parameters up to fp32 re-association of the shard sums
+    from invpref_kdd_2022_amd.models import InvPrefExplicit
+    from invpref_kdd_2022_amd.train import FlatState
+    fs = FlatState(InvPrefExplicit(U, I, E, D), torch.device('cpu'))
+    for arr, off, shp in zip(tr.tab.arrs, fs.offsets, fs.shapes):
+        got = r[0]['param'][off:off + arr.size].reshape(shp)
+        assert np.abs(got - arr).max() < 0.05 * LR
+        assert np.quantile(np.abs(got - arr), 0.99) < 5e-6
+    # E-step: assignments of every row, gathered back from the two shards
+    envs = np.empty(N, np.int64)
+    for x in r:
+        envs[x['rows']] = x['envs']
+    mism = int((envs != tr.envs).sum())
+    assert mism <= 2
+    assert abs(int(r[0]['diff']) - diff) <= mism and np.abs(r[0]['counts'] - np.array([cnt[e] for e in range(E)])).sum() <= 2 * mism
+
+
+def test_row_shard_index_arithmetic():
+    for n, b, w in ((1000, 256, 2), (250154, 8192, 8), (7, 3, 4), (5, 10, 3)):
+        shards = [RowShard(n, b, r, w) for r in range(w)]
+        allrows = np.concatenate([s.local_rows().numpy() for s in shards])
+        assert sorted(allrows.tolist()) == list(range(n))           # a partition of the rows
+        for k in range(shards[0].batch_num):
+            parts = [s.global_rows_of_batch(k) for s in shards]
+            assert parts[0][0] == k * b and parts[-1][1] == min((k + 1) * b, n)
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))   # contiguous, in rank order
+            assert max(p[1] - p[0] for p in parts) - min(p[1] - p[0] for p in parts) <= 1   # balanced
+            for s in shards:
+                lo, hi = s.local_batch_bounds(k)
+                g0, g1 = s.global_rows_of_batch(k)
+                np.testing.assert_array_equal(s.local_rows().numpy()[lo:hi], np.arange(g0, g1))

@@ -107,7 +107,7 @@ int invpref_mstep_grad_hip(const InvPrefTables *tables, const InvPrefTables *gra
  *   mode 0: no interaction; 1 / 2: one / two interactions inline as (partner_row, position, label
  *   bits) = (a, b, c) and (d, e, f); 3: interactions [a, b) of the side's sorted arrays below.
  * Every row of every table must appear in exactly one job (rows the minibatch does not touch as
- * jobs with mode 0).  other_*[j] / pos_*[j]: for the j-th interaction in that side's order (sorted by
+ * jobs with mode 0), except the hot item rows listed at the end of the struct.  other_*[j] / pos_*[j]: for the j-th interaction in that side's order (sorted by
  * own row), its row in the OTHER side's tables and its position inside the minibatch (index into the
  * envs / scores / sample_weights minibatch slices). */
 typedef struct InvPrefRowPlan {
@@ -115,10 +115,17 @@ typedef struct InvPrefRowPlan {
     const int32_t *desc;                      /* [n_rounds][16][8] */
     const int32_t *other_user, *pos_user;     /* [n] */
     const int32_t *other_item, *pos_item;     /* [n] */
+    /* "hot" item rows: rows with more interactions in the minibatch than one workgroup should walk get
+     * NO job; the user-side jobs add their gradient with float atomics into a scratch row (shaped as
+     * 64 contiguous bytes per interaction and instruction) and the finish kernel completes them.
+     * n_hot may be 0 (then the three pointers are ignored) or item_num (no item-side jobs at all). */
+    int32_t n_hot, reserved;
+    const int32_t *hot_rows, *hot_count;      /* [n_hot] item row, its interaction count in this minibatch */
+    const int32_t *item_hot_index;            /* [item_num] index into hot_rows, or -1 */
 } InvPrefRowPlan;
 
 /* The rows-path workspace must be ZERO-FILLED before its first use; every call leaves it zero-filled. */
-size_t invpref_rows_workspace_bytes(const InvPrefTables *tables);
+size_t invpref_rows_workspace_bytes(const InvPrefTables *tables, const InvPrefRowPlan *plan);
 
 /* same contract as invpref_mstep_grad_hip, except that EVERY row of every table of `grads` is
  * OVERWRITTEN (rows the minibatch does not touch get zeros): no zeroing pass is needed.  The four big

@@ -76,7 +76,7 @@ def lib():
                                            vp, vp, vp, C.c_size_t, vp]
         L.invpref_predict_hip.argtypes = [vp, vp, vp, i64, i64, i64, C.c_int, vp, vp]
         L.invpref_rows_workspace_bytes.restype = C.c_size_t
-        L.invpref_rows_workspace_bytes.argtypes = [C.POINTER(Tables)]
+        L.invpref_rows_workspace_bytes.argtypes = [C.POINTER(Tables), vp]
         L.invpref_mstep_rows_grad_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), vp, vp, vp, vp, i64,
                                                    C.POINTER(Coefs), u32, vp, vp, C.c_size_t, vp]
         L.invpref_mstep_rows_adam_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), C.POINTER(Tables),

@@ -54,6 +54,8 @@ struct RowsArgs {
     float *np[4];                 // new parameter tables              (fused == 1)
     float *m[4], *v[4];           // Adam moments                      (fused == 1)
     AdamScalars ad;
+    const int *item_hot_index;    // [item_num]: scratch row of an item whose gradient goes through atomics, or -1
+    float *hot_scratch;           // [n_hot][2][DP] gradient accumulators of those rows (zero on entry, re-zeroed by finish)
     int *sched_state;             // optional device int32[4] = {step (1-based), first step of sched_table, ticket, 0}
     const AdamScalars *sched_table;  // optional device table of per-step Adam scalars (graph replay)
     unsigned long long *stamps;   // diagnostic builds only (INVPREF_STAMPS): [n_tasks][8] s_memrealtime ticks
@@ -175,7 +177,7 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
 #pragma unroll
         for (int c = 0; c < NC; c++) oi[c] = oe[c] = gi[c] = ge[c] = pi[c] = pe[c] = f4zero();
         Sample cur{0, 0, 0.f};
-        int e = 0;
+        int e = 0, hidx = -1;
         float w = 1.f;
         if (active) {
             load_row<NC, VEC>(T_own_inv, row, t.D, l16, oi);
@@ -186,6 +188,7 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
                 load_row<NC, VEC>(T_oth_env, cur.oth, t.D, l16, pe);
                 e = (int)a.envs[cur.ps];
                 if (rw_rec || rw_cls) w = a.weights[cur.ps];
+                if (user_side && a.item_hot_index) hidx = a.item_hot_index[cur.oth];
             }
         }
         if (dma) {
@@ -210,7 +213,7 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
             // request the next interaction before working on this one
             float4 pin[NC], pen[NC];
             Sample nxt{0, 0, 0.f};
-            int en = 0;
+            int en = 0, hn = -1;
             float wn = 1.f;
             if (sidx + 1 < nsmp) {
                 nxt = sample_at(sidx + 1);
@@ -218,6 +221,7 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
                 load_row<NC, VEC>(T_oth_env, nxt.oth, t.D, l16, pen);
                 en = (int)a.envs[nxt.ps];
                 if (rw_rec || rw_cls) wn = a.weights[nxt.ps];
+                if (user_side && a.item_hot_index) hn = a.item_hot_index[nxt.oth];
             }
             const float y = cur.y;
             const float w_rec = rw_rec ? w : 1.f, w_cls = rw_cls ? w : 1.f;
@@ -286,6 +290,31 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
                 gip.z = g_p - k.alpha * gx[jj].z; gip.w = g_p - k.alpha * gx[jj].w;
                 f4add(gi[jj], f4mul(gip, pi[jj]));
                 f4fma(ge[jj], g_q, f4mul(pe[jj], ev[jj]));
+            }
+            if (user_side && hidx >= 0) {
+                // the partner item row takes its gradient through float atomics (it has no job of its own:
+                // too many interactions for one workgroup); transposed through LDS so that one instruction
+                // adds 64 contiguous bytes per interaction.  (A job's slices write their LDS slot only AFTER
+                // the interaction loop, so the slot is free to serve as the transpose buffer here.)
+                float *tr = slots + grp * 2 * DP;
+                float *dst = a.hot_scratch + (int64_t)hidx * 2 * DP;
+#pragma unroll
+                for (int jj = 0; jj < NC; jj++) {
+                    float4 gip;
+                    gip.x = g_p - k.alpha * gx[jj].x; gip.y = g_p - k.alpha * gx[jj].y;
+                    gip.z = g_p - k.alpha * gx[jj].z; gip.w = g_p - k.alpha * gx[jj].w;
+                    *reinterpret_cast<float4 *>(tr + (l16 + kRow * jj) * 4) = f4mul(gip, oi[jj]);
+                    float4 t2 = f4mul(oe[jj], ev[jj]);
+                    t2.x *= g_q; t2.y *= g_q; t2.z *= g_q; t2.w *= g_q;
+                    *reinterpret_cast<float4 *>(tr + DP + (l16 + kRow * jj) * 4) = t2;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+                for (int q4 = 0; q4 < 2 * DP / 16; q4++) {
+                    const int idx = q4 * 16 + l16;           // 16 lanes -> 16 consecutive floats
+                    if ((idx & (DP - 1)) < t.D) atomicAdd(dst + idx, tr[idx]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
             if (user_side) {
                 // ---- E x D partials: env-table row e gets g_q * Pa*Qa (+ its regulariser), classifier row c gets gz_c * x
@@ -365,7 +394,7 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
                 if (l16 == 0) { accLi += li * w_rec; accLe += le * w_rec; accLc += -f_log(ze * rse) * w_cls; }
             }
             // rotate in the prefetched interaction
-            cur = nxt; e = en; w = wn;
+            cur = nxt; e = en; w = wn; hidx = hn;
 #pragma unroll
             for (int c = 0; c < NC; c++) { pi[c] = pin[c]; pe[c] = pen[c]; }
         }
@@ -491,13 +520,77 @@ struct SmallTables {
     float *nEv, *nW, *nb;        // fused == 1: new parameters
     float *mEv, *mW, *mb, *vEv, *vW, *vb;
 };
+// item rows whose gradient arrived through atomics (no job of their own): finished here
+struct HotRows {
+    int n, slab_blocks;          // rows; number of leading blocks that fold the slabs
+    const int *rows, *cnt;       // [n] item row id, interactions of that row in this minibatch
+    float *scratch;              // [n][2][DP]
+    const float *Qi, *Qa;        // current item tables
+    float *gQi, *gQa;            // fused == 0: gradient tables
+    float *nQi, *nQa, *mQi, *mQa, *vQi, *vQa;   // fused == 1
+};
+
+template <int NC, bool VEC>
+__device__ __forceinline__ void finish_hot_rows(const DevTables &t, const HotRows &h, const StepScalars &k,
+                                                int fused, const AdamScalars &ad, int block) {
+    constexpr int DP = NC * 64;
+    const int l16 = threadIdx.x & 15;
+    const int i = block * (int)(blockDim.x >> 4) + (int)(threadIdx.x >> 4);
+    if (i >= h.n) return;
+    const int row = h.rows[i];
+    const float cnt = (float)h.cnt[i];
+    float *sc = h.scratch + (int64_t)i * 2 * DP;
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+        const float *T = tt == 0 ? h.Qi : h.Qa;
+        float4 p[NC], g[NC];
+        load_row<NC, VEC>(T, row, t.D, l16, p);
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            float4 *q = reinterpret_cast<float4 *>(sc + tt * DP + (l16 + kRow * c) * 4);
+            g[c] = *q;
+            *q = f4zero();  // leave the accumulator zeroed for the next step
+            g[c].x += cnt * (k.r2 * p[c].x + k.r1 * c_sign(p[c].x)); g[c].y += cnt * (k.r2 * p[c].y + k.r1 * c_sign(p[c].y));
+            g[c].z += cnt * (k.r2 * p[c].z + k.r1 * c_sign(p[c].z)); g[c].w += cnt * (k.r2 * p[c].w + k.r1 * c_sign(p[c].w));
+        }
+        if (!fused) {
+            store_row<NC, VEC>(tt == 0 ? h.gQi : h.gQa, row, t.D, l16, g);
+        } else {
+            float4 m[NC], v[NC];
+            load_row<NC, VEC>(tt == 0 ? h.mQi : h.mQa, row, t.D, l16, m);
+            load_row<NC, VEC>(tt == 0 ? h.vQi : h.vQa, row, t.D, l16, v);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                adam1f(p[c].x, g[c].x, m[c].x, v[c].x, ad); adam1f(p[c].y, g[c].y, m[c].y, v[c].y, ad);
+                adam1f(p[c].z, g[c].z, m[c].z, v[c].z, ad); adam1f(p[c].w, g[c].w, m[c].w, v[c].w, ad);
+            }
+            store_row<NC, VEC>(tt == 0 ? h.nQi : h.nQa, row, t.D, l16, p);
+            store_row<NC, VEC>(tt == 0 ? h.mQi : h.mQa, row, t.D, l16, m);
+            store_row<NC, VEC>(tt == 0 ? h.vQi : h.vQa, row, t.D, l16, v);
+        }
+    }
+}
 __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTables o, float *__restrict__ slabs,
                                                            int nslabs, int DP, int EMAX, StepScalars k, float l2,
                                                            float l1, int64_t Bnorm, uint32_t flags, int fused,
                                                            AdamScalars ad_in, int *sched_state,
                                                            const AdamScalars *sched_table,
-                                                           float *__restrict__ losses6) {
+                                                           float *__restrict__ losses6, HotRows hot, int nc, int vec) {
     const AdamScalars ad = sched_state ? sched_table[sched_state[0] - sched_state[1]] : ad_in;
+    if ((int)blockIdx.x >= hot.slab_blocks) {
+        // trailing blocks: 64 groups of 16 lanes, one hot item row each
+        const int hb = blockIdx.x - hot.slab_blocks;
+        if (!vec) finish_hot_rows<4, false>(t, hot, k, fused, ad, hb);
+        else if (nc == 1) finish_hot_rows<1, true>(t, hot, k, fused, ad, hb);
+        else if (nc == 2) finish_hot_rows<2, true>(t, hot, k, fused, ad, hb);
+        else finish_hot_rows<4, true>(t, hot, k, fused, ad, hb);
+        if (sched_state && threadIdx.x == 0) {  // same ticket protocol as below
+            __threadfence();
+            const int ticket = atomicAdd(sched_state + 2, 1);
+            if (ticket == (int)gridDim.x - 1) { sched_state[2] = 0; sched_state[0] = sched_state[0] + 1; }
+        }
+        return;
+    }
     __shared__ double part[16][64];
     __shared__ double sloss[kLossSlots];
     __shared__ double sreg[2];
@@ -515,7 +608,7 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
     if (threadIdx.x < 2) sreg[threadIdx.x] = 0.0;
     __syncthreads();
     const bool dense = (flags & INVPREF_DENSE_REG) && !(flags & INVPREF_REG_ONLY_EMBED);
-    const bool last_block = blockIdx.x == gridDim.x - 1;
+    const bool last_block = (int)blockIdx.x == hot.slab_blocks - 1;
     if (sub == 0 && idx < slab_len) {
         double v = 0.0;
         for (int s = 0; s < 16; s++) v += part[s][col];
@@ -635,7 +728,10 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     const int nc = vec ? nc_of(t.D) : 4, emax = emax_of(t.E);
     const int DP = nc * 64, EDP = t.E * DP;
     const int slab_len = 2 * EDP + emax + kLossSlots;
-    if (workspace_bytes < sizeof(float) * (size_t)slab_len * kReplicas) return INVPREF_EWORKSPACE;
+    if (plan->n_hot < 0 || (plan->n_hot > 0 && (!plan->hot_rows || !plan->hot_count || !plan->item_hot_index)))
+        return INVPREF_EINVAL;
+    if (workspace_bytes < sizeof(float) * ((size_t)slab_len * kReplicas + (size_t)plan->n_hot * 2 * DP))
+        return INVPREF_EWORKSPACE;
     StepScalars k;
     k.ca = coefs->invariant_coe; k.cb = coefs->env_aware_coe; k.cc = coefs->env_coe; k.alpha = coefs->alpha;
     k.invB = 1.0f / (float)batch_norm;
@@ -648,6 +744,8 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a.oth[1] = plan->other_item; a.pos[1] = plan->pos_item;
     a.envs = envs; a.scores = scores; a.weights = weights;
     a.k = k; a.flags = flags; a.slabs = (float *)workspace; a.fused = fused; a.ad = ad;
+    a.item_hot_index = plan->n_hot > 0 ? plan->item_hot_index : nullptr;
+    a.hot_scratch = (float *)workspace + (size_t)slab_len * kReplicas;
     a.sched_state = sched ? sched->state : nullptr;
     a.sched_table = sched ? reinterpret_cast<const AdamScalars *>(sched->table) : nullptr;
     // diagnostics: INVPREF_STAMPS=<device pointer, hex> makes the kernel write phase time stamps there
@@ -681,8 +779,15 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
         o.vEv = exp_avg_sq->embed_env; o.vW = exp_avg_sq->classifier_weight; o.vb = exp_avg_sq->classifier_bias;
     }
     const int nfb = (slab_len + 63) / 64;
-    hipLaunchKernelGGL(rows_finish_kernel, dim3(nfb), dim3(1024), 0, st, t, o, (float *)workspace, kReplicas, DP, emax, k,
-                       coefs->L2_coe, coefs->L1_coe, batch_norm, flags, fused, ad, a.sched_state, a.sched_table, losses6);
+    HotRows h{};
+    h.n = plan->n_hot; h.slab_blocks = nfb; h.rows = plan->hot_rows; h.cnt = plan->hot_count; h.scratch = a.hot_scratch;
+    h.Qi = t.Qi; h.Qa = t.Qa;
+    if (!fused) { h.gQi = a.g[1]; h.gQa = a.g[3]; }
+    else { h.nQi = a.np[1]; h.nQa = a.np[3]; h.mQi = a.m[1]; h.mQa = a.m[3]; h.vQi = a.v[1]; h.vQa = a.v[3]; }
+    const int hot_blocks = (plan->n_hot + 63) / 64;  // 1024 threads = 64 groups per block
+    hipLaunchKernelGGL(rows_finish_kernel, dim3(nfb + hot_blocks), dim3(1024), 0, st, t, o, (float *)workspace, kReplicas,
+                       DP, emax, k, coefs->L2_coe, coefs->L1_coe, batch_norm, flags, fused, ad, a.sched_state,
+                       a.sched_table, losses6, h, nc, (int)vec);
     return (int)hipGetLastError();
 }
 
@@ -690,10 +795,10 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
 
 extern "C" {
 
-size_t invpref_rows_workspace_bytes(const InvPrefTables *tables) {
-    if (check_tables(tables)) return 0;
+size_t invpref_rows_workspace_bytes(const InvPrefTables *tables, const InvPrefRowPlan *plan) {
+    if (check_tables(tables) || !plan || plan->n_hot < 0) return 0;
     const size_t slab_len = 2 * (size_t)tables->env_num * 256 + 16 + kLossSlots;
-    return sizeof(float) * slab_len * kReplicas;
+    return sizeof(float) * (slab_len * kReplicas + (size_t)plan->n_hot * 2 * 256);
 }
 
 int invpref_mstep_rows_grad_hip(const InvPrefTables *tables, const InvPrefTables *grads, const InvPrefRowPlan *plan,

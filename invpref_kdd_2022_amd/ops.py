@@ -183,7 +183,7 @@ def mstep_rows_grad(params, grads, dplan, envs, scores, sample_weights, batch_no
     _capi._req(scores, torch.float32, 'scores')
     _capi._req(sample_weights, torch.float32, 'sample_weights')
     cf = Coefs(*[float(c) for c in coefs[:6]])
-    ws = workspace.get_zeroed(lib().invpref_rows_workspace_bytes(C.byref(t)))
+    ws = workspace.get_zeroed(lib().invpref_rows_workspace_bytes(C.byref(t), C.byref(dplan.struct)))
     check(lib().invpref_mstep_rows_grad_hip(C.byref(t), C.byref(g), C.byref(dplan.struct), ptr(_ids(envs, 'envs')),
                                              ptr(scores), ptr(sample_weights), int(batch_norm), C.byref(cf), flags,
                                              ptr(losses6), ptr(ws), ws.numel(), stream_ptr()),
@@ -199,7 +199,7 @@ def mstep_rows_adam(params, new_params, exp_avg, exp_avg_sq, dplan, envs, scores
     _capi._req(scores, torch.float32, 'scores')
     _capi._req(sample_weights, torch.float32, 'sample_weights')
     cf = Coefs(*[float(c) for c in coefs[:6]])
-    ws = workspace.get_zeroed(lib().invpref_rows_workspace_bytes(C.byref(t)))
+    ws = workspace.get_zeroed(lib().invpref_rows_workspace_bytes(C.byref(t), C.byref(dplan.struct)))
     check(lib().invpref_mstep_rows_adam_hip(C.byref(t), C.byref(tn), C.byref(tm), C.byref(tv), C.byref(dplan.struct),
                                              ptr(_ids(envs, 'envs')), ptr(scores), ptr(sample_weights),
                                              int(batch_norm), C.byref(cf), flags, ptr(losses6), int(step), float(lr),

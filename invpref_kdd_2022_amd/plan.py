@@ -24,11 +24,13 @@ class RowPlanStruct(C.Structure):
     """struct InvPrefRowPlan"""
     _fields_ = [('n_rounds', C.c_int32), ('n_item_rounds', C.c_int32), ('rounds_per_task', C.c_int32),
                 ('n', C.c_int32), ('desc', C.c_void_p), ('other_user', C.c_void_p), ('pos_user', C.c_void_p),
-                ('other_item', C.c_void_p), ('pos_item', C.c_void_p)]
+                ('other_item', C.c_void_p), ('pos_item', C.c_void_p), ('n_hot', C.c_int32), ('reserved', C.c_int32),
+                ('hot_rows', C.c_void_p), ('hot_count', C.c_void_p), ('item_hot_index', C.c_void_p)]
 
 
-def _side_rounds(own, oth, pos, y, n_rows: int, per_slice: int, pad_to: int):
-    """desc [n_rounds,16,8] int32 for one side.  own / oth / pos / y are in the side's sorted order."""
+def _side_rounds(own, oth, pos, y, n_rows: int, per_slice: int, pad_to: int, skip=None):
+    """desc [n_rounds,16,8] int32 for one side.  own / oth / pos / y are in the side's sorted order.
+    skip: boolean mask of rows that get no job (hot item rows)."""
     cnt = np.bincount(own, minlength=n_rows).astype(np.int64)
     ptr = np.concatenate([[0], np.cumsum(cnt)])
     ybits = np.ascontiguousarray(y, np.float32).view(np.int32)
@@ -37,7 +39,9 @@ def _side_rounds(own, oth, pos, y, n_rows: int, per_slice: int, pad_to: int):
     need = np.maximum(1, -(-cnt // per_slice))
     slices = np.minimum(GROUPS, 1 << np.ceil(np.log2(need)).astype(np.int64))
     sl_len = np.maximum(-(-cnt // slices), 1)
-    descs = []
+    if skip is not None:
+        slices = np.where(skip, 0, slices)
+    descs = [np.zeros((0, GROUPS, 8), np.int32)]
     for g in (16, 8, 4, 2, 1):
         rows = np.flatnonzero(slices == g)
         if len(rows) == 0:
@@ -80,8 +84,11 @@ def _side_rounds(own, oth, pos, y, n_rows: int, per_slice: int, pad_to: int):
 
 
 def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, user_num: int, item_num: int,
-                   per_slice: int | None = None, rounds_per_task: int | None = None) -> dict:
-    """users/items/scores: ONE minibatch (or this rank's slice of it); scores as the fp32 labels."""
+                   per_slice: int | None = None, rounds_per_task: int | None = None,
+                   hot_threshold: int | None = None) -> dict:
+    """users/items/scores: ONE minibatch (or this rank's slice of it); scores as the fp32 labels.
+    hot_threshold: item rows with MORE interactions than this get no job; their gradient is added with
+    float atomics by the user-side jobs and completed by the finish kernel (-1: every item row)."""
     users = np.asarray(users, dtype=np.int64)
     items = np.asarray(items, dtype=np.int64)
     scores = np.asarray(scores, dtype=np.float32)
@@ -89,17 +96,25 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         per_slice = int(os.environ.get('INVPREF_PLAN_PER_SLICE', '1'))
     if rounds_per_task is None:
         rounds_per_task = int(os.environ.get('INVPREF_PLAN_ROUNDS', '1'))
+    if hot_threshold is None:
+        hot_threshold = int(os.environ.get('INVPREF_PLAN_HOT', '16'))
     n = len(users)
     if n and (cnt_max := max(np.bincount(users).max(), np.bincount(items).max())) >= (1 << 23):
         raise ValueError(f'a row with {cnt_max} interactions in one minibatch overflows the job descriptor')
     pu = np.argsort(users, kind='stable')
     pi = np.argsort(items, kind='stable')
+    icnt = np.bincount(items, minlength=item_num)
+    hot = icnt > hot_threshold
+    hot_rows = np.flatnonzero(hot).astype(np.int32)
+    hot_index = np.full(item_num, -1, np.int32)
+    hot_index[hot_rows] = np.arange(len(hot_rows), dtype=np.int32)
     # item rounds first (they hold the longest jobs; padded to whole workgroups), user rounds after
-    di = _side_rounds(items[pi], users[pi], pi, scores[pi], item_num, per_slice, rounds_per_task)
+    di = _side_rounds(items[pi], users[pi], pi, scores[pi], item_num, per_slice, rounds_per_task, skip=hot)
     du = _side_rounds(users[pu], items[pu], pu, scores[pu], user_num, per_slice, 1)
     return dict(n=n, n_item_rounds=len(di), rounds_per_task=rounds_per_task, desc=np.concatenate([di, du]),
                 other_user=items[pu].astype(np.int32), pos_user=pu.astype(np.int32),
-                other_item=users[pi].astype(np.int32), pos_item=pi.astype(np.int32))
+                other_item=users[pi].astype(np.int32), pos_item=pi.astype(np.int32),
+                hot_rows=hot_rows, hot_count=icnt[hot_rows].astype(np.int32), item_hot_index=hot_index)
 
 
 @dataclass
@@ -111,14 +126,18 @@ class DevicePlan:
 
 
 def upload(plan: dict, device) -> DevicePlan:
-    keys = ('desc', 'other_user', 'pos_user', 'other_item', 'pos_item')
-    flat = np.concatenate([np.ascontiguousarray(plan[k], np.int32).reshape(-1) for k in keys])
-    buf = torch.from_numpy(flat).to(device)
-    ptrs, off = {}, 0
-    for k in keys:
-        ptrs[k] = buf.data_ptr() + 4 * off
-        off += int(np.asarray(plan[k]).size)
+    keys = ('desc', 'other_user', 'pos_user', 'other_item', 'pos_item', 'hot_rows', 'hot_count', 'item_hot_index')
+    parts, ptrs, off = [], {}, 0
+    for k in keys:  # every array starts on a 16-byte boundary of the one device buffer
+        a = np.ascontiguousarray(plan[k], np.int32).reshape(-1)
+        pad = (-len(a)) % 4
+        parts.append(np.concatenate([a, np.zeros(pad, np.int32)]))
+        ptrs[k] = off
+        off += len(a) + pad
+    buf = torch.from_numpy(np.concatenate(parts)).to(device)
+    ptrs = {k: buf.data_ptr() + 4 * o for k, o in ptrs.items()}
     nr, rpt = len(plan['desc']), plan['rounds_per_task']
     st = RowPlanStruct(nr, plan['n_item_rounds'], rpt, plan['n'], ptrs['desc'], ptrs['other_user'],
-                       ptrs['pos_user'], ptrs['other_item'], ptrs['pos_item'])
+                       ptrs['pos_user'], ptrs['other_item'], ptrs['pos_item'], len(plan['hot_rows']), 0,
+                       ptrs['hot_rows'], ptrs['hot_count'], ptrs['item_hot_index'])
     return DevicePlan(st, [buf], -(-nr // rpt), nr)

@@ -227,7 +227,8 @@ class _InvPrefTrainManager:
                                             self.model.item_num)
                 self._plans.append(planlib.upload(pl, self.device))
         if self.use_plan:
-            self._raw_ows = self.workspace.get_zeroed(L.invpref_rows_workspace_bytes(C.byref(self._raw_t)))
+            self._raw_ows = self.workspace.get_zeroed(
+                max(L.invpref_rows_workspace_bytes(C.byref(self._raw_t), C.byref(dp.struct)) for dp in self._plans))
         # ctypes views of both parameter buffers / moments for the fused pass
         self._raw_tabs = {id(st.p_views): _capi.make_tables(st.p_views), id(st.p_views_alt): _capi.make_tables(st.p_views_alt)}
         self._raw_m, self._raw_v = _capi.make_tables(st.m_views), _capi.make_tables(st.v_views)

@@ -169,6 +169,7 @@ def test_mstep_g5_mind_shape():
 
 # ------------------------------------------------------------------ planned, atomic-free rows path
 PER_SLICE = 2
+HOT = 6   # item rows with more than 6 interactions in the minibatch go through the atomics path
 from invpref_kdd_2022_amd import plan as planlib  # noqa: E402
 
 
@@ -179,7 +180,7 @@ def test_rows_grad_matches_oracle_and_is_reproducible(path):
     P = dev_params(params)
     ws = ops.Workspace(DEV)
     flags = ops.flags_of(implicit, rec_w, cls_w, roe, ree)
-    dp = planlib.upload(planlib.build_row_plan(z['u'], z['v'], z['y'], U, I, per_slice=PER_SLICE), DEV)
+    dp = planlib.upload(planlib.build_row_plan(z['u'], z['v'], z['y'], U, I, per_slice=PER_SLICE, hot_threshold=HOT), DEV)
     outs = []
     for _ in range(2):
         Gd = [torch.full_like(p, 7.0) for p in P]  # garbage: the kernel must overwrite every row
@@ -193,8 +194,11 @@ def test_rows_grad_matches_oracle_and_is_reproducible(path):
     for k, g, o in zip(O.PARAM_NAMES, outs[0][0], og):
         assert _relerr(g, o) < 2e-5, k
         assert _relerr(g, z['g_f32_' + k]) < 2e-5, k
-    for a, b in zip(outs[0][0][:4], outs[1][0][:4]):  # big tables: registers + fixed-order sums -> bitwise stable
-        np.testing.assert_array_equal(a, b)
+    for i, (a, b) in enumerate(zip(outs[0][0][:4], outs[1][0][:4])):
+        if i in (0, 2):  # user tables: registers + fixed-order sums -> bitwise stable
+            np.testing.assert_array_equal(a, b)
+        else:            # item tables: rows above the hot threshold take float atomics
+            assert _relerr(a, b) < 1e-6
 
 
 @pytest.mark.parametrize('path', G1[::2], ids=[os.path.basename(p)[3:-4] for p in G1[::2]])
@@ -206,7 +210,7 @@ def test_rows_fused_adam_equals_grad_then_adam(path):
     lr = float(z['coefs'][6])
     ws = ops.Workspace(DEV)
     flags = ops.flags_of(implicit, rec_w, cls_w, roe, ree)
-    dp = planlib.upload(planlib.build_row_plan(z['u'], z['v'], z['y'], U, I, per_slice=PER_SLICE), DEV)
+    dp = planlib.upload(planlib.build_row_plan(z['u'], z['v'], z['y'], U, I, per_slice=PER_SLICE, hot_threshold=HOT), DEV)
     e, y, w = t64(z['e']), t32(z['y']), t32(z['w'])
     # path A: fused, ping-pong buffers
     A = [dev_params(params), [torch.zeros_like(p) for p in dev_params(params)]]

@@ -10,7 +10,11 @@ def check_plan(users, items, U, I, **kw):
     p = planlib.build_row_plan(users, items, y, U, I, **kw)
     desc, rpt, nir = p['desc'], p['rounds_per_task'], p['n_item_rounds']
     n = len(users)
-    assert desc.shape[1:] == (16, 8) and nir % rpt == 0 and 0 < nir < len(desc)
+    assert desc.shape[1:] == (16, 8) and nir % rpt == 0 and 0 <= nir < len(desc)
+    hot = set(p['hot_rows'].tolist())
+    icnt = np.bincount(items, minlength=I)
+    np.testing.assert_array_equal(p['hot_count'], icnt[p['hot_rows']])
+    assert all(p['item_hot_index'][r] == i for i, r in enumerate(p['hot_rows'])) and (p['item_hot_index'] >= 0).sum() == len(hot)
     for side, (own, oth, R, o_key, p_key, rounds) in enumerate((
             (users, items, U, 'other_user', 'pos_user', desc[nir:]),
             (items, users, I, 'other_item', 'pos_item', desc[:nir]))):
@@ -21,7 +25,8 @@ def check_plan(users, items, U, I, **kw):
         d = rounds.reshape(-1, 8)
         act = d[d[:, 0] >= 0]
         leaders = act[(act[:, 1] & 1) == 1]
-        assert sorted(leaders[:, 0].tolist()) == list(range(R))      # every table row is exactly one job
+        jobless = hot if side == 1 else set()
+        assert sorted(leaders[:, 0].tolist()) == [r for r in range(R) if r not in jobless]   # one job per row
         cnt = np.bincount(own, minlength=R)
         np.testing.assert_array_equal(leaders[:, 1] >> 8, cnt[leaders[:, 0]])
         seen = np.zeros(n, np.int32)
@@ -37,7 +42,8 @@ def check_plan(users, items, U, I, **kw):
                     assert own[p_] == row and oth[p_] == o_           # inline copy of the interaction
                     assert np.int32(y_).view(np.float32) == y[p_]
                     seen[p_] += 1
-        assert (seen == 1).all()                                      # every interaction in exactly one slice
+        in_job = np.array([own[i] not in jobless for i in range(n)], bool) if n else np.zeros(0, bool)
+        assert (seen == in_job.astype(np.int32)).all()                # each interaction of a job row in exactly one slice
         for rd in rounds:                                             # slot layout inside a round
             g = (rd[0, 1] >> 1) & 31
             assert g in (1, 2, 4, 8, 16) and (((rd[:, 1] >> 1) & 31) == g).all()
@@ -55,14 +61,16 @@ def test_plan_yahoo_like_batch():
     assert len(p['desc']) < 4000
 
 
+@pytest.mark.parametrize('hot', [-1, 0, 8, 10 ** 9])
 @pytest.mark.parametrize('per_slice,rpt', [(1, 1), (2, 3), (4, 2), (64, 5)])
-def test_plan_parameters(per_slice, rpt):
+def test_plan_parameters(per_slice, rpt, hot):
     rs = np.random.RandomState(per_slice)
     u, v = rs.randint(0, 37, 500), rs.randint(0, 5, 500)  # item rows with ~100 interactions each
-    check_plan(u, v, 40, 7, per_slice=per_slice, rounds_per_task=rpt)
+    check_plan(u, v, 40, 7, per_slice=per_slice, rounds_per_task=rpt, hot_threshold=hot)
 
 
 def test_plan_empty_and_single():
     check_plan(np.zeros(0, np.int64), np.zeros(0, np.int64), 5, 3)
     check_plan(np.array([2]), np.array([0]), 5, 3)
-    check_plan(np.full(300, 1), np.full(300, 2), 4, 4)   # one hot row on both sides: 16 slices of 19
+    check_plan(np.full(300, 1), np.full(300, 2), 4, 4, hot_threshold=10 ** 9)   # one hot row on both sides: 16 slices of 19
+    check_plan(np.full(300, 1), np.full(300, 2), 4, 4, hot_threshold=16)

@@ -71,9 +71,10 @@ def graph_time(fn, inner=20, reps=20):
 print('graph: atomic grad %.1f us, adam %.1f us' % (
     graph_time(lambda: ops.mstep_grad(P, G, u, v, e, y, w, B, coefs, flags, losses, ws)),
     graph_time(lambda: ops.adam_(flat, flat, flat, flat, 1, 0.005))))
-for per_slice, rpt in ((1, 1), (1, 2), (1, 4), (2, 2), (4, 2), (8, 2), (2, 4)):
-    pl = planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, per_slice=per_slice, rounds_per_task=rpt)
+for per_slice, rpt, hot in ((1, 1, 10 ** 9), (1, 1, 16), (1, 1, -1), (1, 2, -1), (2, 1, -1), (2, 2, -1)):
+    pl = planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, per_slice=per_slice, rounds_per_task=rpt,
+                                hot_threshold=hot)
     dp = planlib.upload(pl, dev)
     tg = graph_time(lambda: ops.mstep_rows_grad(P, G, dp, e, y, w, B, coefs, flags, losses, ws))
     tf = graph_time(lambda: ops.mstep_rows_adam(P, P2, M, V, dp, e, y, w, B, coefs, flags, losses, 5, 0.005, ws))
-    print(f'rows per_slice={per_slice} rounds/task={rpt}: tasks {dp.n_tasks:5d} rounds {dp.n_rounds:5d}  grad {tg:.1f} us  fused-adam {tf:.1f} us')
+    print(f'rows per_slice={per_slice} rounds/task={rpt} hot>{hot}: tasks {dp.n_tasks:5d} rounds {dp.n_rounds:5d}  grad {tg:.1f} us  fused-adam {tf:.1f} us')

@@ -26,8 +26,9 @@ ws = ops.Workspace(dev)
 losses = torch.zeros(6, device=dev)
 coefs = (3.35, 9.99, 9.06, 3.13, 0.49, 1.9)
 flags = ops.flags_of(True, False, True, True, False)
-for per_slice, rpt in ((2, 2), (1, 1)):
-    pl = planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, per_slice=per_slice, rounds_per_task=rpt)
+for per_slice, rpt, hot in ((1, 1, -1), (1, 1, 16)):
+    pl = planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, per_slice=per_slice, rounds_per_task=rpt,
+                                hot_threshold=hot)
     dp = planlib.upload(pl, dev)
     for _ in range(5):
         stamps.zero_()
@@ -36,10 +37,12 @@ for per_slice, rpt in ((2, 2), (1, 1)):
     st = stamps.cpu().numpy().reshape(-1, 8)[:dp.n_tasks].astype(np.int64)
     ni = pl['n_item_rounds'] // rpt
     t0 = st[:, 0].min()
-    print(f'== per_slice={per_slice} rpt={rpt} tasks={dp.n_tasks} (item {ni}); 100 MHz ticks = 10 ns')
+    print(f'== per_slice={per_slice} rpt={rpt} hot>{hot} tasks={dp.n_tasks} (item {ni}); 100 MHz ticks = 10 ns')
     print('kernel span (first start -> last end): %.2f us' % ((st[:, 6:8].max() - t0) / 100))
     for name, sl in (('item', slice(0, ni)), ('user', slice(ni, None))):
         s = st[sl]
+        if len(s) == 0:
+            continue
         start = (s[:, 0] - t0) / 100
         print(f' {name}: WG start  min {start.min():.2f} med {np.median(start):.2f} max {start.max():.2f} us')
         names = ['prologue(stage+sync)', 'desc load', 'own rows', 'interactions', 'lds combine', 'row finish(adam)', 'dense flush']
@@ -50,3 +53,5 @@ for per_slice, rpt in ((2, 2), (1, 1)):
             print(f'   {nm:22s} med {np.median(dlt):6.2f}  p90 {np.quantile(dlt, .9):6.2f}  max {dlt.max():6.2f} us')
         life = (s[:, 7 if name == 'user' else 6] - s[:, 0]) / 100
         print(f'   WG lifetime            med {np.median(life):6.2f}  p90 {np.quantile(life, .9):6.2f}  max {life.max():6.2f} us')
+        end = (s[:, 7 if name == 'user' else 6] - t0) / 100
+        print(f'   WG end time            med {np.median(end):6.2f}  p90 {np.quantile(end, .9):6.2f}  max {end.max():6.2f} us; starts after 5us: {(start > 5).sum()}')

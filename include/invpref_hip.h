@@ -106,8 +106,8 @@ int invpref_mstep_grad_hip(const InvPrefTables *tables, const InvPrefTables *gra
  *   meta = leader | slices << 1 | mode << 6 | row_count << 8     (idle slots carry slices too)
  *   mode 0: no interaction; 1 / 2: one / two interactions inline as (partner_row, position, label
  *   bits) = (a, b, c) and (d, e, f); 3: interactions [a, b) of the side's sorted arrays below.
- * Every row of every table must appear in exactly one job (rows the minibatch does not touch as
- * jobs with mode 0), except the hot item rows listed at the end of the struct.  other_*[j] / pos_*[j]: for the j-th interaction in that side's order (sorted by
+ * Every row of every table appears exactly once: in a job, in the hot-row list or in the stream list
+ * (see the end of the struct).  other_*[j] / pos_*[j]: for the j-th interaction in that side's order (sorted by
  * own row), its row in the OTHER side's tables and its position inside the minibatch (index into the
  * envs / scores / sample_weights minibatch slices). */
 typedef struct InvPrefRowPlan {
@@ -122,6 +122,10 @@ typedef struct InvPrefRowPlan {
     int32_t n_hot, reserved;
     const int32_t *hot_rows, *hot_count;      /* [n_hot] item row, its interaction count in this minibatch */
     const int32_t *item_hot_index;            /* [item_num] index into hot_rows, or -1 */
+    /* rows the minibatch does not touch need no job either: they are listed here and streamed through
+     * the dense-Adam step (zero gradient) by workgroups of their own, rows_per_stream_task rows each. */
+    int32_t n_stream_user, n_stream_item, rows_per_stream_task, reserved2;
+    const int32_t *stream_rows;               /* [n_stream_user + n_stream_item], user rows first */
 } InvPrefRowPlan;
 
 /* The rows-path workspace must be ZERO-FILLED before its first use; every call leaves it zero-filled. */

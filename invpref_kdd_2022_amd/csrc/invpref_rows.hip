@@ -54,6 +54,10 @@ struct RowsArgs {
     float *np[4];                 // new parameter tables              (fused == 1)
     float *m[4], *v[4];           // Adam moments                      (fused == 1)
     AdamScalars ad;
+    // rows the minibatch does not touch: no job, just the dense-Adam step (or a zero gradient row),
+    // streamed by dedicated workgroups with several rows in flight per group
+    const int *stream_rows;       // [n_stream_user + n_stream_item] row ids, user rows first
+    int n_stream_user, n_stream_item, rows_per_stream_task, n_job_tasks, n_stream_user_tasks;
     const int *item_hot_index;    // [item_num]: scratch row of an item whose gradient goes through atomics, or -1
     float *hot_scratch;           // [n_hot][2][DP] gradient accumulators of those rows (zero on entry, re-zeroed by finish)
     int *sched_state;             // optional device int32[4] = {step (1-based), first step of sched_table, ticket, 0}
@@ -499,12 +503,67 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
     STAMP(7);
 }
 
+// Untouched rows: gradient exactly zero, so m' = m + (1-b1)(0-m), v' = b2 v, p' = p - step*m'/(sqrt(v')/bc+eps)
+// (the same adam1f as everywhere, fed g = 0).  Each 16-lane group keeps two rows (12 float4 loads) in flight.
+template <int NC, bool VEC>
+__device__ __forceinline__ void stream_task(const DevTables &t, const RowsArgs &a, int side, const int *rows, int n) {
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const AdamScalars ad = a.sched_state ? a.sched_table[a.sched_state[0] - a.sched_state[1]] : a.ad;
+    const float *Tinv = side == 0 ? t.Pu : t.Qi, *Tenv = side == 0 ? t.Pa : t.Qa;
+    for (int i = grp; i < n; i += 2 * kGroups) {
+        const int r0 = rows[i];
+        const bool two = i + kGroups < n;
+        const int r1 = two ? rows[i + kGroups] : r0;
+        if (!a.fused) {
+            float4 z[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) z[c] = f4zero();
+            store_row<NC, VEC>(a.g[side], r0, t.D, l16, z);
+            store_row<NC, VEC>(a.g[2 + side], r0, t.D, l16, z);
+            if (two) { store_row<NC, VEC>(a.g[side], r1, t.D, l16, z); store_row<NC, VEC>(a.g[2 + side], r1, t.D, l16, z); }
+            continue;
+        }
+        float4 p[4][NC], m[4][NC], v[4][NC];  // {r0 inv, r0 env, r1 inv, r1 env}
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int row = q < 2 ? r0 : r1;
+            const int ti = (q & 1) * 2 + side;
+            load_row<NC, VEC>((q & 1) ? Tenv : Tinv, row, t.D, l16, p[q]);
+            load_row<NC, VEC>(a.m[ti], row, t.D, l16, m[q]);
+            load_row<NC, VEC>(a.v[ti], row, t.D, l16, v[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (q >= 2 && !two) break;
+            const int row = q < 2 ? r0 : r1;
+            const int ti = (q & 1) * 2 + side;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                adam1f(p[q][c].x, 0.f, m[q][c].x, v[q][c].x, ad); adam1f(p[q][c].y, 0.f, m[q][c].y, v[q][c].y, ad);
+                adam1f(p[q][c].z, 0.f, m[q][c].z, v[q][c].z, ad); adam1f(p[q][c].w, 0.f, m[q][c].w, v[q][c].w, ad);
+            }
+            store_row<NC, VEC>(a.np[ti], row, t.D, l16, p[q]);
+            store_row<NC, VEC>(a.m[ti], row, t.D, l16, m[q]);
+            store_row<NC, VEC>(a.v[ti], row, t.D, l16, v[q]);
+        }
+    }
+}
+
 template <int NC, bool VEC, int EMAX, bool DREG>
 __global__ __launch_bounds__(256, ROWS_MIN_WAVES) void mstep_rows_kernel(DevTables t, RowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // workgroup b runs rounds [b*rpt, (b+1)*rpt); the item-side rounds come first (they hold the longest
     // jobs) and are padded to a multiple of rpt, so a workgroup never mixes sides.  One code path per
     // side: the item side carries no loss / dense-gradient work.
+    if ((int)blockIdx.x >= a.n_job_tasks) {  // trailing workgroups: untouched rows
+        const int sb = blockIdx.x - a.n_job_tasks;
+        const bool us = sb < a.n_stream_user_tasks;
+        const int first = (us ? sb : sb - a.n_stream_user_tasks) * a.rows_per_stream_task;
+        const int total = us ? a.n_stream_user : a.n_stream_item;
+        const int *list = a.stream_rows + (us ? 0 : a.n_stream_user) + first;
+        stream_task<NC, VEC>(t, a, us ? 0 : 1, list, min(a.rows_per_stream_task, total - first));
+        return;
+    }
     const int r0 = blockIdx.x * a.rounds_per_task;
     const int nr = min(a.rounds_per_task, a.n_rounds - r0);
     const int4 task = make_int4(r0 < a.n_item_rounds ? 1 : 0, r0, nr, 0);
@@ -702,7 +761,7 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     if (sched && (!sched->state || !sched->table || sched->n <= 0)) return INVPREF_EINVAL;
     if (rc) return rc;
     if (!plan || !coefs || !losses6 || !workspace || !envs || !scores || batch_norm <= 0) return INVPREF_EINVAL;
-    if (plan->n_rounds <= 0 || plan->rounds_per_task <= 0 || plan->n_item_rounds < 0 ||
+    if (plan->n_rounds < 0 || plan->rounds_per_task <= 0 || plan->n_item_rounds < 0 ||
         plan->n_item_rounds > plan->n_rounds || plan->n_item_rounds % plan->rounds_per_task != 0 || !plan->desc ||
         !plan->other_user || !plan->pos_user || !plan->other_item || !plan->pos_item)
         return INVPREF_EINVAL;
@@ -739,7 +798,15 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     k.r1 = coefs->L1_coe / (2.0f * (float)batch_norm * (float)t.D);
     a.desc = reinterpret_cast<const int4 *>(plan->desc);
     a.n_rounds = plan->n_rounds; a.n_item_rounds = plan->n_item_rounds; a.rounds_per_task = plan->rounds_per_task;
-    const int n_tasks = (plan->n_rounds + plan->rounds_per_task - 1) / plan->rounds_per_task;
+    const int n_job_tasks = (plan->n_rounds + plan->rounds_per_task - 1) / plan->rounds_per_task;
+    if (plan->n_stream_user < 0 || plan->n_stream_item < 0 || plan->rows_per_stream_task <= 0 ||
+        ((plan->n_stream_user + plan->n_stream_item) > 0 && !plan->stream_rows))
+        return INVPREF_EINVAL;
+    a.stream_rows = plan->stream_rows; a.n_stream_user = plan->n_stream_user; a.n_stream_item = plan->n_stream_item;
+    a.rows_per_stream_task = plan->rows_per_stream_task; a.n_job_tasks = n_job_tasks;
+    a.n_stream_user_tasks = (plan->n_stream_user + plan->rows_per_stream_task - 1) / plan->rows_per_stream_task;
+    const int n_tasks = n_job_tasks + a.n_stream_user_tasks +
+                        (plan->n_stream_item + plan->rows_per_stream_task - 1) / plan->rows_per_stream_task;
     a.oth[0] = plan->other_user; a.pos[0] = plan->pos_user;
     a.oth[1] = plan->other_item; a.pos[1] = plan->pos_item;
     a.envs = envs; a.scores = scores; a.weights = weights;

@@ -25,7 +25,9 @@ class RowPlanStruct(C.Structure):
     _fields_ = [('n_rounds', C.c_int32), ('n_item_rounds', C.c_int32), ('rounds_per_task', C.c_int32),
                 ('n', C.c_int32), ('desc', C.c_void_p), ('other_user', C.c_void_p), ('pos_user', C.c_void_p),
                 ('other_item', C.c_void_p), ('pos_item', C.c_void_p), ('n_hot', C.c_int32), ('reserved', C.c_int32),
-                ('hot_rows', C.c_void_p), ('hot_count', C.c_void_p), ('item_hot_index', C.c_void_p)]
+                ('hot_rows', C.c_void_p), ('hot_count', C.c_void_p), ('item_hot_index', C.c_void_p),
+                ('n_stream_user', C.c_int32), ('n_stream_item', C.c_int32), ('rows_per_stream_task', C.c_int32),
+                ('reserved2', C.c_int32), ('stream_rows', C.c_void_p)]
 
 
 def _side_rounds(own, oth, pos, y, n_rows: int, per_slice: int, pad_to: int, skip=None):
@@ -93,7 +95,7 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     items = np.asarray(items, dtype=np.int64)
     scores = np.asarray(scores, dtype=np.float32)
     if per_slice is None:
-        per_slice = int(os.environ.get('INVPREF_PLAN_PER_SLICE', '1'))
+        per_slice = int(os.environ.get('INVPREF_PLAN_PER_SLICE', '2'))
     if rounds_per_task is None:
         rounds_per_task = int(os.environ.get('INVPREF_PLAN_ROUNDS', '1'))
     if hot_threshold is None:
@@ -109,9 +111,14 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     hot_index = np.full(item_num, -1, np.int32)
     hot_index[hot_rows] = np.arange(len(hot_rows), dtype=np.int32)
     # item rounds first (they hold the longest jobs; padded to whole workgroups), user rounds after
-    di = _side_rounds(items[pi], users[pi], pi, scores[pi], item_num, per_slice, rounds_per_task, skip=hot)
-    du = _side_rounds(users[pu], items[pu], pu, scores[pu], user_num, per_slice, 1)
-    return dict(n=n, n_item_rounds=len(di), rounds_per_task=rounds_per_task, desc=np.concatenate([di, du]),
+    ucnt = np.bincount(users, minlength=user_num)
+    stream_u = np.flatnonzero(ucnt == 0).astype(np.int32)       # untouched rows: streamed, no job
+    stream_i = np.flatnonzero(icnt == 0).astype(np.int32)
+    di = _side_rounds(items[pi], users[pi], pi, scores[pi], item_num, per_slice, rounds_per_task,
+                      skip=hot | (icnt == 0))
+    du = _side_rounds(users[pu], items[pu], pu, scores[pu], user_num, per_slice, 1, skip=(ucnt == 0))
+    return dict(stream_rows=np.concatenate([stream_u, stream_i]), n_stream_user=len(stream_u),
+                n_stream_item=len(stream_i), rows_per_stream_task=int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', '64')),n=n, n_item_rounds=len(di), rounds_per_task=rounds_per_task, desc=np.concatenate([di, du]),
                 other_user=items[pu].astype(np.int32), pos_user=pu.astype(np.int32),
                 other_item=users[pi].astype(np.int32), pos_item=pi.astype(np.int32),
                 hot_rows=hot_rows, hot_count=icnt[hot_rows].astype(np.int32), item_hot_index=hot_index)
@@ -126,7 +133,8 @@ class DevicePlan:
 
 
 def upload(plan: dict, device) -> DevicePlan:
-    keys = ('desc', 'other_user', 'pos_user', 'other_item', 'pos_item', 'hot_rows', 'hot_count', 'item_hot_index')
+    keys = ('desc', 'other_user', 'pos_user', 'other_item', 'pos_item', 'hot_rows', 'hot_count', 'item_hot_index',
+            'stream_rows')
     parts, ptrs, off = [], {}, 0
     for k in keys:  # every array starts on a 16-byte boundary of the one device buffer
         a = np.ascontiguousarray(plan[k], np.int32).reshape(-1)
@@ -139,5 +147,8 @@ def upload(plan: dict, device) -> DevicePlan:
     nr, rpt = len(plan['desc']), plan['rounds_per_task']
     st = RowPlanStruct(nr, plan['n_item_rounds'], rpt, plan['n'], ptrs['desc'], ptrs['other_user'],
                        ptrs['pos_user'], ptrs['other_item'], ptrs['pos_item'], len(plan['hot_rows']), 0,
-                       ptrs['hot_rows'], ptrs['hot_count'], ptrs['item_hot_index'])
-    return DevicePlan(st, [buf], -(-nr // rpt), nr)
+                       ptrs['hot_rows'], ptrs['hot_count'], ptrs['item_hot_index'], plan['n_stream_user'],
+                       plan['n_stream_item'], plan['rows_per_stream_task'], 0, ptrs['stream_rows'])
+    spt = plan['rows_per_stream_task']
+    n_tasks = -(-nr // rpt) + -(-plan['n_stream_user'] // spt) + -(-plan['n_stream_item'] // spt)
+    return DevicePlan(st, [buf], n_tasks, nr)

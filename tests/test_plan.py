@@ -10,7 +10,11 @@ def check_plan(users, items, U, I, **kw):
     p = planlib.build_row_plan(users, items, y, U, I, **kw)
     desc, rpt, nir = p['desc'], p['rounds_per_task'], p['n_item_rounds']
     n = len(users)
-    assert desc.shape[1:] == (16, 8) and nir % rpt == 0 and 0 <= nir < len(desc)
+    assert desc.shape[1:] == (16, 8) and nir % rpt == 0 and 0 <= nir <= len(desc)
+    su, si = p['stream_rows'][:p['n_stream_user']], p['stream_rows'][p['n_stream_user']:]
+    assert len(si) == p['n_stream_item']
+    np.testing.assert_array_equal(su, np.flatnonzero(np.bincount(users, minlength=U) == 0))
+    np.testing.assert_array_equal(si, np.flatnonzero(np.bincount(items, minlength=I) == 0))
     hot = set(p['hot_rows'].tolist())
     icnt = np.bincount(items, minlength=I)
     np.testing.assert_array_equal(p['hot_count'], icnt[p['hot_rows']])
@@ -25,7 +29,7 @@ def check_plan(users, items, U, I, **kw):
         d = rounds.reshape(-1, 8)
         act = d[d[:, 0] >= 0]
         leaders = act[(act[:, 1] & 1) == 1]
-        jobless = hot if side == 1 else set()
+        jobless = (hot | set(si.tolist())) if side == 1 else set(su.tolist())
         assert sorted(leaders[:, 0].tolist()) == [r for r in range(R) if r not in jobless]   # one job per row
         cnt = np.bincount(own, minlength=R)
         np.testing.assert_array_equal(leaders[:, 1] >> 8, cnt[leaders[:, 0]])

@@ -127,7 +127,8 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
     float4 *mv = reinterpret_cast<float4 *>(aL + kLossSlots);
 
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4, wave = threadIdx.x >> 6;
-    const bool dma = VEC && a.fused;
+    // (NC = 4 rows would need 64 KB of LDS for the prefetch: those fetch the moments late instead)
+    const bool dma = VEC && NC <= 2 && a.fused;
     float4 *mv_wave = mv + wave * 4 * NC * 64;
     const bool implicit = a.flags & INVPREF_IMPLICIT;
     const bool rw_rec = a.flags & INVPREF_REWEIGHT_REC, rw_cls = a.flags & INVPREF_REWEIGHT_CLS;
@@ -743,7 +744,8 @@ inline bool dreg_of(int nc, int emax) { return nc * emax <= 4; }
 size_t rows_lds_bytes(int E, int nc, int emax) {
     const size_t DP = (size_t)nc * 64, EDP = (size_t)E * DP;
     const size_t red = (dreg_of(nc, emax) ? 4 : 1) * 2 * EDP;
-    return sizeof(float) * (kGroups * 2 * DP + 2 * EDP + emax + red + emax + kLossSlots) + 16 * (size_t)(4 * 4 * nc * 64);
+    return sizeof(float) * (kGroups * 2 * DP + 2 * EDP + emax + red + emax + kLossSlots) +
+           (nc <= 2 ? 16 * (size_t)(4 * 4 * nc * 64) : 0);
 }
 
 template <typename K>

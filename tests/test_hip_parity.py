@@ -244,3 +244,35 @@ def test_rows_fused_adam_equals_grad_then_adam(path):
     # and against the reference's parameters after three Adam steps (same tolerance as the oracle test)
     for k, pa in zip(O.PARAM_NAMES, A[1]):
         assert np.abs(pa.cpu().numpy() - z['adam3_f32_' + k]).max() < 0.05 * lr, k
+
+
+def test_rows_path_mind_shape_g5():
+    """Planned path at the MIND-shaped fixture (E=16, D=256, B=262 144: NC=4 row chunks, LDS-atomic dense
+    path, thousands of hot item rows) against the reference's recorded step."""
+    z = np.load(os.path.join(G, 'g5_mind_like_step.npz'))
+    U, I, E, D, B, seed = [int(x) for x in z['meta']]
+    data = synth.interactions(seed, U, I, B, implicit=True, zipf=True)
+    tabs = synth.tables(seed + 1, U, I, E, D, std=0.05)
+    P = dev_params(tabs)
+    env0 = z['env0'].astype(np.int64)
+    ws = ops.Workspace(DEV)
+    _, _, sw = ops.stat_envs(t64(env0), E, ws)
+    dp = planlib.upload(planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I), DEV)
+    Gd = [torch.full_like(p, 3.0) for p in P]
+    losses = torch.zeros(6, device=DEV)
+    ops.mstep_rows_grad(P, Gd, dp, t64(env0), t32(data[:, 2]), sw, B, z['coefs'],
+                        ops.flags_of(True, True, True, False, True), losses, ws)
+    L = losses.cpu().numpy()
+    np.testing.assert_allclose(L[:3], z['losses'][:3], rtol=1e-5)
+    for k, g in zip(O.PARAM_NAMES, Gd):
+        g = g.cpu().numpy()
+        gn = np.sqrt((g.astype(np.float64) ** 2).sum())
+        assert abs(gn - float(z['gnorm_' + k])) < 1e-4 * float(z['gnorm_' + k]), k
+        if 'user' in k:
+            ref, got = z['grows_' + k], g[z['urows']]
+        elif 'item' in k:
+            ref, got = z['grows_' + k], g[z['irows']]
+        else:
+            ref, got = z['g_' + k], g
+        tol = 2e-5 if 'embed_' in k and 'env.' not in k else 3e-4
+        assert np.abs(got - ref).max() < tol * np.abs(ref).max() + 1e-9, k

@@ -1,4 +1,3 @@
-python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|^E " | head
-python tools/kbench.py 2>&1 | grep -E "rows per"
-for sr in 32 128; do echo "stream rows $sr"; INVPREF_PLAN_STREAM_ROWS=$sr python tools/kbench.py 2>&1 | grep -E "rows per" | head -2; done
-python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
+python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "g5" 2>&1 | grep -E "passed|failed|^E " | head
+echo "--- MovieLens-scale (U=6040 I=3706 E=8 D=128 B=65536)"; python tools/kbench.py 6040 3706 8 128 65536 2>&1 | grep -E "graph:|rows per" | head -4
+echo "--- MIND-scale (U=50000 I=51283 E=16 D=256 B=262144)"; python tools/kbench.py 50000 51283 16 256 262144 2>&1 | grep -E "graph:|rows per" | head -4

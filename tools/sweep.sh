@@ -1,3 +1,4 @@
-python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "g5" 2>&1 | grep -E "passed|failed|^E " | head
-echo "--- MovieLens-scale (U=6040 I=3706 E=8 D=128 B=65536)"; python tools/kbench.py 6040 3706 8 128 65536 2>&1 | grep -E "graph:|rows per" | head -4
-echo "--- MIND-scale (U=50000 I=51283 E=16 D=256 B=262144)"; python tools/kbench.py 50000 51283 16 256 262144 2>&1 | grep -E "graph:|rows per" | head -4
+for v in "-DREPLICAS=16" "-DREPLICAS=32"; do echo "=== extra: $v"; INVPREF_HIPCC_EXTRA="$v" python -c "from invpref_kdd_2022_amd import build; build.build(force=True)"; python tools/kbench.py 2>&1 | grep "rows per" | head -3; done
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof4 -- python3 $GRAFT_REPO_ROOT/tools/kbench.py > /dev/null 2>&1
+head -4 $GRAFT_REPO_ROOT/gpurun_out/prof4/*/*kernel_stats.csv | cut -c1-150

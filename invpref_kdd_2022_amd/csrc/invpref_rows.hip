@@ -33,6 +33,12 @@ using namespace invpref;
 
 namespace {
 
+#ifndef ABL_NO_DENSE   // timing experiments only (tools/): drop parts of the user-side work
+#define ABL_NO_DENSE 0
+#endif
+#ifndef ABL_NO_REPORTS
+#define ABL_NO_REPORTS 0
+#endif
 #ifndef REPLICAS
 #define REPLICAS 32
 #endif
@@ -349,7 +355,8 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
                         o[jj].w += 2.f * k.r2 * ev[jj].w + 2.f * k.r1 * c_sign(ev[jj].w);
                     }
                 }
-                if (DREG) {
+                if (ABL_NO_DENSE) {
+                } else if (DREG) {
 #pragma unroll
                     for (int turn = 0; turn < 4; turn++) {  // the wave's four groups, one after the other
                         if ((grp & 3) == turn) {
@@ -394,7 +401,7 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
                 }
                 // regulariser REPORTS over the four rows of the interaction (env rows weigh double)
 #pragma unroll
-                for (int jj = 0; jj < NC; jj++) {
+                for (int jj = 0; jj < (ABL_NO_REPORTS ? 0 : NC); jj++) {
                     float s2 = oi[jj].x * oi[jj].x + oi[jj].y * oi[jj].y + oi[jj].z * oi[jj].z + oi[jj].w * oi[jj].w;
                     s2 += oe[jj].x * oe[jj].x + oe[jj].y * oe[jj].y + oe[jj].z * oe[jj].z + oe[jj].w * oe[jj].w;
                     s2 += pi[jj].x * pi[jj].x + pi[jj].y * pi[jj].y + pi[jj].z * pi[jj].z + pi[jj].w * pi[jj].w;

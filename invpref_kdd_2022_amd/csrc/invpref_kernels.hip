@@ -81,7 +81,11 @@ __global__ __launch_bounds__(256) void forward_kernel(DevTables t, const int64_t
 struct Upstream {
     const float *d_inv, *d_env, *d_out;  // [B], [B], [B,E]; any may be null (= zeros)
 };
-template <int NC, bool VEC, int EMAX, bool UPSTREAM>
+// DCOL (large E*D): the E x D partials are not accumulated with LDS atomics (one lane per clock) but by
+// "records": every 16-lane group stores its interaction's x = Pu*Qi, o = g_q*Pa*Qa(+reg) and gz[0..E) in
+// LDS, and after a barrier every thread adds all records into the outputs it owns (one column d, a fixed
+// set of classes c) held in registers -- an outer-product accumulation on the vector ALU.
+template <int NC, bool VEC, int EMAX, bool UPSTREAM, bool DCOL>
 __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads g, const int64_t *__restrict__ users,
                                                            const int64_t *__restrict__ items,
                                                            const int64_t *__restrict__ envs,
@@ -92,8 +96,14 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int DP = NC * 64;
     const int EDP = t.E * DP;
+    const int G = blockDim.x / kRow;
+    // region R holds the aEv|aW accumulators; in DCOL mode the interaction records [G][2][DP] live there
+    // until the very end (the accumulators are registers then), so R = max(2*EDP, G*2*DP) floats
+    const int R = DCOL ? (2 * EDP > G * 2 * DP ? 2 * EDP : G * 2 * DP) : 2 * EDP;
     float *sEv = lds, *sW = sEv + EDP, *aEv = sW + EDP, *aW = aEv + EDP;
-    float *sb = aW + EDP, *ab = sb + EMAX, *aL = ab + EMAX;  // aL[kLossSlots]
+    float *sb = aEv + R, *ab = sb + EMAX, *aL = ab + EMAX;  // aL[kLossSlots]
+    float *rec = aEv;                                     // [G][2][DP]
+    float *recs = aL + kLossSlots;                        // [G][EMAX + 1]  gz[0..EMAX), env id (or -1: no record)
     const int slab_len = 2 * EDP + EMAX + kLossSlots;
     stage_table(sEv, t.Ev, t.E, t.D, DP);
     stage_table(sW, t.W, t.E, t.D, DP);
@@ -109,8 +119,32 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
     const bool reg_env = flags & INVPREF_REG_ENV_EMBED;
     const bool no_grad = flags & INVPREF_NO_GRAD;
     float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
+    // DCOL ownership: thread -> column d_own and classes [c_lo, c_lo + CPT)
+    constexpr int CG = (256 / DP) < EMAX ? (256 / DP) : EMAX;   // class groups (block of 256 threads)
+    constexpr int CPT = (EMAX + CG - 1) / CG;
+    const int d_own = threadIdx.x % DP, c_lo = (threadIdx.x / DP) * CPT;
+    float dW[DCOL ? CPT : 1], dE[DCOL ? CPT : 1], dB[DCOL ? CPT : 1];
+#pragma unroll
+    for (int i = 0; i < (DCOL ? CPT : 1); i++) dW[i] = dE[i] = dB[i] = 0.f;
+    const int grp_id = threadIdx.x >> 4;
+    // every workgroup runs the same number of iterations (the scatter below is a whole-wave affair and
+    // the DCOL accumulation has barriers); a group past the end of the minibatch just contributes nothing
+    const int64_t n_iter = (B + (int64_t)gridDim.x * rows_per_block - 1) / ((int64_t)gridDim.x * rows_per_block);
+    // scatter staging: per wave 4 gradient rows + their 4 destination row ids
+    float *scat = recs + (DCOL ? G * (EMAX + 1) : 0);
+    long long *scat_ids = reinterpret_cast<long long *>(scat + (blockDim.x >> 6) * 4 * DP);
+    const int wv = threadIdx.x >> 6, gw = (threadIdx.x >> 4) & 3, lane = threadIdx.x & 63;
 
-    for (int64_t s = blockIdx.x * rows_per_block + (threadIdx.x >> 4); s < B; s += gridDim.x * rows_per_block) {
+    for (int64_t it = 0, s = blockIdx.x * rows_per_block + (threadIdx.x >> 4); it < n_iter;
+         it++, s += gridDim.x * rows_per_block) {
+      const bool valid = s < B;
+      if (DCOL && l16 == 0) recs[grp_id * (EMAX + 1) + EMAX] = __builtin_bit_cast(float, -1);
+      // the four embedding-row gradients (+ per-occurrence L2/L1 terms) of this group's interaction
+      float4 gPu4[NC], gQi4[NC], gPa4[NC], gQa4[NC];
+#pragma unroll
+      for (int j = 0; j < NC; j++) gPu4[j] = gQi4[j] = gPa4[j] = gQa4[j] = f4zero();
+      long long su = -1, sv = -1;
+      if (valid) {
         const int64_t u = users[s], v = items[s];
         const int e = (int)envs[s];
         const float y = UPSTREAM ? 0.f : scores[s];
@@ -198,7 +232,7 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
                     gx[j].y = __builtin_fmaf(gz, wr[j].y, gx[j].y);
                     gx[j].z = __builtin_fmaf(gz, wr[j].z, gx[j].z);
                     gx[j].w = __builtin_fmaf(gz, wr[j].w, gx[j].w);
-                    if (!no_grad) {
+                    if (!no_grad && !DCOL) {
                         float *dst = aW + c * DP + (l16 + kRow * j) * 4;
                         atomicAdd(dst + 0, gz * x[j].x);
                         atomicAdd(dst + 1, gz * x[j].y);
@@ -206,12 +240,13 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
                         atomicAdd(dst + 3, gz * x[j].w);
                     }
                 }
-                if (l16 == 0 && !no_grad) atomicAdd(ab + c, gz);
+                if (l16 == 0 && !no_grad) {
+                    if (DCOL) recs[grp_id * (EMAX + 1) + c] = gz;
+                    else atomicAdd(ab + c, gz);
+                }
             }
         }
-        // scatter-add the four embedding-row gradients (+ per-occurrence L2/L1 terms)
-        float *gpu = g.Pu + u * (int64_t)t.D, *gqi = g.Qi + v * (int64_t)t.D;
-        float *gpa = g.Pa + u * (int64_t)t.D, *gqa = g.Qa + v * (int64_t)t.D;
+        su = u; sv = v;
 #pragma unroll
         for (int j = 0; j < NC; j++) {
             const int i0 = (l16 + kRow * j) * 4;
@@ -220,18 +255,15 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
                 gip.x = g_p - k.alpha * gx[j].x; gip.y = g_p - k.alpha * gx[j].y;
                 gip.z = g_p - k.alpha * gx[j].z; gip.w = g_p - k.alpha * gx[j].w;
 #define REG(a) (k.r2 * (a) + k.r1 * c_sign(a))
-                o = make_float4(gip.x * qi[j].x + REG(pu[j].x), gip.y * qi[j].y + REG(pu[j].y),
-                                gip.z * qi[j].z + REG(pu[j].z), gip.w * qi[j].w + REG(pu[j].w));
-                atomic_add_f4(gpu, o, i0, t.D, VEC);
-                o = make_float4(gip.x * pu[j].x + REG(qi[j].x), gip.y * pu[j].y + REG(qi[j].y),
-                                gip.z * pu[j].z + REG(qi[j].z), gip.w * pu[j].w + REG(qi[j].w));
-                atomic_add_f4(gqi, o, i0, t.D, VEC);
-                o = make_float4(g_q * (qa[j].x * ev[j].x) + REG(pa[j].x), g_q * (qa[j].y * ev[j].y) + REG(pa[j].y),
-                                g_q * (qa[j].z * ev[j].z) + REG(pa[j].z), g_q * (qa[j].w * ev[j].w) + REG(pa[j].w));
-                atomic_add_f4(gpa, o, i0, t.D, VEC);
-                o = make_float4(g_q * (pa[j].x * ev[j].x) + REG(qa[j].x), g_q * (pa[j].y * ev[j].y) + REG(qa[j].y),
-                                g_q * (pa[j].z * ev[j].z) + REG(qa[j].z), g_q * (pa[j].w * ev[j].w) + REG(qa[j].w));
-                atomic_add_f4(gqa, o, i0, t.D, VEC);
+                // the four gradient rows are kept for the shaped scatter below
+                gPu4[j] = make_float4(gip.x * qi[j].x + REG(pu[j].x), gip.y * qi[j].y + REG(pu[j].y),
+                                      gip.z * qi[j].z + REG(pu[j].z), gip.w * qi[j].w + REG(pu[j].w));
+                gQi4[j] = make_float4(gip.x * pu[j].x + REG(qi[j].x), gip.y * pu[j].y + REG(qi[j].y),
+                                      gip.z * pu[j].z + REG(qi[j].z), gip.w * pu[j].w + REG(qi[j].w));
+                gPa4[j] = make_float4(g_q * (qa[j].x * ev[j].x) + REG(pa[j].x), g_q * (qa[j].y * ev[j].y) + REG(pa[j].y),
+                                      g_q * (qa[j].z * ev[j].z) + REG(pa[j].z), g_q * (qa[j].w * ev[j].w) + REG(pa[j].w));
+                gQa4[j] = make_float4(g_q * (pa[j].x * ev[j].x) + REG(qa[j].x), g_q * (pa[j].y * ev[j].y) + REG(qa[j].y),
+                                      g_q * (pa[j].z * ev[j].z) + REG(qa[j].z), g_q * (pa[j].w * ev[j].w) + REG(qa[j].w));
 #undef REG
                 o = make_float4(g_q * (pa[j].x * qa[j].x), g_q * (pa[j].y * qa[j].y), g_q * (pa[j].z * qa[j].z),
                                 g_q * (pa[j].w * qa[j].w));
@@ -241,8 +273,13 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
                     o.z += 2.f * k.r2 * ev[j].z + 2.f * k.r1 * c_sign(ev[j].z);
                     o.w += 2.f * k.r2 * ev[j].w + 2.f * k.r1 * c_sign(ev[j].w);
                 }
-                float *dst = aEv + e * DP + i0;
-                atomicAdd(dst + 0, o.x); atomicAdd(dst + 1, o.y); atomicAdd(dst + 2, o.z); atomicAdd(dst + 3, o.w);
+                if (DCOL) {
+                    *reinterpret_cast<float4 *>(rec + (grp_id * 2) * DP + i0) = x[j];
+                    *reinterpret_cast<float4 *>(rec + (grp_id * 2 + 1) * DP + i0) = o;
+                } else {
+                    float *dst = aEv + e * DP + i0;
+                    atomicAdd(dst + 0, o.x); atomicAdd(dst + 1, o.y); atomicAdd(dst + 2, o.z); atomicAdd(dst + 3, o.w);
+                }
             }
             if (UPSTREAM) continue;
             // regulariser REPORTS: users+items weigh 1/(2BD), env rows 1/(BD) -> count env terms twice
@@ -262,6 +299,77 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
             accL1 += s1;
         }
         if (l16 == 0) { accLi += li * w_rec; accLe += le * w_rec; accLc += lcls * w_cls; }
+        if (DCOL && l16 == 0 && !no_grad) recs[grp_id * (EMAX + 1) + EMAX] = __builtin_bit_cast(float, e);
+      }  // valid
+      // ---- scatter-add by global float atomics, shaped: one table at a time the wave's four gradient rows
+      // go through LDS and every instruction adds 256 contiguous bytes of ONE row (the shape the atomic unit
+      // runs at full rate with, MI355X_MICROARCH.md); a lane-per-float4 scatter touches 16-byte strides
+      if (!no_grad) {
+          float *sc = scat + wv * 4 * DP;
+          long long *ids = scat_ids + wv * 4;
+          auto scatter_table = [&](const float4 (&G4)[NC], long long rid, float *base) {
+#pragma unroll
+              for (int j = 0; j < NC; j++) *reinterpret_cast<float4 *>(sc + gw * DP + (l16 + kRow * j) * 4) = G4[j];
+              if (l16 == 0) ids[gw] = rid;
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+#pragma unroll
+              for (int g4 = 0; g4 < 4; g4++) {
+                  const long long r = ids[g4];
+                  if (r >= 0) {
+#pragma unroll
+                      for (int kk = 0; kk < NC; kk++) {
+                          const int idx = kk * 64 + lane;
+                          if (idx < t.D) atomicAdd(base + r * (long long)t.D + idx, sc[g4 * DP + idx]);
+                      }
+                  }
+              }
+              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+          };
+          scatter_table(gPu4, su, g.Pu);
+          scatter_table(gQi4, sv, g.Qi);
+          scatter_table(gPa4, su, g.Pa);
+          scatter_table(gQa4, sv, g.Qa);
+      }
+      if (DCOL) {
+          __syncthreads();
+          if (threadIdx.x < CG * DP) {
+#pragma unroll 1
+              for (int g2 = 0; g2 < G; g2++) {
+                  const float *rs = recs + g2 * (EMAX + 1);
+                  const int er = __builtin_bit_cast(int, rs[EMAX]);
+                  if (er < 0) continue;
+                  const float xv = rec[(g2 * 2) * DP + d_own], ov = rec[(g2 * 2 + 1) * DP + d_own];
+#pragma unroll
+                  for (int i = 0; i < CPT; i++) {
+                      const int c = c_lo + i;
+                      if (c < t.E) {
+                          const float gzc = rs[c];
+                          dW[i] = __builtin_fmaf(gzc, xv, dW[i]);
+                          dE[i] += (c == er) ? ov : 0.f;
+                          dB[i] += gzc;
+                      }
+                  }
+              }
+          }
+          __syncthreads();
+      }
+    }
+    if (DCOL) {  // the owned outputs go where the LDS-atomic path keeps its accumulators
+        for (int i = threadIdx.x; i < 2 * EDP; i += blockDim.x) aEv[i] = 0.f;   // (padding columns stay zero)
+        __syncthreads();
+        if (threadIdx.x < CG * DP) {
+#pragma unroll
+            for (int i = 0; i < CPT; i++) {
+                const int c = c_lo + i;
+                if (c < t.E) {
+                    aEv[c * DP + d_own] = dE[i];
+                    aW[c * DP + d_own] = dW[i];
+                    if (d_own == 0) ab[c] = dB[i];
+                }
+            }
+        }
     }
     // workgroup reduction of the loss sums
     accLi = wave_sum(accLi); accLe = wave_sum(accLe); accLc = wave_sum(accLc);
@@ -624,11 +732,17 @@ int invpref_mstep_grad_hip(const InvPrefTables *tables, const InvPrefTables *gra
     k.invB = 1.0f / (float)batch_norm;
     k.r2 = coefs->L2_coe / ((float)batch_norm * (float)t.D);
     k.r1 = coefs->L1_coe / (2.0f * (float)batch_norm * (float)t.D);
-    const size_t lds = sizeof(float) * (4 * (size_t)EDP + 2 * emax + kLossSlots);
+    const bool dcol = nc * emax > 4;
+    const size_t G = (dcol ? 256 : kMstepThreads) / kRow;
+    const size_t R = dcol ? (2 * (size_t)EDP > G * 2 * DP ? 2 * (size_t)EDP : G * 2 * DP) : 2 * (size_t)EDP;
+    const size_t nwaves = (dcol ? 256 : kMstepThreads) / 64;
+    const size_t lds = sizeof(float) * (2 * (size_t)EDP + R + 2 * emax + kLossSlots + (dcol ? G * (emax + 1) : 0) +
+                                        nwaves * 4 * DP) + 8 * nwaves * 4 + 8;
     hipStream_t st = (hipStream_t)stream;
     float *slabs = (float *)workspace;
 #define CALL(NCV, VECV, EMAXV)                                                                                       \
-    hipLaunchKernelGGL((mstep_atomic_kernel<NCV, VECV, EMAXV, false>), dim3(nb), dim3(kMstepThreads), lds, st, t, g, users, \
+    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(mstep_atomic_kernel<NCV, VECV, EMAXV, false, (NCV * EMAXV > 4)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((mstep_atomic_kernel<NCV, VECV, EMAXV, false, (NCV * EMAXV > 4)>), dim3(nb), dim3((NCV * EMAXV > 4) ? 256 : kMstepThreads), lds, st, t, g, users, \
                        items, envs, scores, sample_weights, B, k, flags, slabs, Upstream{nullptr, nullptr, nullptr})
     DISPATCH_NVE(nc, vec, emax, CALL);
 #undef CALL
@@ -664,12 +778,18 @@ int invpref_backward_hip(const InvPrefTables *tables, const InvPrefTables *grads
     k.alpha = alpha;
     k.invB = 1.f;
     const uint32_t fl = flags & INVPREF_IMPLICIT;
-    const size_t lds = sizeof(float) * (4 * (size_t)EDP + 2 * emax + kLossSlots);
+    const bool dcol = nc * emax > 4;
+    const size_t G = (dcol ? 256 : kMstepThreads) / kRow;
+    const size_t R = dcol ? (2 * (size_t)EDP > G * 2 * DP ? 2 * (size_t)EDP : G * 2 * DP) : 2 * (size_t)EDP;
+    const size_t nwaves = (dcol ? 256 : kMstepThreads) / 64;
+    const size_t lds = sizeof(float) * (2 * (size_t)EDP + R + 2 * emax + kLossSlots + (dcol ? G * (emax + 1) : 0) +
+                                        nwaves * 4 * DP) + 8 * nwaves * 4 + 8;
     hipStream_t st = (hipStream_t)stream;
     float *slabs = (float *)workspace;
     const Upstream up{d_invariant_score, d_env_aware_score, d_env_outputs};
 #define CALL(NCV, VECV, EMAXV)                                                                                            \
-    hipLaunchKernelGGL((mstep_atomic_kernel<NCV, VECV, EMAXV, true>), dim3(nb), dim3(kMstepThreads), lds, st, t, g, users, \
+    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(mstep_atomic_kernel<NCV, VECV, EMAXV, true, (NCV * EMAXV > 4)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((mstep_atomic_kernel<NCV, VECV, EMAXV, true, (NCV * EMAXV > 4)>), dim3(nb), dim3((NCV * EMAXV > 4) ? 256 : kMstepThreads), lds, st, t, g, users, \
                        items, envs, (const float *)nullptr, (const float *)nullptr, B, k, fl, slabs, up)
     DISPATCH_NVE(nc, vec, emax, CALL);
 #undef CALL

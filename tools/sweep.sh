@@ -1,1 +1,4 @@
-for v in "" "-DABL_NO_DENSE=1" "-DABL_NO_REPORTS=1" "-DABL_NO_DENSE=1 -DABL_NO_REPORTS=1"; do echo "=== extra: $v"; INVPREF_HIPCC_EXTRA="$v" python -c "from invpref_kdd_2022_amd import build; build.build(force=True)"; python tools/kb2.py 2>&1 | grep "B="; done
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|^E " | head
+echo "--- Yahoo"; python tools/kbench.py 2>&1 | grep -E "graph:"
+echo "--- MovieLens-scale"; python tools/kbench.py 6040 3706 8 128 65536 2>&1 | grep -E "graph:" 
+echo "--- MIND-scale"; python tools/kbench.py 50000 51283 16 256 262144 2>&1 | grep -E "graph:"

@@ -157,6 +157,19 @@ def main():
         ev['m0'].append(e0); ev['m1'].append(e1); ev['a1'].append(e2)
     torch.cuda.synchronize()
 
+    # M-step-only and E-step-only rates (report them separately from the blended figure)
+    a0, a1, a2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    a0.record()
+    for _ in range(3):
+        mgr.train_a_epoch()
+    a1.record()
+    mgr.cluster(); mgr.stat_envs()
+    a2.record()
+    torch.cuda.synchronize()
+    detail = {'mstep_interactions_per_s_per_gpu': 3 * mgr.users_tensor.shape[0] / (a0.elapsed_time(a1) * 1e-3),
+              'estep_interactions_per_s_per_gpu': mgr.users_tensor.shape[0] / (a1.elapsed_time(a2) * 1e-3),
+              'estep_ms': a1.elapsed_time(a2)}
+
     inter = args.steps * B_PER_GPU * world
     value = inter / dt
     # per-op device time from HIP events recorded on the launch stream inside the timed region
@@ -192,7 +205,7 @@ def main():
                    'interactions_per_gpu': N_PER_GPU, 'batch_per_gpu': B_PER_GPU, 'global_batch': B_PER_GPU * world,
                    'estep_every_steps': ESTEP_EVERY, 'parallelism': f'row-shard x{world}, 1 all-reduce/step',
                    'hip_graph_epochs': bool(mgr._graphs)},
-        'roofline': roofline,
+        'roofline': roofline, 'detail': detail,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()

@@ -71,6 +71,7 @@ struct RowsArgs {
     float *hot_scratch;           // [n_hot][2][DP] gradient accumulators of those rows (zero on entry, re-zeroed by finish)
     int *sched_state;             // optional device int32[4] = {step (1-based), first step of sched_table, ticket, 0}
     const AdamScalars *sched_table;  // optional device table of per-step Adam scalars (graph replay)
+    int stamps_nodrain;           // diagnostic: do not drain memory operations before a stamp
     unsigned long long *stamps;   // diagnostic builds only (INVPREF_STAMPS): [n_tasks][8] s_memrealtime ticks
 };
 
@@ -79,7 +80,7 @@ struct RowsArgs {
 #define STAMP(i)                                                                  \
     do {                                                                          \
         if (a.stamps) {                                                           \
-            __builtin_amdgcn_s_waitcnt(0);                                        \
+            if (!a.stamps_nodrain) __builtin_amdgcn_s_waitcnt(0);                 \
             if (threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
         }                                                                         \
     } while (0)
@@ -578,12 +579,14 @@ __global__ __launch_bounds__(256, ROWS_MIN_WAVES) void mstep_rows_kernel(DevTabl
     // jobs) and are padded to a multiple of rpt, so a workgroup never mixes sides.  One code path per
     // side: the item side carries no loss / dense-gradient work.
     if ((int)blockIdx.x >= a.n_job_tasks) {  // trailing workgroups: untouched rows
+        STAMP(0);
         const int sb = blockIdx.x - a.n_job_tasks;
         const bool us = sb < a.n_stream_user_tasks;
         const int first = (us ? sb : sb - a.n_stream_user_tasks) * a.rows_per_stream_task;
         const int total = us ? a.n_stream_user : a.n_stream_item;
         const int *list = a.stream_rows + (us ? 0 : a.n_stream_user) + first;
         stream_task<NC, VEC>(t, a, us ? 0 : 1, list, min(a.rows_per_stream_task, total - first));
+        STAMP(7);
         return;
     }
     const int r0 = blockIdx.x * a.rounds_per_task;
@@ -841,6 +844,8 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     // diagnostics: INVPREF_STAMPS=<device pointer, hex> makes the kernel write phase time stamps there
     static const char *stamp_env = getenv("INVPREF_STAMPS");
     a.stamps = stamp_env ? reinterpret_cast<unsigned long long *>(strtoull(stamp_env, nullptr, 16)) : nullptr;
+    static const bool nodrain = getenv("INVPREF_STAMPS_NODRAIN") != nullptr;
+    a.stamps_nodrain = nodrain;
     const size_t lds = rows_lds_bytes(t.E, nc, emax);
     if (lds > 160 * 1024) return INVPREF_EUNSUPPORTED;
 #define CALL(NCV, VECV, EMAXV, DREGV)                                                                 \

@@ -26,7 +26,8 @@ ws = ops.Workspace(dev)
 losses = torch.zeros(6, device=dev)
 coefs = (3.35, 9.99, 9.06, 3.13, 0.49, 1.9)
 flags = ops.flags_of(True, False, True, True, False)
-for per_slice, rpt, hot in ((1, 1, -1), (1, 1, 16)):
+os.environ['INVPREF_STAMPS_NODRAIN'] = '1'
+for per_slice, rpt, hot in ((2, 1, 16), (1, 1, 16)):
     pl = planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, per_slice=per_slice, rounds_per_task=rpt,
                                 hot_threshold=hot)
     dp = planlib.upload(pl, dev)
@@ -35,23 +36,15 @@ for per_slice, rpt, hot in ((1, 1, -1), (1, 1, 16)):
         ops.mstep_rows_adam(P, P2, M, V, dp, e, y, w, B, coefs, flags, losses, 5, 0.005, ws)
     torch.cuda.synchronize()
     st = stamps.cpu().numpy().reshape(-1, 8)[:dp.n_tasks].astype(np.int64)
+    nr = dp.n_rounds
     ni = pl['n_item_rounds'] // rpt
+    njob = -(-nr // rpt)
     t0 = st[:, 0].min()
-    print(f'== per_slice={per_slice} rpt={rpt} hot>{hot} tasks={dp.n_tasks} (item {ni}); 100 MHz ticks = 10 ns')
-    print('kernel span (first start -> last end): %.2f us' % ((st[:, 6:8].max() - t0) / 100))
-    for name, sl in (('item', slice(0, ni)), ('user', slice(ni, None))):
-        s = st[sl]
-        if len(s) == 0:
+    end = np.where(st[:, 7] > 0, st[:, 7], st[:, 6])
+    print(f'== per_slice={per_slice} rpt={rpt} hot>{hot}: tasks {dp.n_tasks} = item {ni} + user {njob - ni} + stream {dp.n_tasks - njob}; span {(end.max() - t0) / 100:.2f} us')
+    for name, sl in (('item', slice(0, ni)), ('user', slice(ni, njob)), ('stream', slice(njob, None))):
+        s0, e0 = (st[sl, 0] - t0) / 100, (end[sl] - t0) / 100
+        if len(s0) == 0:
             continue
-        start = (s[:, 0] - t0) / 100
-        print(f' {name}: WG start  min {start.min():.2f} med {np.median(start):.2f} max {start.max():.2f} us')
-        names = ['prologue(stage+sync)', 'desc load', 'own rows', 'interactions', 'lds combine', 'row finish(adam)', 'dense flush']
-        for i, nm in enumerate(names):
-            if i == 6 and name == 'item':
-                continue
-            dlt = (s[:, i + 1] - s[:, i]) / 100
-            print(f'   {nm:22s} med {np.median(dlt):6.2f}  p90 {np.quantile(dlt, .9):6.2f}  max {dlt.max():6.2f} us')
-        life = (s[:, 7 if name == 'user' else 6] - s[:, 0]) / 100
-        print(f'   WG lifetime            med {np.median(life):6.2f}  p90 {np.quantile(life, .9):6.2f}  max {life.max():6.2f} us')
-        end = (s[:, 7 if name == 'user' else 6] - t0) / 100
-        print(f'   WG end time            med {np.median(end):6.2f}  p90 {np.quantile(end, .9):6.2f}  max {end.max():6.2f} us; starts after 5us: {(start > 5).sum()}')
+        life = e0 - s0
+        print(f'  {name:6s} n={len(s0):4d} start med {np.median(s0):5.2f} p90 {np.quantile(s0, .9):5.2f} max {s0.max():5.2f} | life med {np.median(life):5.2f} p90 {np.quantile(life, .9):5.2f} max {life.max():5.2f} | end med {np.median(e0):5.2f} max {e0.max():5.2f}')

@@ -185,6 +185,23 @@ int invpref_backward_hip(const InvPrefTables *tables, const InvPrefTables *grads
 int invpref_predict_hip(const float *user_table, const float *item_table, const int64_t *users, int64_t n_users,
                         int64_t item_num, int64_t factor_num, int apply_sigmoid, float *out, void *stream);
 
+/* ---- evaluation (the first "next" row): the per-user part of
+ * ImplicitTestManager.evaluate_batch (evaluate.py:88-120) on a rating matrix produced by
+ * invpref_predict_hip.  CSR inputs (int32, device): for test user j (row j of `ratings`)
+ *   mask_items[mask_ptr[j] .. mask_ptr[j+1])       train items, rating := -1024      (evaluate.py:94-101)
+ *   highlight_items[...] (highlight_ptr may be NULL)  item pool, rating += 1024      (evaluate.py:103-111)
+ *   truth_items[truth_ptr[j] .. truth_ptr[j+1])    SORTED ground-truth items         (evaluate.py:11-19)
+ * Outputs [n_users, k]: the top-k item ids in descending rating order (lowest id first among equal
+ * ratings) and 1.0/0.0 hit labels (get_label).  ratings is not modified.  k <= 64, k <= n_items <= 36864. */
+int invpref_eval_topk_hip(const float *ratings, int64_t n_users, int64_t n_items, const int32_t *mask_ptr,
+                          const int32_t *mask_items, const int32_t *highlight_ptr, const int32_t *highlight_items,
+                          const int32_t *truth_ptr, const int32_t *truth_items, int32_t k, int32_t *out_items,
+                          float *out_hits, void *stream);
+
+/* ---- ExplicitTestManager.evaluate (evaluate.py:187-212): out2 (device double[2]) = {sum (pred-target)^2,
+ * sum |pred-target|}; mse / rmse / mae follow on the host. */
+int invpref_eval_error_sums_hip(const float *pred, const float *target, int64_t n, double *out2, void *stream);
+
 /* ---- dense Adam: replaces optimizer.zero_grad() + optimizer.step() of torch.optim.Adam with
  * default betas/eps (train.py:41, :155-157) over one flat fp32 buffer of n parameters.
  * step is 1-based.  zero_grad != 0 also clears grad (the next step's zero_grad()). */

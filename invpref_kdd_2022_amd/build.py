@@ -10,7 +10,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libinvpref_hip.so')
 OBJDIR = os.path.join(PKG, 'build')
-SOURCES = ['invpref_kernels.hip', 'invpref_rows.hip']
+SOURCES = ['invpref_kernels.hip', 'invpref_rows.hip', 'invpref_eval.hip']
 HEADERS = ['canon_math.hpp', 'kernel_common.hpp', os.path.join('..', '..', 'include', 'invpref_hip.h')]
 # -ffp-contract=off: every fma of the canonical arithmetic is written explicitly
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-ffp-contract=off',

@@ -22,6 +22,7 @@ sys.dont_write_bytecode = True
 sys.modules.setdefault('seaborn', types.ModuleType('seaborn'))  # utils.py:5 imports it, unused
 sys.path.insert(0, '/root/reference')
 sys.path.insert(0, '/root/repo')
+sys.path.insert(0, '/root/repo/tests')
 
 import hashlib
 import os
@@ -305,8 +306,47 @@ def gen_g5():
     np.savez_compressed(os.path.join(OUT, 'g5_mind_like_step.npz'), **out)
 
 
+# ------------------------------------------------------------------ g6: evaluation
+from eval_fixture import StubImplicitLoader as _StubImplicitLoader, eval_fixture  # noqa: E402  (tests/eval_fixture.py)
+
+
+def gen_g6():
+    import evaluate as ref_eval
+    U, I, E, D = 400, 1000, 4, 64
+    tabs = synth.tables(78, U, I, E, D, std=0.3)
+    users, mask, pool, truth = eval_fixture()
+    model = ref_models.InvPrefImplicit(U, I, E, D)
+    load_tables(model, tabs)
+    out = {}
+    for use_pool in (False, True):
+        tm = ref_eval.ImplicitTestManager(model, _StubImplicitLoader(users, mask, pool, truth), test_batch_size=64,
+                                          top_k_list=[3, 5, 7], use_item_pool=use_pool)
+        with torch.no_grad():
+            res = tm.evaluate()
+        out[f'pool{int(use_pool)}'] = np.array([[res[m][k] for k in (3, 5, 7)] for m in ('ndcg', 'recall', 'precision')])
+        print('g6 implicit eval', use_pool, res)
+    # explicit: mse / rmse / mae on synthetic test pairs
+    m2 = ref_models.InvPrefExplicit(U, I, E, D)
+    load_tables(m2, tabs)
+    rs = np.random.RandomState(79)
+    pairs = np.stack([rs.randint(0, U, 5000), rs.randint(0, I, 5000)], 1).astype(np.int64)
+    scores = rs.randint(1, 6, 5000).astype(np.float32)
+
+    class L:
+        all_test_pairs_tensor = torch.from_numpy(pairs)
+        all_test_scores_tensor = torch.from_numpy(scores)
+
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = ref_eval.ExplicitTestManager(m2, L()).evaluate()
+    print('g6 explicit eval', res)
+    np.savez_compressed(os.path.join(OUT, 'g6_eval.npz'), meta=np.array([U, I, E, D]), pool0=out['pool0'],
+                        pool1=out['pool1'], explicit=np.array([res['mse'], res['rmse'], res['mae']]),
+                        pairs=pairs.astype(np.int32), scores=scores)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6']
     torch.manual_seed(0)
     for name in which:
         globals()['gen_' + name]()

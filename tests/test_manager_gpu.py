@@ -185,3 +185,53 @@ def test_sharded_step_sequence_equals_fused_path(monkeypatch):
     for k in O.PARAM_NAMES:
         dlt = np.abs(res[0][2][k] - res[1][2][k])
         assert dlt.max() < 0.05 * float(z['coefs'][6]) and np.quantile(dlt, 0.99) < 2e-6, k
+
+
+# ------------------------------------------------------------------ evaluation
+def test_implicit_evaluator_matches_reference_and_oracle():
+    from eval_fixture import StubImplicitLoader, eval_fixture
+    from invpref_kdd_2022_amd.evaluate import ImplicitTestManager
+    z = np.load(os.path.join(G, 'g6_eval.npz'))
+    U, I, E, D = [int(x) for x in z['meta']]
+    tabs = synth.tables(78, U, I, E, D, std=0.3)
+    users, mask, pool, truth = eval_fixture()
+    model = InvPrefImplicit(U, I, E, D).to(DEV)
+    model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+    for use_pool in (False, True):
+        tm = ImplicitTestManager(model, StubImplicitLoader(users, mask, pool, truth), test_batch_size=64,
+                                 top_k_list=[3, 5, 7], use_item_pool=use_pool)
+        res = tm.evaluate()
+        got = np.array([[res[m][k] for k in (3, 5, 7)] for m in ('ndcg', 'recall', 'precision')])
+        # vs the reference's own evaluate.py on the reference model (scores differ by ~1 ulp: a near-tie at the
+        # k-th place could swap one item for one user; 230 users -> allow 1/230 of one hit per metric)
+        assert np.abs(got - z[f'pool{int(use_pool)}']).max() < 1.0 / 230 + 1e-9
+        # vs a numpy restatement on the ORACLE's scores (bit-identical to the HIP scores): exact top-k ids
+        items, hits = tm.topk(0, len(users))
+        items, hits = items.cpu().numpy(), hits.cpu().numpy()
+        tab = O.Tables(tabs)
+        for j, u in enumerate(users[:60]):
+            inv, _, _ = O.forward(tab, np.full(I, u), np.arange(I), np.zeros(I, np.int64), True)
+            row = inv.copy()
+            row[list(mask[u])] = -1024.0
+            if use_pool:
+                row[list(pool[u])] += 1024.0
+            order = np.argsort(-row, kind='stable')[:7]
+            np.testing.assert_array_equal(items[j], order)
+            np.testing.assert_array_equal(hits[j], np.array([float(i in truth[u]) for i in order], np.float32))
+        np.testing.assert_allclose(got, z[f'pool{int(use_pool)}'], rtol=0, atol=1.0 / 230 + 1e-9)
+
+
+def test_explicit_evaluator_matches_reference():
+    from invpref_kdd_2022_amd.evaluate import ExplicitTestManager
+    z = np.load(os.path.join(G, 'g6_eval.npz'))
+    U, I, E, D = [int(x) for x in z['meta']]
+    tabs = synth.tables(78, U, I, E, D, std=0.3)
+    model = InvPrefExplicit(U, I, E, D).to(DEV)
+    model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+
+    class L:
+        all_test_pairs_tensor = torch.from_numpy(z['pairs'].astype(np.int64))
+        all_test_scores_tensor = torch.from_numpy(z['scores'])
+
+    res = ExplicitTestManager(model, L()).evaluate()
+    np.testing.assert_allclose([res['mse'], res['rmse'], res['mae']], z['explicit'], rtol=2e-6)

@@ -42,6 +42,23 @@ class StubEvaluator:
         return {}
 
 
+def pmc_traffic_bytes(kernel_name: str):
+    """L2<->fabric bytes per launch of `kernel_name` from the committed rocprofv3 PMC summaries (separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, tools/profile.sh).  Counters are in KiB;
+    FETCH_SIZE is doubled (gfx950 counts 128-byte read requests as 64 bytes, MI355X_MICROARCH.md §HBM)."""
+    import csv
+    import glob
+    tot = {}
+    for cname, scale in (('FETCH_SIZE', 2048.0), ('WRITE_SIZE', 1024.0)):
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', f'pmc_{cname.split("_")[0].lower()}_summary.csv')))
+        if not files:
+            return None
+        for row in csv.DictReader(open(files[-1])):
+            if kernel_name in row['kernel'] and row['counter'] == cname:
+                tot[cname] = float(row['mean_value']) * scale
+    return tot['FETCH_SIZE'] + tot['WRITE_SIZE'] if len(tot) == 2 else None
+
+
 def cpu_baseline(seconds_budget: float = 12.0):
     """The oracle (C port, one thread) on the same Yahoo-shaped workload, bounded sample."""
     from invpref_kdd_2022_amd import synth
@@ -147,14 +164,20 @@ def main():
     # calls issued eagerly (events cannot be read back from inside a replayed graph), one epoch's worth
     if getattr(mgr, '_raw_ptrs', None) is None:
         mgr._raw_setup()
-    ev = {'m0': [], 'm1': [], 'a1': []}
+    from invpref_kdd_2022_amd import _capi
+    ev = {'m0': [], 'mk': [], 'm1': [], 'a1': []}
     stream = torch.cuda.current_stream().cuda_stream
+    fused = mgr.use_plan and world == 1
     for k in range(nb):
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0, ek, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        if fused:  # the library records ek between mstep_rows_kernel and rows_finish_kernel
+            ek.record()  # (creates the underlying hipEvent_t)
+            _capi.lib().invpref_set_profile_event(ek.cuda_event)
         e0.record()
         mgr._raw_step(k, mgr.alpha, stream, mid_event=e1)
         e2.record()
-        ev['m0'].append(e0); ev['m1'].append(e1); ev['a1'].append(e2)
+        ev['m0'].append(e0); ev['mk'].append(ek); ev['m1'].append(e1); ev['a1'].append(e2)
+    _capi.lib().invpref_set_profile_event(None)
     torch.cuda.synchronize()
 
     # M-step-only and E-step-only rates (report them separately from the blended figure)
@@ -180,11 +203,14 @@ def main():
     # 4 row reads, 4 gradient-row adds) + Adam 32P (28 B/param + 4 B zeroing).  The fused owner pass never
     # stores the gradient, so it is priced at what it must move: B*(32+16D) + 24P (p,m,v read; p',m',v' written).
     bytes_m_survey, bytes_a_survey = B_PER_GPU * (32 + 32 * D), 32 * P
-    fused = mgr.use_plan and world == 1
     if fused:
-        nbytes = B_PER_GPU * (32 + 16 * D) + 24 * P
-        roof = {'kernel': 'mstep_rows_kernel (+rows_finish_kernel), Adam fused', 'bytes': nbytes, 'ms': ms_m}
-        other = {'step_ms_events': ms_m, 'GBs_at_survey_unfused_pricing': (bytes_m_survey + bytes_a_survey) / (ms_m * 1e-3) / 1e9}
+        # dominant kernel alone: mstep_rows_kernel (M-step + Adam of the four big tables); the three small
+        # tables (E*D + E*D + E parameters) are finished by rows_finish_kernel and are not counted here
+        ms_k = float(np.median([a.elapsed_time(b) for a, b in zip(ev['m0'], ev['mk'])]))
+        nbytes = B_PER_GPU * (32 + 16 * D) + 24 * (P - 2 * E * D - 64)
+        roof = {'kernel': 'mstep_rows_kernel (M-step with fused Adam)', 'bytes': nbytes, 'ms': ms_k}
+        other = {'rows_plus_finish_ms_events': ms_m, 'rows_kernel_ms_events': ms_k,
+                 'GBs_of_pair_at_survey_unfused_pricing': (bytes_m_survey + bytes_a_survey) / (ms_m * 1e-3) / 1e9}
     else:
         bytes_m = bytes_m_survey
         if ms_a >= ms_m:
@@ -194,8 +220,10 @@ def main():
         other = {'mstep_ms': ms_m, 'mstep_GBs': bytes_m / (ms_m * 1e-3) / 1e9, 'adam_ms': ms_a,
                  'adam_GBs': bytes_a_survey / (ms_a * 1e-3) / 1e9}
     achieved = roof['bytes'] / (roof['ms'] * 1e-3) / 1e9
+    traffic = pmc_traffic_bytes(roof['kernel'].split()[0])
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel': roof['kernel'],
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/)',
+                'kernel': roof['kernel'],
                 'avg_launch_ms': roof['ms'], 'algorithmic_bytes_per_launch': roof['bytes'], 'other': other}
     out = {
         'metric': 'training interactions/sec, Yahoo-implicit InvPref', 'value': value, 'unit': 'interactions/s',

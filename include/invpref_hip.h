@@ -151,6 +151,11 @@ int invpref_mstep_rows_adam_hip(const InvPrefTables *tables, const InvPrefTables
                                 uint32_t flags, float *losses6, int64_t step, double lr, double beta1, double beta2,
                                 double eps, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Profiling aid (bench.py's roofline figure): while a hipEvent_t is registered here, every planned M-step
+ * call records it on its stream BETWEEN mstep_rows_kernel and rows_finish_kernel, so the dominant kernel
+ * can be timed alone with events.  Process-global, not thread-safe; pass NULL to switch it off. */
+int invpref_set_profile_event(void *event);
+
 /* ---- the same pass for HIP-graph replay.  A captured launch freezes its kernel arguments, so the
  * per-step Adam scalars cannot be passed by value: they are looked up on the device as
  * table[state[0] - state[1]], and the pass advances state[0] when it is done.

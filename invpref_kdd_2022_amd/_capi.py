@@ -22,7 +22,7 @@ EXPORTS = [
     'invpref_stat_envs_hip', 'invpref_sample_weights_hip', 'invpref_backward_hip', 'invpref_predict_hip',
     'invpref_rows_workspace_bytes', 'invpref_mstep_rows_grad_hip', 'invpref_mstep_rows_adam_hip',
     'invpref_adam_schedule_fill', 'invpref_mstep_rows_adam_sched_hip', 'invpref_eval_topk_hip',
-    'invpref_eval_error_sums_hip',
+    'invpref_eval_error_sums_hip', 'invpref_set_profile_event',
 ]
 
 
@@ -89,6 +89,7 @@ def lib():
                                                         vp, C.POINTER(AdamSchedule), vp, C.c_size_t, vp]
         L.invpref_eval_topk_hip.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
         L.invpref_eval_error_sums_hip.argtypes = [vp, vp, i64, vp, vp]
+        L.invpref_set_profile_event.argtypes = [vp]
         L.invpref_device_name.argtypes = [C.c_char_p, C.c_size_t]
         if L.invpref_abi_version() != 1:
             raise InvPrefError('libinvpref_hip.so ABI version mismatch')

@@ -27,14 +27,14 @@ __global__ __launch_bounds__(256) void topk_mask_kernel(const float *__restrict_
     float *row = lds + (size_t)wave * n_items;
     const float *src = ratings + u * (int64_t)n_items;
     for (int i = lane; i < n_items; i += 64) row[i] = src[i];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    WAVE_LDS_FENCE();
     __builtin_amdgcn_wave_barrier();
     for (int j = mask_ptr[u] + lane; j < mask_ptr[u + 1]; j += 64) row[mask_items[j]] = -1024.0f;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    WAVE_LDS_FENCE();
     __builtin_amdgcn_wave_barrier();
     if (hl_ptr)
         for (int j = hl_ptr[u] + lane; j < hl_ptr[u + 1]; j += 64) row[hl_items[j]] += 1024.0f;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    WAVE_LDS_FENCE();
     __builtin_amdgcn_wave_barrier();
     const int g0 = gt_ptr[u], g1 = gt_ptr[u + 1];
     for (int k = 0; k < K; k++) {
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void topk_mask_kernel(const float *__restrict_
             out_hits[u * K + k] = (lo < g1 && gt_items[lo] == bi) ? 1.0f : 0.0f;
             if (bi < n_items) row[bi] = -__builtin_inff();
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        WAVE_LDS_FENCE();
         __builtin_amdgcn_wave_barrier();
     }
 }

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
 #pragma unroll
               for (int j = 0; j < NC; j++) *reinterpret_cast<float4 *>(sc + gw * DP + (l16 + kRow * j) * 4) = G4[j];
               if (l16 == 0) ids[gw] = rid;
-              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              WAVE_LDS_FENCE();
               __builtin_amdgcn_wave_barrier();
 #pragma unroll
               for (int g4 = 0; g4 < 4; g4++) {
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
                       }
                   }
               }
-              __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+              WAVE_LDS_FENCE();
               __builtin_amdgcn_wave_barrier();
           };
           scatter_table(gPu4, su, g.Pu);

@@ -334,13 +334,13 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
                     t2.x *= g_q; t2.y *= g_q; t2.z *= g_q; t2.w *= g_q;
                     *reinterpret_cast<float4 *>(tr + DP + (l16 + kRow * jj) * 4) = t2;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                WAVE_LDS_FENCE();
 #pragma unroll
                 for (int q4 = 0; q4 < 2 * DP / 16; q4++) {
                     const int idx = q4 * 16 + l16;           // 16 lanes -> 16 consecutive floats
                     if ((idx & (DP - 1)) < t.D) atomicAdd(dst + idx, tr[idx]);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                WAVE_LDS_FENCE();
             }
             if (user_side) {
                 // ---- E x D partials: env-table row e gets g_q * Pa*Qa (+ its regulariser), classifier row c gets gz_c * x
@@ -378,7 +378,7 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
                                 }
                             }
                         }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        WAVE_LDS_FENCE();
                         __builtin_amdgcn_wave_barrier();
                     }
                 } else {

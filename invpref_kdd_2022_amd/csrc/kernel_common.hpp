@@ -12,6 +12,13 @@
 #include "../../include/invpref_hip.h"
 #include "canon_math.hpp"
 
+// Ordering of LDS traffic between the lanes of ONE wavefront (a lane reads what another lane of the same
+// wave wrote): LDS operations of a wave execute in issue order, so it is enough to keep the compiler from
+// reordering across this point and to drain the LDS counter.  A wavefront-scope __builtin_amdgcn_fence also
+// waits for every outstanding GLOBAL operation (vmcnt(0)) -- with float atomics in flight that is
+// microseconds per fence (measured: 2.5 us per interaction in the user-side path).
+#define WAVE_LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
 namespace invpref {
 
 constexpr int kRow = 16;          // lanes per interaction

@@ -27,7 +27,7 @@ losses = torch.zeros(6, device=dev)
 coefs = (3.35, 9.99, 9.06, 3.13, 0.49, 1.9)
 flags = ops.flags_of(True, False, True, True, False)
 os.environ['INVPREF_STAMPS_NODRAIN'] = '1'
-for per_slice, rpt, hot in ((2, 1, 16), (1, 1, 16)):
+for per_slice, rpt, hot in ((1, 1, 16), (1, 1, 10 ** 9)):
     pl = planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, per_slice=per_slice, rounds_per_task=rpt,
                                 hot_threshold=hot)
     dp = planlib.upload(pl, dev)
@@ -47,4 +47,9 @@ for per_slice, rpt, hot in ((2, 1, 16), (1, 1, 16)):
         if len(s0) == 0:
             continue
         life = e0 - s0
+        if name != 'stream':
+            ph = (st[sl, 1:8] - st[sl, 0:7]) / 100
+            ok = st[sl, 7] > 0 if name == 'user' else np.ones(len(s0), bool)
+            names = ['prologue', 'desc+issue', 'wait sync', 'interactions', 'combine', 'finish(rounds)', 'flush']
+            print('     phases med: ' + '  '.join(f'{n} {np.median(ph[:, i]):.2f}' for i, n in enumerate(names[:7 if name == 'user' else 6])))
         print(f'  {name:6s} n={len(s0):4d} start med {np.median(s0):5.2f} p90 {np.quantile(s0, .9):5.2f} max {s0.max():5.2f} | life med {np.median(life):5.2f} p90 {np.quantile(life, .9):5.2f} max {life.max():5.2f} | end med {np.median(e0):5.2f} max {e0.max():5.2f}')

@@ -741,7 +741,7 @@ int invpref_mstep_grad_hip(const InvPrefTables *tables, const InvPrefTables *gra
     hipStream_t st = (hipStream_t)stream;
     float *slabs = (float *)workspace;
 #define CALL(NCV, VECV, EMAXV)                                                                                       \
-    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(mstep_atomic_kernel<NCV, VECV, EMAXV, false, (NCV * EMAXV > 4)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mstep_atomic_kernel<NCV, VECV, EMAXV, false, (NCV * EMAXV > 4)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL((mstep_atomic_kernel<NCV, VECV, EMAXV, false, (NCV * EMAXV > 4)>), dim3(nb), dim3((NCV * EMAXV > 4) ? 256 : kMstepThreads), lds, st, t, g, users, \
                        items, envs, scores, sample_weights, B, k, flags, slabs, Upstream{nullptr, nullptr, nullptr})
     DISPATCH_NVE(nc, vec, emax, CALL);
@@ -788,7 +788,7 @@ int invpref_backward_hip(const InvPrefTables *tables, const InvPrefTables *grads
     float *slabs = (float *)workspace;
     const Upstream up{d_invariant_score, d_env_aware_score, d_env_outputs};
 #define CALL(NCV, VECV, EMAXV)                                                                                            \
-    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(mstep_atomic_kernel<NCV, VECV, EMAXV, true, (NCV * EMAXV > 4)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mstep_atomic_kernel<NCV, VECV, EMAXV, true, (NCV * EMAXV > 4)>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL((mstep_atomic_kernel<NCV, VECV, EMAXV, true, (NCV * EMAXV > 4)>), dim3(nb), dim3((NCV * EMAXV > 4) ? 256 : kMstepThreads), lds, st, t, g, users, \
                        items, envs, (const float *)nullptr, (const float *)nullptr, B, k, fl, slabs, up)
     DISPATCH_NVE(nc, vec, emax, CALL);

@@ -1,0 +1,140 @@
+"""GPU: edge cases of the hot path through the C ABI -- ragged / tiny / maximum sizes, empty shards,
+extreme scores -- each against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from invpref_kdd_2022_amd import ops, plan as planlib, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+COEFS = (2.05, 8.63, 5.1, 7.73, 0.0015, 1.74)
+
+
+def dev(tabs):
+    return [torch.from_numpy(np.ascontiguousarray(tabs[k], np.float32)).to(DEV) for k in ops.PARAM_NAMES]
+
+
+def t64(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.int64)).to(DEV)
+
+
+def t32(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(DEV)
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize('U,I,E,D,B', [(1, 1, 1, 4, 1), (3, 2, 2, 1, 5), (7, 5, 16, 256, 17), (9, 4, 3, 255, 33),
+                                        (50, 40, 4, 64, 1), (50, 40, 4, 64, 4097)])
+@pytest.mark.parametrize('implicit', [True, False])
+def test_ragged_and_extreme_shapes(U, I, E, D, B, implicit):
+    rs = np.random.RandomState(U * 1000 + B)
+    tabs = synth.tables(B + D, U, I, E, D, std=0.3)
+    u, v, e = rs.randint(0, U, B), rs.randint(0, I, B), rs.randint(0, E, B)
+    y = (rs.randint(0, 2, B) if implicit else rs.randint(1, 6, B)).astype(np.float32)
+    w = rs.uniform(0.1, 1, B).astype(np.float32)
+    P, tab, ws = dev(tabs), O.Tables(tabs), ops.Workspace(DEV)
+    # forward + E-step: bit exact
+    inv, env, out = ops.forward(P, t64(u), t64(v), t64(e), implicit)
+    oi, oe, oo = O.forward(tab, u, v, e, implicit)
+    np.testing.assert_array_equal(inv.cpu().numpy(), oi)
+    np.testing.assert_array_equal(out.cpu().numpy(), oo)
+    new, counts, diff, cw, sw = ops.estep(P, t64(u), t64(v), t32(y), implicit, t64(e), ws)
+    on, oc, od, _ = O.estep(tab, u, v, y, implicit, old_envs=e)
+    np.testing.assert_array_equal(new.cpu().numpy(), on)
+    np.testing.assert_array_equal(counts.cpu().numpy(), oc)
+    assert int(diff.item()) == od
+    # M-step, plan-free and planned, all flags on
+    flags = ops.flags_of(implicit, True, True, False, True)
+    og, ol = O.mstep(tab, u, v, e, y, w, COEFS, O.flags_of(implicit, True, True, False, True))
+    G1 = [torch.zeros_like(p) for p in P]
+    l1 = torch.zeros(6, device=DEV)
+    ops.mstep_grad(P, G1, t64(u), t64(v), t64(e), t32(y), t32(w), B, COEFS, flags, l1, ws)
+    dp = planlib.upload(planlib.build_row_plan(u, v, y, U, I), DEV)
+    G2 = [torch.full_like(p, 9.0) for p in P]
+    l2 = torch.zeros(6, device=DEV)
+    ops.mstep_rows_grad(P, G2, dp, t64(e), t32(y), t32(w), B, COEFS, flags, l2, ws)
+    for L in (l1, l2):
+        np.testing.assert_allclose(L.cpu().numpy(), ol, rtol=2e-5)
+    for k, a, b, o in zip(O.PARAM_NAMES, G1, G2, og):
+        assert relerr(a.cpu().numpy(), o) < 5e-5, ('atomic', k)
+        assert relerr(b.cpu().numpy(), o) < 5e-5, ('rows', k)
+
+
+def test_empty_minibatch_shard():
+    """a rank whose slice of a minibatch is empty still has to run the dense-Adam step on every row"""
+    U, I, E, D = 20, 10, 4, 64
+    tabs = synth.tables(1, U, I, E, D, std=0.2)
+    P = dev(tabs)
+    ws = ops.Workspace(DEV)
+    z64, z32 = torch.zeros(1, dtype=torch.int64, device=DEV), torch.zeros(1, device=DEV)
+    dp = planlib.upload(planlib.build_row_plan(np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32), U, I), DEV)
+    G = [torch.full_like(p, 5.0) for p in P]
+    losses = torch.zeros(6, device=DEV)
+    ops.mstep_rows_grad(P, G, dp, z64, z32, z32, 100, COEFS, ops.flags_of(True, True, True, True, False), losses, ws)
+    for g in G:
+        assert float(g.abs().max()) == 0.0
+    assert float(losses.abs().max()) == 0.0
+    P2 = [torch.zeros_like(p) for p in P]
+    M = [torch.full_like(p, 0.01) for p in P]
+    V = [torch.full_like(p, 1e-4) for p in P]
+    ops.mstep_rows_adam(P, P2, M, V, dp, z64, z32, z32, 100, COEFS, ops.flags_of(True, True, True, True, False), losses,
+                        3, 0.01, ws)
+    for k, p, p2 in zip(O.PARAM_NAMES, tabs.values(), P2):
+        po = np.ascontiguousarray(p, np.float32).reshape(-1).copy()
+        m, v = np.full_like(po, 0.01), np.full_like(po, 1e-4)
+        O.adam(po, np.zeros_like(po), m, v, 3, 0.01)
+        assert np.abs(p2.cpu().numpy().reshape(-1) - po).max() < 1e-7, k
+
+
+def test_saturated_scores_follow_aten_clamps():
+    """|logit| large: sigmoid saturates to exactly 0/1, BCE clamps the log at -100 and the backward
+    denominator at 1e-12 (aten); the HIP path and the oracle must agree there too."""
+    U, I, E, D, B = 4, 4, 2, 16, 16
+    tabs = synth.tables(5, U, I, E, D, std=3.0)   # dot products of magnitude ~100
+    rs = np.random.RandomState(0)
+    u, v, e = rs.randint(0, U, B), rs.randint(0, I, B), rs.randint(0, E, B)
+    y = rs.randint(0, 2, B).astype(np.float32)
+    P, tab, ws = dev(tabs), O.Tables(tabs), ops.Workspace(DEV)
+    inv, env, _ = ops.forward(P, t64(u), t64(v), t64(e), True)
+    oi, oe, _ = O.forward(tab, u, v, e, True)
+    np.testing.assert_array_equal(inv.cpu().numpy(), oi)
+    assert ((oi == 0) | (oi == 1)).any()
+    new, _, _, _, _ = ops.estep(P, t64(u), t64(v), t32(y), True, None, ws, want_weights=False)
+    on, _, _, dist = O.estep(tab, u, v, y, True, want_dist=True)
+    np.testing.assert_array_equal(new.cpu().numpy(), on)
+    assert np.isfinite(dist).all() and dist.max() <= 100.0
+    G = [torch.zeros_like(p) for p in P]
+    losses = torch.zeros(6, device=DEV)
+    flags = ops.flags_of(True, False, False, True, False)
+    ops.mstep_grad(P, G, t64(u), t64(v), t64(e), t32(y), None, B, COEFS, flags, losses, ws)
+    og, ol = O.mstep(tab, u, v, e, y, None, COEFS, O.flags_of(True, False, False, True, False))
+    assert np.isfinite(losses.cpu().numpy()).all()
+    np.testing.assert_allclose(losses.cpu().numpy(), ol, rtol=1e-4)
+
+
+def test_train_loop_end_to_end_with_device_evaluator():
+    from eval_fixture import StubImplicitLoader, eval_fixture
+    from invpref_kdd_2022_amd.evaluate import ImplicitTestManager
+    from invpref_kdd_2022_amd.models import InvPrefImplicit
+    from invpref_kdd_2022_amd.train import ImplicitTrainManager
+    U, I, E, D = 400, 1000, 4, 64
+    data = synth.interactions(5, U, I, 20000, implicit=True)
+    model = InvPrefImplicit(U, I, E, D, reg_only_embed=True, reg_env_embed=False)
+    users, mask, pool, truth = eval_fixture()
+    ev = ImplicitTestManager(model, StubImplicitLoader(users, mask, pool, truth), 128, [3, 5, 7], use_item_pool=True)
+    np.random.seed(1)
+    mgr = ImplicitTrainManager(model, ev, DEV, torch.from_numpy(data).to(DEV), batch_size=4096, epochs=6,
+                               cluster_interval=2, evaluate_interval=3, lr=0.005, invariant_coe=3.35, env_aware_coe=9.99,
+                               env_coe=9.06, L2_coe=3.13, L1_coe=0.49, alpha=1.9, use_class_re_weight=True,
+                               use_recommend_re_weight=False)
+    (losses, lep), (tests, tep), (diffs, cnts, cep) = mgr.train(silent=True, auto=True)
+    assert lep == [1, 2, 3, 4, 5, 6] and tep == [0, 3, 6] and cep == [2, 4, 6]
+    assert all(np.isfinite(list(d.values())).all() for d in losses) and losses[-1]['loss'] < losses[0]['loss']
+    assert set(tests[0]) == {'ndcg', 'recall', 'precision'} and set(tests[0]['ndcg']) == {3, 5, 7}
+    assert all(sum(c.values()) == len(data) for c in cnts) and len(diffs) == 3

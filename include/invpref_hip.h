@@ -124,8 +124,12 @@ typedef struct InvPrefRowPlan {
     const int32_t *item_hot_index;            /* [item_num] index into hot_rows, or -1 */
     /* rows the minibatch does not touch need no job either: they are listed here and streamed through
      * the dense-Adam step (zero gradient) by workgroups of their own, rows_per_stream_task rows each. */
-    int32_t n_stream_user, n_stream_item, rows_per_stream_task, reserved2;
+    int32_t n_stream_user, n_stream_item, rows_per_stream_task, dense_per_task;
     const int32_t *stream_rows;               /* [n_stream_user + n_stream_item], user rows first */
+    /* dense tasks: everything that is a reduction ACROSS rows (gradients of embed_env / classifier, loss
+     * sums, the hot rows' atomics) is computed by workgroups that walk the minibatch in its own order,
+     * dense_per_task interactions each: the ids of the minibatch as int32. */
+    const int32_t *batch_users, *batch_items; /* [n] */
 } InvPrefRowPlan;
 
 /* The rows-path workspace must be ZERO-FILLED before its first use; every call leaves it zero-filled. */

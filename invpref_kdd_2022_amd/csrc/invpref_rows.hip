@@ -33,12 +33,6 @@ using namespace invpref;
 
 namespace {
 
-#ifndef ABL_NO_DENSE   // timing experiments only (tools/): drop parts of the user-side work
-#define ABL_NO_DENSE 0
-#endif
-#ifndef ABL_NO_REPORTS
-#define ABL_NO_REPORTS 0
-#endif
 #ifndef REPLICAS
 #define REPLICAS 32
 #endif
@@ -67,6 +61,8 @@ struct RowsArgs {
     // streamed by dedicated workgroups with several rows in flight per group
     const int *stream_rows;       // [n_stream_user + n_stream_item] row ids, user rows first
     int n_stream_user, n_stream_item, rows_per_stream_task, n_job_tasks, n_stream_user_tasks;
+    const int *batch_users, *batch_items;   // [n] ids of the minibatch in its own order (dense tasks)
+    int n, dense_per_task, n_dense_tasks;
     const int *item_hot_index;    // [item_num]: scratch row of an item whose gradient goes through atomics, or -1
     float *hot_scratch;           // [n_hot][2][DP] gradient accumulators of those rows (zero on entry, re-zeroed by finish)
     int *sched_state;             // optional device int32[4] = {step (1-based), first step of sched_table, ticket, 0}
@@ -123,29 +119,92 @@ __device__ __forceinline__ float4 f4xor_lanes(float4 v, int m) {
     return make_float4(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64), __shfl_xor(v.z, m, 64), __shfl_xor(v.w, m, 64));
 }
 
-// DREG ("dense areas"): the E x D partials (classifier weight / env table gradients) of the user-side
-// jobs are kept in LDS, one private area per WAVE, updated with plain read-modify-write; the four
-// groups of a wave take turns (wave-level fence between turns), so no atomics and no VGPRs are
-// spent.  For large E*D (four areas would not fit comfortably) the workgroup shares one area through
-// LDS atomics instead (slower, still correct).
 struct Sample {
     int oth, ps;
     float y;
 };
 
-template <int NC, bool VEC, int EMAX, bool DREG, bool USER>
+// ---- forward + analytic backward of ONE interaction on a 16-lane group (M-step arithmetic: hardware
+// exp/log/rcp).  Rows in canonical roles: pu/qi invariant user/item rows, pa/qa env-aware rows, ev the env row.
+template <int NC, int EMAX>
+struct Eval {
+    float g_p, g_q, li, le, lcls;
+    float gz[EMAX];
+    float4 x[NC], gx[NC];   // x = Pu*Qi ; gx = sum_c gz_c W_c
+};
+template <int NC, int EMAX>
+__device__ __forceinline__ void eval_interaction(Eval<NC, EMAX> &o, const float4 (&pu)[NC], const float4 (&qi)[NC],
+                                                 const float4 (&pa)[NC], const float4 (&qa)[NC], const float4 (&ev)[NC],
+                                                 const float *sW, const float *sb, int E, int e, float y, float cw_rec,
+                                                 float cw_cls, const StepScalars &k, bool implicit, int l16) {
+    const float p = dot2<NC>(pu, qi), q = dot3<NC>(pa, qa, ev);
+    if (implicit) {
+        const float sp = f_sigmoid(p), sq = f_sigmoid(q), sv = sp * sq;
+        o.li = f_bce(sp, y);
+        o.le = f_bce(sv, y);
+        const float d_inv = k.ca * cw_rec * f_dbce(sp, y);
+        const float d_env = k.cb * cw_rec * f_dbce(sv, y);
+        o.g_p = (d_inv + d_env * sq) * (sp * (1.f - sp));
+        o.g_q = d_env * sp * (sq * (1.f - sq));
+    } else {
+        const float s2 = p + q;
+        o.li = (p - y) * (p - y);
+        o.le = (s2 - y) * (s2 - y);
+        const float d_env = k.cb * cw_rec * 2.f * (s2 - y);
+        o.g_p = k.ca * cw_rec * 2.f * (p - y) + d_env;
+        o.g_q = d_env;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) o.x[c] = f4mul(pu[c], qi[c]);
+    float z[EMAX], mx = -__builtin_inff();
+#pragma unroll
+    for (int c = 0; c < EMAX; c++) {
+        z[c] = -__builtin_inff();
+        if (c < E) {
+            float4 wr[NC];
+            lds_row<NC>(sW, c, l16, wr);
+            z[c] = dot2<NC>(o.x, wr) + sb[c];
+            mx = z[c] > mx ? z[c] : mx;
+        }
+    }
+    float se = 0.f, ze = 0.f;
+#pragma unroll
+    for (int c = 0; c < EMAX; c++)
+        if (c < E) { z[c] = f_exp(z[c] - mx); se += z[c]; }
+#pragma unroll
+    for (int c = 0; c < EMAX; c++) ze = (c == e) ? z[c] : ze;
+    const float rse = f_rcp(se);
+    o.lcls = -f_log(ze * rse);
+#pragma unroll
+    for (int c = 0; c < NC; c++) o.gx[c] = f4zero();
+#pragma unroll
+    for (int c = 0; c < EMAX; c++) {
+        o.gz[c] = 0.f;
+        if (c < E) {
+            o.gz[c] = k.cc * cw_cls * (z[c] * rse - (c == e ? 1.f : 0.f));
+            float4 wr[NC];
+            lds_row<NC>(sW, c, l16, wr);
+#pragma unroll
+            for (int jj = 0; jj < NC; jj++) f4fma(o.gx[jj], o.gz[c], wr[jj]);
+        }
+    }
+}
+
+// =====================================================================================
+// job task: rounds of row jobs of ONE side.  Symmetric in the two sides: a job only produces its own
+// row's two gradient rows; everything that is a reduction ACROSS rows (E x D gradients, loss sums,
+// regulariser reports, hot-row atomics) belongs to the dense tasks below.
+// =====================================================================================
+template <int NC, bool VEC, int EMAX, bool USER>
 __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a, const int4 task, float *lds) {
     constexpr int DP = NC * 64;
     constexpr int side = USER ? 0 : 1;
-    constexpr bool user_side = USER;
     const int EDP = t.E * DP;
     float *slots = lds;                                  // [16][2][DP] slice partials
     float *sEv = slots + kGroups * 2 * DP, *sW = sEv + EDP, *sb = sW + EDP;   // staged small tables
-    float *red = sb + EMAX;                              // DREG: [4 waves][2*EDP]; else one shared [2*EDP]
-    float *ab = red + (DREG ? 4 : 1) * 2 * EDP, *aL = ab + EMAX;             // [EMAX], [kLossSlots]
     // Adam moments of the rows being finished, prefetched by LDS-DMA (no VGPRs held across the
     // interaction loop): [4 waves][m_inv, v_inv, m_env, v_env][NC chunks][64 lanes] float4
-    float4 *mv = reinterpret_cast<float4 *>(aL + kLossSlots);
+    float4 *mv = reinterpret_cast<float4 *>(sb + EMAX);
 
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4, wave = threadIdx.x >> 6;
     // (NC = 4 rows would need 64 KB of LDS for the prefetch: those fetch the moments late instead)
@@ -153,11 +212,10 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
     float4 *mv_wave = mv + wave * 4 * NC * 64;
     const bool implicit = a.flags & INVPREF_IMPLICIT;
     const bool rw_rec = a.flags & INVPREF_REWEIGHT_REC, rw_cls = a.flags & INVPREF_REWEIGHT_CLS;
-    const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
     const StepScalars k = a.k;
     const int *oth_ids = a.oth[side], *pos = a.pos[side];
-    const float *T_own_inv = user_side ? t.Pu : t.Qi, *T_own_env = user_side ? t.Pa : t.Qa;
-    const float *T_oth_inv = user_side ? t.Qi : t.Pu, *T_oth_env = user_side ? t.Qa : t.Pa;
+    const float *T_own_inv = USER ? t.Pu : t.Qi, *T_own_env = USER ? t.Pa : t.Qa;
+    const float *T_oth_inv = USER ? t.Qi : t.Pu, *T_oth_env = USER ? t.Qa : t.Pa;
     // Adam scalars of this step: by value, or (graph replay: kernel arguments are frozen) looked up
     // by the device-side step counter that rows_finish_kernel advances
     const AdamScalars ad = a.sched_state ? a.sched_table[a.sched_state[0] - a.sched_state[1]] : a.ad;
@@ -167,18 +225,7 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
     int4 d = a.desc[(task.y * kGroups + grp) * 2], d1 = a.desc[(task.y * kGroups + grp) * 2 + 1];
     stage_table(sEv, t.Ev, t.E, t.D, DP);
     stage_table(sW, t.W, t.E, t.D, DP);
-    for (int i = threadIdx.x; i < EMAX; i += blockDim.x) { sb[i] = (i < t.E) ? t.b[i] : 0.f; ab[i] = 0.f; }
-    if (threadIdx.x < kLossSlots) aL[threadIdx.x] = 0.f;
-    if (user_side) {
-        if (DREG) {  // each wave clears its own area (only that wave ever touches it)
-            float *area = red + wave * 2 * EDP;
-            for (int i = (threadIdx.x & 63) * 4; i < 2 * EDP; i += 256) *reinterpret_cast<float4 *>(area + i) = f4zero();
-        } else {
-            for (int i = threadIdx.x; i < 2 * EDP; i += blockDim.x) red[i] = 0.f;
-        }
-    }
-    float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
-    float *area = red + (DREG ? wave * 2 * EDP : 0);  // [EDP] env-table part, [EDP] classifier part
+    for (int i = threadIdx.x; i < EMAX; i += blockDim.x) sb[i] = (i < t.E) ? t.b[i] : 0.f;
     STAMP(1);
 
     for (int r = task.y; r < task.y + task.z; r++) {
@@ -198,12 +245,12 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
             return sm;
         };
         // everything that depends only on the descriptor is requested together: own rows, the Adam
-        // moments of the row (needed last) and the first interaction's partner rows / env / weight
+        // moments of the row (needed last, LDS-DMA) and the first interaction's partner rows / env / weight
         float4 oi[NC], oe[NC], gi[NC], ge[NC], pi[NC], pe[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++) oi[c] = oe[c] = gi[c] = ge[c] = pi[c] = pe[c] = f4zero();
         Sample cur{0, 0, 0.f};
-        int e = 0, hidx = -1;
+        int e = 0;
         float w = 1.f;
         if (active) {
             load_row<NC, VEC>(T_own_inv, row, t.D, l16, oi);
@@ -214,7 +261,6 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
                 load_row<NC, VEC>(T_oth_env, cur.oth, t.D, l16, pe);
                 e = (int)a.envs[cur.ps];
                 if (rw_rec || rw_cls) w = a.weights[cur.ps];
-                if (user_side && a.item_hot_index) hidx = a.item_hot_index[cur.oth];
             }
         }
         if (dma) {
@@ -236,194 +282,27 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
         }
         if (r == task.y) { __syncthreads(); STAMP(3); }  // staged tables visible (the gathers above are in flight)
         for (int sidx = 0; sidx < nsmp; sidx++) {
-            // request the next interaction before working on this one
-            float4 pin[NC], pen[NC];
-            Sample nxt{0, 0, 0.f};
-            int en = 0, hn = -1;
-            float wn = 1.f;
-            if (sidx + 1 < nsmp) {
-                nxt = sample_at(sidx + 1);
-                load_row<NC, VEC>(T_oth_inv, nxt.oth, t.D, l16, pin);
-                load_row<NC, VEC>(T_oth_env, nxt.oth, t.D, l16, pen);
-                en = (int)a.envs[nxt.ps];
-                if (rw_rec || rw_cls) wn = a.weights[nxt.ps];
-                if (user_side && a.item_hot_index) hn = a.item_hot_index[nxt.oth];
+            if (sidx > 0) {  // (the first interaction's gathers were issued with the own rows)
+                cur = sample_at(sidx);
+                load_row<NC, VEC>(T_oth_inv, cur.oth, t.D, l16, pi);
+                load_row<NC, VEC>(T_oth_env, cur.oth, t.D, l16, pe);
+                e = (int)a.envs[cur.ps];
+                if (rw_rec || rw_cls) w = a.weights[cur.ps];
             }
-            const float y = cur.y;
-            const float w_rec = rw_rec ? w : 1.f, w_cls = rw_cls ? w : 1.f;
-            const float cw_rec = w_rec * k.invB, cw_cls = w_cls * k.invB;
+            const float cw_rec = (rw_rec ? w : 1.f) * k.invB, cw_cls = (rw_cls ? w : 1.f) * k.invB;
             float4 ev[NC];
             lds_row<NC>(sEv, e, l16, ev);
-            const float p = user_side ? dot2<NC>(oi, pi) : dot2<NC>(pi, oi);
-            const float q = user_side ? dot3<NC>(oe, pe, ev) : dot3<NC>(pe, oe, ev);
-            float g_p, g_q, li, le;
-            if (implicit) {
-                const float sp = f_sigmoid(p), sq = f_sigmoid(q), sv = sp * sq;
-                li = f_bce(sp, y);
-                le = f_bce(sv, y);
-                const float d_inv = k.ca * cw_rec * f_dbce(sp, y);
-                const float d_env = k.cb * cw_rec * f_dbce(sv, y);
-                g_p = (d_inv + d_env * sq) * (sp * (1.f - sp));
-                g_q = d_env * sp * (sq * (1.f - sq));
-            } else {
-                const float s2 = p + q;
-                li = (p - y) * (p - y);
-                le = (s2 - y) * (s2 - y);
-                const float d_env = k.cb * cw_rec * 2.f * (s2 - y);
-                g_p = k.ca * cw_rec * 2.f * (p - y) + d_env;
-                g_q = d_env;
-            }
-            float4 x[NC];
-#pragma unroll
-            for (int c = 0; c < NC; c++) x[c] = user_side ? f4mul(oi[c], pi[c]) : f4mul(pi[c], oi[c]);
-            float z[EMAX], mx = -__builtin_inff();
-#pragma unroll
-            for (int c = 0; c < EMAX; c++) {
-                z[c] = -__builtin_inff();
-                if (c < t.E) {
-                    float4 wr[NC];
-                    lds_row<NC>(sW, c, l16, wr);
-                    z[c] = dot2<NC>(x, wr) + sb[c];
-                    mx = z[c] > mx ? z[c] : mx;
-                }
-            }
-            float se = 0.f, ze = 0.f;
-#pragma unroll
-            for (int c = 0; c < EMAX; c++)
-                if (c < t.E) { z[c] = f_exp(z[c] - mx); se += z[c]; }
-#pragma unroll
-            for (int c = 0; c < EMAX; c++) ze = (c == e) ? z[c] : ze;
-            const float rse = f_rcp(se);
-            float gz[EMAX];
-            float4 gx[NC];
-#pragma unroll
-            for (int c = 0; c < NC; c++) gx[c] = f4zero();
-#pragma unroll
-            for (int c = 0; c < EMAX; c++) {
-                gz[c] = 0.f;
-                if (c < t.E) {
-                    gz[c] = k.cc * cw_cls * (z[c] * rse - (c == e ? 1.f : 0.f));
-                    float4 wr[NC];
-                    lds_row<NC>(sW, c, l16, wr);
-#pragma unroll
-                    for (int jj = 0; jj < NC; jj++) f4fma(gx[jj], gz[c], wr[jj]);
-                }
-            }
+            Eval<NC, EMAX> o;
+            if (USER) eval_interaction<NC, EMAX>(o, oi, pi, oe, pe, ev, sW, sb, t.E, e, cur.y, cw_rec, cw_cls, k, implicit, l16);
+            else eval_interaction<NC, EMAX>(o, pi, oi, pe, oe, ev, sW, sb, t.E, e, cur.y, cw_rec, cw_cls, k, implicit, l16);
 #pragma unroll
             for (int jj = 0; jj < NC; jj++) {
                 float4 gip;
-                gip.x = g_p - k.alpha * gx[jj].x; gip.y = g_p - k.alpha * gx[jj].y;
-                gip.z = g_p - k.alpha * gx[jj].z; gip.w = g_p - k.alpha * gx[jj].w;
+                gip.x = o.g_p - k.alpha * o.gx[jj].x; gip.y = o.g_p - k.alpha * o.gx[jj].y;
+                gip.z = o.g_p - k.alpha * o.gx[jj].z; gip.w = o.g_p - k.alpha * o.gx[jj].w;
                 f4add(gi[jj], f4mul(gip, pi[jj]));
-                f4fma(ge[jj], g_q, f4mul(pe[jj], ev[jj]));
+                f4fma(ge[jj], o.g_q, f4mul(pe[jj], ev[jj]));
             }
-            if (user_side && hidx >= 0) {
-                // the partner item row takes its gradient through float atomics (it has no job of its own:
-                // too many interactions for one workgroup); transposed through LDS so that one instruction
-                // adds 64 contiguous bytes per interaction.  (A job's slices write their LDS slot only AFTER
-                // the interaction loop, so the slot is free to serve as the transpose buffer here.)
-                float *tr = slots + grp * 2 * DP;
-                float *dst = a.hot_scratch + (int64_t)hidx * 2 * DP;
-#pragma unroll
-                for (int jj = 0; jj < NC; jj++) {
-                    float4 gip;
-                    gip.x = g_p - k.alpha * gx[jj].x; gip.y = g_p - k.alpha * gx[jj].y;
-                    gip.z = g_p - k.alpha * gx[jj].z; gip.w = g_p - k.alpha * gx[jj].w;
-                    *reinterpret_cast<float4 *>(tr + (l16 + kRow * jj) * 4) = f4mul(gip, oi[jj]);
-                    float4 t2 = f4mul(oe[jj], ev[jj]);
-                    t2.x *= g_q; t2.y *= g_q; t2.z *= g_q; t2.w *= g_q;
-                    *reinterpret_cast<float4 *>(tr + DP + (l16 + kRow * jj) * 4) = t2;
-                }
-                WAVE_LDS_FENCE();
-#pragma unroll
-                for (int q4 = 0; q4 < 2 * DP / 16; q4++) {
-                    const int idx = q4 * 16 + l16;           // 16 lanes -> 16 consecutive floats
-                    if ((idx & (DP - 1)) < t.D) atomicAdd(dst + idx, tr[idx]);
-                }
-                WAVE_LDS_FENCE();
-            }
-            if (user_side) {
-                // ---- E x D partials: env-table row e gets g_q * Pa*Qa (+ its regulariser), classifier row c gets gz_c * x
-                float4 o[NC];
-#pragma unroll
-                for (int jj = 0; jj < NC; jj++) {
-                    o[jj] = f4mul(oe[jj], pe[jj]);
-                    o[jj].x *= g_q; o[jj].y *= g_q; o[jj].z *= g_q; o[jj].w *= g_q;
-                    if (reg_env) {
-                        o[jj].x += 2.f * k.r2 * ev[jj].x + 2.f * k.r1 * c_sign(ev[jj].x);
-                        o[jj].y += 2.f * k.r2 * ev[jj].y + 2.f * k.r1 * c_sign(ev[jj].y);
-                        o[jj].z += 2.f * k.r2 * ev[jj].z + 2.f * k.r1 * c_sign(ev[jj].z);
-                        o[jj].w += 2.f * k.r2 * ev[jj].w + 2.f * k.r1 * c_sign(ev[jj].w);
-                    }
-                }
-                if (ABL_NO_DENSE) {
-                } else if (DREG) {
-#pragma unroll
-                    for (int turn = 0; turn < 4; turn++) {  // the wave's four groups, one after the other
-                        if ((grp & 3) == turn) {
-#pragma unroll
-                            for (int jj = 0; jj < NC; jj++) {
-                                float4 *dst = reinterpret_cast<float4 *>(area + e * DP + (l16 + kRow * jj) * 4);
-                                float4 cv = *dst;
-                                f4add(cv, o[jj]);
-                                *dst = cv;
-#pragma unroll
-                                for (int c = 0; c < EMAX; c++) {
-                                    if (c < t.E) {
-                                        float4 *dw = reinterpret_cast<float4 *>(area + EDP + c * DP + (l16 + kRow * jj) * 4);
-                                        float4 cw = *dw;
-                                        f4fma(cw, gz[c], x[jj]);
-                                        *dw = cw;
-                                    }
-                                }
-                            }
-                        }
-                        WAVE_LDS_FENCE();
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                } else {
-#pragma unroll
-                    for (int jj = 0; jj < NC; jj++) {
-                        float *dst = area + e * DP + (l16 + kRow * jj) * 4;
-                        atomicAdd(dst + 0, o[jj].x); atomicAdd(dst + 1, o[jj].y); atomicAdd(dst + 2, o[jj].z); atomicAdd(dst + 3, o[jj].w);
-#pragma unroll
-                        for (int c = 0; c < EMAX; c++) {
-                            if (c < t.E) {
-                                float *dw = area + EDP + c * DP + (l16 + kRow * jj) * 4;
-                                atomicAdd(dw + 0, gz[c] * x[jj].x); atomicAdd(dw + 1, gz[c] * x[jj].y);
-                                atomicAdd(dw + 2, gz[c] * x[jj].z); atomicAdd(dw + 3, gz[c] * x[jj].w);
-                            }
-                        }
-                    }
-                }
-                if (l16 == 0) {
-#pragma unroll
-                    for (int c = 0; c < EMAX; c++) if (c < t.E) atomicAdd(ab + c, gz[c]);
-                }
-                // regulariser REPORTS over the four rows of the interaction (env rows weigh double)
-#pragma unroll
-                for (int jj = 0; jj < (ABL_NO_REPORTS ? 0 : NC); jj++) {
-                    float s2 = oi[jj].x * oi[jj].x + oi[jj].y * oi[jj].y + oi[jj].z * oi[jj].z + oi[jj].w * oi[jj].w;
-                    s2 += oe[jj].x * oe[jj].x + oe[jj].y * oe[jj].y + oe[jj].z * oe[jj].z + oe[jj].w * oe[jj].w;
-                    s2 += pi[jj].x * pi[jj].x + pi[jj].y * pi[jj].y + pi[jj].z * pi[jj].z + pi[jj].w * pi[jj].w;
-                    s2 += pe[jj].x * pe[jj].x + pe[jj].y * pe[jj].y + pe[jj].z * pe[jj].z + pe[jj].w * pe[jj].w;
-                    float s1 = fabsf(oi[jj].x) + fabsf(oi[jj].y) + fabsf(oi[jj].z) + fabsf(oi[jj].w);
-                    s1 += fabsf(oe[jj].x) + fabsf(oe[jj].y) + fabsf(oe[jj].z) + fabsf(oe[jj].w);
-                    s1 += fabsf(pi[jj].x) + fabsf(pi[jj].y) + fabsf(pi[jj].z) + fabsf(pi[jj].w);
-                    s1 += fabsf(pe[jj].x) + fabsf(pe[jj].y) + fabsf(pe[jj].z) + fabsf(pe[jj].w);
-                    if (reg_env) {
-                        s2 += 2.f * (ev[jj].x * ev[jj].x + ev[jj].y * ev[jj].y + ev[jj].z * ev[jj].z + ev[jj].w * ev[jj].w);
-                        s1 += 2.f * (fabsf(ev[jj].x) + fabsf(ev[jj].y) + fabsf(ev[jj].z) + fabsf(ev[jj].w));
-                    }
-                    accL2 += s2;
-                    accL1 += s1;
-                }
-                if (l16 == 0) { accLi += li * w_rec; accLe += le * w_rec; accLc += -f_log(ze * rse) * w_cls; }
-            }
-            // rotate in the prefetched interaction
-            cur = nxt; e = en; w = wn; hidx = hn;
-#pragma unroll
-            for (int c = 0; c < NC; c++) { pi[c] = pin[c]; pe[c] = pen[c]; }
         }
         if (r == task.y) STAMP(4);
         // ---- slices of one row meet through LDS: plain stores, fixed-order sum by the leader
@@ -451,7 +330,7 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
         // ---- the leader finishes the row
         if (active && leader) {
             const float cnt = (float)(meta >> 8);
-            if (cnt != 0.f) {  // an untouched row has a zero gradient; Adam still moves it (dense semantics)
+            if (cnt != 0.f) {
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     gi[c].x += cnt * (k.r2 * oi[c].x + k.r1 * c_sign(oi[c].x)); gi[c].y += cnt * (k.r2 * oi[c].y + k.r1 * c_sign(oi[c].y));
@@ -495,10 +374,164 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
             }
         }
     }
-
     STAMP(6);
-    if (!user_side) return;
-    // ---- dense partials of this workgroup -> replica slab
+}
+
+// =====================================================================================
+// dense task: a contiguous run of the minibatch's interactions, 16 at a time.  Everything that is a
+// reduction ACROSS rows lives here, off the critical path of the row jobs:
+//   * E x D gradients of embed_env / classifier (+ bias): every group records x = Pu*Qi,
+//     o = g_q*Pa*Qa (+ env regulariser), gz[0..E) and the env id in LDS; after a barrier every thread adds
+//     all 16 records into the outputs it OWNS (one column d, a strided set of classes c) held in
+//     registers -- an outer-product accumulation on the vector ALU, no atomics, any E*D;
+//   * the five loss / regulariser-report sums;
+//   * the gradient of HOT item rows (float atomics shaped as 64 contiguous bytes per instruction).
+// The workgroup's totals go to one of the replica slabs with float atomics (~2 KB per workgroup).
+// =====================================================================================
+template <int NC, bool VEC, int EMAX>
+__device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a, int s0, int s1, float *lds) {
+    constexpr int DP = NC * 64;
+    const int EDP = t.E * DP;
+    float *sEv = lds, *sW = sEv + EDP, *sb = sW + EDP;
+    // records are double-buffered (one barrier per iteration) and the hot-row transpose has its own buffer
+    // while that fits comfortably (NC <= 2); NC = 4 uses one record buffer for everything and more barriers
+    constexpr bool DBUF = NC <= 2;
+    float *rec0 = sb + EMAX;                             // [DBUF ? 2 : 1][16][2][DP]  x, o
+    float *recs0 = rec0 + (DBUF ? 2 : 1) * kGroups * 2 * DP;   // [DBUF ? 2 : 1][16][EMAX + 1]  gz[0..EMAX), env id (-1: none)
+    float *aL = recs0 + (DBUF ? 2 : 1) * kGroups * (EMAX + 1); // [kLossSlots]
+    float *trbuf = aL + kLossSlots;                      // DBUF: [16][2][DP] hot-row transpose buffer
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const bool implicit = a.flags & INVPREF_IMPLICIT;
+    const bool rw_rec = a.flags & INVPREF_REWEIGHT_REC, rw_cls = a.flags & INVPREF_REWEIGHT_CLS;
+    const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
+    const StepScalars k = a.k;
+    STAMP(0);
+    stage_table(sEv, t.Ev, t.E, t.D, DP);
+    stage_table(sW, t.W, t.E, t.D, DP);
+    for (int i = threadIdx.x; i < EMAX; i += blockDim.x) sb[i] = (i < t.E) ? t.b[i] : 0.f;
+    if (threadIdx.x < kLossSlots) aL[threadIdx.x] = 0.f;
+    // output ownership: thread -> column d_own, classes cg, cg + CG, ...
+    constexpr int CG = (256 / DP) < EMAX ? (256 / DP) : EMAX;
+    constexpr int CPT = (EMAX + CG - 1) / CG;
+    const int d_own = threadIdx.x % DP, cg = threadIdx.x / DP;
+    float dW[CPT], dE[CPT], dB[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; i++) dW[i] = dE[i] = dB[i] = 0.f;
+    float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
+    __syncthreads();
+    STAMP(1);
+
+    for (int base = s0, it = 0; base < s1; base += kGroups, it++) {
+        float *rec = rec0 + (DBUF ? (it & 1) : 0) * kGroups * 2 * DP;
+        float *recs = recs0 + (DBUF ? (it & 1) : 0) * kGroups * (EMAX + 1);
+        const int s = base + grp;
+        const bool valid = s < s1;
+        int e = -1, hidx = -1;
+        float4 hq[NC], ha[NC];  // hot item row gradients of this interaction
+#pragma unroll
+        for (int c = 0; c < NC; c++) hq[c] = ha[c] = f4zero();
+        if (valid) {
+            const int u = a.batch_users[s], v = a.batch_items[s];
+            e = (int)a.envs[s];
+            const float y = a.scores[s];
+            const float w = (rw_rec || rw_cls) ? a.weights[s] : 1.f;
+            const float w_rec = rw_rec ? w : 1.f, w_cls = rw_cls ? w : 1.f;
+            if (a.item_hot_index) hidx = a.item_hot_index[v];
+            float4 pu[NC], qi[NC], pa[NC], qa[NC], ev[NC];
+            load_row<NC, VEC>(t.Pu, u, t.D, l16, pu);
+            load_row<NC, VEC>(t.Qi, v, t.D, l16, qi);
+            load_row<NC, VEC>(t.Pa, u, t.D, l16, pa);
+            load_row<NC, VEC>(t.Qa, v, t.D, l16, qa);
+            lds_row<NC>(sEv, e, l16, ev);
+            Eval<NC, EMAX> o;
+            eval_interaction<NC, EMAX>(o, pu, qi, pa, qa, ev, sW, sb, t.E, e, y, w_rec * k.invB, w_cls * k.invB, k, implicit, l16);
+            // record for the E x D accumulation
+#pragma unroll
+            for (int jj = 0; jj < NC; jj++) {
+                float4 oo = f4mul(pa[jj], qa[jj]);
+                oo.x *= o.g_q; oo.y *= o.g_q; oo.z *= o.g_q; oo.w *= o.g_q;
+                if (reg_env) {
+                    oo.x += 2.f * k.r2 * ev[jj].x + 2.f * k.r1 * c_sign(ev[jj].x);
+                    oo.y += 2.f * k.r2 * ev[jj].y + 2.f * k.r1 * c_sign(ev[jj].y);
+                    oo.z += 2.f * k.r2 * ev[jj].z + 2.f * k.r1 * c_sign(ev[jj].z);
+                    oo.w += 2.f * k.r2 * ev[jj].w + 2.f * k.r1 * c_sign(ev[jj].w);
+                }
+                *reinterpret_cast<float4 *>(rec + (grp * 2) * DP + (l16 + kRow * jj) * 4) = o.x[jj];
+                *reinterpret_cast<float4 *>(rec + (grp * 2 + 1) * DP + (l16 + kRow * jj) * 4) = oo;
+                if (hidx >= 0) {
+                    float4 gip;
+                    gip.x = o.g_p - k.alpha * o.gx[jj].x; gip.y = o.g_p - k.alpha * o.gx[jj].y;
+                    gip.z = o.g_p - k.alpha * o.gx[jj].z; gip.w = o.g_p - k.alpha * o.gx[jj].w;
+                    hq[jj] = f4mul(gip, pu[jj]);
+                    ha[jj] = f4mul(pa[jj], ev[jj]);
+                    ha[jj].x *= o.g_q; ha[jj].y *= o.g_q; ha[jj].z *= o.g_q; ha[jj].w *= o.g_q;
+                }
+                // regulariser REPORTS over the four rows of the interaction (env rows weigh double: 1/(BD) vs 1/(2BD))
+                float s2 = pu[jj].x * pu[jj].x + pu[jj].y * pu[jj].y + pu[jj].z * pu[jj].z + pu[jj].w * pu[jj].w;
+                s2 += pa[jj].x * pa[jj].x + pa[jj].y * pa[jj].y + pa[jj].z * pa[jj].z + pa[jj].w * pa[jj].w;
+                s2 += qi[jj].x * qi[jj].x + qi[jj].y * qi[jj].y + qi[jj].z * qi[jj].z + qi[jj].w * qi[jj].w;
+                s2 += qa[jj].x * qa[jj].x + qa[jj].y * qa[jj].y + qa[jj].z * qa[jj].z + qa[jj].w * qa[jj].w;
+                float s1 = fabsf(pu[jj].x) + fabsf(pu[jj].y) + fabsf(pu[jj].z) + fabsf(pu[jj].w);
+                s1 += fabsf(pa[jj].x) + fabsf(pa[jj].y) + fabsf(pa[jj].z) + fabsf(pa[jj].w);
+                s1 += fabsf(qi[jj].x) + fabsf(qi[jj].y) + fabsf(qi[jj].z) + fabsf(qi[jj].w);
+                s1 += fabsf(qa[jj].x) + fabsf(qa[jj].y) + fabsf(qa[jj].z) + fabsf(qa[jj].w);
+                if (reg_env) {
+                    s2 += 2.f * (ev[jj].x * ev[jj].x + ev[jj].y * ev[jj].y + ev[jj].z * ev[jj].z + ev[jj].w * ev[jj].w);
+                    s1 += 2.f * (fabsf(ev[jj].x) + fabsf(ev[jj].y) + fabsf(ev[jj].z) + fabsf(ev[jj].w));
+                }
+                accL2 += s2;
+                accL1 += s1;
+            }
+            if (l16 < EMAX) {
+                float gsel = 0.f;
+#pragma unroll
+                for (int c = 0; c < EMAX; c++) gsel = (l16 == c) ? o.gz[c] : gsel;
+                recs[grp * (EMAX + 1) + l16] = gsel;
+            }
+            if (l16 == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; accLc += o.lcls * w_cls; }
+        }
+        if (l16 == 0) recs[grp * (EMAX + 1) + EMAX] = __builtin_bit_cast(float, e);
+        __syncthreads();
+        if (threadIdx.x < CG * DP) {
+#pragma unroll 1
+            for (int g2 = 0; g2 < kGroups; g2++) {
+                const float *rs = recs + g2 * (EMAX + 1);
+                const int er = __builtin_bit_cast(int, rs[EMAX]);
+                if (er < 0) continue;
+                const float xv = rec[(g2 * 2) * DP + d_own], ov = rec[(g2 * 2 + 1) * DP + d_own];
+#pragma unroll
+                for (int i = 0; i < CPT; i++) {
+                    const int c = cg + CG * i;
+                    if (c < t.E) {
+                        const float gzc = rs[c];
+                        dW[i] = __builtin_fmaf(gzc, xv, dW[i]);
+                        dE[i] += (c == er) ? ov : 0.f;
+                        dB[i] += gzc;
+                    }
+                }
+            }
+        }
+        if (!DBUF) __syncthreads();
+        // hot item rows: shaped atomics through a transpose buffer (NC = 4: the now free record slot)
+        if (hidx >= 0) {
+            float *tr = (DBUF ? trbuf : rec) + grp * 2 * DP;
+            float *dst = a.hot_scratch + (int64_t)hidx * 2 * DP;
+#pragma unroll
+            for (int jj = 0; jj < NC; jj++) {
+                *reinterpret_cast<float4 *>(tr + (l16 + kRow * jj) * 4) = hq[jj];
+                *reinterpret_cast<float4 *>(tr + DP + (l16 + kRow * jj) * 4) = ha[jj];
+            }
+            WAVE_LDS_FENCE();
+#pragma unroll
+            for (int q4 = 0; q4 < 2 * DP / 16; q4++) {
+                const int idx = q4 * 16 + l16;           // 16 lanes -> 16 consecutive floats
+                if ((idx & (DP - 1)) < t.D) atomicAdd(dst + idx, tr[idx]);
+            }
+        }
+        if (!DBUF) __syncthreads();  // the record slots are rewritten by the next iteration
+    }
+    STAMP(6);
+    // ---- this workgroup's totals -> replica slab
     accLi = wave_sum(accLi); accLe = wave_sum(accLe); accLc = wave_sum(accLc);
     accL2 = wave_sum(accL2); accL1 = wave_sum(accL1);
     if ((threadIdx.x & 63) == 0) {
@@ -508,21 +541,18 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
     __syncthreads();
     const int slab_len = 2 * EDP + EMAX + kLossSlots;
     float *slab = a.slabs + (int64_t)(blockIdx.x % kReplicas) * slab_len;
-    for (int i = threadIdx.x * 4; i < 2 * EDP; i += blockDim.x * 4) {
-        float4 x = *reinterpret_cast<const float4 *>(red + i);
-        if (DREG) {
+    if (threadIdx.x < CG * DP) {
 #pragma unroll
-            for (int wq = 1; wq < 4; wq++) f4add(x, *reinterpret_cast<const float4 *>(red + wq * 2 * EDP + i));
+        for (int i = 0; i < CPT; i++) {
+            const int c = cg + CG * i;
+            if (c < t.E && d_own < t.D) {
+                if (dE[i] != 0.f) atomicAdd(slab + c * DP + d_own, dE[i]);
+                if (dW[i] != 0.f) atomicAdd(slab + EDP + c * DP + d_own, dW[i]);
+                if (d_own == 0 && dB[i] != 0.f) atomicAdd(slab + 2 * EDP + c, dB[i]);
+            }
         }
-        if (x.x != 0.f) atomicAdd(slab + i + 0, x.x);
-        if (x.y != 0.f) atomicAdd(slab + i + 1, x.y);
-        if (x.z != 0.f) atomicAdd(slab + i + 2, x.z);
-        if (x.w != 0.f) atomicAdd(slab + i + 3, x.w);
     }
-    for (int i = threadIdx.x; i < EMAX + kLossSlots; i += blockDim.x) {
-        const float x = ab[i];  // ab then aL are adjacent
-        if (x != 0.f) atomicAdd(slab + 2 * EDP + i, x);
-    }
+    if (threadIdx.x < kLossSlots) { const float x = aL[threadIdx.x]; if (x != 0.f) atomicAdd(slab + 2 * EDP + EMAX + threadIdx.x, x); }
     STAMP(7);
 }
 
@@ -572,15 +602,21 @@ __device__ __forceinline__ void stream_task(const DevTables &t, const RowsArgs &
     }
 }
 
-template <int NC, bool VEC, int EMAX, bool DREG>
+template <int NC, bool VEC, int EMAX>
 __global__ __launch_bounds__(256, ROWS_MIN_WAVES) void mstep_rows_kernel(DevTables t, RowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // workgroup b runs rounds [b*rpt, (b+1)*rpt); the item-side rounds come first (they hold the longest
-    // jobs) and are padded to a multiple of rpt, so a workgroup never mixes sides.  One code path per
-    // side: the item side carries no loss / dense-gradient work.
-    if ((int)blockIdx.x >= a.n_job_tasks) {  // trailing workgroups: untouched rows
+    // grid = [dense tasks | job tasks | stream tasks]: the dense tasks walk several interactions in
+    // sequence and start first; every branch below is workgroup-uniform
+    int b = blockIdx.x;
+    if (b < a.n_dense_tasks) {
+        const int s0 = b * a.dense_per_task;
+        dense_task<NC, VEC, EMAX>(t, a, s0, min(s0 + a.dense_per_task, a.n), lds);
+        return;
+    }
+    b -= a.n_dense_tasks;
+    if (b >= a.n_job_tasks) {  // trailing workgroups: untouched rows
         STAMP(0);
-        const int sb = blockIdx.x - a.n_job_tasks;
+        const int sb = b - a.n_job_tasks;
         const bool us = sb < a.n_stream_user_tasks;
         const int first = (us ? sb : sb - a.n_stream_user_tasks) * a.rows_per_stream_task;
         const int total = us ? a.n_stream_user : a.n_stream_item;
@@ -589,11 +625,13 @@ __global__ __launch_bounds__(256, ROWS_MIN_WAVES) void mstep_rows_kernel(DevTabl
         STAMP(7);
         return;
     }
-    const int r0 = blockIdx.x * a.rounds_per_task;
+    // job workgroup b runs rounds [b*rpt, (b+1)*rpt); the item-side rounds come first (they hold the longer
+    // jobs) and are padded to a multiple of rpt, so a workgroup never mixes sides
+    const int r0 = b * a.rounds_per_task;
     const int nr = min(a.rounds_per_task, a.n_rounds - r0);
     const int4 task = make_int4(r0 < a.n_item_rounds ? 1 : 0, r0, nr, 0);
-    if (task.x == 0) rows_task<NC, VEC, EMAX, DREG, true>(t, a, task, lds);
-    else rows_task<NC, VEC, EMAX, DREG, false>(t, a, task, lds);
+    if (task.x == 0) rows_task<NC, VEC, EMAX, true>(t, a, task, lds);
+    else rows_task<NC, VEC, EMAX, false>(t, a, task, lds);
 }
 
 // folds (and re-zeroes) the replica slabs: gradients of embed_env / classifier (+ classifier
@@ -765,13 +803,14 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
 
 void *g_profile_event = nullptr;  // see invpref_set_profile_event()
 
-inline bool dreg_of(int nc, int emax) { return nc * emax <= 4; }
-
 size_t rows_lds_bytes(int E, int nc, int emax) {
     const size_t DP = (size_t)nc * 64, EDP = (size_t)E * DP;
-    const size_t red = (dreg_of(nc, emax) ? 4 : 1) * 2 * EDP;
-    return sizeof(float) * (kGroups * 2 * DP + 2 * EDP + emax + red + emax + kLossSlots) +
-           (nc <= 2 ? 16 * (size_t)(4 * 4 * nc * 64) : 0);
+    // job task: slice slots + staged tables + LDS-DMA moment buffers; dense task: staged tables + records
+    const size_t job = sizeof(float) * (kGroups * 2 * DP + 2 * EDP + emax) + (nc <= 2 ? 16 * (size_t)(4 * 4 * nc * 64) : 0);
+    const size_t nbuf = nc <= 2 ? 2 : 1;
+    const size_t dense = sizeof(float) * (2 * EDP + emax + nbuf * (kGroups * 2 * DP + kGroups * (emax + 1)) + kLossSlots +
+                                          (nc <= 2 ? kGroups * 2 * DP : 0));
+    return job > dense ? job : dense;
 }
 
 template <typename K>
@@ -833,8 +872,13 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a.stream_rows = plan->stream_rows; a.n_stream_user = plan->n_stream_user; a.n_stream_item = plan->n_stream_item;
     a.rows_per_stream_task = plan->rows_per_stream_task; a.n_job_tasks = n_job_tasks;
     a.n_stream_user_tasks = (plan->n_stream_user + plan->rows_per_stream_task - 1) / plan->rows_per_stream_task;
-    const int n_tasks = n_job_tasks + a.n_stream_user_tasks +
+    if (plan->dense_per_task <= 0 || (plan->n > 0 && (!plan->batch_users || !plan->batch_items))) return INVPREF_EINVAL;
+    a.batch_users = plan->batch_users; a.batch_items = plan->batch_items; a.n = plan->n;
+    a.dense_per_task = plan->dense_per_task;
+    a.n_dense_tasks = (plan->n + plan->dense_per_task - 1) / plan->dense_per_task;
+    const int n_tasks = a.n_dense_tasks + n_job_tasks + a.n_stream_user_tasks +
                         (plan->n_stream_item + plan->rows_per_stream_task - 1) / plan->rows_per_stream_task;
+    if (n_tasks <= 0) return INVPREF_EINVAL;
     a.oth[0] = plan->other_user; a.pos[0] = plan->pos_user;
     a.oth[1] = plan->other_item; a.pos[1] = plan->pos_item;
     a.envs = envs; a.scores = scores; a.weights = weights;
@@ -850,19 +894,19 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a.stamps_nodrain = nodrain;
     const size_t lds = rows_lds_bytes(t.E, nc, emax);
     if (lds > 160 * 1024) return INVPREF_EUNSUPPORTED;
-#define CALL(NCV, VECV, EMAXV, DREGV)                                                                 \
+#define CALL(NCV, VECV, EMAXV)                                                                        \
     do {                                                                                              \
-        if ((rc = ensure_lds(mstep_rows_kernel<NCV, VECV, EMAXV, DREGV>, lds))) return rc;            \
-        hipLaunchKernelGGL((mstep_rows_kernel<NCV, VECV, EMAXV, DREGV>), dim3(n_tasks), dim3(256), lds, st, t, a); \
+        if ((rc = ensure_lds(mstep_rows_kernel<NCV, VECV, EMAXV>, lds))) return rc;                   \
+        hipLaunchKernelGGL((mstep_rows_kernel<NCV, VECV, EMAXV>), dim3(n_tasks), dim3(256), lds, st, t, a); \
     } while (0)
     if (!vec) {
-        if (emax == 4) CALL(4, false, 4, false); else if (emax == 8) CALL(4, false, 8, false); else CALL(4, false, 16, false);
+        if (emax == 4) CALL(4, false, 4); else if (emax == 8) CALL(4, false, 8); else CALL(4, false, 16);
     } else if (nc == 1) {
-        if (emax == 4) CALL(1, true, 4, true); else if (emax == 8) CALL(1, true, 8, false); else CALL(1, true, 16, false);
+        if (emax == 4) CALL(1, true, 4); else if (emax == 8) CALL(1, true, 8); else CALL(1, true, 16);
     } else if (nc == 2) {
-        if (emax == 4) CALL(2, true, 4, false); else if (emax == 8) CALL(2, true, 8, false); else CALL(2, true, 16, false);
+        if (emax == 4) CALL(2, true, 4); else if (emax == 8) CALL(2, true, 8); else CALL(2, true, 16);
     } else {
-        if (emax == 4) CALL(4, true, 4, false); else if (emax == 8) CALL(4, true, 8, false); else CALL(4, true, 16, false);
+        if (emax == 4) CALL(4, true, 4); else if (emax == 8) CALL(4, true, 8); else CALL(4, true, 16);
     }
 #undef CALL
     hipError_t err = hipGetLastError();

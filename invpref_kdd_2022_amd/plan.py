@@ -27,7 +27,8 @@ class RowPlanStruct(C.Structure):
                 ('other_item', C.c_void_p), ('pos_item', C.c_void_p), ('n_hot', C.c_int32), ('reserved', C.c_int32),
                 ('hot_rows', C.c_void_p), ('hot_count', C.c_void_p), ('item_hot_index', C.c_void_p),
                 ('n_stream_user', C.c_int32), ('n_stream_item', C.c_int32), ('rows_per_stream_task', C.c_int32),
-                ('reserved2', C.c_int32), ('stream_rows', C.c_void_p)]
+                ('dense_per_task', C.c_int32), ('stream_rows', C.c_void_p), ('batch_users', C.c_void_p),
+                ('batch_items', C.c_void_p)]
 
 
 def _side_rounds(own, oth, pos, y, n_rows: int, per_slice: int, pad_to: int, skip=None):
@@ -117,7 +118,9 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     di = _side_rounds(items[pi], users[pi], pi, scores[pi], item_num, per_slice, rounds_per_task,
                       skip=hot | (icnt == 0))
     du = _side_rounds(users[pu], items[pu], pu, scores[pu], user_num, per_slice, 1, skip=(ucnt == 0))
-    return dict(stream_rows=np.concatenate([stream_u, stream_i]), n_stream_user=len(stream_u),
+    return dict(batch_users=users.astype(np.int32), batch_items=items.astype(np.int32),
+                dense_per_task=int(os.environ.get('INVPREF_PLAN_DENSE', '32')),
+                stream_rows=np.concatenate([stream_u, stream_i]), n_stream_user=len(stream_u),
                 n_stream_item=len(stream_i), rows_per_stream_task=int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', '64')),n=n, n_item_rounds=len(di), rounds_per_task=rounds_per_task, desc=np.concatenate([di, du]),
                 other_user=items[pu].astype(np.int32), pos_user=pu.astype(np.int32),
                 other_item=users[pi].astype(np.int32), pos_item=pi.astype(np.int32),
@@ -134,7 +137,7 @@ class DevicePlan:
 
 def upload(plan: dict, device) -> DevicePlan:
     keys = ('desc', 'other_user', 'pos_user', 'other_item', 'pos_item', 'hot_rows', 'hot_count', 'item_hot_index',
-            'stream_rows')
+            'stream_rows', 'batch_users', 'batch_items')
     parts, ptrs, off = [], {}, 0
     for k in keys:  # every array starts on a 16-byte boundary of the one device buffer
         a = np.ascontiguousarray(plan[k], np.int32).reshape(-1)
@@ -148,7 +151,9 @@ def upload(plan: dict, device) -> DevicePlan:
     st = RowPlanStruct(nr, plan['n_item_rounds'], rpt, plan['n'], ptrs['desc'], ptrs['other_user'],
                        ptrs['pos_user'], ptrs['other_item'], ptrs['pos_item'], len(plan['hot_rows']), 0,
                        ptrs['hot_rows'], ptrs['hot_count'], ptrs['item_hot_index'], plan['n_stream_user'],
-                       plan['n_stream_item'], plan['rows_per_stream_task'], 0, ptrs['stream_rows'])
+                       plan['n_stream_item'], plan['rows_per_stream_task'], plan['dense_per_task'],
+                       ptrs['stream_rows'], ptrs['batch_users'], ptrs['batch_items'])
     spt = plan['rows_per_stream_task']
-    n_tasks = -(-nr // rpt) + -(-plan['n_stream_user'] // spt) + -(-plan['n_stream_item'] // spt)
+    n_tasks = -(-nr // rpt) + -(-plan['n_stream_user'] // spt) + -(-plan['n_stream_item'] // spt) \
+        + -(-plan['n'] // plan['dense_per_task'])
     return DevicePlan(st, [buf], n_tasks, nr)

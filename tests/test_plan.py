@@ -11,6 +11,9 @@ def check_plan(users, items, U, I, **kw):
     desc, rpt, nir = p['desc'], p['rounds_per_task'], p['n_item_rounds']
     n = len(users)
     assert desc.shape[1:] == (16, 8) and nir % rpt == 0 and 0 <= nir <= len(desc)
+    np.testing.assert_array_equal(p['batch_users'], users)
+    np.testing.assert_array_equal(p['batch_items'], items)
+    assert p['dense_per_task'] > 0
     su, si = p['stream_rows'][:p['n_stream_user']], p['stream_rows'][p['n_stream_user']:]
     assert len(si) == p['n_stream_item']
     np.testing.assert_array_equal(su, np.flatnonzero(np.bincount(users, minlength=U) == 0))

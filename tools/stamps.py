@@ -27,7 +27,8 @@ losses = torch.zeros(6, device=dev)
 coefs = (3.35, 9.99, 9.06, 3.13, 0.49, 1.9)
 flags = ops.flags_of(True, False, True, True, False)
 os.environ['INVPREF_STAMPS_NODRAIN'] = '1'
-for per_slice, rpt, hot in ((1, 1, 16), (1, 1, 10 ** 9)):
+for per_slice, rpt, hot, dense in ((2, 1, 16, 32), (2, 1, 16, 16), (1, 1, 16, 32)):
+    os.environ['INVPREF_PLAN_DENSE'] = str(dense)
     pl = planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, per_slice=per_slice, rounds_per_task=rpt,
                                 hot_threshold=hot)
     dp = planlib.upload(pl, dev)
@@ -36,20 +37,15 @@ for per_slice, rpt, hot in ((1, 1, 16), (1, 1, 10 ** 9)):
         ops.mstep_rows_adam(P, P2, M, V, dp, e, y, w, B, coefs, flags, losses, 5, 0.005, ws)
     torch.cuda.synchronize()
     st = stamps.cpu().numpy().reshape(-1, 8)[:dp.n_tasks].astype(np.int64)
-    nr = dp.n_rounds
+    nd = -(-B // dense)
     ni = pl['n_item_rounds'] // rpt
-    njob = -(-nr // rpt)
+    njob = -(-dp.n_rounds // rpt)
     t0 = st[:, 0].min()
     end = np.where(st[:, 7] > 0, st[:, 7], st[:, 6])
-    print(f'== per_slice={per_slice} rpt={rpt} hot>{hot}: tasks {dp.n_tasks} = item {ni} + user {njob - ni} + stream {dp.n_tasks - njob}; span {(end.max() - t0) / 100:.2f} us')
-    for name, sl in (('item', slice(0, ni)), ('user', slice(ni, njob)), ('stream', slice(njob, None))):
+    print(f'== per_slice={per_slice} hot>{hot} dense/task={dense}: tasks {dp.n_tasks} = dense {nd} + item {ni} + user {njob - ni} + stream {dp.n_tasks - njob - nd}; span {(end.max() - t0) / 100:.2f} us')
+    for name, sl in (('dense', slice(0, nd)), ('item', slice(nd, nd + ni)), ('user', slice(nd + ni, nd + njob)), ('stream', slice(nd + njob, None))):
         s0, e0 = (st[sl, 0] - t0) / 100, (end[sl] - t0) / 100
         if len(s0) == 0:
             continue
         life = e0 - s0
-        if name != 'stream':
-            ph = (st[sl, 1:8] - st[sl, 0:7]) / 100
-            ok = st[sl, 7] > 0 if name == 'user' else np.ones(len(s0), bool)
-            names = ['prologue', 'desc+issue', 'wait sync', 'interactions', 'combine', 'finish(rounds)', 'flush']
-            print('     phases med: ' + '  '.join(f'{n} {np.median(ph[:, i]):.2f}' for i, n in enumerate(names[:7 if name == 'user' else 6])))
         print(f'  {name:6s} n={len(s0):4d} start med {np.median(s0):5.2f} p90 {np.quantile(s0, .9):5.2f} max {s0.max():5.2f} | life med {np.median(life):5.2f} p90 {np.quantile(life, .9):5.2f} max {life.max():5.2f} | end med {np.median(e0):5.2f} max {e0.max():5.2f}')

@@ -706,8 +706,8 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
         else if (nc == 1) finish_hot_rows<1, true>(t, hot, k, fused, ad, hb);
         else if (nc == 2) finish_hot_rows<2, true>(t, hot, k, fused, ad, hb);
         else finish_hot_rows<4, true>(t, hot, k, fused, ad, hb);
+        __syncthreads();  // every wave of this block is done with the step's Adam scalars
         if (sched_state && threadIdx.x == 0) {  // same ticket protocol as below
-            __threadfence();
             const int ticket = atomicAdd(sched_state + 2, 1);
             if (ticket == (int)gridDim.x - 1) { sched_state[2] = 0; sched_state[0] = sched_state[0] + 1; }
         }
@@ -719,6 +719,21 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
     const int EDP = t.E * DP, slab_len = 2 * EDP + EMAX + kLossSlots;
     const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + col;
+    // parameter / moment of the output this thread will finish (sub == 0 threads), requested up front
+    float pre_p = 0.f, pre_m = 0.f, pre_v = 0.f;
+    if (sub == 0 && idx < 2 * EDP + EMAX) {
+        const bool isB = idx >= 2 * EDP, isW = !isB && idx >= EDP;
+        const int r = isB ? 0 : (isW ? idx - EDP : idx);
+        const int e = isB ? idx - 2 * EDP : r / DP, d = isB ? 0 : r - e * DP;
+        if (e < t.E && d < t.D) {
+            const int off = isB ? e : e * t.D + d;
+            pre_p = isB ? t.b[off] : (isW ? t.W[off] : t.Ev[off]);
+            if (fused) {
+                pre_m = (isB ? o.mb : (isW ? o.mW : o.mEv))[off];
+                pre_v = (isB ? o.vb : (isW ? o.vW : o.vEv))[off];
+            }
+        }
+    }
     double acc = 0.0;
     if (idx < slab_len)
         for (int s = sub; s < nslabs; s += 16) {
@@ -741,13 +756,13 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
             if (d < t.D) {
                 const int off = e * t.D + d;
                 float gv = (float)v;
-                float pv = isW ? t.W[off] : t.Ev[off];
+                float pv = pre_p;
                 if (isW && dense) gv += 2.f * l2 / ((float)t.D * (float)t.E) * pv + l1 / ((float)t.D * (float)t.E) * c_sign(pv);
                 if (!fused) {
                     (isW ? o.gW : o.gEv)[off] = gv;
                 } else {
                     float *mp = (isW ? o.mW : o.mEv) + off, *vp = (isW ? o.vW : o.vEv) + off;
-                    float mm = *mp, vv = *vp;
+                    float mm = pre_m, vv = pre_v;
                     adam1(pv, gv, mm, vv, ad);
                     (isW ? o.nW : o.nEv)[off] = pv; *mp = mm; *vp = vv;
                 }
@@ -755,12 +770,12 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
         } else if (idx < 2 * EDP + EMAX) {
             const int e = idx - 2 * EDP;
             if (e < t.E) {
-                float gv = (float)v, pv = t.b[e];
+                float gv = (float)v, pv = pre_p;
                 if (dense) gv += 2.f * l2 / (float)t.E * pv + l1 / (float)t.E * c_sign(pv);
                 if (!fused) {
                     o.gb[e] = gv;
                 } else {
-                    float mm = o.mb[e], vv = o.vb[e];
+                    float mm = pre_m, vv = pre_v;
                     adam1(pv, gv, mm, vv, ad);
                     o.nb[e] = pv; o.mb[e] = mm; o.vb[e] = vv;
                 }
@@ -792,7 +807,6 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
     // the step is over: the block that finishes LAST (ticket) advances the device-side step counter;
     // every block read the counter before taking its ticket, so no block can see the new value
     if (sched_state && threadIdx.x == 0) {
-        __threadfence();
         const int ticket = atomicAdd(sched_state + 2, 1);
         if (ticket == (int)gridDim.x - 1) {
             sched_state[2] = 0;

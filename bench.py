@@ -59,6 +59,19 @@ def pmc_traffic_bytes(kernel_name: str):
     return tot['FETCH_SIZE'] + tot['WRITE_SIZE'] if len(tot) == 2 else None
 
 
+def rocprof_avg_ms(kernel_name: str):
+    """average duration of `kernel_name` in the committed `rocprofv3 --kernel-trace --stats` summary of this command"""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'rocprofv3_kernel_stats_bench_*.csv')))
+    if not files:
+        return None
+    for row in csv.DictReader(open(files[-1])):
+        if kernel_name in row['Name']:
+            return float(row['AverageNs']) * 1e-6
+    return None
+
+
 def cpu_baseline(seconds_budget: float = 12.0):
     """The oracle (C port, one thread) on the same Yahoo-shaped workload, bounded sample."""
     from invpref_kdd_2022_amd import synth
@@ -168,6 +181,9 @@ def main():
     ev = {'m0': [], 'mk': [], 'm1': [], 'a1': []}
     stream = torch.cuda.current_stream().cuda_stream
     fused = mgr.use_plan and world == 1
+    # keep the stream backlogged while the instrumented steps are enqueued, so that an event's time stamp is
+    # taken right before the next kernel starts and not while the GPU waits for the host
+    torch.cuda._sleep(int(4e6))
     for k in range(nb):
         e0, ek, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
         if fused:  # the library records ek between mstep_rows_kernel and rows_finish_kernel
@@ -224,7 +240,8 @@ def main():
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/)',
                 'kernel': roof['kernel'],
-                'avg_launch_ms': roof['ms'], 'algorithmic_bytes_per_launch': roof['bytes'], 'other': other}
+                'avg_launch_ms': roof['ms'], 'algorithmic_bytes_per_launch': roof['bytes'],
+                'rocprofv3_avg_launch_ms': rocprof_avg_ms(roof['kernel'].split()[0]), 'other': other}
     out = {
         'metric': 'training interactions/sec, Yahoo-implicit InvPref', 'value': value, 'unit': 'interactions/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,

@@ -98,18 +98,6 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
-__device__ __forceinline__ void atomic_add_f4(float *p, float4 v, int i0, int D, bool vec) {
-    if (vec || i0 + 3 < D) {
-        atomicAdd(p + i0 + 0, v.x);
-        atomicAdd(p + i0 + 1, v.y);
-        atomicAdd(p + i0 + 2, v.z);
-        atomicAdd(p + i0 + 3, v.w);
-    } else {
-        if (i0 + 0 < D) atomicAdd(p + i0 + 0, v.x);
-        if (i0 + 1 < D) atomicAdd(p + i0 + 1, v.y);
-        if (i0 + 2 < D) atomicAdd(p + i0 + 2, v.z);
-    }
-}
 
 
 struct StepScalars {

@@ -223,8 +223,8 @@ class _InvPrefTrainManager:
             lo, hi = self.shard.local_batch_bounds(k)
             self._raw_batches.append((lo, hi - lo, self.shard.global_batch_len(k)))
         self._raw_mstep, self._raw_adam = L.invpref_mstep_grad_hip, L.invpref_adam_hip
-        self._raw_owner_grad, self._raw_owner_adam = L.invpref_mstep_rows_grad_hip, L.invpref_mstep_rows_adam_hip
-        self._raw_owner_adam_sched = L.invpref_mstep_rows_adam_sched_hip
+        self._raw_rows_grad, self._raw_rows_adam = L.invpref_mstep_rows_grad_hip, L.invpref_mstep_rows_adam_hip
+        self._raw_rows_adam_sched = L.invpref_mstep_rows_adam_sched_hip
         if self.use_plan and self._plans is None:
             u, v = self.users_tensor.cpu().numpy(), self.items_tensor.cpu().numpy()
             y = self.scores_tensor.cpu().numpy()
@@ -258,13 +258,13 @@ class _InvPrefTrainManager:
             # fused M-step + Adam: one pass, gradient never stored, parameters ping-pong
             st.step += 1
             if sched:  # graph capture: Adam scalars come from the device-side schedule
-                rc = self._raw_owner_adam_sched(
+                rc = self._raw_rows_adam_sched(
                     C.byref(t_cur), C.byref(self._raw_tabs[id(st.p_views_alt)]), C.byref(self._raw_m),
                     C.byref(self._raw_v), C.byref(self._plans[k].struct), pe + 8 * lo, py + 4 * lo, pw + 4 * lo, bn,
                     C.byref(cf), self._flags, lp, C.byref(self._sched['struct']), self._raw_ows.data_ptr(),
                     self._raw_ows.numel(), stream)
             else:
-                rc = self._raw_owner_adam(
+                rc = self._raw_rows_adam(
                     C.byref(t_cur), C.byref(self._raw_tabs[id(st.p_views_alt)]), C.byref(self._raw_m),
                     C.byref(self._raw_v), C.byref(self._plans[k].struct), pe + 8 * lo, py + 4 * lo, pw + 4 * lo, bn,
                     C.byref(cf), self._flags, lp, st.step, self.lr, 0.9, 0.999, 1e-8, self._raw_ows.data_ptr(),
@@ -276,7 +276,7 @@ class _InvPrefTrainManager:
                 mid_event.record()
             return
         if self.use_plan:
-            rc = self._raw_owner_grad(C.byref(t_cur), C.byref(self._raw_g), C.byref(self._plans[k].struct),
+            rc = self._raw_rows_grad(C.byref(t_cur), C.byref(self._raw_g), C.byref(self._plans[k].struct),
                                       pe + 8 * lo, py + 4 * lo, pw + 4 * lo, bn, C.byref(cf), self._flags, lp,
                                       self._raw_ows.data_ptr(), self._raw_ows.numel(), stream)
         else:
@@ -284,7 +284,7 @@ class _InvPrefTrainManager:
                                  py + 4 * lo, pw + 4 * lo, n, bn, C.byref(cf), self._flags, lp,
                                  self._raw_ws.data_ptr(), self._raw_ws.numel(), stream)
         if rc:
-            _capi.check(rc, 'invpref_mstep_(owner_)grad_hip')
+            _capi.check(rc, 'invpref_mstep_(rows_)grad_hip')
         if multi:
             if self.world_size > 1 or self._collective_ok:
                 all_reduce_sum_(st.grad_ext, self.process_group)

@@ -493,18 +493,18 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
         if (l16 == 0) recs[grp * (EMAX + 1) + EMAX] = __builtin_bit_cast(float, e);
         __syncthreads();
         if (threadIdx.x < CG * DP) {
-#pragma unroll 1
+            // (an empty record slot holds env id -1 and zeroed gz: it adds exact zeros, no branch needed)
+#pragma unroll(CPT <= 2 ? 8 : 2)
             for (int g2 = 0; g2 < kGroups; g2++) {
                 const float *rs = recs + g2 * (EMAX + 1);
                 const int er = __builtin_bit_cast(int, rs[EMAX]);
-                if (er < 0) continue;
                 const float xv = rec[(g2 * 2) * DP + d_own], ov = rec[(g2 * 2 + 1) * DP + d_own];
 #pragma unroll
                 for (int i = 0; i < CPT; i++) {
                     const int c = cg + CG * i;
                     if (c < t.E) {
-                        const float gzc = rs[c];
-                        dW[i] = __builtin_fmaf(gzc, xv, dW[i]);
+                        const float gzc = er >= 0 ? rs[c] : 0.f;
+                        dW[i] = __builtin_fmaf(gzc, er >= 0 ? xv : 0.f, dW[i]);
                         dE[i] += (c == er) ? ov : 0.f;
                         dB[i] += gzc;
                     }

@@ -12,7 +12,7 @@ import os
 import torch
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, 'libinvpref_hip.so')
+LIB_PATH = os.environ.get('INVPREF_LIB') or os.path.join(PKG, 'libinvpref_hip.so')  # INVPREF_LIB: kernel A/B builds
 
 IMPLICIT, REWEIGHT_REC, REWEIGHT_CLS, REG_ONLY_EMBED, REG_ENV_EMBED, DENSE_REG, NO_GRAD = 1, 2, 4, 8, 16, 32, 64
 

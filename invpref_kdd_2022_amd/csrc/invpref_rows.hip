@@ -81,25 +81,36 @@ struct RowsArgs {
         }                                                                         \
     } while (0)
 
-// Row stores are streaming (nontemporal): the 25 MB of p', m', v' a step writes are not read again
-// before the next kernel, and lines left dirty in L2 are written back at the kernel boundary, where
-// that time is exposed (measured: ~5 us per step at Yahoo size).
+// Row-store cache policy, measured on the real loop (ping-pong parameter buffers, 31 different plans,
+// tools/kb3.py): plain stores for everything.  The new parameters p' are gathered by the very next
+// step and m', v' are re-read by it, so they should stay in the cache hierarchy: nontemporal p'
+// stores cost +2 us per step (the next step's gathers miss), nontemporal m'/v' stores +0.5 us.
+// (Replaying ONE minibatch without the buffer swap shows the opposite, which is why the loop is the
+// benchmark.)  Load hints (nt / sc0 / sc1 on the moment prefetch and the streamed rows) made no difference.
 typedef float v4f __attribute__((ext_vector_type(4)));
-template <int NC, bool VEC>
+// build-time knobs for A/B runs: 0 plain, 1 nontemporal
+#ifndef ROWS_ST_P
+#define ROWS_ST_P 0
+#endif
+#ifndef ROWS_ST_MV
+#define ROWS_ST_MV 0
+#endif
+template <int MODE>
+__device__ __forceinline__ void store4(float *p, float4 r) {
+    if (MODE == 0) *reinterpret_cast<float4 *>(p) = r;
+    else {
+        v4f val = {r.x, r.y, r.z, r.w};
+        __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(p));
+    }
+}
+template <int NC, bool VEC, int MODE = ROWS_ST_MV>
 __device__ __forceinline__ void store_row(float *__restrict__ base, int64_t row, int D, int l16, const float4 (&r)[NC]) {
     float *p = base + row * (int64_t)D;
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const int i0 = (l16 + kRow * c) * 4;
         if (VEC) {
-            if (i0 < D) {
-#ifdef ROWS_PLAIN_STORES
-                *reinterpret_cast<float4 *>(p + i0) = r[c];
-#else
-                v4f val = {r[c].x, r[c].y, r[c].z, r[c].w};
-                __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(p + i0));
-#endif
-            }
+            if (i0 < D) store4<MODE>(p + i0, r[c]);
         } else {
             if (i0 + 0 < D) p[i0 + 0] = r[c].x;
             if (i0 + 1 < D) p[i0 + 1] = r[c].y;
@@ -365,10 +376,10 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
                     adam1f(oe[c].x, ge[c].x, me[c].x, ve[c].x, ad); adam1f(oe[c].y, ge[c].y, me[c].y, ve[c].y, ad);
                     adam1f(oe[c].z, ge[c].z, me[c].z, ve[c].z, ad); adam1f(oe[c].w, ge[c].w, me[c].w, ve[c].w, ad);
                 }
-                store_row<NC, VEC>(a.np[side], row, t.D, l16, oi);
+                store_row<NC, VEC, ROWS_ST_P>(a.np[side], row, t.D, l16, oi);
                 store_row<NC, VEC>(a.m[side], row, t.D, l16, mi);
                 store_row<NC, VEC>(a.v[side], row, t.D, l16, vi);
-                store_row<NC, VEC>(a.np[2 + side], row, t.D, l16, oe);
+                store_row<NC, VEC, ROWS_ST_P>(a.np[2 + side], row, t.D, l16, oe);
                 store_row<NC, VEC>(a.m[2 + side], row, t.D, l16, me);
                 store_row<NC, VEC>(a.v[2 + side], row, t.D, l16, ve);
             }
@@ -494,7 +505,7 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
         __syncthreads();
         if (threadIdx.x < CG * DP) {
             // (an empty record slot holds env id -1 and zeroed gz: it adds exact zeros, no branch needed)
-#pragma unroll(CPT <= 2 ? 8 : 2)
+#pragma unroll CPT <= 2 ? 8 : 2
             for (int g2 = 0; g2 < kGroups; g2++) {
                 const float *rs = recs + g2 * (EMAX + 1);
                 const int er = __builtin_bit_cast(int, rs[EMAX]);
@@ -595,7 +606,7 @@ __device__ __forceinline__ void stream_task(const DevTables &t, const RowsArgs &
                 adam1f(p[q][c].x, 0.f, m[q][c].x, v[q][c].x, ad); adam1f(p[q][c].y, 0.f, m[q][c].y, v[q][c].y, ad);
                 adam1f(p[q][c].z, 0.f, m[q][c].z, v[q][c].z, ad); adam1f(p[q][c].w, 0.f, m[q][c].w, v[q][c].w, ad);
             }
-            store_row<NC, VEC>(a.np[ti], row, t.D, l16, p[q]);
+            store_row<NC, VEC, ROWS_ST_P>(a.np[ti], row, t.D, l16, p[q]);
             store_row<NC, VEC>(a.m[ti], row, t.D, l16, m[q]);
             store_row<NC, VEC>(a.v[ti], row, t.D, l16, v[q]);
         }
@@ -686,7 +697,7 @@ __device__ __forceinline__ void finish_hot_rows(const DevTables &t, const HotRow
                 adam1f(p[c].x, g[c].x, m[c].x, v[c].x, ad); adam1f(p[c].y, g[c].y, m[c].y, v[c].y, ad);
                 adam1f(p[c].z, g[c].z, m[c].z, v[c].z, ad); adam1f(p[c].w, g[c].w, m[c].w, v[c].w, ad);
             }
-            store_row<NC, VEC>(tt == 0 ? h.nQi : h.nQa, row, t.D, l16, p);
+            store_row<NC, VEC, ROWS_ST_P>(tt == 0 ? h.nQi : h.nQa, row, t.D, l16, p);
             store_row<NC, VEC>(tt == 0 ? h.mQi : h.mQa, row, t.D, l16, m);
             store_row<NC, VEC>(tt == 0 ? h.vQi : h.vQa, row, t.D, l16, v);
         }

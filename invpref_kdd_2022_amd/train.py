@@ -215,7 +215,11 @@ class _InvPrefTrainManager:
         self._raw_t = _capi.make_tables(st.p_views)
         self._raw_g = _capi.make_tables(st.g_views)
         self._raw_ws = self.workspace.get(L.invpref_mstep_workspace_bytes(C.byref(self._raw_t), self.batch_size))
-        self._epoch_losses = torch.zeros(self.batch_num, 6, dtype=torch.float32, device=self.device)
+        # one graph replays up to _graph_epochs epochs (fewer, longer launches: the GPU idles ~60 us
+        # between two replays); each epoch of a replay writes its own [batch_num, 6] slice of the loss buffer
+        self._graph_epochs = max(1, min(8, 2048 // self.batch_num))
+        self._epoch_losses = torch.zeros(self._graph_epochs, self.batch_num, 6, dtype=torch.float32, device=self.device)
+        self._loss_slot = 0
         self._raw_ptrs = (self.users_tensor.data_ptr(), self.items_tensor.data_ptr(), self.envs.data_ptr(),
                           self.scores_tensor.data_ptr(), self.sample_weights.data_ptr())
         self._raw_batches = []
@@ -252,7 +256,7 @@ class _InvPrefTrainManager:
             st.losses6.zero_()
             lp = st.losses6.data_ptr()
         else:
-            lp = self._epoch_losses.data_ptr() + 24 * k
+            lp = self._epoch_losses.data_ptr() + 24 * (self._loss_slot * self.batch_num + k)
         t_cur = self._raw_tabs[id(st.p_views)]
         if self.use_plan and not multi:
             # fused M-step + Adam: one pass, gradient never stored, parameters ping-pong
@@ -288,7 +292,7 @@ class _InvPrefTrainManager:
         if multi:
             if self.world_size > 1 or self._collective_ok:
                 all_reduce_sum_(st.grad_ext, self.process_group)
-            self._epoch_losses[k] += st.losses6
+            self._epoch_losses[self._loss_slot, k] += st.losses6
         if mid_event is not None:
             mid_event.record()
         st.step += 1
@@ -327,15 +331,40 @@ class _InvPrefTrainManager:
             sc['state'].copy_(torch.tensor([first, sc['base'], 0, 0], dtype=torch.int32))
             self._sched_synced = True
 
-    def _issue_epoch(self, stream, sched: bool):
-        self._epoch_losses.zero_()
-        for k in range(self.batch_num):
-            self._raw_step(k, self._alpha_for(k), stream, sched=sched)
+    def _issue_epochs(self, stream, sched: bool, n: int):
+        self._epoch_losses[:n].zero_()
+        for j in range(n):
+            self._loss_slot = j
+            for k in range(self.batch_num):
+                self._raw_step(k, self._alpha_for(k), stream, sched=sched)
+        self._loss_slot = 0
 
     def train_a_epoch(self) -> dict:
-        """train.py:204-233, without the per-batch host syncs (one read-back per epoch).  On one GPU
-        with a fixed alpha the whole epoch (batch_num fused steps) is captured once per parameter-buffer
-        parity into a HIP graph and replayed: one launch per epoch instead of 2*batch_num."""
+        """train.py:204-233, without the per-batch host syncs (one read-back per epoch)."""
+        return self.train_epochs(1)[0]
+
+    def train_epochs(self, n: int, sync: bool = True):
+        """n consecutive train_a_epoch() calls with ONE host read-back at the end: the epochs are
+        enqueued back to back, so the GPU does not idle between them while the host fetches losses
+        (train() uses this between two evaluate/cluster events).  Returns the n loss dicts in order;
+        with sync=False nothing is read back and the device tensor [n, 6] (LOSS_KEYS order) is returned
+        instead -- loss_dicts() turns it into the dicts later."""
+        dev, left = [], int(n)
+        while left > 0:
+            dev.append(self._enqueue_epochs(left))
+            left -= dev[-1].shape[0]
+        out = torch.cat(dev) if dev else torch.zeros(0, 6, device=self.device)
+        return self.loss_dicts(out) if sync else out
+
+    @staticmethod
+    def loss_dicts(dev_losses: torch.Tensor) -> list:
+        return [dict(zip(LOSS_KEYS, v)) for v in dev_losses.tolist()]
+
+    def _enqueue_epochs(self, want: int) -> torch.Tensor:
+        """Issues up to `want` epochs on the current stream and returns their mean losses as a device
+        tensor [n_issued, 6].  On one GPU with a fixed alpha, runs of whole epochs (batch_num fused steps
+        each) are captured once per (parameter-buffer parity, run length) into a HIP graph and replayed:
+        one launch per run instead of 2*batch_num per epoch."""
         self.model.train()
         if getattr(self, '_raw_ptrs', None) is None or self._raw_ptrs[2] != self.envs.data_ptr() \
                 or self._raw_ptrs[4] != self.sample_weights.data_ptr():
@@ -343,32 +372,63 @@ class _InvPrefTrainManager:
             self._graphs.clear()
         st = self.state
         graph_ok = self.use_graph and self.use_plan and self.world_size == 1 and not self.update_alpha \
-            and not self._force_sharded_path
+            and not self._force_sharded_path and self.batch_num <= self._SCHED_N // 2
         if graph_ok and self._graph_warm:
-            self._sched_prepare(self.batch_num)
-            key = id(st.p_views)
-            g = self._graphs.get(key)
-            if g is None:
-                step0, views0 = st.step, st.p_views
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._issue_epoch(torch.cuda.current_stream().cuda_stream, sched=True)
-                # capture records, it does not run: put the host-side bookkeeping back
-                st.step = step0
-                if st.p_views is not views0:
-                    st.swap()
-                self._graphs[key] = g
+            n = min(want, self._graph_epochs)
+            steps = n * self.batch_num
+            self._sched_prepare(steps)
+            g = self._graph_for(n)
             g.replay()
-            st.step += self.batch_num
-            if self.batch_num % 2:
+            st.step += steps
+            if steps % 2:
                 st.swap()
         else:
-            self._issue_epoch(torch.cuda.current_stream().cuda_stream, sched=False)
+            n = 1
+            self._issue_epochs(torch.cuda.current_stream().cuda_stream, False, 1)
             self._graph_warm = True
             self._sched_synced = False
-        self.epoch_cnt += 1
-        vals = self._epoch_losses.mean(dim=0).tolist()
-        return dict(zip(LOSS_KEYS, vals))
+        self.epoch_cnt += n
+        return self._epoch_losses[:n].mean(dim=1)
+
+    def _graph_for(self, n: int):
+        """The HIP graph of n epochs starting from the current parameter buffer (captured on first use)."""
+        st = self.state
+        key = (id(st.p_views), n)
+        g = self._graphs.get(key)
+        if g is None:
+            step0, views0 = st.step, st.p_views
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._issue_epochs(torch.cuda.current_stream().cuda_stream, True, n)
+            # capture records, it does not run: put the host-side bookkeeping back
+            st.step = step0
+            if st.p_views is not views0:
+                st.swap()
+            self._graphs[key] = g
+        return g
+
+    def prepare_graphs(self, run_lengths) -> None:
+        """Captures the epoch graphs for the given run lengths (epochs per replay) and both parameter
+        buffers ahead of time, so that no capture happens inside a timed loop.  Needs one eager epoch
+        before it (train_epochs(1)); nothing is executed and no state changes."""
+        if not self._graph_warm or getattr(self, '_raw_ptrs', None) is None:
+            raise RuntimeError('prepare_graphs(): run one epoch first (train_epochs(1))')
+        self._sched_prepare(self.batch_num)
+        for n in sorted({min(max(1, int(x)), self._graph_epochs) for x in run_lengths}):
+            for _ in range(2):
+                self._graph_for(n)
+                self.state.swap()
+
+    def _epochs_to_next_event(self) -> int:
+        """How many epochs train() may enqueue before the next evaluate / cluster / end of training."""
+        r = 1
+        while r < 64:
+            e = self.epoch_cnt + r
+            if e >= self.epochs or e % self.cluster_interval == 0 \
+                    or (e % self.evaluate_interval == 0 and e >= self.test_begin_epoch):
+                break
+            r += 1
+        return r
 
     # ------------------------------------------------------------------ E-step
     def _eps_rows(self, n_rows: int) -> torch.Tensor:
@@ -390,8 +450,9 @@ class _InvPrefTrainManager:
             done += len(idx)
         return torch.from_numpy(out).to(self.device)
 
-    def cluster(self) -> int:
-        """train.py:235-259 (+ the stat_envs that always follows it is fused in: train.py:330)."""
+    def cluster(self, sync: bool = True):
+        """train.py:235-259 (+ the stat_envs that always follows it is fused in: train.py:330).
+        sync=False: no read-back, returns diff_num as a device int64[1] tensor."""
         self.model.eval()
         eps = self._eps_rows(self.users_tensor.shape[0]) if self.cluster_use_random_sort else None
         # new assignments overwrite self.envs in place (the kernel reads old_envs[i] before writing i)
@@ -405,7 +466,7 @@ class _InvPrefTrainManager:
             counts, diff = cd[:-1].contiguous(), cd[-1:]
             cw, sw = ops.sample_weights(self.envs, counts, self.n_total, self.envs_num)
         self._pending_stat = (counts, cw, sw)
-        return int(diff.item())
+        return int(diff.item()) if sync else diff.clone()
 
     def cluster_a_batch(self, batch_users_tensor, batch_items_tensor, batch_scores_tensor) -> torch.Tensor:
         """train.py:169-202 for one batch (single-rank semantics)."""
@@ -418,8 +479,8 @@ class _InvPrefTrainManager:
                                     self.implicit, None, self.workspace, eps_rows=eps, want_weights=False)
         return new
 
-    def stat_envs(self) -> dict:
-        """train.py:268-280."""
+    def stat_envs(self, sync: bool = True):
+        """train.py:268-280.  sync=False: no read-back, returns the per-env counts as a device tensor."""
         pend = getattr(self, '_pending_stat', None)
         if pend is not None:
             counts, cw, sw = pend
@@ -433,7 +494,7 @@ class _InvPrefTrainManager:
         # in place: the epoch loop (and a captured HIP graph of it) holds pointers into these buffers
         self.class_weights.copy_(cw)
         self.sample_weights.copy_(sw)
-        return {env: int(c) for env, c in enumerate(counts.tolist())}
+        return {env: int(c) for env, c in enumerate(counts.tolist())} if sync else counts.clone()
 
     def update_each_env_count(self):  # train.py:261-266
         counts, _, _ = ops.stat_envs(self.envs, self.envs_num, self.workspace, want_sample_weights=False)
@@ -455,13 +516,21 @@ class _InvPrefTrainManager:
             print('test at epoch:', self.epoch_cnt)
             print(transfer_loss_dict_to_line_str(temp_eval_result))
 
+        # nothing printed -> nothing is read back inside the loop (losses, diff_num and env counts stay on
+        # the device until the end, or until an evaluation needs the host anyway): the GPU never waits
+        # for the host between epochs and E-steps
+        defer = bool(silent or auto)
         while self.epoch_cnt < self.epochs:
-            temp_loss_dict = self.train_a_epoch()
-            train_epoch_index_list.append(self.epoch_cnt)
-            loss_result_list.append(temp_loss_dict)
-            if not silent and not auto:
-                print('train epoch:', self.epoch_cnt)
-                print(transfer_loss_dict_to_line_str(temp_loss_dict))
+            # the epochs up to the next evaluate/cluster event are enqueued together (one read-back);
+            # the records and the printed lines are the same, in the same order, as one epoch at a time
+            first = self.epoch_cnt + 1
+            run = self.train_epochs(self._epochs_to_next_event(), sync=not defer)
+            for i in range(len(run)):
+                train_epoch_index_list.append(first + i)
+                loss_result_list.append(run[i])
+                if not defer:
+                    print('train epoch:', first + i)
+                    print(transfer_loss_dict_to_line_str(run[i]))
 
             if (self.epoch_cnt % self.evaluate_interval) == 0 and self.epoch_cnt >= self.test_begin_epoch:
                 temp_eval_result = self.evaluator.evaluate()
@@ -474,17 +543,23 @@ class _InvPrefTrainManager:
             if (self.epoch_cnt % self.cluster_interval) == 0:
                 if (self.begin_cluster_epoch is None or self.begin_cluster_epoch <= self.epoch_cnt) \
                         and (self.stop_cluster_epoch is None or self.stop_cluster_epoch > self.epoch_cnt):
-                    diff_num = self.cluster()
+                    diff_num = self.cluster(sync=not defer)
                 else:
                     diff_num = 0
                 cluster_diff_num_list.append(diff_num)
-                envs_cnt = self.stat_envs()
+                envs_cnt = self.stat_envs(sync=not defer)
                 cluster_epoch_list.append(self.epoch_cnt)
                 envs_cnt_list.append(envs_cnt)
-                if not silent and not auto:
+                if not defer:
                     print('cluster at epoch:', self.epoch_cnt)
                     print('diff num:', diff_num)
                     print(transfer_loss_dict_to_line_str(envs_cnt))
+
+        if defer:  # one read-back for everything
+            loss_result_list = [dict(zip(LOSS_KEYS, v)) for v in torch.stack(loss_result_list).tolist()] \
+                if loss_result_list else []
+            cluster_diff_num_list = [int(d.item()) if torch.is_tensor(d) else d for d in cluster_diff_num_list]
+            envs_cnt_list = [{env: int(c) for env, c in enumerate(t.tolist())} for t in envs_cnt_list]
 
         return (loss_result_list, train_epoch_index_list), \
                (test_result_list, test_epoch_list), \

@@ -161,15 +161,21 @@ int invpref_mstep_rows_adam_hip(const InvPrefTables *tables, const InvPrefTables
 int invpref_set_profile_event(void *event);
 
 /* ---- the same pass for HIP-graph replay.  A captured launch freezes its kernel arguments, so the
- * per-step Adam scalars cannot be passed by value: they are looked up on the device as
- * table[state[0] - state[1]], and the pass advances state[0] when it is done.
- *   state: device int32[4] = {next step (1-based), step that table[0] belongs to, 0, 0}
+ * per-step Adam scalars cannot be passed by value: they live in one of two device slots, picked by the
+ * frozen argument `slot` = (step & 1).  A pass for step s reads slot s&1 and fills the other slot with
+ * step s+1 and table[s+1 - base] for its successor (no ticket, no ordering between workgroups: nobody
+ * reads that slot before the next launch).
+ *   state: device int32[16], slot p at state + 8p = {step (1-based), base = step that table[0] belongs to,
+ *          table[step - base] (6 floats)}.  Before the first pass (and after a refill / rebase) the caller
+ *          writes slot (step & 1) for the step about to run.
  *   table: device float[n][6], filled on the host by invpref_adam_schedule_fill() and uploaded.
- * The caller keeps state[0] - state[1] inside [0, n) (refill + rebase between replays). */
+ *   slot : parity of the step this call performs; consecutive calls alternate.
+ * The caller keeps step - base inside [0, n). */
 typedef struct InvPrefAdamSchedule {
     int32_t *state;
     const float *table;
     int32_t n;
+    int32_t slot;
 } InvPrefAdamSchedule;
 int invpref_adam_schedule_fill(float *host_table, int64_t first_step, int64_t n, double lr, double beta1, double beta2,
                                double eps);

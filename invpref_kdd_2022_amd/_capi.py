@@ -45,7 +45,7 @@ class Coefs(C.Structure):
 
 class AdamSchedule(C.Structure):
     """struct InvPrefAdamSchedule"""
-    _fields_ = [('state', C.c_void_p), ('table', C.c_void_p), ('n', C.c_int32)]
+    _fields_ = [('state', C.c_void_p), ('table', C.c_void_p), ('n', C.c_int32), ('slot', C.c_int32)]
 
 
 _lib = None

@@ -65,8 +65,9 @@ struct RowsArgs {
     int n, dense_per_task, n_dense_tasks;
     const int *item_hot_index;    // [item_num]: scratch row of an item whose gradient goes through atomics, or -1
     float *hot_scratch;           // [n_hot][2][DP] gradient accumulators of those rows (zero on entry, re-zeroed by finish)
-    int *sched_state;             // optional device int32[4] = {step (1-based), first step of sched_table, ticket, 0}
+    int *sched_state;             // optional device int32[16]: two slots {step, base, AdamScalars}, see InvPrefAdamSchedule
     const AdamScalars *sched_table;  // optional device table of per-step Adam scalars (graph replay)
+    int sched_n, sched_slot;
     int stamps_nodrain;           // diagnostic: do not drain memory operations before a stamp
     unsigned long long *stamps;   // diagnostic builds only (INVPREF_STAMPS): [n_tasks][8] s_memrealtime ticks
 };
@@ -229,7 +230,7 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
     const float *T_oth_inv = USER ? t.Qi : t.Pu, *T_oth_env = USER ? t.Qa : t.Pa;
     // Adam scalars of this step: by value, or (graph replay: kernel arguments are frozen) looked up
     // by the device-side step counter that rows_finish_kernel advances
-    const AdamScalars ad = a.sched_state ? a.sched_table[a.sched_state[0] - a.sched_state[1]] : a.ad;
+    const AdamScalars ad = a.sched_state ? *reinterpret_cast<const AdamScalars *>(a.sched_state + 8 * a.sched_slot + 2) : a.ad;
 
     STAMP(0);
     // the first round's descriptor goes out before anything else: every gather below hangs on it
@@ -572,7 +573,7 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
 template <int NC, bool VEC>
 __device__ __forceinline__ void stream_task(const DevTables &t, const RowsArgs &a, int side, const int *rows, int n) {
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const AdamScalars ad = a.sched_state ? a.sched_table[a.sched_state[0] - a.sched_state[1]] : a.ad;
+    const AdamScalars ad = a.sched_state ? *reinterpret_cast<const AdamScalars *>(a.sched_state + 8 * a.sched_slot + 2) : a.ad;
     const float *Tinv = side == 0 ? t.Pu : t.Qi, *Tenv = side == 0 ? t.Pa : t.Qa;
     for (int i = grp; i < n; i += 2 * kGroups) {
         const int r0 = rows[i];
@@ -707,9 +708,19 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
                                                            int nslabs, int DP, int EMAX, StepScalars k, float l2,
                                                            float l1, int64_t Bnorm, uint32_t flags, int fused,
                                                            AdamScalars ad_in, int *sched_state,
-                                                           const AdamScalars *sched_table,
+                                                           const AdamScalars *sched_table, int sched_n, int sched_slot,
                                                            float *__restrict__ losses6, HotRows hot, int nc, int vec) {
-    const AdamScalars ad = sched_state ? sched_table[sched_state[0] - sched_state[1]] : ad_in;
+    const AdamScalars ad = sched_state ? *reinterpret_cast<const AdamScalars *>(sched_state + 8 * sched_slot + 2) : ad_in;
+    // the device-side schedule moves on: one thread fills the OTHER slot with the next step's number and
+    // Adam scalars.  Nobody reads that slot before the next launch, so no ordering between blocks is needed.
+    if (sched_state && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int *cur = sched_state + 8 * sched_slot;
+        int *nxt = sched_state + 8 * (sched_slot ^ 1);
+        const int next = cur[0] + 1, base = cur[1], idx = next - base;
+        nxt[0] = next;
+        nxt[1] = base;
+        if (idx >= 0 && idx < sched_n) *reinterpret_cast<AdamScalars *>(nxt + 2) = sched_table[idx];
+    }
     if ((int)blockIdx.x >= hot.slab_blocks) {
         // trailing blocks: 64 groups of 16 lanes, one hot item row each
         const int hb = blockIdx.x - hot.slab_blocks;
@@ -717,11 +728,6 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
         else if (nc == 1) finish_hot_rows<1, true>(t, hot, k, fused, ad, hb);
         else if (nc == 2) finish_hot_rows<2, true>(t, hot, k, fused, ad, hb);
         else finish_hot_rows<4, true>(t, hot, k, fused, ad, hb);
-        __syncthreads();  // every wave of this block is done with the step's Adam scalars
-        if (sched_state && threadIdx.x == 0) {  // same ticket protocol as below
-            const int ticket = atomicAdd(sched_state + 2, 1);
-            if (ticket == (int)gridDim.x - 1) { sched_state[2] = 0; sched_state[0] = sched_state[0] + 1; }
-        }
         return;
     }
     __shared__ double part[16][64];
@@ -815,15 +821,6 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
             losses6[5] += (float)((double)k.ca * Li + (double)k.cb * Le + (double)k.cc * Lc + (double)l2 * L2 + (double)l1 * L1);
         }
     }
-    // the step is over: the block that finishes LAST (ticket) advances the device-side step counter;
-    // every block read the counter before taking its ticket, so no block can see the new value
-    if (sched_state && threadIdx.x == 0) {
-        const int ticket = atomicAdd(sched_state + 2, 1);
-        if (ticket == (int)gridDim.x - 1) {
-            sched_state[2] = 0;
-            sched_state[0] = sched_state[0] + 1;
-        }
-    }
 }
 
 void *g_profile_event = nullptr;  // see invpref_set_profile_event()
@@ -912,6 +909,8 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a.hot_scratch = (float *)workspace + (size_t)slab_len * kReplicas;
     a.sched_state = sched ? sched->state : nullptr;
     a.sched_table = sched ? reinterpret_cast<const AdamScalars *>(sched->table) : nullptr;
+    a.sched_n = sched ? sched->n : 0;
+    a.sched_slot = sched ? (sched->slot & 1) : 0;
     // diagnostics: INVPREF_STAMPS=<device pointer, hex> makes the kernel write phase time stamps there
     static const char *stamp_env = getenv("INVPREF_STAMPS");
     a.stamps = stamp_env ? reinterpret_cast<unsigned long long *>(strtoull(stamp_env, nullptr, 16)) : nullptr;
@@ -957,7 +956,7 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     const int hot_blocks = (plan->n_hot + 63) / 64;  // 1024 threads = 64 groups per block
     hipLaunchKernelGGL(rows_finish_kernel, dim3(nfb + hot_blocks), dim3(1024), 0, st, t, o, (float *)workspace, kReplicas,
                        DP, emax, k, coefs->L2_coe, coefs->L1_coe, batch_norm, flags, fused, ad, a.sched_state,
-                       a.sched_table, losses6, h, nc, (int)vec);
+                       a.sched_table, a.sched_n, a.sched_slot, losses6, h, nc, (int)vec);
     return (int)hipGetLastError();
 }
 

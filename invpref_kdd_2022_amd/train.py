@@ -262,6 +262,7 @@ class _InvPrefTrainManager:
             # fused M-step + Adam: one pass, gradient never stored, parameters ping-pong
             st.step += 1
             if sched:  # graph capture: Adam scalars come from the device-side schedule
+                self._sched['struct'].slot = st.step & 1
                 rc = self._raw_rows_adam_sched(
                     C.byref(t_cur), C.byref(self._raw_tabs[id(st.p_views_alt)]), C.byref(self._raw_m),
                     C.byref(self._raw_v), C.byref(self._plans[k].struct), pe + 8 * lo, py + 4 * lo, pw + 4 * lo, bn,
@@ -315,8 +316,8 @@ class _InvPrefTrainManager:
         st, L = self.state, _capi.lib()
         if self._sched is None:
             table = torch.zeros(self._SCHED_N, 6, dtype=torch.float32, device=self.device)
-            state = torch.zeros(4, dtype=torch.int32, device=self.device)
-            self._sched = dict(table=table, state=state, base=-(10 ** 9),
+            state = torch.zeros(16, dtype=torch.int32, device=self.device)
+            self._sched = dict(table=table, state=state, base=-(10 ** 9), host=None,
                                struct=_capi.AdamSchedule(state.data_ptr(), table.data_ptr(), self._SCHED_N))
         sc = self._sched
         first = st.step + 1
@@ -325,10 +326,13 @@ class _InvPrefTrainManager:
             _capi.check(L.invpref_adam_schedule_fill(host.ctypes.data, first, self._SCHED_N, self.lr, 0.9, 0.999, 1e-8),
                         'invpref_adam_schedule_fill')
             sc['table'].copy_(torch.from_numpy(host))
-            sc['base'] = first
+            sc['base'], sc['host'] = first, host
             self._sched_synced = False
         if not self._sched_synced:  # the device counter follows the host's after eager steps / refills
-            sc['state'].copy_(torch.tensor([first, sc['base'], 0, 0], dtype=torch.int32))
+            st16, o = np.zeros(16, np.int32), 8 * (first & 1)  # the slot of the step about to run
+            st16[o:o + 2] = first, sc['base']
+            st16[o + 2:o + 8] = sc['host'][first - sc['base']].view(np.int32)
+            sc['state'].copy_(torch.from_numpy(st16))
             self._sched_synced = True
 
     def _issue_epochs(self, stream, sched: bool, n: int):
@@ -393,7 +397,7 @@ class _InvPrefTrainManager:
     def _graph_for(self, n: int):
         """The HIP graph of n epochs starting from the current parameter buffer (captured on first use)."""
         st = self.state
-        key = (id(st.p_views), n)
+        key = (id(st.p_views), n, st.step & 1)
         g = self._graphs.get(key)
         if g is None:
             step0, views0 = st.step, st.p_views
@@ -415,9 +419,12 @@ class _InvPrefTrainManager:
             raise RuntimeError('prepare_graphs(): run one epoch first (train_epochs(1))')
         self._sched_prepare(self.batch_num)
         for n in sorted({min(max(1, int(x)), self._graph_epochs) for x in run_lengths}):
-            for _ in range(2):
+            step0 = self.state.step
+            for _ in range(2):  # a fused step swaps the buffers and flips the schedule slot: both move together
                 self._graph_for(n)
                 self.state.swap()
+                self.state.step += 1
+            self.state.step = step0
 
     def _epochs_to_next_event(self) -> int:
         """How many epochs train() may enqueue before the next evaluate / cluster / end of training."""

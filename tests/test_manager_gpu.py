@@ -240,7 +240,7 @@ def test_train_epochs_single_readback_equals_epoch_by_epoch():
     with contextlib.redirect_stdout(io.StringIO()) as out:
         (losses2, _), _, (diffs2, cnts2, _) = mgr2.train(silent=False)
     assert out.getvalue().count('train epoch:') == 7 and out.getvalue().count('cluster at epoch:') == 2
-    np.testing.assert_allclose([l[k] for l in losses2 for k in LOSS_KEYS], [l[k] for l in losses for k in LOSS_KEYS], rtol=2e-5)
+    np.testing.assert_allclose([l[k] for l in losses2 for k in LOSS_KEYS], [l[k] for l in losses for k in LOSS_KEYS], rtol=2e-4)
     assert abs(diffs2[0] - diffs[0]) <= 3 and all(abs(cnts2[0][e] - cnts[0][e]) <= 3 for e in cnts[0])
 
 

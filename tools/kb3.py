@@ -54,7 +54,8 @@ L = _capi.lib()
 host = np.zeros((8192, 6), np.float32)
 L.invpref_adam_schedule_fill(host.ctypes.data, 1, 8192, 0.005, 0.9, 0.999, 1e-8)
 s_table = torch.from_numpy(host).to(dev)
-s_state = torch.tensor([1, 1, 0, 0], dtype=torch.int32, device=dev)
+st16 = np.zeros(16, np.int32); st16[8:10] = 1; st16[10:16] = host[0].view(np.int32)
+s_state0 = torch.from_numpy(st16).to(dev); s_state = s_state0.clone()
 s_struct = _capi.AdamSchedule(s_state.data_ptr(), s_table.data_ptr(), 8192)
 tabs_c = {id(P): _capi.make_tables(P), id(P2): _capi.make_tables(P2)}
 tm, tv = _capi.make_tables(M), _capi.make_tables(V)
@@ -67,13 +68,14 @@ def seq_sched(steps=30):
         a, b = P, P2
         st = torch.cuda.current_stream().cuda_stream
         for k in range(steps):
+            s_struct.slot = (k + 1) & 1
             rc = L.invpref_mstep_rows_adam_sched_hip(C.byref(tabs_c[id(a)]), C.byref(tabs_c[id(b)]), C.byref(tm), C.byref(tv),
                                                      C.byref(plans[k].struct), e.data_ptr() + 8 * k * B, y.data_ptr() + 4 * k * B,
                                                      w.data_ptr() + 4 * k * B, B, C.byref(cf), flags, losses.data_ptr(),
                                                      C.byref(s_struct), ows.data_ptr(), ows.numel(), st)
             assert rc == 0
             a, b = b, a
-        s_state.zero_(); s_state.add_(1)   # keep the step inside the table over many replays
+        s_state.copy_(s_state0)   # keep the step inside the table over many replays
         return steps
     return run
 

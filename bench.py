@@ -211,9 +211,9 @@ def main():
     # M-step-only and E-step-only rates (report them separately from the blended figure)
     a0, a1, a2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     a0.record()
-    mgr.train_epochs(3)
+    mgr.train_epochs(3, sync=False)
     a1.record()
-    mgr.cluster(); mgr.stat_envs()
+    mgr.cluster(sync=False); mgr.stat_envs(sync=False)
     a2.record()
     torch.cuda.synchronize()
     detail = {'mstep_interactions_per_s_per_gpu': 3 * mgr.users_tensor.shape[0] / (a0.elapsed_time(a1) * 1e-3),

@@ -209,3 +209,38 @@ class Trainer:
         new, counts, diff, _ = estep(self.tab, self.u, self.v, self.y, self.implicit, old_envs=self.envs)
         self.envs = new
         return diff
+
+
+# ---------------------------------------------------------------------------------------------
+# PureMF baselines (baseline_models.py:12-69 implicit, :652-704 explicit; Basic*TrainManager
+# train.py:345-461, :1022-1138) as the degenerate case of the InvPref step:
+# with the env-aware tables, embed_env and the classifier all zero, E = 1 and coefficients
+# (1, 0, 0, 2*L2_coe, 2*L1_coe, alpha=0), the InvPref loss
+#     1*L_inv + (2 L2_coe) * (|Pu[u]|^2 + |Qi[v]|^2) / (2BD) + (2 L1_coe) * (|Pu[u]|_1 + |Qi[v]|_1) / (2BD)
+# IS the PureMF loss  BCE|MSE + L2_coe*(|Pu[u]|^2/(BD) + |Qi[v]|^2/(BD)) + L1_coe*(...), the zero tables
+# receive exactly-zero gradients (sign(0) = 0, g_q = 0, softmax over one class - onehot = 0) and stay zero
+# under Adam.  The REPORTED regularisers are 2x InvPref's.
+def pure_mf_params(user_emb, item_emb):
+    U, D = user_emb.shape
+    I = item_emb.shape[0]
+    z = np.zeros
+    return {PARAM_NAMES[0]: user_emb, PARAM_NAMES[1]: item_emb, PARAM_NAMES[2]: z((U, D), np.float32),
+            PARAM_NAMES[3]: z((I, D), np.float32), PARAM_NAMES[4]: z((1, D), np.float32),
+            PARAM_NAMES[5]: z((1, D), np.float32), PARAM_NAMES[6]: z((1,), np.float32)}
+
+
+def pure_mf_coefs(L2_coe: float, L1_coe: float):
+    return np.array([1.0, 0.0, 0.0, 2.0 * L2_coe, 2.0 * L1_coe, 0.0])
+
+
+def pure_mf_losses(losses6):
+    """InvPref's six loss outputs -> PureMF's [score_loss, L2_reg, L1_reg, loss] (train.py:399-404)."""
+    l = np.asarray(losses6, np.float64)
+    return np.stack([l[..., 0], 2.0 * l[..., 3], 2.0 * l[..., 4], l[..., 5]], axis=-1)
+
+
+def pure_mf_trainer(user_emb, item_emb, data, *, implicit: bool, batch_size: int, lr: float, L2_coe: float,
+                    L1_coe: float, prec='f32') -> Trainer:
+    return Trainer(pure_mf_params(user_emb, item_emb), data, np.zeros(len(data), np.int64), implicit=implicit,
+                   batch_size=batch_size, coefs=pure_mf_coefs(L2_coe, L1_coe), lr=lr, reweight_rec=False,
+                   reweight_cls=False, reg_only_embed=True, reg_env_embed=False, prec=prec)

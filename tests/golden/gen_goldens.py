@@ -14,6 +14,8 @@ What each fixture pins:
   g3    Coat-explicit 30-epoch trajectory + first cluster -> §8 a7,a8,a10-a14
   g4    Yahoo-shaped implicit trajectory, 5 epochs + E-step
   g5    MIND-shaped single step (E=16, D=256, B=262144)
+  g6    evaluate.py metrics on a seeded model / loader stub   -> §8 f1
+  g7    PureMF baselines (Basic*TrainManager)                 -> §8 f2
 """
 import sys
 import types
@@ -345,8 +347,54 @@ def gen_g6():
                         pairs=pairs.astype(np.int32), scores=scores)
 
 
+from pure_mf_fixture import pure_mf_inputs  # noqa: E402  (tests/pure_mf_fixture.py, shared with the tests)
+
+
+def gen_g7():
+    """PureMF baselines through the reference's Basic{Implicit,Explicit}TrainManager:
+    first-batch loss terms + gradients, per-epoch loss dicts, final parameters."""
+    import baseline_models as ref_base
+    for kind in ('implicit', 'explicit'):
+        (U, I, D, n, bs, epochs), data, init, cfg = pure_mf_inputs(kind)
+        cls = ref_base.PureMatrixFactorization if kind == 'implicit' else ref_base.PureExplicitMatrixFactorization
+        mcls = ref_train.BasicImplicitTrainManager if kind == 'implicit' else ref_train.BasicExplicitTrainManager
+        out = {'meta': np.array([U, I, D, n, bs, epochs]), 'cfg': np.array([cfg['lr'], cfg['L2_coe'], cfg['L1_coe']])}
+        # first-batch terms and gradients, fp32 and fp64
+        for dt, tag in ((torch.float32, 'f32'), (torch.float64, 'f64')):
+            model = cls(U, I, D).to(dt)
+            model.load_state_dict({k: torch.from_numpy(v).to(dt) for k, v in init.items()})
+            u, v = torch.from_numpy(data[:bs, 0]), torch.from_numpy(data[:bs, 1])
+            y = torch.from_numpy(data[:bs, 2]).to(dt)
+            sl = model(u, v, y)
+            l2, l1 = model.get_L2_reg(u, v), model.get_L1_reg(u, v)
+            loss = sl + l2 * cfg['L2_coe'] + l1 * cfg['L1_coe']
+            loss.backward()
+            out[f'step_losses_{tag}'] = np.array([float(sl), float(l2), float(l1), float(loss)], np.float64)
+            out[f'step_g_user_{tag}'] = model.user_emb.weight.grad.numpy().copy()
+            out[f'step_g_item_{tag}'] = model.item_emb.weight.grad.numpy().copy()
+            if dt == torch.float32:
+                out['step_scores'] = model(u[:512], v[:512]).detach().numpy().copy()
+        # trajectory
+        model = cls(U, I, D)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in init.items()})
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):  # the explicit manager prints its score tensor
+            mgr = mcls(model=model, evaluator=StubEvaluator(), device=CPU, training_data=torch.from_numpy(data),
+                       batch_size=bs, epochs=epochs, evaluate_interval=10 ** 9, lr=cfg['lr'], L2_coe=cfg['L2_coe'],
+                       L1_coe=cfg['L1_coe'])
+            (losses, loss_epochs), (tests, test_epochs) = mgr.train(silent=True)
+        keys = ['score_loss', 'L2_reg', 'L1_reg', 'loss']
+        out['traj'] = np.array([[d[k] for k in keys] for d in losses], np.float64)
+        out['loss_epochs'] = np.array(loss_epochs)
+        out['test_epochs'] = np.array(test_epochs)
+        for k, p in model.state_dict().items():
+            out['final_' + k] = p.numpy().copy()
+        np.savez_compressed(os.path.join(OUT, f'g7_pure_mf_{kind}.npz'), **out)
+        print('g7', kind, out['traj'][0], out['traj'][-1])
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
     torch.manual_seed(0)
     for name in which:
         globals()['gen_' + name]()

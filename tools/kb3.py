@@ -80,13 +80,23 @@ def seq_sched(steps=30):
     return run
 
 
-def seq(pingpong, multiplan, steps=30):
+import copy
+def no_stream(dp):
+    st = planlib.RowPlanStruct.from_buffer_copy(dp.struct)
+    st.n_stream_user = 0; st.n_stream_item = 0
+    d = copy.copy(dp); d.struct = st
+    return d
+plans_ns = [no_stream(p) for p in plans]
+
+
+def seq(pingpong, multiplan, steps=30, pl=None):
+    pl = pl or plans
     def run():
         a, b = P, P2
         for k in range(steps):
             kk = k if multiplan else 0
             sl = slice(kk * B, (kk + 1) * B)
-            ops.mstep_rows_adam(a, b, M, V, plans[kk], e[sl], y[sl], w[sl], B, coefs, flags, losses, 5, 0.005, ws)
+            ops.mstep_rows_adam(a, b, M, V, pl[kk], e[sl], y[sl], w[sl], B, coefs, flags, losses, 5, 0.005, ws)
             if pingpong:
                 a, b = b, a
         return steps
@@ -94,5 +104,6 @@ def seq(pingpong, multiplan, steps=30):
 
 
 combos = ((False, False), (True, True)) if os.environ.get('KB3_SHORT') else ((False, False), (False, True), (True, False), (True, True))
+print('without stream tasks pp=1 mp=1: %.2f us' % graph_time(seq(True, True, pl=plans_ns)))
 print('sched variant pp=1 mp=1: %.2f us' % graph_time(seq_sched()))
 print(os.environ.get('INVPREF_LIB', 'default'), ' '.join(f'pp={int(pp)} mp={int(mp)}: {graph_time(seq(pp, mp)):.2f} us' for pp, mp in combos))

@@ -45,6 +45,13 @@ extern "C" {
                                      set on exactly one rank when a minibatch is row-sharded */
 
 #define INVPREF_NO_GRAD 64u       /* invpref_mstep_grad_hip: report the loss terms only, write no gradient */
+#define INVPREF_PURE_MF 128u      /* planned M-step entry points (invpref_mstep_rows_*): PureMF baseline step
+                                     (baseline_models.py:12-69, :652-704 under Basic*TrainManager, train.py:345-461,
+                                     :1022-1138) = the InvPref step with the env-aware tables, embed_env and the
+                                     classifier ABSENT: env_num must be 1, those five pointers (and `envs`) are
+                                     ignored and may be NULL in every table struct.  With coefficients
+                                     (1, 0, 0, 2*L2_coe, 2*L1_coe, 0) the reported terms are
+                                     losses6 = {score_loss, -, 0, L2_reg/2, L1_reg/2, loss} of train.py:399-404 */
 
 /* The seven parameter tensors of InvPrefImplicit/InvPrefExplicit (models.py:283-291, :197-201),
  * in state_dict order.  Also used for gradients and Adam moments (same shapes). */

@@ -14,7 +14,7 @@ import torch
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('INVPREF_LIB') or os.path.join(PKG, 'libinvpref_hip.so')  # INVPREF_LIB: kernel A/B builds
 
-IMPLICIT, REWEIGHT_REC, REWEIGHT_CLS, REG_ONLY_EMBED, REG_ENV_EMBED, DENSE_REG, NO_GRAD = 1, 2, 4, 8, 16, 32, 64
+IMPLICIT, REWEIGHT_REC, REWEIGHT_CLS, REG_ONLY_EMBED, REG_ENV_EMBED, DENSE_REG, NO_GRAD, PURE_MF = 1, 2, 4, 8, 16, 32, 64, 128
 
 EXPORTS = [
     'invpref_abi_version', 'invpref_device_name', 'invpref_forward_hip', 'invpref_mstep_workspace_bytes',
@@ -136,6 +136,17 @@ def make_tables(tensors) -> Tables:
     if pa.shape != (U, D) or qa.shape != (I, D) or ev.shape != (E, D) or w.shape != (E, D) or b.shape != (E,):
         raise InvPrefError('inconsistent table shapes')
     return Tables(U, I, E, D, *[t.data_ptr() for t in tensors])
+
+
+def make_pure_tables(tensors) -> Tables:
+    """tensors: [user table, item table] of a PureMF model (INVPREF_PURE_MF: the other five tables are absent)."""
+    pu, qi = tensors
+    for n, t in zip(('user_emb', 'item_emb'), tensors):
+        _req(t, torch.float32, n)
+    U, D = pu.shape
+    if qi.shape[1] != D:
+        raise InvPrefError('inconsistent table shapes')
+    return Tables(U, qi.shape[0], 1, D, pu.data_ptr(), qi.data_ptr(), None, None, None, None, None)
 
 
 def device_name() -> str:

@@ -224,6 +224,9 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
     float4 *mv_wave = mv + wave * 4 * NC * 64;
     const bool implicit = a.flags & INVPREF_IMPLICIT;
     const bool rw_rec = a.flags & INVPREF_REWEIGHT_REC, rw_cls = a.flags & INVPREF_REWEIGHT_CLS;
+    // PureMF (INVPREF_PURE_MF): the env-aware tables, embed_env and the classifier are absent -- their
+    // rows stay the zeros they are initialised to below and are neither loaded nor stored
+    const bool pure = a.flags & INVPREF_PURE_MF;
     const StepScalars k = a.k;
     const int *oth_ids = a.oth[side], *pos = a.pos[side];
     const float *T_own_inv = USER ? t.Pu : t.Qi, *T_own_env = USER ? t.Pa : t.Qa;
@@ -237,7 +240,7 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
     int4 d = a.desc[(task.y * kGroups + grp) * 2], d1 = a.desc[(task.y * kGroups + grp) * 2 + 1];
     stage_table(sEv, t.Ev, t.E, t.D, DP);
     stage_table(sW, t.W, t.E, t.D, DP);
-    for (int i = threadIdx.x; i < EMAX; i += blockDim.x) sb[i] = (i < t.E) ? t.b[i] : 0.f;
+    for (int i = threadIdx.x; i < EMAX; i += blockDim.x) sb[i] = (i < t.E && t.b) ? t.b[i] : 0.f;
     STAMP(1);
 
     for (int r = task.y; r < task.y + task.z; r++) {
@@ -266,12 +269,14 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
         float w = 1.f;
         if (active) {
             load_row<NC, VEC>(T_own_inv, row, t.D, l16, oi);
-            load_row<NC, VEC>(T_own_env, row, t.D, l16, oe);
+            if (!pure) load_row<NC, VEC>(T_own_env, row, t.D, l16, oe);
             if (nsmp > 0) {
                 cur = sample_at(0);
                 load_row<NC, VEC>(T_oth_inv, cur.oth, t.D, l16, pi);
-                load_row<NC, VEC>(T_oth_env, cur.oth, t.D, l16, pe);
-                e = (int)a.envs[cur.ps];
+                if (!pure) {
+                    load_row<NC, VEC>(T_oth_env, cur.oth, t.D, l16, pe);
+                    e = (int)a.envs[cur.ps];
+                }
                 if (rw_rec || rw_cls) w = a.weights[cur.ps];
             }
         }
@@ -285,7 +290,7 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     const int i0 = (l16 + kRow * c) * 4;
-                    if (mine && i0 < t.D)
+                    if (mine && i0 < t.D && !(pure && tn >= 2))
                         __builtin_amdgcn_global_load_lds(
                             (const __attribute__((address_space(1))) void *)(src_tab + (int64_t)row * t.D + i0),
                             (__attribute__((address_space(3))) void *)(mv_wave + (tn * NC + c) * 64), 16, 0, 0);
@@ -297,8 +302,10 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
             if (sidx > 0) {  // (the first interaction's gathers were issued with the own rows)
                 cur = sample_at(sidx);
                 load_row<NC, VEC>(T_oth_inv, cur.oth, t.D, l16, pi);
-                load_row<NC, VEC>(T_oth_env, cur.oth, t.D, l16, pe);
-                e = (int)a.envs[cur.ps];
+                if (!pure) {
+                    load_row<NC, VEC>(T_oth_env, cur.oth, t.D, l16, pe);
+                    e = (int)a.envs[cur.ps];
+                }
                 if (rw_rec || rw_cls) w = a.weights[cur.ps];
             }
             const float cw_rec = (rw_rec ? w : 1.f) * k.invB, cw_cls = (rw_cls ? w : 1.f) * k.invB;
@@ -353,7 +360,7 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
             }
             if (!a.fused) {
                 store_row<NC, VEC>(a.g[side], row, t.D, l16, gi);
-                store_row<NC, VEC>(a.g[2 + side], row, t.D, l16, ge);
+                if (!pure) store_row<NC, VEC>(a.g[2 + side], row, t.D, l16, ge);
             } else {
                 float4 mi[NC], vi[NC], me[NC], ve[NC];
                 if (dma) {
@@ -367,8 +374,10 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
                 } else {
                     load_row<NC, VEC>(a.m[side], row, t.D, l16, mi);
                     load_row<NC, VEC>(a.v[side], row, t.D, l16, vi);
-                    load_row<NC, VEC>(a.m[2 + side], row, t.D, l16, me);
-                    load_row<NC, VEC>(a.v[2 + side], row, t.D, l16, ve);
+                    if (!pure) {
+                        load_row<NC, VEC>(a.m[2 + side], row, t.D, l16, me);
+                        load_row<NC, VEC>(a.v[2 + side], row, t.D, l16, ve);
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
@@ -380,9 +389,11 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
                 store_row<NC, VEC, ROWS_ST_P>(a.np[side], row, t.D, l16, oi);
                 store_row<NC, VEC>(a.m[side], row, t.D, l16, mi);
                 store_row<NC, VEC>(a.v[side], row, t.D, l16, vi);
-                store_row<NC, VEC, ROWS_ST_P>(a.np[2 + side], row, t.D, l16, oe);
-                store_row<NC, VEC>(a.m[2 + side], row, t.D, l16, me);
-                store_row<NC, VEC>(a.v[2 + side], row, t.D, l16, ve);
+                if (!pure) {
+                    store_row<NC, VEC, ROWS_ST_P>(a.np[2 + side], row, t.D, l16, oe);
+                    store_row<NC, VEC>(a.m[2 + side], row, t.D, l16, me);
+                    store_row<NC, VEC>(a.v[2 + side], row, t.D, l16, ve);
+                }
             }
         }
     }
@@ -416,11 +427,12 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
     const bool implicit = a.flags & INVPREF_IMPLICIT;
     const bool rw_rec = a.flags & INVPREF_REWEIGHT_REC, rw_cls = a.flags & INVPREF_REWEIGHT_CLS;
     const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
+    const bool pure = a.flags & INVPREF_PURE_MF;
     const StepScalars k = a.k;
     STAMP(0);
     stage_table(sEv, t.Ev, t.E, t.D, DP);
     stage_table(sW, t.W, t.E, t.D, DP);
-    for (int i = threadIdx.x; i < EMAX; i += blockDim.x) sb[i] = (i < t.E) ? t.b[i] : 0.f;
+    for (int i = threadIdx.x; i < EMAX; i += blockDim.x) sb[i] = (i < t.E && t.b) ? t.b[i] : 0.f;
     if (threadIdx.x < kLossSlots) aL[threadIdx.x] = 0.f;
     // output ownership: thread -> column d_own, classes cg, cg + CG, ...
     constexpr int CG = (256 / DP) < EMAX ? (256 / DP) : EMAX;
@@ -444,7 +456,7 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
         for (int c = 0; c < NC; c++) hq[c] = ha[c] = f4zero();
         if (valid) {
             const int u = a.batch_users[s], v = a.batch_items[s];
-            e = (int)a.envs[s];
+            e = pure ? 0 : (int)a.envs[s];
             const float y = a.scores[s];
             const float w = (rw_rec || rw_cls) ? a.weights[s] : 1.f;
             const float w_rec = rw_rec ? w : 1.f, w_cls = rw_cls ? w : 1.f;
@@ -452,8 +464,13 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
             float4 pu[NC], qi[NC], pa[NC], qa[NC], ev[NC];
             load_row<NC, VEC>(t.Pu, u, t.D, l16, pu);
             load_row<NC, VEC>(t.Qi, v, t.D, l16, qi);
-            load_row<NC, VEC>(t.Pa, u, t.D, l16, pa);
-            load_row<NC, VEC>(t.Qa, v, t.D, l16, qa);
+            if (!pure) {
+                load_row<NC, VEC>(t.Pa, u, t.D, l16, pa);
+                load_row<NC, VEC>(t.Qa, v, t.D, l16, qa);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; c++) pa[c] = qa[c] = f4zero();
+            }
             lds_row<NC>(sEv, e, l16, ev);
             Eval<NC, EMAX> o;
             eval_interaction<NC, EMAX>(o, pu, qi, pa, qa, ev, sW, sb, t.E, e, y, w_rec * k.invB, w_cls * k.invB, k, implicit, l16);
@@ -537,7 +554,7 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
 #pragma unroll
             for (int q4 = 0; q4 < 2 * DP / 16; q4++) {
                 const int idx = q4 * 16 + l16;           // 16 lanes -> 16 consecutive floats
-                if ((idx & (DP - 1)) < t.D) atomicAdd(dst + idx, tr[idx]);
+                if ((idx & (DP - 1)) < t.D && !(pure && idx >= DP)) atomicAdd(dst + idx, tr[idx]);  // (PureMF: no env-aware half)
             }
         }
         if (!DBUF) __syncthreads();  // the record slots are rewritten by the next iteration
@@ -575,6 +592,7 @@ __device__ __forceinline__ void stream_task(const DevTables &t, const RowsArgs &
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const AdamScalars ad = a.sched_state ? *reinterpret_cast<const AdamScalars *>(a.sched_state + 8 * a.sched_slot + 2) : a.ad;
     const float *Tinv = side == 0 ? t.Pu : t.Qi, *Tenv = side == 0 ? t.Pa : t.Qa;
+    const bool pure = a.flags & INVPREF_PURE_MF;
     for (int i = grp; i < n; i += 2 * kGroups) {
         const int r0 = rows[i];
         const bool two = i + kGroups < n;
@@ -584,8 +602,11 @@ __device__ __forceinline__ void stream_task(const DevTables &t, const RowsArgs &
 #pragma unroll
             for (int c = 0; c < NC; c++) z[c] = f4zero();
             store_row<NC, VEC>(a.g[side], r0, t.D, l16, z);
-            store_row<NC, VEC>(a.g[2 + side], r0, t.D, l16, z);
-            if (two) { store_row<NC, VEC>(a.g[side], r1, t.D, l16, z); store_row<NC, VEC>(a.g[2 + side], r1, t.D, l16, z); }
+            if (!pure) store_row<NC, VEC>(a.g[2 + side], r0, t.D, l16, z);
+            if (two) {
+                store_row<NC, VEC>(a.g[side], r1, t.D, l16, z);
+                if (!pure) store_row<NC, VEC>(a.g[2 + side], r1, t.D, l16, z);
+            }
             continue;
         }
         float4 p[4][NC], m[4][NC], v[4][NC];  // {r0 inv, r0 env, r1 inv, r1 env}
@@ -593,23 +614,26 @@ __device__ __forceinline__ void stream_task(const DevTables &t, const RowsArgs &
         for (int q = 0; q < 4; q++) {
             const int row = q < 2 ? r0 : r1;
             const int ti = (q & 1) * 2 + side;
-            load_row<NC, VEC>((q & 1) ? Tenv : Tinv, row, t.D, l16, p[q]);
-            load_row<NC, VEC>(a.m[ti], row, t.D, l16, m[q]);
-            load_row<NC, VEC>(a.v[ti], row, t.D, l16, v[q]);
+            if (!(pure && (q & 1))) {
+                load_row<NC, VEC>((q & 1) ? Tenv : Tinv, row, t.D, l16, p[q]);
+                load_row<NC, VEC>(a.m[ti], row, t.D, l16, m[q]);
+                load_row<NC, VEC>(a.v[ti], row, t.D, l16, v[q]);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            if (q >= 2 && !two) break;
             const int row = q < 2 ? r0 : r1;
             const int ti = (q & 1) * 2 + side;
+            if ((q < 2 || two) && !(pure && (q & 1))) {
 #pragma unroll
-            for (int c = 0; c < NC; c++) {
-                adam1f(p[q][c].x, 0.f, m[q][c].x, v[q][c].x, ad); adam1f(p[q][c].y, 0.f, m[q][c].y, v[q][c].y, ad);
-                adam1f(p[q][c].z, 0.f, m[q][c].z, v[q][c].z, ad); adam1f(p[q][c].w, 0.f, m[q][c].w, v[q][c].w, ad);
+                for (int c = 0; c < NC; c++) {
+                    adam1f(p[q][c].x, 0.f, m[q][c].x, v[q][c].x, ad); adam1f(p[q][c].y, 0.f, m[q][c].y, v[q][c].y, ad);
+                    adam1f(p[q][c].z, 0.f, m[q][c].z, v[q][c].z, ad); adam1f(p[q][c].w, 0.f, m[q][c].w, v[q][c].w, ad);
+                }
+                store_row<NC, VEC, ROWS_ST_P>(a.np[ti], row, t.D, l16, p[q]);
+                store_row<NC, VEC>(a.m[ti], row, t.D, l16, m[q]);
+                store_row<NC, VEC>(a.v[ti], row, t.D, l16, v[q]);
             }
-            store_row<NC, VEC, ROWS_ST_P>(a.np[ti], row, t.D, l16, p[q]);
-            store_row<NC, VEC>(a.m[ti], row, t.D, l16, m[q]);
-            store_row<NC, VEC>(a.v[ti], row, t.D, l16, v[q]);
         }
     }
 }
@@ -666,7 +690,7 @@ struct HotRows {
 
 template <int NC, bool VEC>
 __device__ __forceinline__ void finish_hot_rows(const DevTables &t, const HotRows &h, const StepScalars &k,
-                                                int fused, const AdamScalars &ad, int block) {
+                                                int fused, const AdamScalars &ad, int block, bool pure) {
     constexpr int DP = NC * 64;
     const int l16 = threadIdx.x & 15;
     const int i = block * (int)(blockDim.x >> 4) + (int)(threadIdx.x >> 4);
@@ -676,6 +700,7 @@ __device__ __forceinline__ void finish_hot_rows(const DevTables &t, const HotRow
     float *sc = h.scratch + (int64_t)i * 2 * DP;
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
+        if (pure && tt) break;
         const float *T = tt == 0 ? h.Qi : h.Qa;
         float4 p[NC], g[NC];
         load_row<NC, VEC>(T, row, t.D, l16, p);
@@ -724,10 +749,10 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
     if ((int)blockIdx.x >= hot.slab_blocks) {
         // trailing blocks: 64 groups of 16 lanes, one hot item row each
         const int hb = blockIdx.x - hot.slab_blocks;
-        if (!vec) finish_hot_rows<4, false>(t, hot, k, fused, ad, hb);
-        else if (nc == 1) finish_hot_rows<1, true>(t, hot, k, fused, ad, hb);
-        else if (nc == 2) finish_hot_rows<2, true>(t, hot, k, fused, ad, hb);
-        else finish_hot_rows<4, true>(t, hot, k, fused, ad, hb);
+        if (!vec) finish_hot_rows<4, false>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
+        else if (nc == 1) finish_hot_rows<1, true>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
+        else if (nc == 2) finish_hot_rows<2, true>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
+        else finish_hot_rows<4, true>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
         return;
     }
     __shared__ double part[16][64];
@@ -736,13 +761,14 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
     const int EDP = t.E * DP, slab_len = 2 * EDP + EMAX + kLossSlots;
     const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + col;
+    const bool pure = flags & INVPREF_PURE_MF;  // no small tables to finish: only the loss sums are folded
     // parameter / moment of the output this thread will finish (sub == 0 threads), requested up front
     float pre_p = 0.f, pre_m = 0.f, pre_v = 0.f;
     if (sub == 0 && idx < 2 * EDP + EMAX) {
         const bool isB = idx >= 2 * EDP, isW = !isB && idx >= EDP;
         const int r = isB ? 0 : (isW ? idx - EDP : idx);
         const int e = isB ? idx - 2 * EDP : r / DP, d = isB ? 0 : r - e * DP;
-        if (e < t.E && d < t.D) {
+        if (e < t.E && d < t.D && !pure) {
             const int off = isB ? e : e * t.D + d;
             pre_p = isB ? t.b[off] : (isW ? t.W[off] : t.Ev[off]);
             if (fused) {
@@ -761,7 +787,7 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
     part[sub][col] = acc;
     if (threadIdx.x < 2) sreg[threadIdx.x] = 0.0;
     __syncthreads();
-    const bool dense = (flags & INVPREF_DENSE_REG) && !(flags & INVPREF_REG_ONLY_EMBED);
+    const bool dense = (flags & INVPREF_DENSE_REG) && !(flags & INVPREF_REG_ONLY_EMBED) && !pure;
     const bool last_block = (int)blockIdx.x == hot.slab_blocks - 1;
     if (sub == 0 && idx < slab_len) {
         double v = 0.0;
@@ -770,7 +796,7 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
             const bool isW = idx >= EDP;
             const int r = isW ? idx - EDP : idx;
             const int e = r / DP, d = r - e * DP;
-            if (d < t.D) {
+            if (d < t.D && !pure) {
                 const int off = e * t.D + d;
                 float gv = (float)v;
                 float pv = pre_p;
@@ -786,7 +812,7 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
             }
         } else if (idx < 2 * EDP + EMAX) {
             const int e = idx - 2 * EDP;
-            if (e < t.E) {
+            if (e < t.E && !pure) {
                 float gv = (float)v, pv = pre_p;
                 if (dense) gv += 2.f * l2 / (float)t.E * pv + l1 / (float)t.E * c_sign(pv);
                 if (!fused) {
@@ -846,10 +872,12 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
                 void *workspace, size_t workspace_bytes, hipStream_t st, int fused, const InvPrefTables *grads,
                 const InvPrefTables *new_tables, const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
                 const AdamScalars &ad, const InvPrefAdamSchedule *sched = nullptr) {
-    int rc = check_tables(tables);
+    const bool pure = flags & INVPREF_PURE_MF;
+    int rc = check_tables(tables, pure);
     if (sched && (!sched->state || !sched->table || sched->n <= 0)) return INVPREF_EINVAL;
     if (rc) return rc;
-    if (!plan || !coefs || !losses6 || !workspace || !envs || !scores || batch_norm <= 0) return INVPREF_EINVAL;
+    if (!plan || !coefs || !losses6 || !workspace || (!envs && !pure) || !scores || batch_norm <= 0) return INVPREF_EINVAL;
+    if (pure && (flags & (INVPREF_REWEIGHT_CLS | INVPREF_REG_ENV_EMBED))) return INVPREF_EINVAL;
     if (plan->n_rounds < 0 || plan->rounds_per_task <= 0 || plan->n_item_rounds < 0 ||
         plan->n_item_rounds > plan->n_rounds || plan->n_item_rounds % plan->rounds_per_task != 0 || !plan->desc ||
         !plan->other_user || !plan->pos_user || !plan->other_item || !plan->pos_item)
@@ -859,12 +887,14 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     bool vec = vec_ok(tables);
     RowsArgs a{};
     if (!fused) {
-        if ((rc = check_tables(grads))) return rc;
+        if ((rc = check_tables(grads, pure))) return rc;
         vec = vec && vec_ok(grads);
         a.g[0] = grads->embed_user_invariant; a.g[1] = grads->embed_item_invariant;
         a.g[2] = grads->embed_user_env_aware; a.g[3] = grads->embed_item_env_aware;
     } else {
-        if ((rc = check_tables(new_tables)) || (rc = check_tables(exp_avg)) || (rc = check_tables(exp_avg_sq))) return rc;
+        if ((rc = check_tables(new_tables, pure)) || (rc = check_tables(exp_avg, pure)) ||
+            (rc = check_tables(exp_avg_sq, pure)))
+            return rc;
         vec = vec && vec_ok(new_tables) && vec_ok(exp_avg) && vec_ok(exp_avg_sq);
         const InvPrefTables *src[3] = {new_tables, exp_avg, exp_avg_sq};
         float **dst[3] = {a.np, a.m, a.v};
@@ -970,7 +1000,7 @@ int invpref_set_profile_event(void *event) {
 }
 
 size_t invpref_rows_workspace_bytes(const InvPrefTables *tables, const InvPrefRowPlan *plan) {
-    if (check_tables(tables) || !plan || plan->n_hot < 0) return 0;
+    if (check_tables(tables, tables && !tables->embed_user_env_aware) || !plan || plan->n_hot < 0) return 0;
     const size_t slab_len = 2 * (size_t)tables->env_num * 256 + 16 + kLossSlots;
     return sizeof(float) * (slab_len * kReplicas + (size_t)plan->n_hot * 2 * 256);
 }

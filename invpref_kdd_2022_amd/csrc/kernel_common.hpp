@@ -84,11 +84,11 @@ __device__ __forceinline__ float dot3(const float4 (&a)[NC], const float4 (&b)[N
     return row16_sum(s);
 }
 
-// stage a small [E][D] table into LDS as [E][DP] zero padded
+// stage a small [E][D] table into LDS as [E][DP] zero padded (an absent table, INVPREF_PURE_MF, stages zeros)
 __device__ __forceinline__ void stage_table(float *dst, const float *__restrict__ src, int E, int D, int DP) {
     for (int i = threadIdx.x; i < E * DP; i += blockDim.x) {
         const int e = i / DP, d = i - e * DP;
-        dst[i] = (d < D) ? src[e * D + d] : 0.f;
+        dst[i] = (src && d < D) ? src[e * D + d] : 0.f;
     }
 }
 
@@ -125,12 +125,14 @@ __device__ __forceinline__ void adam1f(float &p, float g, float &m, float &v, co
 }
 
 // host-side helpers
-inline int check_tables(const InvPrefTables *t) {
+inline int check_tables(const InvPrefTables *t, bool pure_mf = false) {
     if (!t) return INVPREF_EINVAL;
     if (t->user_num <= 0 || t->item_num <= 0 || t->env_num <= 0 || t->factor_num <= 0) return INVPREF_EINVAL;
     if (t->factor_num > INVPREF_MAX_FACTORS || t->env_num > INVPREF_MAX_ENVS) return INVPREF_EUNSUPPORTED;
-    if (!t->embed_user_invariant || !t->embed_item_invariant || !t->embed_user_env_aware || !t->embed_item_env_aware ||
-        !t->embed_env || !t->classifier_weight || !t->classifier_bias)
+    if (!t->embed_user_invariant || !t->embed_item_invariant) return INVPREF_EINVAL;
+    if (pure_mf) return t->env_num == 1 ? 0 : INVPREF_EINVAL;  // INVPREF_PURE_MF: the other five tables are ignored
+    if (!t->embed_user_env_aware || !t->embed_item_env_aware || !t->embed_env || !t->classifier_weight ||
+        !t->classifier_bias)
         return INVPREF_EINVAL;
     return 0;
 }
@@ -146,7 +148,7 @@ inline DevGrads dev_grads(const InvPrefTables *t) {
 inline bool vec_ok(const InvPrefTables *t) {
     auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     return (t->factor_num % 4 == 0) && al(t->embed_user_invariant) && al(t->embed_item_invariant) &&
-           al(t->embed_user_env_aware) && al(t->embed_item_env_aware);
+           al(t->embed_user_env_aware) && al(t->embed_item_env_aware);  // (null pointers count as aligned)
 }
 inline int nc_of(int D) { return D <= 64 ? 1 : (D <= 128 ? 2 : 4); }
 inline int emax_of(int E) { return E <= 4 ? 4 : (E <= 8 ? 8 : 16); }

@@ -191,17 +191,22 @@ def mstep_rows_grad(params, grads, dplan, envs, scores, sample_weights, batch_no
 
 
 def mstep_rows_adam(params, new_params, exp_avg, exp_avg_sq, dplan, envs, scores, sample_weights, batch_norm: int,
-                     coefs, flags: int, losses6: torch.Tensor, step: int, lr: float, workspace: Workspace,
-                     beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:
-    """M-step + Adam in one pass: reads params, writes new_params, updates the moments in place."""
-    t, tn = make_tables(params), make_tables(new_params)
-    tm, tv = make_tables(exp_avg), make_tables(exp_avg_sq)
+                    coefs, flags: int, losses6: torch.Tensor, step: int, lr: float, workspace: Workspace,
+                    beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, pure: bool = False) -> None:
+    """M-step + Adam in one pass: reads params, writes new_params, updates the moments in place.
+    pure=True: PureMF step (INVPREF_PURE_MF): the table lists hold [user table, item table] only, envs /
+    sample_weights may be None."""
+    mk = _capi.make_pure_tables if pure else make_tables
+    t, tn = mk(params), mk(new_params)
+    tm, tv = mk(exp_avg), mk(exp_avg_sq)
     _capi._req(scores, torch.float32, 'scores')
     _capi._req(sample_weights, torch.float32, 'sample_weights')
+    if pure:
+        flags |= _capi.PURE_MF
     cf = Coefs(*[float(c) for c in coefs[:6]])
     ws = workspace.get_zeroed(lib().invpref_rows_workspace_bytes(C.byref(t), C.byref(dplan.struct)))
     check(lib().invpref_mstep_rows_adam_hip(C.byref(t), C.byref(tn), C.byref(tm), C.byref(tv), C.byref(dplan.struct),
-                                             ptr(_ids(envs, 'envs')), ptr(scores), ptr(sample_weights),
-                                             int(batch_norm), C.byref(cf), flags, ptr(losses6), int(step), float(lr),
-                                             float(beta1), float(beta2), float(eps), ptr(ws), ws.numel(),
-                                             stream_ptr()), 'invpref_mstep_rows_adam_hip')
+                                             ptr(None if envs is None else _ids(envs, 'envs')), ptr(scores),
+                                             ptr(sample_weights), int(batch_norm), C.byref(cf), flags, ptr(losses6),
+                                             int(step), float(lr), float(beta1), float(beta2), float(eps), ptr(ws),
+                                             ws.numel(), stream_ptr()), 'invpref_mstep_rows_adam_hip')

@@ -43,8 +43,9 @@ def transfer_loss_dict_to_line_str(d: dict) -> str:
 class FlatState:
     """params / grads / exp_avg / exp_avg_sq as four flat buffers + per-table views."""
 
-    def __init__(self, model, device):
-        tabs = model.tables()
+    def __init__(self, tabs, device):
+        """tabs: the model's parameter tensors (InvPref: the seven of state_dict order; PureMF: two)."""
+        tabs = list(tabs)
         self.shapes = [tuple(p.shape) for p in tabs]
         self.offsets = []
         off = 0
@@ -88,6 +89,8 @@ class FlatState:
 
 class _InvPrefTrainManager:
     implicit = True
+    _pure = False                       # PureMF managers (baseline.py) reuse the epoch engine below
+    _make_tables = staticmethod(_capi.make_tables)
 
     def __init__(
             self, model, evaluator, device: torch.device, training_data: torch.Tensor, batch_size: int,
@@ -148,7 +151,7 @@ class _InvPrefTrainManager:
         self._eps_rows_cnt = math.factorial(self.envs_num)
 
         self.model.to(self.device)
-        self.state = FlatState(model, self.device)
+        self.state = FlatState(model.tables(), self.device)
         self.workspace = ops.Workspace(self.device)
         self._flags = ops.flags_of(self.implicit, use_recommend_re_weight, use_class_re_weight,
                                    model.reg_only_embed, model.reg_env_embed, dense_reg=(self.rank == 0))
@@ -212,9 +215,11 @@ class _InvPrefTrainManager:
     def _raw_setup(self):
         st = self.state
         L = _capi.lib()
-        self._raw_t = _capi.make_tables(st.p_views)
-        self._raw_g = _capi.make_tables(st.g_views)
-        self._raw_ws = self.workspace.get(L.invpref_mstep_workspace_bytes(C.byref(self._raw_t), self.batch_size))
+        mk = self._make_tables
+        self._raw_t = mk(st.p_views)
+        self._raw_g = mk(st.g_views)
+        if not self._pure:
+            self._raw_ws = self.workspace.get(L.invpref_mstep_workspace_bytes(C.byref(self._raw_t), self.batch_size))
         # one graph replays up to _graph_epochs epochs (fewer, longer launches: the GPU idles ~60 us
         # between two replays); each epoch of a replay writes its own [batch_num, 6] slice of the loss buffer
         self._graph_epochs = max(1, min(8, 2048 // self.batch_num))
@@ -241,8 +246,8 @@ class _InvPrefTrainManager:
             self._raw_ows = self.workspace.get_zeroed(
                 max(L.invpref_rows_workspace_bytes(C.byref(self._raw_t), C.byref(dp.struct)) for dp in self._plans))
         # ctypes views of both parameter buffers / moments for the fused pass
-        self._raw_tabs = {id(st.p_views): _capi.make_tables(st.p_views), id(st.p_views_alt): _capi.make_tables(st.p_views_alt)}
-        self._raw_m, self._raw_v = _capi.make_tables(st.m_views), _capi.make_tables(st.v_views)
+        self._raw_tabs = {id(st.p_views): mk(st.p_views), id(st.p_views_alt): mk(st.p_views_alt)}
+        self._raw_m, self._raw_v = mk(st.m_views), mk(st.v_views)
 
     def _raw_step(self, k: int, alpha: float, stream, mid_event=None, sched=False):
         st = self.state
@@ -250,7 +255,7 @@ class _InvPrefTrainManager:
             self._sched_synced = False
         lo, n, bn = self._raw_batches[k]
         pu, pi, pe, py, pw = self._raw_ptrs
-        cf = _capi.Coefs(self.invariant_coe, self.env_aware_coe, self.env_coe, self.L2_coe, self.L1_coe, alpha)
+        cf = _capi.Coefs(*self._coefs(alpha))
         multi = self.world_size > 1 or self._force_sharded_path
         if multi:
             st.losses6.zero_()

@@ -146,7 +146,7 @@ def test_row_sharded_training_matches_single_process(tmp_path):
     # sharded parameters == single-process parameters up to fp32 re-association of the shard sums
     from invpref_kdd_2022_amd.models import InvPrefExplicit
     from invpref_kdd_2022_amd.train import FlatState
-    fs = FlatState(InvPrefExplicit(U, I, E, D), torch.device('cpu'))
+    fs = FlatState(InvPrefExplicit(U, I, E, D).tables(), torch.device('cpu'))
     for arr, off, shp in zip(tr.tab.arrs, fs.offsets, fs.shapes):
         got = r[0]['param'][off:off + arr.size].reshape(shp)
         assert np.abs(got - arr).max() < 0.05 * LR

@@ -1,0 +1,113 @@
+"""GPU: PureMF baselines through the drop-in modules / managers of
+invpref_kdd_2022_amd.baseline against the goldens recorded from the reference (g7) and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from invpref_kdd_2022_amd import ops, plan as planlib
+from invpref_kdd_2022_amd.baseline import (PURE_LOSS_KEYS, BasicExplicitTrainManager, BasicImplicitTrainManager,
+                                           BasicUniformImplicitTrainManager, PureExplicitMatrixFactorization,
+                                           PureMatrixFactorization)
+from oracle import oracle as O
+from pure_mf_fixture import pure_mf_inputs
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), 'golden')
+DEV = torch.device('cuda:0')
+
+
+class StubEvaluator:
+    def evaluate(self):
+        return {'stub': 0.0}
+
+
+def _model(kind, init, U, I, D):
+    m = (PureMatrixFactorization if kind == 'implicit' else PureExplicitMatrixFactorization)(U, I, D)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in init.items()})
+    return m
+
+
+@pytest.mark.parametrize('kind', ['implicit', 'explicit'])
+def test_fused_step_vs_reference_and_oracle(kind):
+    """One fused PureMF step through the C ABI (INVPREF_PURE_MF, absent tables = NULL): loss terms vs the
+    reference (1e-5), parameters after the step vs oracle gradient + oracle Adam."""
+    z = np.load(os.path.join(G, f'g7_pure_mf_{kind}.npz'))
+    (U, I, D, n, bs, epochs), data, init, cfg = pure_mf_inputs(kind)
+    P = [torch.from_numpy(init[k]).to(DEV) for k in ('user_emb.weight', 'item_emb.weight')]
+    P2, M, V = ([torch.zeros_like(p) for p in P] for _ in range(3))
+    dp = planlib.upload(planlib.build_row_plan(data[:bs, 0], data[:bs, 1], data[:bs, 2], U, I), DEV)
+    y = torch.from_numpy(data[:bs, 2].astype(np.float32)).to(DEV)
+    losses = torch.zeros(6, device=DEV)
+    flags = ops.flags_of(kind == 'implicit', False, False, True, False, dense_reg=False)
+    coefs = O.pure_mf_coefs(cfg['L2_coe'], cfg['L1_coe'])
+    ops.mstep_rows_adam(P, P2, M, V, dp, None, y, None, bs, coefs, flags, losses, 1, cfg['lr'], ops.Workspace(DEV), pure=True)
+    np.testing.assert_allclose(O.pure_mf_losses(losses.cpu().numpy()), z['step_losses_f32'], rtol=1e-5)
+    tab = O.Tables(O.pure_mf_params(init['user_emb.weight'], init['item_emb.weight']))
+    grads, _ = O.mstep(tab, data[:bs, 0], data[:bs, 1], np.zeros(bs, np.int64), data[:bs, 2], None, coefs,
+                       O.flags_of(kind == 'implicit', False, False, True, False))
+    for p0, g, p2, ref_g in zip(tab.arrs[:2], grads[:2], P2, (z['step_g_user_f32'], z['step_g_item_f32'])):
+        assert np.abs(g - ref_g).max() <= 2e-6 * np.abs(ref_g).max()
+        po = p0.reshape(-1).copy()
+        O.adam(po, g.reshape(-1), np.zeros_like(po), np.zeros_like(po), 1, cfg['lr'])
+        # first Adam step moves every touched element by ~lr: compare the moves
+        assert np.abs(p2.cpu().numpy().reshape(-1) - po).max() < 0.02 * cfg['lr']
+
+
+@pytest.mark.parametrize('kind', ['implicit', 'explicit'])
+def test_manager_trajectory_vs_reference(kind):
+    z = np.load(os.path.join(G, f'g7_pure_mf_{kind}.npz'))
+    (U, I, D, n, bs, epochs), data, init, cfg = pure_mf_inputs(kind)
+    model = _model(kind, init, U, I, D)
+    cls = BasicImplicitTrainManager if kind == 'implicit' else BasicExplicitTrainManager
+    mgr = cls(model=model, evaluator=StubEvaluator(), device=DEV, training_data=torch.from_numpy(data).to(DEV),
+              batch_size=bs, epochs=epochs, evaluate_interval=10 ** 9, lr=cfg['lr'], L2_coe=cfg['L2_coe'],
+              L1_coe=cfg['L1_coe'])
+    (losses, loss_epochs), (tests, test_epochs) = mgr.train(silent=True)
+    assert loss_epochs == list(z['loss_epochs']) and test_epochs == list(z['test_epochs'])
+    assert list(losses[0].keys()) == PURE_LOSS_KEYS
+    np.testing.assert_allclose([[d[k] for k in PURE_LOSS_KEYS] for d in losses], z['traj'], rtol=2e-5)
+    sd = model.state_dict()
+    assert set(sd.keys()) == {'user_emb.weight', 'item_emb.weight'}
+    for k in sd:
+        assert np.abs(sd[k].cpu().numpy() - z['final_' + k]).max() < 1e-3, k
+    # epoch by epoch (one read-back each, HIP graphs warm) continues the same trajectory as the oracle
+    tr = O.pure_mf_trainer(init['user_emb.weight'], init['item_emb.weight'], data, implicit=(kind == 'implicit'),
+                           batch_size=bs, lr=cfg['lr'], L2_coe=cfg['L2_coe'], L1_coe=cfg['L1_coe'])
+    for _ in range(epochs):
+        tr.train_a_epoch()
+    want = O.pure_mf_losses(tr.train_a_epoch())
+    got = mgr.train_a_epoch()
+    np.testing.assert_allclose([got[k] for k in PURE_LOSS_KEYS], want, rtol=5e-5)
+
+
+def test_train_a_batch_and_unfused_surface():
+    """train_a_batch on caller-supplied tensors (plan built on the fly) equals the first step of the
+    reference; the module's unfused surface (forward / get_L*_reg / autograd / predict) matches g7."""
+    kind = 'implicit'
+    z = np.load(os.path.join(G, f'g7_pure_mf_{kind}.npz'))
+    (U, I, D, n, bs, epochs), data, init, cfg = pure_mf_inputs(kind)
+    model = _model(kind, init, U, I, D)
+    td = torch.from_numpy(data).to(DEV)
+    mgr = BasicUniformImplicitTrainManager(model, StubEvaluator(), DEV, td, td[:100], bs, epochs, 10 ** 9, cfg['lr'],
+                                           cfg['L2_coe'], cfg['L1_coe'])
+    assert mgr.uniform_user.shape == (100,)
+    # unfused surface first (parameters still at init)
+    u, v, y = td[:bs, 0], td[:bs, 1], td[:bs, 2].float()
+    sl = model(u, v, y)
+    l2, l1 = model.get_L2_reg(u, v), model.get_L1_reg(u, v)
+    loss = sl + l2 * cfg['L2_coe'] + l1 * cfg['L1_coe']
+    np.testing.assert_allclose([float(sl), float(l2), float(l1), float(loss)], z['step_losses_f32'], rtol=1e-5)
+    loss.backward()
+    for p, ref in ((model.user_emb.weight, z['step_g_user_f32']), (model.item_emb.weight, z['step_g_item_f32'])):
+        assert np.abs(p.grad.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+    np.testing.assert_allclose(model(u[:512], v[:512]).detach().cpu().numpy(), z['step_scores'], rtol=2e-6, atol=1e-7)
+    pr = model.predict(u[:8])
+    assert pr.shape == (8, I)
+    np.testing.assert_allclose(pr[0, int(v[0])].item(), z['step_scores'][0], rtol=2e-6)
+    # fused train_a_batch
+    d = mgr.train_a_batch(u, v, y)
+    np.testing.assert_allclose([d[k] for k in PURE_LOSS_KEYS], z['step_losses_f32'], rtol=1e-5)
+    with pytest.raises(AttributeError):
+        mgr.cluster()

@@ -10,6 +10,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libinvpref_hip.so')
 OBJDIR = os.path.join(PKG, 'build')
+INGEST_LIB = os.path.join(PKG, 'libinvpref_ingest.so')   # host-only data ingest (include/invpref_ingest.h)
+INGEST_SRC = os.path.join(CSRC, 'invpref_ingest.cpp')
 SOURCES = ['invpref_kernels.hip', 'invpref_rows.hip', 'invpref_eval.hip']
 HEADERS = ['canon_math.hpp', 'kernel_common.hpp', os.path.join('..', '..', 'include', 'invpref_hip.h')]
 # -ffp-contract=off: every fma of the canonical arithmetic is written explicitly
@@ -32,7 +34,20 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_ingest(force: bool = False, verbose: bool = False) -> str:
+    hdr = os.path.join(PKG, '..', 'include', 'invpref_ingest.h')
+    if force or not os.path.exists(INGEST_LIB) or \
+            os.path.getmtime(INGEST_LIB) < max(os.path.getmtime(INGEST_SRC), os.path.getmtime(hdr)):
+        cxx = shutil.which('g++') or _hipcc()
+        cmd = [cxx, '-O2', '-std=c++17', '-shared', '-fPIC', '-pthread', '-Wall', INGEST_SRC, '-o', INGEST_LIB]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return INGEST_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    build_ingest(force, verbose)
     if force or needs_build():
         os.makedirs(OBJDIR, exist_ok=True)
         extra = os.environ.get('INVPREF_HIPCC_EXTRA', '').split()

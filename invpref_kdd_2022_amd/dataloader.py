@@ -1,0 +1,328 @@
+"""Drop-in data loaders: ``YahooImplicitBCELossDataLoader`` /
+``YahooUniformImplicitBCELossDataLoader`` / ``ExplicitDataLoader`` / ``ExplicitUniformDataLoader``
+(reference dataloader.py:118-264, :388-500) with the same constructor signatures, attributes and
+properties, on top of the native ingest library (include/invpref_ingest.h):
+
+* the CSVs are parsed once by ``invpref_csv_read_f64`` (mmap, threads) instead of ``pd.read_csv`` PLUS a second
+  per-line python pass (utils.py:208-234);
+* the per-user item sets (train positives, ground truth, item pool: utils.py:236-251) are built as CSR arrays by
+  ``invpref_csr_sets``; the ``list``-of-``set`` attributes of the reference are lazy views over them, and
+  ``ImplicitTestManager`` takes the CSR arrays directly (``csr_for_eval``);
+* ``save_packed`` / ``from_packed`` keep the parsed arrays as one ``.npz``-free directory of ``.npy`` files that are
+  memory-mapped on load (int32 ids, int8 / fp16 scores), so a second run does not parse text at all.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import build as _build
+
+_lib = None
+
+
+class IngestError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = _build.INGEST_LIB
+        if not os.path.exists(path):
+            raise IngestError(f'{path} is missing: build it with `python -m invpref_kdd_2022_amd.build`')
+        L = C.CDLL(path)
+        L.invpref_csv_shape.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.invpref_csv_read_f64.argtypes = [C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+        L.invpref_csr_sets.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+        L.invpref_csr_sets.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def read_csv(path: str) -> np.ndarray:
+    """``pd.read_csv(path).values`` for an all-numeric file, as float64 [rows, cols]."""
+    rows, cols, hdr = C.c_int64(), C.c_int32(), C.c_int32()
+    rc = lib().invpref_csv_shape(path.encode(), C.byref(rows), C.byref(cols), C.byref(hdr))
+    if rc:
+        raise IngestError(f'{path}: cannot read (code {rc})')
+    out = np.empty((rows.value, cols.value), np.float64)
+    if out.size == 0:
+        return out
+    rc = lib().invpref_csv_read_f64(path.encode(), rows, cols, hdr, out.ctypes.data, 0)
+    if rc:
+        raise IngestError(f'{path}: not a numeric CSV with {cols.value} columns per line (code {rc})')
+    return out
+
+
+def csr_sets(users: np.ndarray, items: np.ndarray, n_users: int):
+    """(indptr int64[n_users+1], indices int64[nnz]): sorted distinct items of every user."""
+    users = np.ascontiguousarray(users, np.int64)
+    items = np.ascontiguousarray(items, np.int64)
+    indptr = np.empty(n_users + 1, np.int64)
+    indices = np.empty(max(len(users), 1), np.int64)
+    nnz = lib().invpref_csr_sets(users.ctypes.data, items.ctypes.data, len(users), n_users, indptr.ctypes.data,
+                                 indices.ctypes.data)
+    if nnz < 0:
+        raise IngestError(f'csr_sets failed (code {nnz}): a user id outside [0, {n_users})')
+    return indptr, indices[:nnz].copy()
+
+
+class CsrSets:
+    """Reads like the reference's ``list`` of ``set``s (utils.py:236-251) over a CSR pair."""
+
+    def __init__(self, indptr: np.ndarray, indices: np.ndarray):
+        self.indptr, self.indices = indptr, indices
+
+    def __len__(self):
+        return len(self.indptr) - 1
+
+    def __getitem__(self, user_id: int) -> set:
+        if user_id < 0:
+            user_id += len(self)
+        if not 0 <= user_id < len(self):
+            raise IndexError('list index out of range')
+        return set(self.indices[self.indptr[user_id]:self.indptr[user_id + 1]].tolist())
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def rows(self, users) -> tuple:
+        """CSR restricted to the given users, int32 (the layout ``invpref_eval_topk_hip`` takes)."""
+        users = np.asarray(users, np.int64)
+        lens = self.indptr[users + 1] - self.indptr[users]
+        ptr = np.zeros(len(users) + 1, np.int32)
+        np.cumsum(lens, out=ptr[1:])
+        idx = np.concatenate([self.indices[self.indptr[u]:self.indptr[u + 1]] for u in users]) if len(users) \
+            else np.zeros(0, np.int64)
+        return ptr, idx.astype(np.int32)
+
+
+def _sorted_unique(a: np.ndarray) -> list:
+    return np.unique(a).tolist()
+
+
+class BaseImplicitBCELossDataLoader:  # dataloader.py:60-115 (interface only)
+    def __init__(self, dataset_path: str):
+        self.dataset_path = dataset_path
+
+
+class YahooImplicitBCELossDataLoader(BaseImplicitBCELossDataLoader):
+    """reference dataloader.py:118-243"""
+
+    def __init__(self, dataset_path: str, device: torch.device, has_item_pool_file: bool = False):
+        super().__init__(dataset_path)
+        self.train_data_path = self.dataset_path + '/train.csv'
+        self.test_data_path = self.dataset_path + '/test.csv'
+        self.has_item_pool = has_item_pool_file
+        train = read_csv(self.train_data_path)
+        test = read_csv(self.test_data_path)
+        pool = read_csv(self.dataset_path + '/test_item_pool.csv') if has_item_pool_file else None
+        self._init_from_arrays(train, test, pool, device)
+
+    def _init_from_arrays(self, train, test, pool, device):
+        self._train_data = train.astype(np.int64)   # dataloader.py:127
+        self._test_data = test.astype(np.int64)
+        tu, ti = self._train_data[:, 0], self._train_data[:, 1]
+        self.user_list, self.item_list = _sorted_unique(tu), _sorted_unique(ti)
+        self.test_user_list = _sorted_unique(self._test_data[:, 0])
+        self.test_item_list = _sorted_unique(self._test_data[:, 1])
+        # the reference keeps the raw text values (score as float): dataloader.py:146-155
+        self._train_pairs_values = train
+        pos = train[:, 2] > 0
+        self.user_positive_interaction = CsrSets(*csr_sets(tu[pos], ti[pos], int(tu[pos].max()) + 1 if pos.any() else 0))
+        self.ground_truth = CsrSets(*csr_sets(self._test_data[:, 0], self._test_data[:, 1],
+                                              int(self._test_data[:, 0].max()) + 1))
+        if self.has_item_pool:
+            self.item_pool_path = self.dataset_path + '/test_item_pool.csv'
+            p = pool.astype(np.int64)
+            self.item_pool = CsrSets(*csr_sets(p[:, 0], p[:, 1], int(p[:, 0].max()) + 1))
+        self._user_num = max(self.user_list + self.test_user_list) + 1
+        self._item_num = max(self.item_list + self.test_item_list) + 1
+        self.test_users_tensor = torch.LongTensor(self.test_user_list).to(device)
+        self.sorted_ground_truth = [self.get_user_ground_truth(u) for u in self.test_user_list]
+
+    # ---- packed form: parsed once, memory-mapped afterwards
+    def save_packed(self, directory: str) -> None:
+        os.makedirs(directory, exist_ok=True)
+        t = self._train_pairs_values
+        np.save(os.path.join(directory, 'train_ids.npy'), self._train_data[:, :2].astype(np.int32))
+        sc = t[:, 2]
+        np.save(os.path.join(directory, 'train_scores.npy'),
+                sc.astype(np.int8) if np.array_equal(sc, sc.astype(np.int8)) else sc.astype(np.float16 if np.array_equal(sc, sc.astype(np.float16)) else np.float64))
+        np.save(os.path.join(directory, 'test_ids.npy'), self._test_data.astype(np.int32))
+        if self.has_item_pool:
+            np.save(os.path.join(directory, 'pool_ptr.npy'), self.item_pool.indptr)
+            np.save(os.path.join(directory, 'pool_idx.npy'), self.item_pool.indices.astype(np.int32))
+        with open(os.path.join(directory, 'meta.json'), 'w') as f:
+            json.dump({'format': 1, 'kind': 'implicit', 'has_item_pool': bool(self.has_item_pool),
+                       'dataset_path': self.dataset_path}, f)
+
+    @classmethod
+    def from_packed(cls, directory: str, device: torch.device):
+        with open(os.path.join(directory, 'meta.json')) as f:
+            meta = json.load(f)
+        if meta.get('format') != 1 or meta.get('kind') != 'implicit':
+            raise IngestError(f'{directory}: not a packed implicit dataset')
+        ld = lambda n: np.load(os.path.join(directory, n), mmap_mode='r')  # noqa: E731
+        ids, sc = ld('train_ids.npy'), ld('train_scores.npy')
+        train = np.concatenate([ids.astype(np.float64), sc.astype(np.float64)[:, None]], axis=1)
+        self = cls.__new__(cls)
+        BaseImplicitBCELossDataLoader.__init__(self, meta['dataset_path'])
+        self.train_data_path = self.dataset_path + '/train.csv'
+        self.test_data_path = self.dataset_path + '/test.csv'
+        self.has_item_pool = meta['has_item_pool']
+        pool = None
+        if self.has_item_pool:
+            ptr, idx = ld('pool_ptr.npy'), ld('pool_idx.npy')
+            users = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+            pool = np.stack([users, idx], axis=1).astype(np.float64)
+        self._init_from_arrays(train, ld('test_ids.npy').astype(np.float64), pool, device)
+        return self
+
+    def csr_for_eval(self):
+        """CSR arrays of the sorted test users for ImplicitTestManager (no python sets involved)."""
+        users = np.asarray(self.test_user_list, np.int64)
+        n_pos = len(self.user_positive_interaction)
+        mask = CsrSets(np.concatenate([self.user_positive_interaction.indptr,
+                                       np.full(max(0, self._user_num - n_pos), self.user_positive_interaction.indptr[-1])]),
+                       self.user_positive_interaction.indices)
+        out = dict(mask=mask.rows(users), truth=self.ground_truth.rows(users))
+        if self.has_item_pool:
+            out['highlight'] = self.item_pool.rows(users)
+        return out
+
+    def user_mask_items(self, user_id: int) -> set:
+        return self.user_positive_interaction[user_id]
+
+    def user_highlight_items(self, user_id: int) -> set:
+        if not self.has_item_pool:
+            raise NotImplementedError('Not has item pool!')
+        return self.item_pool[user_id]
+
+    @property
+    def all_test_users_by_sorted_tensor(self) -> torch.Tensor:
+        return self.test_users_tensor
+
+    @property
+    def all_test_users_by_sorted_list(self) -> list:
+        return self.test_user_list
+
+    def get_user_ground_truth(self, user_id: int) -> set:
+        return self.ground_truth[user_id]
+
+    @property
+    def get_sorted_all_test_users_ground_truth(self) -> list:
+        return self.sorted_ground_truth
+
+    @property
+    def train_data_len(self) -> int:
+        return self._train_data.shape[0]
+
+    @property
+    def test_data_len(self) -> int:
+        return self._test_data.shape[0]
+
+    @property
+    def user_num(self) -> int:
+        return self._user_num
+
+    @property
+    def item_num(self) -> int:
+        return self._item_num
+
+    @property
+    def test_data_np(self) -> np.ndarray:
+        return self._test_data
+
+    @property
+    def train_data_np(self) -> np.ndarray:
+        return self._train_data
+
+    @property
+    def train_data_df(self):
+        import pandas as pd
+        return pd.DataFrame(self._train_data, columns=['user_id', 'item_id', 'score'])
+
+    @property
+    def test_data_df(self):
+        import pandas as pd
+        return pd.DataFrame(self._test_data, columns=['user_id', 'item_id'])
+
+    train_df = train_data_df
+    test_df = test_data_df
+
+
+class YahooUniformImplicitBCELossDataLoader(YahooImplicitBCELossDataLoader):
+    """reference dataloader.py:246-263"""
+
+    def __init__(self, dataset_path: str, device: torch.device, has_item_pool_file: bool = False):
+        super().__init__(dataset_path, device, has_item_pool_file)
+        self.uniform_data_path = self.dataset_path + '/uniform_train.csv'
+        self._uniform_data = read_csv(self.uniform_data_path).astype(np.int64)
+
+    @property
+    def uniform_data_np(self) -> np.ndarray:
+        return self._uniform_data
+
+    @property
+    def uniform_data_len(self) -> int:
+        return self._uniform_data.shape[0]
+
+
+class ExplicitDataLoader:
+    """reference dataloader.py:388-484"""
+
+    def __init__(self, dataset_path: str, device: torch.device):
+        self.dataset_path = dataset_path
+        self.device = device
+        self.train_data_path = self.dataset_path + '/train.csv'
+        self.test_data_path = self.dataset_path + '/test.csv'
+        self._train_data = read_csv(self.train_data_path).astype(np.int64)
+        self._test_data = read_csv(self.test_data_path).astype(np.int64)
+        self._train_data_tensor = torch.LongTensor(self._train_data).to(self.device)
+        self._test_data_tensor = torch.LongTensor(self._test_data).to(self.device)
+        self.user_positive_interaction = []
+        self._user_num = int(np.max(self._train_data[:, 0])) + 1     # dataloader.py:404-405: train ids only
+        self._item_num = int(np.max(self._train_data[:, 1])) + 1
+        self._train_pairs = self._train_data[:, 0:2].astype(np.int64).reshape(-1, 2)
+        self._test_pairs = self._test_data[:, 0:2].astype(np.int64).reshape(-1, 2)
+        self._train_pairs_tensor = torch.LongTensor(self._train_pairs).to(self.device)
+        self._test_pairs_tensor = torch.LongTensor(self._test_pairs).to(self.device)
+        self._train_scores = self._train_data[:, 2].astype(np.float64).reshape(-1)
+        self._test_scores = self._test_data[:, 2].astype(np.float64).reshape(-1)
+        self._train_scores_tensor = torch.Tensor(self._train_scores).to(self.device)
+        self._test_scores_tensor = torch.Tensor(self._test_scores).to(self.device)
+
+    all_test_pairs_np = property(lambda self: self._test_pairs)
+    all_test_scores_np = property(lambda self: self._test_scores)
+    test_data_np = property(lambda self: self._test_data)
+    all_train_pairs_np = property(lambda self: self._train_pairs)
+    all_train_scores_np = property(lambda self: self._train_scores)
+    train_data_np = property(lambda self: self._train_data)
+    train_data_len = property(lambda self: self._train_data.shape[0])
+    test_data_len = property(lambda self: self._test_data.shape[0])
+    user_num = property(lambda self: self._user_num)
+    item_num = property(lambda self: self._item_num)
+    all_test_pairs_tensor = property(lambda self: self._test_pairs_tensor)
+    all_test_scores_tensor = property(lambda self: self._test_scores_tensor)
+    test_data_tensor = property(lambda self: self._test_data_tensor)
+    all_train_pairs_tensor = property(lambda self: self._train_pairs_tensor)
+    all_train_scores_tensor = property(lambda self: self._train_scores_tensor)
+    train_data_tensor = property(lambda self: self._train_data_tensor)
+
+
+class ExplicitUniformDataLoader(ExplicitDataLoader):
+    """reference dataloader.py:486-500"""
+
+    def __init__(self, dataset_path: str, device: torch.device):
+        super().__init__(dataset_path, device)
+        self.uniform_data_path = self.dataset_path + '/uniform_train.csv'
+        self._uniform_data = read_csv(self.uniform_data_path).astype(np.int64)
+
+    uniform_data_np = property(lambda self: self._uniform_data)
+    uniform_data_len = property(lambda self: self._uniform_data.shape[0])

@@ -58,19 +58,28 @@ class ImplicitTestManager:
     def _prepare(self, device):
         dl = self.data_loader
         users = list(dl.all_test_users_by_sorted_list)
-        truth = dl.get_sorted_all_test_users_ground_truth
-        mp, mi = _csr([dl.user_mask_items(u) for u in users])
-        tp, ti = _csr(truth)
+        if hasattr(dl, 'csr_for_eval'):  # this package's loaders hand over CSR arrays (dataloader.py): no sets walked
+            ev = dl.csr_for_eval()
+            (mp, mi), (tp, ti) = ev['mask'], ev['truth']
+            truth_len = np.diff(tp)
+            if self.use_item_pool:
+                hp, hi = ev['highlight']
+        else:                            # any loader with the reference's interface (python sets)
+            truth = dl.get_sorted_all_test_users_ground_truth
+            mp, mi = _csr([dl.user_mask_items(u) for u in users])
+            tp, ti = _csr(truth)
+            truth_len = [len(t) for t in truth]
+            if self.use_item_pool:
+                hp, hi = _csr([dl.user_highlight_items(u) for u in users])
         arrs = dict(mask_ptr=mp, mask_items=mi, truth_ptr=tp, truth_items=ti)
         if self.use_item_pool:
-            hp, hi = _csr([dl.user_highlight_items(u) for u in users])
             arrs.update(hl_ptr=hp, hl_items=hi)
         self._dev = {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in arrs.items()}
         for k in ('mask_items', 'truth_items', 'hl_items'):  # a zero-length tensor has no valid pointer
             if k in self._dev and self._dev[k].numel() == 0:
                 self._dev[k] = torch.zeros(1, dtype=torch.int32, device=device)
         self._users = torch.as_tensor(np.asarray(users, np.int64)).to(device)
-        self._truth_len = np.array([len(t) for t in truth], np.float64)
+        self._truth_len = np.asarray(truth_len, np.float64)
 
     def topk(self, lo: int, hi: int):
         """(items int32[n,k], hits fp32[n,k]) for test users [lo, hi) of the sorted list."""

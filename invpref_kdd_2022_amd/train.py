@@ -37,7 +37,7 @@ _ALIGN = 64  # floats; every table starts on a 256-byte boundary of the flat buf
 
 
 def transfer_loss_dict_to_line_str(d: dict) -> str:
-    return ' '.join(f'{k}: {v}' for k, v in d.items())
+    return ', '.join(f'{k}: {v}' for k, v in d.items())  # utils.py:254-260
 
 
 class FlatState:

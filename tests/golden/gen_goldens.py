@@ -16,6 +16,7 @@ What each fixture pins:
   g5    MIND-shaped single step (E=16, D=256, B=262144)
   g6    evaluate.py metrics on a seeded model / loader stub   -> §8 f1
   g7    PureMF baselines (Basic*TrainManager)                 -> §8 f2
+  g8    data loaders on a small seeded CSV data set           -> §8 f3
 """
 import sys
 import types
@@ -393,8 +394,87 @@ def gen_g7():
         print('g7', kind, out['traj'][0], out['traj'][-1])
 
 
+def _sets_to_csr(sets):
+    ptr = np.zeros(len(sets) + 1, np.int64)
+    idx = []
+    for i, s in enumerate(sets):
+        a = sorted(s)
+        idx.extend(a)
+        ptr[i + 1] = ptr[i] + len(a)
+    return ptr, np.array(idx, np.int64)
+
+
+def gen_g8():
+    """Data loaders: a small seeded CSV data set (written here, committed as a fixture) read by
+    the reference's own loaders; what they expose is stored as arrays."""
+    import contextlib, io
+    import dataloader as ref_dl
+    rs = np.random.RandomState(808)
+    U, I = 60, 40
+    root = os.path.join(OUT, 'ds_small')
+    for kind in ('implicit', 'explicit'):
+        d = os.path.join(root, kind)
+        os.makedirs(d, exist_ok=True)
+        n = 900
+        users, items = rs.randint(0, U - 3, n), rs.randint(0, I - 2, n)   # the top ids only appear in test
+        scores = (rs.random_sample(n) < 0.45).astype(int) if kind == 'implicit' else rs.randint(1, 6, n)
+        with open(os.path.join(d, 'train.csv'), 'w') as f:
+            f.write('user_id,item_id,score\n')
+            f.writelines(f'{u},{i},{s}\n' for u, i, s in zip(users, items, scores))
+        tu = np.sort(rs.choice(U, 45, replace=False))
+        with open(os.path.join(d, 'test.csv'), 'w') as f:
+            if kind == 'implicit':
+                f.write('user_id,item_id\n')
+                for u in tu:
+                    for i in np.sort(rs.choice(I, rs.randint(1, 6), replace=False)):
+                        f.write(f'{u},{i}\n')
+            else:
+                f.write('user_id,item_id,score\n')
+                for u in tu:
+                    for i in np.sort(rs.choice(I - 2, rs.randint(1, 6), replace=False)):
+                        f.write(f'{u},{i},{rs.randint(1, 6)}\n')
+        with open(os.path.join(d, 'uniform_train.csv'), 'w') as f:
+            f.write('user_id,item_id,score\n')
+            f.writelines(f'{rs.randint(0, U - 3)},{rs.randint(0, I - 2)},{rs.randint(0, 2) if kind == "implicit" else rs.randint(1, 6)}\n'
+                         for _ in range(50))
+        if kind == 'implicit':
+            with open(os.path.join(d, 'test_item_pool.csv'), 'w') as f:
+                f.write('user_id,item_id\n')
+                for u in tu:
+                    for i in np.sort(rs.choice(I, rs.randint(8, 20), replace=False)):
+                        f.write(f'{u},{i}\n')
+        out = {}
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            if kind == 'implicit':
+                ld = ref_dl.YahooUniformImplicitBCELossDataLoader(d, CPU, has_item_pool_file=True)
+            else:
+                ld = ref_dl.ExplicitUniformDataLoader(d, CPU)
+        out['train_data_np'], out['test_data_np'] = ld.train_data_np, ld.test_data_np
+        out['uniform_data_np'] = ld.uniform_data_np
+        out['dims'] = np.array([ld.user_num, ld.item_num, ld.train_data_len, ld.test_data_len, ld.uniform_data_len])
+        if kind == 'implicit':
+            out['test_user_list'] = np.array(ld.all_test_users_by_sorted_list)
+            out['test_users_tensor'] = ld.all_test_users_by_sorted_tensor.numpy()
+            out['user_list'], out['item_list'] = np.array(ld.user_list), np.array(ld.item_list)
+            out['test_item_list'] = np.array(ld.test_item_list)
+            out['pos_ptr'], out['pos_idx'] = _sets_to_csr(ld.user_positive_interaction)
+            out['truth_ptr'], out['truth_idx'] = _sets_to_csr(ld.ground_truth)
+            out['pool_ptr'], out['pool_idx'] = _sets_to_csr(ld.item_pool)
+            out['sorted_truth_ptr'], out['sorted_truth_idx'] = _sets_to_csr(ld.get_sorted_all_test_users_ground_truth)
+            out['mask_of_test_users_ptr'], out['mask_of_test_users_idx'] = _sets_to_csr(
+                [ld.user_mask_items(u) if u < len(ld.user_positive_interaction) else set() for u in ld.all_test_users_by_sorted_list])
+        else:
+            for k in ('all_test_pairs_np', 'all_test_scores_np', 'all_train_pairs_np', 'all_train_scores_np'):
+                out[k] = getattr(ld, k)
+            for k in ('all_test_pairs_tensor', 'all_test_scores_tensor', 'test_data_tensor', 'all_train_pairs_tensor',
+                      'all_train_scores_tensor', 'train_data_tensor'):
+                out[k] = getattr(ld, k).numpy()
+        np.savez_compressed(os.path.join(OUT, f'g8_loader_{kind}.npz'), **out)
+        print('g8', kind, out['dims'])
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
     torch.manual_seed(0)
     for name in which:
         globals()['gen_' + name]()

@@ -111,3 +111,32 @@ def test_train_a_batch_and_unfused_surface():
     np.testing.assert_allclose([d[k] for k in PURE_LOSS_KEYS], z['step_losses_f32'], rtol=1e-5)
     with pytest.raises(AttributeError):
         mgr.cluster()
+
+
+def test_loader_to_evaluator_hand_over():
+    """dataloader.py's CSR hand-over gives ImplicitTestManager the same metrics as walking the loader's
+    python sets (the reference interface), on the committed fixture data set, with and without item pool."""
+    from invpref_kdd_2022_amd import dataloader as dl
+    from invpref_kdd_2022_amd.evaluate import ImplicitTestManager
+
+    class SetsOnly:  # hides csr_for_eval: forces the set-walking path
+        def __init__(self, ld):
+            self._ld = ld
+            self.all_test_users_by_sorted_list = ld.all_test_users_by_sorted_list
+            self.get_sorted_all_test_users_ground_truth = ld.get_sorted_all_test_users_ground_truth
+
+        def user_mask_items(self, u):
+            return self._ld.user_mask_items(u) if u < len(self._ld.user_positive_interaction) else set()
+
+        def user_highlight_items(self, u):
+            return self._ld.user_highlight_items(u)
+
+    ld = dl.YahooImplicitBCELossDataLoader(os.path.join(G, 'ds_small', 'implicit'), DEV, has_item_pool_file=True)
+    torch.manual_seed(3)
+    model = PureMatrixFactorization(ld.user_num, ld.item_num, 16).to(DEV)
+    with torch.no_grad():
+        model.user_emb.weight.mul_(30.)
+    for pool in (False, True):
+        a = ImplicitTestManager(model, ld, 16, [3, 5], use_item_pool=pool).evaluate()
+        b = ImplicitTestManager(model, SetsOnly(ld), 16, [3, 5], use_item_pool=pool).evaluate()
+        assert a == b and set(a) == {'ndcg', 'recall', 'precision'} and 0. < a['recall'][5] <= 1.

@@ -224,6 +224,21 @@ int invpref_eval_topk_hip(const float *ratings, int64_t n_users, int64_t n_items
  * sum |pred-target|}; mse / rmse / mae follow on the host. */
 int invpref_eval_error_sums_hip(const float *pred, const float *target, int64_t n, double *out2, void *stream);
 
+/* ---- ImplicitTrainStaticPopularityManager.static_pop (train.py:509-571): for every environment e, ten float64
+ * means over the interactions currently assigned to e (their `users`/`items`), in the reference's key order:
+ *   0 users_cnt_weight      mean over interactions of user_cnt[u]           1 items_cnt_weight      ... item_cnt[i]
+ *   2 users_normalize_cnt_weight   ... user_cnt_norm[u]                      3 items_normalize_cnt_weight ... item_cnt_norm[i]
+ *   4 users_cnt             mean over the DISTINCT users of e of user_cnt   5 items_cnt             (distinct items)
+ *   6 users_normalize_cnt   distinct users, user_cnt_norm                   7 items_normalize_cnt   (distinct items)
+ *   8 pair_cnt_add          mean of user_cnt[u] + item_cnt[i]               9 pair_normalize_cnt_multiply  mean of norm[u]*norm[i]
+ * user_cnt / item_cnt / *_norm are the loader's tables (dataloader.py:273-291).  An empty environment gives NaN
+ * (np.mean of an empty array).  out: device double[env_num][10].  Integer sums are exact. */
+size_t invpref_static_pop_workspace_bytes(int64_t user_num, int64_t item_num, int64_t env_num);
+int invpref_static_pop_hip(const int64_t *users, const int64_t *items, const int64_t *envs, int64_t n, int64_t user_num,
+                           int64_t item_num, int64_t env_num, const int64_t *user_cnt, const int64_t *item_cnt,
+                           const double *user_cnt_norm, const double *item_cnt_norm, double *out, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* ---- dense Adam: replaces optimizer.zero_grad() + optimizer.step() of torch.optim.Adam with
  * default betas/eps (train.py:41, :155-157) over one flat fp32 buffer of n parameters.
  * step is 1-based.  zero_grad != 0 also clears grad (the next step's zero_grad()). */

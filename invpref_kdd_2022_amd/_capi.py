@@ -22,7 +22,8 @@ EXPORTS = [
     'invpref_stat_envs_hip', 'invpref_sample_weights_hip', 'invpref_backward_hip', 'invpref_predict_hip',
     'invpref_rows_workspace_bytes', 'invpref_mstep_rows_grad_hip', 'invpref_mstep_rows_adam_hip',
     'invpref_adam_schedule_fill', 'invpref_mstep_rows_adam_sched_hip', 'invpref_eval_topk_hip',
-    'invpref_eval_error_sums_hip', 'invpref_set_profile_event',
+    'invpref_eval_error_sums_hip', 'invpref_set_profile_event', 'invpref_static_pop_workspace_bytes',
+    'invpref_static_pop_hip',
 ]
 
 
@@ -90,6 +91,9 @@ def lib():
         L.invpref_eval_topk_hip.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
         L.invpref_eval_error_sums_hip.argtypes = [vp, vp, i64, vp, vp]
         L.invpref_set_profile_event.argtypes = [vp]
+        L.invpref_static_pop_workspace_bytes.argtypes = [i64, i64, i64]
+        L.invpref_static_pop_workspace_bytes.restype = C.c_size_t
+        L.invpref_static_pop_hip.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
         L.invpref_device_name.argtypes = [C.c_char_p, C.c_size_t]
         if L.invpref_abi_version() != 1:
             raise InvPrefError('libinvpref_hip.so ABI version mismatch')

@@ -75,9 +75,117 @@ __global__ __launch_bounds__(256) void err_sums_kernel(const float *__restrict__
     if ((threadIdx.x & 63) == 0) { atomicAdd(out2, s2); atomicAdd(out2 + 1, s1); }
 }
 
+// ---- static_pop (train.py:509-571).  Accumulators per env: [0] interactions, [1] sum user_cnt, [2] sum item_cnt
+// (integers, exact), then doubles: [3] sum user_norm, [4] sum item_norm, [5] sum norm*norm; distinct users:
+// [6] count, [7] sum user_cnt, [8] sum user_norm; distinct items: [9] count, [10] sum item_cnt, [11] sum item_norm.
+constexpr int kPopAcc = 12;
+__device__ __forceinline__ void acc_i(unsigned long long *a, long long v) { atomicAdd(a, (unsigned long long)v); }
+
+__global__ __launch_bounds__(256) void pop_interactions_kernel(const int64_t *__restrict__ users, const int64_t *__restrict__ items,
+                                                               const int64_t *__restrict__ envs, int64_t n, int U, int I, int E,
+                                                               const int64_t *__restrict__ ucnt, const int64_t *__restrict__ icnt,
+                                                               const double *__restrict__ un, const double *__restrict__ in,
+                                                               unsigned long long *__restrict__ acc, unsigned char *__restrict__ fu,
+                                                               unsigned char *__restrict__ fi) {
+    __shared__ unsigned long long si[INVPREF_MAX_ENVS][3];
+    __shared__ double sd[INVPREF_MAX_ENVS][3];
+    for (int t = threadIdx.x; t < INVPREF_MAX_ENVS * 3; t += blockDim.x) { si[t / 3][t % 3] = 0; sd[t / 3][t % 3] = 0.0; }
+    __syncthreads();
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)envs[j];
+        if (e < 0 || e >= E) continue;
+        const int64_t u = users[j], i = items[j];
+        const double a = un[u], b = in[i];
+        acc_i(&si[e][0], 1); acc_i(&si[e][1], ucnt[u]); acc_i(&si[e][2], icnt[i]);
+        atomicAdd(&sd[e][0], a); atomicAdd(&sd[e][1], b); atomicAdd(&sd[e][2], a * b);
+        fu[(int64_t)e * U + u] = 1;   // presence marks: same value from every writer
+        fi[(int64_t)e * I + i] = 1;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < E * 3; t += blockDim.x) {
+        const int e = t / 3, q = t % 3;
+        if (si[e][q]) atomicAdd(acc + e * kPopAcc + q, si[e][q]);
+        if (sd[e][q] != 0.0) atomicAdd(reinterpret_cast<double *>(acc + e * kPopAcc + 3 + q), sd[e][q]);
+    }
+}
+
+// distinct users (side 0) / items (side 1) of every env: one thread per (env, row) presence mark
+__global__ __launch_bounds__(256) void pop_distinct_kernel(const unsigned char *__restrict__ flags, int rows, int E,
+                                                           const int64_t *__restrict__ cnt, const double *__restrict__ norm,
+                                                           unsigned long long *__restrict__ acc, int base) {
+    __shared__ unsigned long long si[INVPREF_MAX_ENVS][2];
+    __shared__ double sd[INVPREF_MAX_ENVS];
+    for (int t = threadIdx.x; t < INVPREF_MAX_ENVS; t += blockDim.x) { si[t][0] = si[t][1] = 0; sd[t] = 0.0; }
+    __syncthreads();
+    const int64_t total = (int64_t)E * rows;
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+        if (!flags[j]) continue;
+        const int e = (int)(j / rows), r = (int)(j - (int64_t)e * rows);
+        acc_i(&si[e][0], 1); acc_i(&si[e][1], cnt[r]);
+        atomicAdd(&sd[e], norm[r]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        if (si[e][0]) {
+            atomicAdd(acc + e * kPopAcc + base, si[e][0]);
+            atomicAdd(acc + e * kPopAcc + base + 1, si[e][1]);
+            atomicAdd(reinterpret_cast<double *>(acc + e * kPopAcc + base + 2), sd[e]);
+        }
+    }
+}
+
+__global__ void pop_means_kernel(const unsigned long long *__restrict__ acc, int E, double *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const unsigned long long *a = acc + e * kPopAcc;
+    const double *d = reinterpret_cast<const double *>(a);
+    const double n = (double)a[0], nu = (double)a[6], ni = (double)a[9];
+    double *o = out + e * 10;
+    o[0] = (double)a[1] / n; o[1] = (double)a[2] / n;      // 0/0 = NaN: np.mean of an empty selection
+    o[2] = d[3] / n; o[3] = d[4] / n;
+    o[4] = (double)a[7] / nu; o[5] = (double)a[10] / ni;
+    o[6] = d[8] / nu; o[7] = d[11] / ni;
+    o[8] = (double)(a[1] + a[2]) / n; o[9] = d[5] / n;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t invpref_static_pop_workspace_bytes(int64_t user_num, int64_t item_num, int64_t env_num) {
+    if (user_num <= 0 || item_num <= 0 || env_num <= 0 || env_num > INVPREF_MAX_ENVS) return 0;
+    return sizeof(unsigned long long) * kPopAcc * (size_t)env_num + (size_t)env_num * (size_t)(user_num + item_num);
+}
+
+int invpref_static_pop_hip(const int64_t *users, const int64_t *items, const int64_t *envs, int64_t n, int64_t user_num,
+                           int64_t item_num, int64_t env_num, const int64_t *user_cnt, const int64_t *item_cnt,
+                           const double *user_cnt_norm, const double *item_cnt_norm, double *out, void *workspace,
+                           size_t workspace_bytes, void *stream) {
+    if (n < 0 || user_num <= 0 || item_num <= 0 || env_num <= 0 || !user_cnt || !item_cnt || !user_cnt_norm ||
+        !item_cnt_norm || !out || !workspace || (n > 0 && (!users || !items || !envs)))
+        return INVPREF_EINVAL;
+    if (env_num > INVPREF_MAX_ENVS || user_num > INT32_MAX || item_num > INT32_MAX) return INVPREF_EUNSUPPORTED;
+    const size_t need = invpref_static_pop_workspace_bytes(user_num, item_num, env_num);
+    if (workspace_bytes < need) return INVPREF_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(workspace, 0, need, st);
+    if (e != hipSuccess) return (int)e;
+    auto *acc = reinterpret_cast<unsigned long long *>(workspace);
+    auto *fu = reinterpret_cast<unsigned char *>(acc + kPopAcc * env_num);
+    auto *fi = fu + (size_t)env_num * (size_t)user_num;
+    const int E = (int)env_num, U = (int)user_num, I = (int)item_num;
+    if (n > 0) {
+        const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+        hipLaunchKernelGGL(pop_interactions_kernel, dim3(nb), dim3(256), 0, st, users, items, envs, n, U, I, E, user_cnt,
+                           item_cnt, user_cnt_norm, item_cnt_norm, acc, fu, fi);
+        const unsigned nu = (unsigned)std::min<int64_t>(((int64_t)E * U + 255) / 256, 2048);
+        hipLaunchKernelGGL(pop_distinct_kernel, dim3(nu), dim3(256), 0, st, fu, U, E, user_cnt, user_cnt_norm, acc, 6);
+        const unsigned ni = (unsigned)std::min<int64_t>(((int64_t)E * I + 255) / 256, 2048);
+        hipLaunchKernelGGL(pop_distinct_kernel, dim3(ni), dim3(256), 0, st, fi, I, E, item_cnt, item_cnt_norm, acc, 9);
+    }
+    hipLaunchKernelGGL(pop_means_kernel, dim3(1), dim3(64), 0, st, acc, E, out);
+    return (int)hipGetLastError();
+}
 
 int invpref_eval_topk_hip(const float *ratings, int64_t n_users, int64_t n_items, const int32_t *mask_ptr,
                           const int32_t *mask_items, const int32_t *highlight_ptr, const int32_t *highlight_items,

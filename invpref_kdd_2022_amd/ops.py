@@ -210,3 +210,25 @@ def mstep_rows_adam(params, new_params, exp_avg, exp_avg_sq, dplan, envs, scores
                                              ptr(sample_weights), int(batch_norm), C.byref(cf), flags, ptr(losses6),
                                              int(step), float(lr), float(beta1), float(beta2), float(eps), ptr(ws),
                                              ws.numel(), stream_ptr()), 'invpref_mstep_rows_adam_hip')
+
+
+POP_KEYS = ['users_cnt_weight_result', 'items_cnt_weight_result', 'users_normalize_cnt_weight_result',
+            'items_normalize_cnt_weight_result', 'users_cnt_result', 'items_cnt_result', 'users_normalize_cnt_result',
+            'items_normalize_cnt_result', 'pair_cnt_add_result', 'pair_normalize_cnt_multiply_result']  # train.py:558-569
+
+
+def static_pop(users, items, envs, env_num: int, user_cnt, item_cnt, user_norm, item_norm, workspace: Workspace):
+    """-> float64 [env_num, 10] per-environment popularity means in POP_KEYS order (train.py:509-571)."""
+    for t, n in ((users, 'users'), (items, 'items'), (envs, 'envs'), (user_cnt, 'user_cnt'), (item_cnt, 'item_cnt')):
+        _ids(t, n)
+    _capi._req(user_norm, torch.float64, 'user_norm')
+    _capi._req(item_norm, torch.float64, 'item_norm')
+    U, I = user_cnt.numel(), item_cnt.numel()
+    if user_norm.numel() != U or item_norm.numel() != I or not (users.numel() == items.numel() == envs.numel()):
+        raise InvPrefError('static_pop: inconsistent sizes')
+    out = torch.empty(env_num, 10, dtype=torch.float64, device=users.device)
+    ws = workspace.get(lib().invpref_static_pop_workspace_bytes(U, I, env_num))
+    check(lib().invpref_static_pop_hip(ptr(users), ptr(items), ptr(envs), users.numel(), U, I, env_num, ptr(user_cnt),
+                                       ptr(item_cnt), ptr(user_norm), ptr(item_norm), ptr(out), ptr(ws), ws.numel(),
+                                       stream_ptr()), 'invpref_static_pop_hip')
+    return out

@@ -516,17 +516,23 @@ class _InvPrefTrainManager:
 
     # ------------------------------------------------------------------ outer loop (train.py:282-342)
     def train(self, silent: bool = False, auto: bool = False):
+        return self._train_span(silent, auto, initial=True)
+
+    def _train_span(self, silent: bool, auto: bool, initial: bool):
+        """The outer loop from the current epoch up to self.epochs; `initial` runs the epoch-0 evaluation and
+        stat_envs of train.py:292-301 first."""
         test_result_list, test_epoch_list = [], []
         cluster_diff_num_list, cluster_epoch_list, envs_cnt_list = [], [], []
         loss_result_list, train_epoch_index_list = [], []
 
-        temp_eval_result = self.evaluator.evaluate()
-        test_result_list.append(temp_eval_result)
-        test_epoch_list.append(self.epoch_cnt)
-        self.stat_envs()
-        if not silent and not auto:
-            print('test at epoch:', self.epoch_cnt)
-            print(transfer_loss_dict_to_line_str(temp_eval_result))
+        if initial:
+            temp_eval_result = self.evaluator.evaluate()
+            test_result_list.append(temp_eval_result)
+            test_epoch_list.append(self.epoch_cnt)
+            self.stat_envs()
+            if not silent and not auto:
+                print('test at epoch:', self.epoch_cnt)
+                print(transfer_loss_dict_to_line_str(temp_eval_result))
 
         # nothing printed -> nothing is read back inside the loop (losses, diff_num and env counts stay on
         # the device until the end, or until an evaluation needs the host anyway): the GPU never waits
@@ -608,3 +614,74 @@ class ImplicitTrainManager(_InvPrefTrainManager):
 class ExplicitTrainManager(_InvPrefTrainManager):
     """reference train.py:693-1019 (MSELoss)."""
     implicit = False
+
+
+class ImplicitTrainStaticPopularityManager(ImplicitTrainManager):
+    """reference train.py:484-690: ImplicitTrainManager + per-environment popularity statistics every
+    `static_pop_interval` epochs.  The statistics are one device pass over the resident interactions
+    (`invpref_static_pop_hip`) instead of numpy boolean masks per environment.  Single GPU."""
+
+    def __init__(self, model, evaluator, device, data_loader, training_data, batch_size, epochs, cluster_interval,
+                 evaluate_interval, lr, invariant_coe, env_aware_coe, env_coe, L2_coe, L1_coe, static_pop_interval,
+                 alpha=None, use_class_re_weight=False, test_begin_epoch=0, begin_cluster_epoch=None,
+                 stop_cluster_epoch=None, cluster_use_random_sort=True, use_recommend_re_weight=True):
+        super().__init__(model=model, evaluator=evaluator, device=device, training_data=training_data,
+                         batch_size=batch_size, epochs=epochs, cluster_interval=cluster_interval,
+                         evaluate_interval=evaluate_interval, lr=lr, invariant_coe=invariant_coe,
+                         env_aware_coe=env_aware_coe, env_coe=env_coe, L2_coe=L2_coe, L1_coe=L1_coe, alpha=alpha,
+                         use_class_re_weight=use_class_re_weight, test_begin_epoch=test_begin_epoch,
+                         begin_cluster_epoch=begin_cluster_epoch, stop_cluster_epoch=stop_cluster_epoch,
+                         cluster_use_random_sort=cluster_use_random_sort,
+                         use_recommend_re_weight=use_recommend_re_weight, rank=0, world_size=1)
+        self.training_np = training_data.cpu().numpy()
+        self.static_pop_interval = static_pop_interval
+        self.data_loader = data_loader
+        dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.device)  # noqa: E731
+        self._pop_tabs = (dev(data_loader.user_inter_cnt_np, np.int64), dev(data_loader.item_inter_cnt_np, np.int64),
+                          dev(data_loader.user_inter_cnt_normalize_np, np.float64),
+                          dev(data_loader.item_inter_cnt_normalize_np, np.float64))
+
+    def static_pop(self) -> dict:
+        """train.py:509-571: {statistic: {env: mean}}."""
+        out = ops.static_pop(self.users_tensor, self.items_tensor, self.envs, self.envs_num, *self._pop_tabs,
+                             self.workspace).tolist()
+        return {key: {env: out[env][j] for env in range(self.envs_num)} for j, key in enumerate(ops.POP_KEYS)}
+
+    def final_cluster_stat(self, colors_list: list):
+        """train.py:573-601: per-interaction popularity values grouped by environment, for the scatter plot."""
+        assert len(colors_list) == self.envs_num
+        envs = self.envs.cpu().numpy()
+        order = np.argsort(envs, kind='stable')           # env 0 rows first, original order inside an env
+        u, i = self.training_np[order, 0], self.training_np[order, 1]
+        dl = self.data_loader
+        colors = [colors_list[e] for e in envs[order].tolist()]
+        return (dl.query_users_inter_cnt(u).tolist(), dl.query_items_inter_cnt(i).tolist(),
+                dl.query_users_inter_cnt_normalize(u).tolist(), dl.query_items_inter_cnt_normalize(i).tolist(), colors)
+
+    def train(self, silent: bool = False, auto: bool = False):
+        """train.py:603-690: the InvPref loop + `static_pop` every static_pop_interval epochs; a fourth result tuple."""
+        import json
+        stat_dicts, stat_epochs = [], []
+        epochs_total = self.epochs
+        loss_l, loss_e, test_l, test_e, diff_l, cnt_l, cl_e = [], [], [], [], [], [], []
+        first = True
+        while first or self.epoch_cnt < epochs_total:
+            # run the base loop up to the next statistics epoch (it evaluates at its start only the first time)
+            nxt = min(epochs_total, (self.epoch_cnt // self.static_pop_interval + 1) * self.static_pop_interval)
+            self.epochs = nxt
+            (l, le), (t, te), (d, c, ce) = self._train_span(silent, auto, initial=first)
+            first = False
+            loss_l += l; loss_e += le; test_l += t; test_e += te; diff_l += d; cnt_l += c; cl_e += ce
+            if self.epoch_cnt % self.static_pop_interval == 0 and self.epoch_cnt > 0:
+                pop = self.static_pop()
+                stat_epochs.append(self.epoch_cnt)
+                stat_dicts.append(pop)
+                if not silent and not auto:
+                    print('pop stat at epoch:', self.epoch_cnt)
+                    print(json.dumps(pop, indent=4))
+            if self.epoch_cnt >= epochs_total:
+                break
+        self.epochs = epochs_total
+        merged = {key: {env: [d[key][env] for d in stat_dicts] for env in stat_dicts[0][key]} for key in stat_dicts[0]} \
+            if stat_dicts else {}
+        return (loss_l, loss_e), (test_l, test_e), (diff_l, cnt_l, cl_e), (merged, stat_epochs)

@@ -17,6 +17,7 @@ What each fixture pins:
   g6    evaluate.py metrics on a seeded model / loader stub   -> §8 f1
   g7    PureMF baselines (Basic*TrainManager)                 -> §8 f2
   g8    data loaders on a small seeded CSV data set           -> §8 f3
+  g9    static_pop / final_cluster_stat                       -> §8 f4
 """
 import sys
 import types
@@ -473,8 +474,45 @@ def gen_g8():
         print('g8', kind, out['dims'])
 
 
+POP_KEYS = ['users_cnt_weight_result', 'items_cnt_weight_result', 'users_normalize_cnt_weight_result',
+            'items_normalize_cnt_weight_result', 'users_cnt_result', 'items_cnt_result', 'users_normalize_cnt_result',
+            'items_normalize_cnt_result', 'pair_cnt_add_result', 'pair_normalize_cnt_multiply_result']
+
+
+def gen_g9():
+    """static_pop / final_cluster_stat of ImplicitTrainStaticPopularityManager on the fixture data
+    set with a seeded env assignment (env 3 of 5 left empty: np.mean of nothing = nan)."""
+    import contextlib, io, warnings
+    import dataloader as ref_dl
+    d = os.path.join(OUT, 'ds_small', 'implicit')
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        ld = ref_dl.ImplicitBCELossDataLoaderStaticPopularity(d, CPU, has_item_pool_file=True)
+    E = 5
+    model = ref_models.InvPrefImplicit(ld.user_num, ld.item_num, E, 8)
+    np.random.seed(909)
+    mgr = ref_train.ImplicitTrainStaticPopularityManager(
+        model=model, evaluator=StubEvaluator(), device=CPU, data_loader=ld, training_data=torch.from_numpy(ld.train_data_np),
+        batch_size=256, epochs=1, cluster_interval=1, evaluate_interval=1, lr=0.01, invariant_coe=1., env_aware_coe=1.,
+        env_coe=1., L2_coe=0.1, L1_coe=0.1, static_pop_interval=1, alpha=1.)
+    envs = np.random.RandomState(910).choice([0, 1, 2, 4], ld.train_data_len).astype(np.int64)
+    mgr.envs = torch.from_numpy(envs)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        res = mgr.static_pop()
+    out = {'envs': envs, 'E': np.array(E),
+           'pop': np.array([[res[k][e] for k in POP_KEYS] for e in range(E)], np.float64),
+           'user_cnt': ld.user_inter_cnt_np, 'item_cnt': ld.item_inter_cnt_np,
+           'user_norm': ld.user_inter_cnt_normalize_np, 'item_norm': ld.item_inter_cnt_normalize_np}
+    uc, ic, un, inn, colors = mgr.final_cluster_stat(['c0', 'c1', 'c2', 'c3', 'c4'])
+    out['fcs_user_cnt'], out['fcs_item_cnt'] = np.array(uc), np.array(ic)
+    out['fcs_user_norm'], out['fcs_item_norm'] = np.array(un), np.array(inn)
+    out['fcs_color_idx'] = np.array([int(c[1]) for c in colors])
+    np.savez_compressed(os.path.join(OUT, 'g9_static_pop.npz'), **out)
+    print('g9', out['pop'][0], out['pop'][3])
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
     torch.manual_seed(0)
     for name in which:
         globals()['gen_' + name]()

@@ -1,5 +1,6 @@
-"""GPU: PureMF baselines through the drop-in modules / managers of
-invpref_kdd_2022_amd.baseline against the goldens recorded from the reference (g7) and the oracle."""
+"""GPU: the "next" rows of SURVEY.md §8(f) beyond evaluation -- PureMF baselines (f2) through the drop-in
+modules / managers of invpref_kdd_2022_amd.baseline against the goldens recorded from the reference (g7) and the
+oracle; the loader -> evaluator hand-over (f3); the static-popularity manager (f4, golden g9)."""
 import os
 
 import numpy as np
@@ -140,3 +141,43 @@ def test_loader_to_evaluator_hand_over():
         a = ImplicitTestManager(model, ld, 16, [3, 5], use_item_pool=pool).evaluate()
         b = ImplicitTestManager(model, SetsOnly(ld), 16, [3, 5], use_item_pool=pool).evaluate()
         assert a == b and set(a) == {'ndcg', 'recall', 'precision'} and 0. < a['recall'][5] <= 1.
+
+
+def test_static_pop_manager_vs_reference():
+    """ImplicitTrainStaticPopularityManager.static_pop / final_cluster_stat on the fixture data set
+    with the env assignment of golden g9 (one empty environment -> NaN like np.mean of nothing)."""
+    from invpref_kdd_2022_amd import dataloader as dl
+    from invpref_kdd_2022_amd.models import InvPrefImplicit
+    from invpref_kdd_2022_amd.train import ImplicitTrainStaticPopularityManager
+    z = np.load(os.path.join(G, 'g9_static_pop.npz'))
+    ld = dl.ImplicitBCELossDataLoaderStaticPopularity(os.path.join(G, 'ds_small', 'implicit'), DEV, has_item_pool_file=True)
+    np.testing.assert_array_equal(ld.user_inter_cnt_np, z['user_cnt'])
+    np.testing.assert_array_equal(ld.item_inter_cnt_np, z['item_cnt'])
+    np.testing.assert_array_equal(ld.user_inter_cnt_normalize_np, z['user_norm'])
+    np.testing.assert_array_equal(ld.item_inter_cnt_normalize_np, z['item_norm'])
+    E = int(z['E'])
+    np.random.seed(1)
+    mgr = ImplicitTrainStaticPopularityManager(
+        model=InvPrefImplicit(ld.user_num, ld.item_num, E, 8), evaluator=StubEvaluator(), device=DEV, data_loader=ld,
+        training_data=torch.from_numpy(ld.train_data_np).to(DEV), batch_size=256, epochs=4, cluster_interval=3,
+        evaluate_interval=2, lr=0.01, invariant_coe=1., env_aware_coe=1., env_coe=1., L2_coe=0.1, L1_coe=0.1,
+        static_pop_interval=2, alpha=1., cluster_use_random_sort=False)
+    mgr.envs.copy_(torch.from_numpy(z['envs']))
+    res = mgr.static_pop()
+    assert list(res.keys()) == ops.POP_KEYS and list(res[ops.POP_KEYS[0]].keys()) == list(range(E))
+    got = np.array([[res[k][e] for k in ops.POP_KEYS] for e in range(E)])
+    assert np.isnan(got[3]).all() and np.isnan(z['pop'][3]).all()
+    keep = [0, 1, 2, 4]
+    np.testing.assert_allclose(got[keep], z['pop'][keep], rtol=1e-13)
+    np.testing.assert_array_equal(got[keep][:, [0, 1, 4, 5, 8]], z['pop'][keep][:, [0, 1, 4, 5, 8]])  # integer sums: exact
+    uc, ic, un, inn, colors = mgr.final_cluster_stat(['c0', 'c1', 'c2', 'c3', 'c4'])
+    np.testing.assert_array_equal(uc, z['fcs_user_cnt'])
+    np.testing.assert_array_equal(ic, z['fcs_item_cnt'])
+    np.testing.assert_array_equal(un, z['fcs_user_norm'])
+    np.testing.assert_array_equal(inn, z['fcs_item_norm'])
+    assert [int(c[1]) for c in colors] == list(z['fcs_color_idx'])
+    # the outer loop: 4 epochs, evaluate every 2, cluster every 3, statistics every 2 -> four result tuples
+    (l, le), (t, te), (d, c, ce), (stat, se) = mgr.train(silent=True)
+    assert le == [1, 2, 3, 4] and te == [0, 2, 4] and ce == [3] and se == [2, 4] and len(d) == 1
+    assert set(stat.keys()) == set(ops.POP_KEYS) and len(stat[ops.POP_KEYS[0]][0]) == 2
+    assert mgr.epochs == 4

@@ -334,6 +334,7 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
             }
             __syncthreads();
             if (active && leader) {
+#pragma unroll 4
                 for (int s = 1; s < slices; s++) {
                     const float *oth_slot = slots + (grp + s) * 2 * DP;
 #pragma unroll
@@ -522,19 +523,33 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
         if (l16 == 0) recs[grp * (EMAX + 1) + EMAX] = __builtin_bit_cast(float, e);
         __syncthreads();
         if (threadIdx.x < CG * DP) {
-            // (an empty record slot holds env id -1 and zeroed gz: it adds exact zeros, no branch needed)
-#pragma unroll CPT <= 2 ? 8 : 2
-            for (int g2 = 0; g2 < kGroups; g2++) {
-                const float *rs = recs + g2 * (EMAX + 1);
-                const int er = __builtin_bit_cast(int, rs[EMAX]);
-                const float xv = rec[(g2 * 2) * DP + d_own], ov = rec[(g2 * 2 + 1) * DP + d_own];
+            // Branch-free on purpose (the loads of all 16 records are issued back to back; with per-record
+            // branches every record paid two LDS round trips in sequence).  An empty record slot holds env
+            // id -1: its stale x / o / gz are masked by selects.  Classes c >= E accumulate garbage that is
+            // never stored.
+            constexpr int BATCH = CPT <= 2 ? 8 : 2;   // records whose LDS reads are in flight together
+#pragma unroll 1
+            for (int g0 = 0; g0 < kGroups; g0 += BATCH) {
+                int er[BATCH];
+                float xr[BATCH], orr[BATCH], gr[BATCH][CPT];
 #pragma unroll
-                for (int i = 0; i < CPT; i++) {
-                    const int c = cg + CG * i;
-                    if (c < t.E) {
-                        const float gzc = er >= 0 ? rs[c] : 0.f;
-                        dW[i] = __builtin_fmaf(gzc, er >= 0 ? xv : 0.f, dW[i]);
-                        dE[i] += (c == er) ? ov : 0.f;
+                for (int b = 0; b < BATCH; b++) {       // unconditional loads first ...
+                    const float *rs = recs + (g0 + b) * (EMAX + 1);
+                    er[b] = __builtin_bit_cast(int, rs[EMAX]);
+                    xr[b] = rec[((g0 + b) * 2) * DP + d_own];
+                    orr[b] = rec[((g0 + b) * 2 + 1) * DP + d_own];
+#pragma unroll
+                    for (int i = 0; i < CPT; i++) gr[b][i] = rs[cg + CG * i];
+                }
+#pragma unroll
+                for (int b = 0; b < BATCH; b++) {       // ... then selects and arithmetic only
+                    const bool ok = er[b] >= 0;
+                    const float xv = ok ? xr[b] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < CPT; i++) {
+                        const float gzc = ok ? gr[b][i] : 0.f;
+                        dW[i] = __builtin_fmaf(gzc, xv, dW[i]);
+                        dE[i] += (cg + CG * i == er[b]) ? orr[b] : 0.f;
                         dB[i] += gzc;
                     }
                 }

@@ -104,6 +104,19 @@ def seq(pingpong, multiplan, steps=30, pl=None):
 
 
 combos = ((False, False), (True, True)) if os.environ.get('KB3_SHORT') else ((False, False), (False, True), (True, False), (True, True))
+empty = planlib.upload(planlib.build_row_plan(np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32), U, I), dev)
+def seq_stream_only(steps=30):
+    def run():
+        a, b = P, P2
+        for k in range(steps):
+            ops.mstep_rows_adam(a, b, M, V, empty, e[:1], y[:1], w[:1], 1, coefs, flags, losses, 5, 0.005, ws)
+            a, b = b, a
+        return steps
+    return run
+try:
+    print('stream tasks only (every row untouched: pure fused-Adam streaming, 50 MB) pp=1: %.2f us, tasks %d' % (graph_time(seq_stream_only()), empty.n_tasks))
+except Exception as ex:
+    print('stream-only failed:', ex)
 print('without stream tasks pp=1 mp=1: %.2f us' % graph_time(seq(True, True, pl=plans_ns)))
 print('sched variant pp=1 mp=1: %.2f us' % graph_time(seq_sched()))
 print(os.environ.get('INVPREF_LIB', 'default'), ' '.join(f'pp={int(pp)} mp={int(mp)}: {graph_time(seq(pp, mp)):.2f} us' for pp, mp in combos))

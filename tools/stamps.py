@@ -49,3 +49,7 @@ for per_slice, rpt, hot, dense in ((2, 1, 16, 32), (2, 1, 16, 16), (1, 1, 16, 32
             continue
         life = e0 - s0
         print(f'  {name:6s} n={len(s0):4d} start med {np.median(s0):5.2f} p90 {np.quantile(s0, .9):5.2f} max {s0.max():5.2f} | life med {np.median(life):5.2f} p90 {np.quantile(life, .9):5.2f} max {life.max():5.2f} | end med {np.median(e0):5.2f} max {e0.max():5.2f}')
+
+    d = st[:nd].astype(np.float64)
+    ph = np.diff(d[:, [0, 1, 2, 3, 4, 5, 6, 7]], axis=1) / 100
+    print('  dense phases (us, median): stage+sync %.2f | ids+gather %.2f | eval %.2f | records+sync %.2f | accumulate %.2f | hot atomics + 2nd iteration %.2f | epilogue %.2f' % tuple(np.median(ph, axis=0)))

@@ -431,6 +431,19 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
     const bool pure = a.flags & INVPREF_PURE_MF;
     const StepScalars k = a.k;
     STAMP(0);
+    // The ids and the four rows of an iteration are requested one phase early.  First iteration: the ids go
+    // out before the staging loads (both fly together), the rows before the barrier that makes the staged
+    // tables visible.  Next iteration: the ids at the top of this one, the rows right after this iteration's
+    // records are written (its rows are dead by then) -- they fly under the barrier and the accumulation.
+    const int first_s = s0 + (int)(threadIdx.x >> 4);
+    int id_u = 0, id_v = 0, id_e = -1;
+    float id_y = 0.f, id_w = 1.f;
+    if (first_s < s1) {
+        id_u = a.batch_users[first_s]; id_v = a.batch_items[first_s];
+        id_e = pure ? 0 : (int)a.envs[first_s];
+        id_y = a.scores[first_s];
+        id_w = (rw_rec || rw_cls) ? a.weights[first_s] : 1.f;
+    }
     stage_table(sEv, t.Ev, t.E, t.D, DP);
     stage_table(sW, t.W, t.E, t.D, DP);
     for (int i = threadIdx.x; i < EMAX; i += blockDim.x) sb[i] = (i < t.E && t.b) ? t.b[i] : 0.f;
@@ -443,35 +456,51 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
 #pragma unroll
     for (int i = 0; i < CPT; i++) dW[i] = dE[i] = dB[i] = 0.f;
     float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
+    int n_u = id_u, n_v = id_v, n_e = id_e, n_hidx = -1;
+    float n_y = id_y, n_w = id_w;
+    float4 pu[NC], qi[NC], pa[NC], qa[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) pu[c] = qi[c] = pa[c] = qa[c] = f4zero();
+    auto fetch_ids = [&](int base) {      // ids / label / weight of the group's interaction of iteration `base`
+        const int s = base + grp;
+        n_e = -1; n_hidx = -1;
+        if (s < s1) {
+            n_u = a.batch_users[s]; n_v = a.batch_items[s];
+            n_e = pure ? 0 : (int)a.envs[s];
+            n_y = a.scores[s];
+            n_w = (rw_rec || rw_cls) ? a.weights[s] : 1.f;
+        }
+    };
+    auto fetch_rows = [&]() {             // its four rows (+ the hot-row index of the item)
+        if (n_e >= 0) {
+            if (a.item_hot_index) n_hidx = a.item_hot_index[n_v];
+            load_row<NC, VEC>(t.Pu, n_u, t.D, l16, pu);
+            load_row<NC, VEC>(t.Qi, n_v, t.D, l16, qi);
+            if (!pure) {
+                load_row<NC, VEC>(t.Pa, n_u, t.D, l16, pa);
+                load_row<NC, VEC>(t.Qa, n_v, t.D, l16, qa);
+            }
+        }
+    };
+    fetch_rows();
     __syncthreads();
     STAMP(1);
 
     for (int base = s0, it = 0; base < s1; base += kGroups, it++) {
         float *rec = rec0 + (DBUF ? (it & 1) : 0) * kGroups * 2 * DP;
         float *recs = recs0 + (DBUF ? (it & 1) : 0) * kGroups * (EMAX + 1);
-        const int s = base + grp;
-        const bool valid = s < s1;
-        int e = -1, hidx = -1;
+        const int e = n_e, hidx = n_hidx;
+        const float cur_y = n_y, cur_w = n_w;
+        const bool valid = e >= 0;
+        const bool more = base + kGroups < s1;
+        if (more) fetch_ids(base + kGroups);
         float4 hq[NC], ha[NC];  // hot item row gradients of this interaction
 #pragma unroll
         for (int c = 0; c < NC; c++) hq[c] = ha[c] = f4zero();
         if (valid) {
-            const int u = a.batch_users[s], v = a.batch_items[s];
-            e = pure ? 0 : (int)a.envs[s];
-            const float y = a.scores[s];
-            const float w = (rw_rec || rw_cls) ? a.weights[s] : 1.f;
+            const float y = cur_y, w = cur_w;
             const float w_rec = rw_rec ? w : 1.f, w_cls = rw_cls ? w : 1.f;
-            if (a.item_hot_index) hidx = a.item_hot_index[v];
-            float4 pu[NC], qi[NC], pa[NC], qa[NC], ev[NC];
-            load_row<NC, VEC>(t.Pu, u, t.D, l16, pu);
-            load_row<NC, VEC>(t.Qi, v, t.D, l16, qi);
-            if (!pure) {
-                load_row<NC, VEC>(t.Pa, u, t.D, l16, pa);
-                load_row<NC, VEC>(t.Qa, v, t.D, l16, qa);
-            } else {
-#pragma unroll
-                for (int c = 0; c < NC; c++) pa[c] = qa[c] = f4zero();
-            }
+            float4 ev[NC];
             lds_row<NC>(sEv, e, l16, ev);
             Eval<NC, EMAX> o;
             eval_interaction<NC, EMAX>(o, pu, qi, pa, qa, ev, sW, sb, t.E, e, y, w_rec * k.invB, w_cls * k.invB, k, implicit, l16);
@@ -521,6 +550,7 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
             if (l16 == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; accLc += o.lcls * w_cls; }
         }
         if (l16 == 0) recs[grp * (EMAX + 1) + EMAX] = __builtin_bit_cast(float, e);
+        if (more) fetch_rows();
         __syncthreads();
         if (threadIdx.x < CG * DP) {
             // Branch-free on purpose (the loads of all 16 records are issued back to back; with per-record

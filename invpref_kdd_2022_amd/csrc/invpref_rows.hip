@@ -887,9 +887,11 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
             const double Bn = (double)Bnorm, BD2 = Bn * (double)t.D * 2.0;
             const double Li = sloss[0] / Bn, Le = sloss[1] / Bn, Lc = sloss[2] / Bn;
             const double L2 = sloss[3] / BD2 + sreg[0], L1 = sloss[4] / BD2 + sreg[1];
-            losses6[0] += (float)Li; losses6[1] += (float)Le; losses6[2] += (float)Lc;
-            losses6[3] += (float)L2; losses6[4] += (float)L1;
-            losses6[5] += (float)((double)k.ca * Li + (double)k.cb * Le + (double)k.cc * Lc + (double)l2 * L2 + (double)l1 * L1);
+            // added with fire-and-forget atomics: a plain `+=` would hold the kernel's end back by one more
+            // memory round trip (the same single fp32 addition either way)
+            atomicAdd(losses6 + 0, (float)Li); atomicAdd(losses6 + 1, (float)Le); atomicAdd(losses6 + 2, (float)Lc);
+            atomicAdd(losses6 + 3, (float)L2); atomicAdd(losses6 + 4, (float)L1);
+            atomicAdd(losses6 + 5, (float)((double)k.ca * Li + (double)k.cb * Le + (double)k.cc * Lc + (double)l2 * L2 + (double)l1 * L1));
         }
     }
 }

@@ -26,7 +26,8 @@ ws = ops.Workspace(dev)
 losses = torch.zeros(6, device=dev)
 coefs = (3.35, 9.99, 9.06, 3.13, 0.49, 1.9)
 flags = ops.flags_of(True, False, True, True, False)
-os.environ['INVPREF_STAMPS_NODRAIN'] = '1'
+if os.environ.get('STAMPS_DRAIN') != '1':
+    os.environ['INVPREF_STAMPS_NODRAIN'] = '1'
 for per_slice, rpt, hot, dense in ((2, 1, 16, 32), (2, 1, 16, 16), (1, 1, 16, 32)):
     os.environ['INVPREF_PLAN_DENSE'] = str(dense)
     pl = planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, per_slice=per_slice, rounds_per_task=rpt,
@@ -50,6 +51,10 @@ for per_slice, rpt, hot, dense in ((2, 1, 16, 32), (2, 1, 16, 16), (1, 1, 16, 32
         life = e0 - s0
         print(f'  {name:6s} n={len(s0):4d} start med {np.median(s0):5.2f} p90 {np.quantile(s0, .9):5.2f} max {s0.max():5.2f} | life med {np.median(life):5.2f} p90 {np.quantile(life, .9):5.2f} max {life.max():5.2f} | end med {np.median(e0):5.2f} max {e0.max():5.2f}')
 
+    for name, sl in (('item', slice(nd, nd + ni)), ('user', slice(nd + ni, nd + njob))):
+        j = st[sl].astype(np.float64)
+        ph = np.diff(j[:, :7], axis=1) / 100
+        print('  %s job phases (us, median): stage issue %.2f | descriptor %.2f | gathers+sync %.2f | interactions %.2f | slice meet %.2f | adam+store %.2f' % ((name,) + tuple(np.median(ph, axis=0))))
     d = st[:nd].astype(np.float64)
     ph = np.diff(d[:, [0, 1, 2, 3, 4, 5, 6, 7]], axis=1) / 100
     print('  dense phases (us, median): stage+sync %.2f | ids+gather %.2f | eval %.2f | records+sync %.2f | accumulate %.2f | hot atomics + 2nd iteration %.2f | epilogue %.2f' % tuple(np.median(ph, axis=0)))

@@ -6,8 +6,9 @@
 
 Workload (BASELINE.json configs[1]): Yahoo!R3-implicit-shaped synthetic data,
 U=15 400, I=1 000, 250 154 interactions PER GPU, E=4, D=64, minibatch 8 192 rows PER GPU (weak
-scaling: the global minibatch is 8 192*N rows, row-sharded, one RCCL all-reduce of the flat gradient
-buffer per step), reference Yahoo hyper-parameters (Yahoo_InvPref_Implicit.py:17-41).
+scaling: the global minibatch is 8 192*N rows; every rank takes the interactions of the users it owns and
+one RCCL all-reduce per step carries the shared -- item-side -- part of the flat gradient buffer, DESIGN.md
+§6), reference Yahoo hyper-parameters (Yahoo_InvPref_Implicit.py:17-41).
 
 A "step" is one optimiser step of the M-step (fused gradient kernel + dense Adam) on one minibatch;
 every 155 steps (= cluster_interval 5 epochs x 31 minibatches) the E-step (+ stat_envs) over all
@@ -259,7 +260,7 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'yahoo_r3_implicit_shaped', 'users': U, 'items': I, 'envs': E, 'factor_num': D,
                    'interactions_per_gpu': N_PER_GPU, 'batch_per_gpu': B_PER_GPU, 'global_batch': B_PER_GPU * world,
-                   'estep_every_steps': ESTEP_EVERY, 'parallelism': f'row-shard x{world}, 1 all-reduce/step',
+                   'estep_every_steps': ESTEP_EVERY, 'parallelism': (f'{mgr.shard_mode}-sharded x{world}, 1 all-reduce/step ({4 * (mgr.state.n - mgr._ar_lo)} B)' if world > 1 else 'single GPU'),
                    'hip_graph_epochs': bool(mgr._graphs)},
         'roofline': roofline, 'detail': detail,
     }

@@ -244,6 +244,12 @@ int invpref_static_pop_hip(const int64_t *users, const int64_t *items, const int
  * step is 1-based.  zero_grad != 0 also clears grad (the next step's zero_grad()). */
 int invpref_adam_hip(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step,
                      double lr, double beta1, double beta2, double eps, int zero_grad, void *stream);
+/* The same step over 1..4 pieces [offsets[r], offsets[r] + lengths[r]) of the flat buffers in one launch (host
+ * arrays; every offset and length a multiple of 4 floats).  A user-sharded rank updates its own rows of the two
+ * user tables and the shared tail (item tables, embed_env, classifier) this way. */
+int invpref_adam_ranges_hip(float *param, float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *offsets,
+                            const int64_t *lengths, int32_t n_ranges, int64_t step, double lr, double beta1, double beta2,
+                            double eps, int zero_grad, void *stream);
 
 /* ---- E-step: replaces cluster() / cluster_a_batch() / cluster_predict() (train.py:235-259,
  * :169-202; models.py:409-411) over all N interactions, followed by stat_envs() (train.py:268-280).

@@ -481,6 +481,29 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float 
     }
 }
 
+// the same rule over up to four pieces of the flat buffers in ONE launch (user-sharded runs: a rank updates
+// its own rows of the two user tables + the shared tail); offsets and lengths are multiples of 4 floats
+struct AdamRanges {
+    int64_t off4[4], end4[4];   // piece r covers float4 indices [off4[r], off4[r] + len4[r]); end4 = running total
+    int n;
+};
+__global__ __launch_bounds__(256) void adam_ranges_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
+                                                          float *__restrict__ v, AdamRanges r, AdamScalars a, int zero_grad) {
+    const int64_t total = r.end4[r.n - 1];
+    for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+        int q = 0;
+        while (j >= r.end4[q]) q++;
+        const int64_t i = r.off4[q] + (j - (q ? r.end4[q - 1] : 0));
+        float4 pp = reinterpret_cast<float4 *>(p)[i], gg = reinterpret_cast<float4 *>(g)[i];
+        float4 mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+        adam1(pp.x, gg.x, mm.x, vv.x, a); adam1(pp.y, gg.y, mm.y, vv.y, a);
+        adam1(pp.z, gg.z, mm.z, vv.z, a); adam1(pp.w, gg.w, mm.w, vv.w, a);
+        reinterpret_cast<float4 *>(p)[i] = pp; reinterpret_cast<float4 *>(m)[i] = mm;
+        reinterpret_cast<float4 *>(v)[i] = vv;
+        if (zero_grad) reinterpret_cast<float4 *>(g)[i] = f4zero();
+    }
+}
+
 // =====================================================================================
 // E-step  (train.py:169-202, :235-259): argmin_e dist_e, lowest index on ties
 // =====================================================================================
@@ -846,6 +869,38 @@ int invpref_adam_hip(float *param, float *grad, float *exp_avg, float *exp_avg_s
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, n, a, zero_grad);
+    return (int)hipGetLastError();
+}
+
+int invpref_adam_ranges_hip(float *param, float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *offsets,
+                            const int64_t *lengths, int32_t n_ranges, int64_t step, double lr, double beta1, double beta2,
+                            double eps, int zero_grad, void *stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !offsets || !lengths || n_ranges < 1 || n_ranges > 4 || step < 1)
+        return INVPREF_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15u)
+        return INVPREF_EINVAL;
+    AdamRanges r{};
+    int64_t total = 0;
+    for (int i = 0; i < n_ranges; i++) {
+        if (offsets[i] < 0 || lengths[i] <= 0 || (offsets[i] & 3) || (lengths[i] & 3)) return INVPREF_EINVAL;
+        r.off4[i] = offsets[i] >> 2;
+        total += lengths[i] >> 2;
+        r.end4[i] = total;
+    }
+    r.n = n_ranges;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    AdamScalars a;
+    a.step_size = (float)(lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.w1 = (float)(1.0 - beta1);
+    a.b2 = (float)beta2;
+    a.w2 = (float)(1.0 - beta2);
+    a.eps = (float)eps;
+    int64_t nb = (total + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(adam_ranges_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, r, a, zero_grad);
     return (int)hipGetLastError();
 }
 

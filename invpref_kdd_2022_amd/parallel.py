@@ -1,4 +1,18 @@
-"""Row sharding of the InvPref hot path over the GPUs of one node.
+"""Sharding of the InvPref hot path over the GPUs of one node.
+
+Two ways to give every rank its share of a minibatch's interaction rows (both keep `utils.mini_batch`'s
+minibatches, reference utils.py:12-19, and ONE all-reduce per optimiser step):
+
+* ``UserShard`` (default): rank r owns a contiguous range of USERS and takes, from every minibatch, the
+  interactions of its users.  A user row's gradient is then complete on its owner, so the user tables need no
+  exchange at all (each rank applies Adam to its own user rows only); what is all-reduced is the item tables'
+  gradient + the small tables + the loss tail -- 0.5 MB instead of 8.4 MB at Yahoo size (U = 15 400, I = 1 000),
+  which matters on xGMI where an 8.4 MB ring all-reduce costs far more than the 20 us step.  Non-owned user
+  rows go stale on a rank; ``sync_parameters()`` of the manager refreshes them before an evaluation.
+* ``RowShard``: the literal row split described next (parameters fully replicated, the whole flat gradient
+  all-reduced).
+
+RowShard:
 
 The reference has no distributed code at all.  The path shards naturally by interaction row:
 ``mini_batch`` (reference utils.py:12-19) yields contiguous, unshuffled slices, so minibatch k is
@@ -52,6 +66,59 @@ class RowShard:
         """global row index of every local row, in local order (int64, CPU)."""
         parts = [torch.arange(*self.global_rows_of_batch(k), dtype=torch.int64) for k in range(self.batch_num)]
         return torch.cat(parts) if parts else torch.empty(0, dtype=torch.int64)
+
+
+    def select_in_batch(self, k: int, arr):
+        """this rank's part of a per-row array of minibatch k (global order)"""
+        a, b = self.slice_in_batch(k)
+        return arr[a:b]
+
+    def user_range(self, user_num: int):
+        """rows of the user tables this rank keeps up to date: all of them (replicated)"""
+        return 0, user_num
+
+
+class UserShard:
+    """Rank r owns users [r*U/W, (r+1)*U/W) and, of every minibatch, the interactions of those users (in
+    minibatch order).  Same query interface as RowShard."""
+
+    def __init__(self, users, n_total: int, batch_size: int, user_num: int, rank: int = 0, world_size: int = 1):
+        import numpy as np
+        if not (0 <= rank < world_size):
+            raise ValueError('rank out of range')
+        users = np.asarray(users, dtype=np.int64)
+        assert len(users) == n_total
+        self.n_total, self.batch_size, self.rank, self.world_size = n_total, batch_size, rank, world_size
+        self.user_num = user_num
+        self.batch_num = (n_total + batch_size - 1) // batch_size
+        self._lo, self._hi = (rank * user_num) // world_size, ((rank + 1) * user_num) // world_size
+        self._mask = (users >= self._lo) & (users < self._hi)
+        self._rows = np.flatnonzero(self._mask)
+        per_batch = np.add.reduceat(self._mask.astype(np.int64), np.arange(0, n_total, batch_size)) if n_total else []
+        self._local_off = [0]
+        for c in per_batch:
+            self._local_off.append(self._local_off[-1] + int(c))
+
+    def global_batch_len(self, k: int) -> int:
+        return min(self.batch_size, self.n_total - k * self.batch_size)
+
+    def local_batch_bounds(self, k: int):
+        return self._local_off[k], self._local_off[k + 1]
+
+    @property
+    def n_local(self) -> int:
+        return self._local_off[-1]
+
+    def local_rows(self) -> torch.Tensor:
+        return torch.from_numpy(self._rows.copy())
+
+    def select_in_batch(self, k: int, arr):
+        lo = k * self.batch_size
+        return arr[self._mask[lo:lo + self.global_batch_len(k)]]
+
+    def user_range(self, user_num: int):
+        assert user_num == self.user_num
+        return self._lo, self._hi
 
 
 def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:

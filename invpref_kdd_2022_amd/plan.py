@@ -88,10 +88,12 @@ def _side_rounds(own, oth, pos, y, n_rows: int, per_slice: int, pad_to: int, ski
 
 def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, user_num: int, item_num: int,
                    per_slice: int | None = None, rounds_per_task: int | None = None,
-                   hot_threshold: int | None = None) -> dict:
+                   hot_threshold: int | None = None, user_range=None) -> dict:
     """users/items/scores: ONE minibatch (or this rank's slice of it); scores as the fp32 labels.
     hot_threshold: item rows with MORE interactions than this get no job; their gradient is added with
-    float atomics by the user-side jobs and completed by the finish kernel (-1: every item row)."""
+    float atomics by the user-side jobs and completed by the finish kernel (-1: every item row).
+    user_range: (lo, hi) user rows this rank is responsible for (user-sharded runs): untouched user rows
+    outside it are not streamed (nobody reads their gradient or updates them here)."""
     users = np.asarray(users, dtype=np.int64)
     items = np.asarray(items, dtype=np.int64)
     scores = np.asarray(scores, dtype=np.float32)
@@ -113,7 +115,11 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     hot_index[hot_rows] = np.arange(len(hot_rows), dtype=np.int32)
     # item rounds first (they hold the longest jobs; padded to whole workgroups), user rounds after
     ucnt = np.bincount(users, minlength=user_num)
-    stream_u = np.flatnonzero(ucnt == 0).astype(np.int32)       # untouched rows: streamed, no job
+    untouched_u = ucnt == 0
+    if user_range is not None:
+        untouched_u[:user_range[0]] = False
+        untouched_u[user_range[1]:] = False
+    stream_u = np.flatnonzero(untouched_u).astype(np.int32)     # untouched rows: streamed, no job
     stream_i = np.flatnonzero(icnt == 0).astype(np.int32)
     di = _side_rounds(items[pi], users[pi], pi, scores[pi], item_num, per_slice, rounds_per_task,
                       skip=hot | (icnt == 0))

@@ -11,8 +11,9 @@ the work inside is re-designed for MI355X:
 * ``cluster`` + ``stat_envs`` = one E-step launch over all local interactions + one finish launch;
 * no per-batch host syncs: ``train_a_epoch`` reads the loss terms back once per epoch.
 
-Row sharding: with ``world_size`` G > 1 every minibatch ``[kB,(k+1)B)`` is cut
-into G contiguous row slices; rank r keeps only its slices of users/items/scores/envs/weights.
+Sharding (parallel.py): with ``world_size`` G > 1 every rank keeps only its share of
+every minibatch ``[kB,(k+1)B)`` -- by default the interactions of the users it owns (only the item-side
+gradient is all-reduced), with INVPREF_SHARD=rows a contiguous row slice (everything all-reduced).
 Every mean() keeps the GLOBAL batch length as denominator, so summing the per-rank gradient
 buffers reproduces the single-GPU gradient.
 """
@@ -30,7 +31,7 @@ import ctypes as C
 
 from . import _capi, ops
 from . import plan as planlib
-from .parallel import RowShard, all_reduce_sum_
+from .parallel import RowShard, UserShard, all_reduce_sum_
 
 LOSS_KEYS = ('invariant_loss', 'env_aware_loss', 'envs_loss', 'L2_reg', 'L1_reg', 'loss')
 _ALIGN = 64  # floats; every table starts on a 256-byte boundary of the flat buffer
@@ -43,15 +44,17 @@ def transfer_loss_dict_to_line_str(d: dict) -> str:
 class FlatState:
     """params / grads / exp_avg / exp_avg_sq as four flat buffers + per-table views."""
 
-    def __init__(self, tabs, device):
-        """tabs: the model's parameter tensors (InvPref: the seven of state_dict order; PureMF: two)."""
+    def __init__(self, tabs, device, order=None):
+        """tabs: the model's parameter tensors (InvPref: the seven of state_dict order; PureMF: two).
+        order: physical placement of the tables inside the flat buffers (default: as listed).  A user-sharded
+        run puts the two user tables first, so that everything the ranks share is ONE contiguous range."""
         tabs = list(tabs)
         self.shapes = [tuple(p.shape) for p in tabs]
-        self.offsets = []
+        self.offsets = [0] * len(tabs)
         off = 0
-        for p in tabs:
-            self.offsets.append(off)
-            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        for i in (range(len(tabs)) if order is None else order):
+            self.offsets[i] = off
+            off += (tabs[i].numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.n = off
         self.param = torch.zeros(self.n, dtype=torch.float32, device=device)
         # +8: the six loss partials ride at the tail of the gradient buffer so that ONE all-reduce
@@ -118,7 +121,18 @@ class _InvPrefTrainManager:
         self.n_total = n_total
         self.batch_size = batch_size
         self.batch_num = math.ceil(n_total / batch_size)
-        self.shard = RowShard(n_total, batch_size, self.rank, self.world_size)
+        # multi-GPU: users are partitioned by default (parallel.UserShard: only the item-side gradient is
+        # all-reduced); INVPREF_SHARD=rows selects the literal row split with fully replicated parameters
+        # (testing aid INVPREF_FORCE_SHARDED_PATH=1: the sharded step sequence, either layout, on one rank)
+        forced = os.environ.get('INVPREF_FORCE_SHARDED_PATH', '0') == '1'
+        self.shard_mode = os.environ.get('INVPREF_SHARD', 'users') if (self.world_size > 1 or forced) else 'rows'
+        if self.shard_mode not in ('users', 'rows'):
+            raise ValueError('INVPREF_SHARD must be "users" or "rows"')
+        if self.shard_mode == 'users':
+            self.shard = UserShard(training_data[:, 0].cpu().numpy(), n_total, batch_size, model.user_num, self.rank,
+                                   self.world_size)
+        else:
+            self.shard = RowShard(n_total, batch_size, self.rank, self.world_size)
         rows = self.shard.local_rows().to(training_data.device)
         td = training_data.index_select(0, rows) if self.world_size > 1 else training_data
         # full tensors keep the reference attribute names; *_local are what the kernels read
@@ -151,7 +165,11 @@ class _InvPrefTrainManager:
         self._eps_rows_cnt = math.factorial(self.envs_num)
 
         self.model.to(self.device)
-        self.state = FlatState(model.tables(), self.device)
+        # user-sharded: [Pu | Pa | Qi | Qa | Ev | W | b]: the replicated part (items + small tables) and the loss
+        # tail form one contiguous range for the all-reduce, the owned user rows two ranges for Adam
+        self.state = FlatState(model.tables(), self.device,
+                               order=[0, 2, 1, 3, 4, 5, 6] if self.shard_mode == 'users' else None)
+        self._setup_ranges(model)
         self.workspace = ops.Workspace(self.device)
         self._flags = ops.flags_of(self.implicit, use_recommend_re_weight, use_class_re_weight,
                                    model.reg_only_embed, model.reg_env_embed, dense_reg=(self.rank == 0))
@@ -175,6 +193,47 @@ class _InvPrefTrainManager:
         self._sched = None
         self._sched_synced = False
 
+    def _setup_ranges(self, model):
+        """What one optimiser step exchanges and updates on this rank: `_ar_lo` = first float of the flat
+        gradient that is all-reduced (through the loss tail), `_adam_ranges` = (offset, length) pieces of the
+        flat buffers this rank applies Adam to."""
+        st = self.state
+        if self.shard_mode == 'users':
+            lo, hi = self.shard.user_range(model.user_num)
+            D = model.factor_num
+            self._ar_lo = st.offsets[1]                      # embed_item_invariant: start of the replicated part
+            self._adam_ranges = [(st.offsets[0] + lo * D, (hi - lo) * D), (st.offsets[2] + lo * D, (hi - lo) * D),
+                                 (self._ar_lo, st.n - self._ar_lo)]
+            self._adam_ranges = [r for r in self._adam_ranges if r[1] > 0]
+        else:
+            self._ar_lo = 0
+            self._adam_ranges = [(0, st.n)]
+
+    def sync_parameters(self) -> None:
+        """User-sharded runs: bring every rank's copy of the user tables up to date (each rank contributes its
+        own rows; one all-reduce per table).  Called before evaluations and at the end of train(); a no-op
+        otherwise.  The Adam moments of foreign rows are not exchanged (nothing reads them)."""
+        if self.world_size == 1 or self.shard_mode != 'users':
+            return
+        lo, hi = self.shard.user_range(self.model.user_num)
+        for i in (0, 2):
+            view = self.state.p_views[i]
+            tmp = torch.zeros_like(view)
+            tmp[lo:hi] = view[lo:hi]
+            all_reduce_sum_(tmp, self.process_group)
+            view.copy_(tmp)
+
+    def _all_reduce_step(self):
+        """the one exchange of an optimiser step: the shared part of the flat gradient + the loss tail"""
+        all_reduce_sum_(self.state.grad_ext[self._ar_lo:], self.process_group)
+
+    def _coefs_struct(self, alpha):
+        """ctypes coefficient block for `alpha` (cached: alpha is usually fixed)"""
+        c = getattr(self, '_cf_cache', None)
+        if c is None or c[0] != alpha:
+            c = self._cf_cache = (alpha, _capi.Coefs(*self._coefs(alpha)))
+        return c[1]
+
     # ------------------------------------------------------------------ M-step
     def _coefs(self, alpha):
         return (self.invariant_coe, self.env_aware_coe, self.env_coe, self.L2_coe, self.L1_coe, alpha)
@@ -189,14 +248,17 @@ class _InvPrefTrainManager:
         ops.mstep_grad(st.p_views, st.g_views, users, items, envs, scores, weights, batch_norm, self._coefs(alpha),
                        self._flags, losses6, self.workspace)
         if self.world_size > 1:
-            all_reduce_sum_(st.grad_ext, self.process_group)
+            self._all_reduce_step()
         st.step += 1
         self._sched_synced = False
-        ops.adam_(st.param, st.grad, st.exp_avg, st.exp_avg_sq, st.step, self.lr, zero_grad=True)
+        for o, n in self._adam_ranges:
+            ops.adam_(st.param[o:o + n], st.grad[o:o + n], st.exp_avg[o:o + n], st.exp_avg_sq[o:o + n], st.step, self.lr,
+                      zero_grad=True)
 
     def train_a_batch(self, batch_users_tensor, batch_items_tensor, batch_scores_tensor, batch_envs_tensor,
                       batch_sample_weights, alpha) -> dict:
-        """train.py:94-167.  In a row-sharded run the arguments are this rank's slice of the batch."""
+        """train.py:94-167.  In a sharded run the arguments are this rank's share of the batch (user-sharded:
+        the interactions of the users this rank owns)."""
         assert batch_users_tensor.shape == batch_items_tensor.shape == batch_scores_tensor.shape \
             == batch_envs_tensor.shape
         bn = batch_users_tensor.shape[0]
@@ -232,6 +294,12 @@ class _InvPrefTrainManager:
             lo, hi = self.shard.local_batch_bounds(k)
             self._raw_batches.append((lo, hi - lo, self.shard.global_batch_len(k)))
         self._raw_mstep, self._raw_adam = L.invpref_mstep_grad_hip, L.invpref_adam_hip
+        self._raw_adam_ranges = L.invpref_adam_ranges_hip
+        rg = getattr(self, '_adam_ranges', [(0, st.n)])
+        self._adam_ranges_c = None
+        if len(rg) > 1 and len(rg) <= 4 and all(o % 4 == 0 and n % 4 == 0 for o, n in rg):
+            self._adam_ranges_c = ((C.c_int64 * len(rg))(*[o for o, _ in rg]), (C.c_int64 * len(rg))(*[n for _, n in rg]),
+                                   len(rg))
         self._raw_rows_grad, self._raw_rows_adam = L.invpref_mstep_rows_grad_hip, L.invpref_mstep_rows_adam_hip
         self._raw_rows_adam_sched = L.invpref_mstep_rows_adam_sched_hip
         if self.use_plan and self._plans is None:
@@ -240,7 +308,8 @@ class _InvPrefTrainManager:
             self._plans = []
             for lo, n, _ in self._raw_batches:
                 pl = planlib.build_row_plan(u[lo:lo + n], v[lo:lo + n], y[lo:lo + n], self.model.user_num,
-                                            self.model.item_num)
+                                            self.model.item_num,
+                                            user_range=None if self._pure else self.shard.user_range(self.model.user_num))
                 self._plans.append(planlib.upload(pl, self.device))
         if self.use_plan:
             self._raw_ows = self.workspace.get_zeroed(
@@ -255,13 +324,11 @@ class _InvPrefTrainManager:
             self._sched_synced = False
         lo, n, bn = self._raw_batches[k]
         pu, pi, pe, py, pw = self._raw_ptrs
-        cf = _capi.Coefs(*self._coefs(alpha))
+        cf = self._coefs_struct(alpha)
         multi = self.world_size > 1 or self._force_sharded_path
-        if multi:
-            st.losses6.zero_()
-            lp = st.losses6.data_ptr()
-        else:
-            lp = self._epoch_losses.data_ptr() + 24 * (self._loss_slot * self.batch_num + k)
+        # every step's six loss terms go straight into the epoch's loss buffer (this rank's partial sums in a
+        # sharded run: they are all-reduced once per epoch, not per step)
+        lp = self._epoch_losses.data_ptr() + 24 * (self._loss_slot * self.batch_num + k)
         t_cur = self._raw_tabs[id(st.p_views)]
         if self.use_plan and not multi:
             # fused M-step + Adam: one pass, gradient never stored, parameters ping-pong
@@ -297,16 +364,24 @@ class _InvPrefTrainManager:
             _capi.check(rc, 'invpref_mstep_(rows_)grad_hip')
         if multi:
             if self.world_size > 1 or self._collective_ok:
-                all_reduce_sum_(st.grad_ext, self.process_group)
-            self._epoch_losses[self._loss_slot, k] += st.losses6
+                all_reduce_sum_(st.grad[self._ar_lo:], self.process_group)   # the step's one exchange
         if mid_event is not None:
             mid_event.record()
         st.step += 1
-        # the planned gradient pass overwrites every row, so the gradient buffer needs no zeroing
-        rc = self._raw_adam(st.param.data_ptr(), st.grad.data_ptr(), st.exp_avg.data_ptr(), st.exp_avg_sq.data_ptr(),
-                            st.n, st.step, self.lr, 0.9, 0.999, 1e-8, 0 if self.use_plan else 1, stream)
-        if rc:
-            _capi.check(rc, 'invpref_adam_hip')
+        # the planned gradient pass overwrites every row it is responsible for, so the gradient buffer needs no zeroing
+        pp, pg, pm, pv = st.param.data_ptr(), st.grad.data_ptr(), st.exp_avg.data_ptr(), st.exp_avg_sq.data_ptr()
+        zero = 0 if self.use_plan else 1
+        if self._adam_ranges_c is not None:   # every piece in one launch
+            offs, lens, cnt = self._adam_ranges_c
+            rc = self._raw_adam_ranges(pp, pg, pm, pv, offs, lens, cnt, st.step, self.lr, 0.9, 0.999, 1e-8, zero, stream)
+            if rc:
+                _capi.check(rc, 'invpref_adam_ranges_hip')
+        else:
+            for o, n in self._adam_ranges:
+                rc = self._raw_adam(pp + 4 * o, pg + 4 * o, pm + 4 * o, pv + 4 * o, n, st.step, self.lr, 0.9, 0.999, 1e-8,
+                                    zero, stream)
+                if rc:
+                    _capi.check(rc, 'invpref_adam_hip')
 
     def _alpha_for(self, k: int) -> float:
         if self.update_alpha:  # train.py:214-217
@@ -394,6 +469,8 @@ class _InvPrefTrainManager:
         else:
             n = 1
             self._issue_epochs(torch.cuda.current_stream().cuda_stream, False, 1)
+            if self.world_size > 1:
+                all_reduce_sum_(self._epoch_losses[:1], self.process_group)   # per-rank loss partials -> totals
             self._graph_warm = True
             self._sched_synced = False
         self.epoch_cnt += n
@@ -453,8 +530,7 @@ class _InvPrefTrainManager:
         for k in range(self.batch_num):
             glen = self.shard.global_batch_len(k)
             idx = np.random.randint(0, self._eps_rows_cnt, glen)  # same numpy stream as the reference
-            a, b = self.shard.slice_in_batch(k)
-            idx = idx[a:b]
+            idx = self.shard.select_in_batch(k, idx)
             if self._eps_rows_cnt <= 40320:
                 out[done:done + len(idx)] = table[idx]
             else:
@@ -526,6 +602,7 @@ class _InvPrefTrainManager:
         loss_result_list, train_epoch_index_list = [], []
 
         if initial:
+            self.sync_parameters()
             temp_eval_result = self.evaluator.evaluate()
             test_result_list.append(temp_eval_result)
             test_epoch_list.append(self.epoch_cnt)
@@ -551,6 +628,7 @@ class _InvPrefTrainManager:
                     print(transfer_loss_dict_to_line_str(run[i]))
 
             if (self.epoch_cnt % self.evaluate_interval) == 0 and self.epoch_cnt >= self.test_begin_epoch:
+                self.sync_parameters()
                 temp_eval_result = self.evaluator.evaluate()
                 test_result_list.append(temp_eval_result)
                 test_epoch_list.append(self.epoch_cnt)
@@ -573,6 +651,7 @@ class _InvPrefTrainManager:
                     print('diff num:', diff_num)
                     print(transfer_loss_dict_to_line_str(envs_cnt))
 
+        self.sync_parameters()  # (user-sharded runs: every rank ends with the complete model)
         if defer:  # one read-back for everything
             loss_result_list = [dict(zip(LOSS_KEYS, v)) for v in torch.stack(loss_result_list).tolist()] \
                 if loss_result_list else []

@@ -1,7 +1,8 @@
-"""CPU, world_size 2 over gloo: the row-sharded training path (parallel.RowShard, FlatState layout,
-one all-reduce of the flat gradient buffer with the loss tail, sharded E-step counts) run through the
-REAL manager code with the HIP ops swapped for the CPU oracle (test infrastructure), against the
-single-process oracle trajectory."""
+"""CPU, world_size 2 over gloo: the sharded training paths -- parallel.UserShard (default: users
+partitioned, only the item-side gradient + small tables + loss tail all-reduced, Adam on the owned user rows)
+and parallel.RowShard (rows split, everything all-reduced) -- with the FlatState layout, the per-step
+exchange, the sharded E-step counts and sync_parameters() run through the REAL manager code with the HIP
+ops swapped for the CPU oracle (test infrastructure), against the single-process oracle trajectory."""
 import os
 import socket
 
@@ -12,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from invpref_kdd_2022_amd import ops, synth
-from invpref_kdd_2022_amd.parallel import RowShard
+from invpref_kdd_2022_amd.parallel import RowShard, UserShard
 from oracle import oracle as O
 
 U, I, E, D, N, B = 60, 40, 3, 16, 1000, 256
@@ -89,17 +90,22 @@ def _make_manager(rank, world, data, tabs):
                                 world_size=world, **COEFS)
 
 
-def _worker(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+def _worker(rank, world, port, out_dir, mode):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), INVPREF_SHARD=mode)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         _oracle_ops(ops)
         data = synth.interactions(3, U, I, N, implicit=False, zipf=False)
         tabs = synth.tables(4, U, I, E, D, std=0.2)
         mgr = _make_manager(rank, world, data, tabs)
-        # this rank holds exactly its row slices of every minibatch, in order
-        rows = RowShard(N, B, rank, world).local_rows().numpy()
+        # this rank holds exactly its share of every minibatch, in order
+        ref_shard = RowShard(N, B, rank, world) if mode == 'rows' else UserShard(data[:, 0], N, B, U, rank, world)
+        rows = ref_shard.local_rows().numpy()
+        assert mgr.shard_mode == mode and type(mgr.shard) is type(ref_shard)
         np.testing.assert_array_equal(mgr.users_tensor.numpy(), data[rows, 0])
+        if mode == 'users':
+            lo, hi = mgr.shard.user_range(U)
+            assert ((data[rows, 0] >= lo) & (data[rows, 0] < hi)).all()
         mgr.stat_envs()
         losses = []
         for _ in range(2):
@@ -110,7 +116,11 @@ def _worker(rank, world, port, out_dir):
                                                 mgr.sample_weights[lo:hi], mgr.alpha))
             diff = mgr.cluster()
             cnt = mgr.stat_envs()
-        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), param=mgr.state.param.numpy(),
+        stale = mgr.state.param.numpy().copy()
+        mgr.sync_parameters()   # user-sharded: foreign user rows were never updated on this rank
+        if mode == 'users' and world > 1:
+            assert not np.array_equal(stale, mgr.state.param.numpy())
+        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), param=mgr.state.param.numpy(), offsets=np.array(mgr.state.offsets),
                  losses=np.array([[d[k] for k in d] for d in losses]), diff=diff,
                  counts=np.array([cnt[e] for e in range(E)]), envs=mgr.envs.numpy(), rows=rows)
     finally:
@@ -118,9 +128,10 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_row_sharded_training_matches_single_process(tmp_path):
+@pytest.mark.parametrize('mode', ['users', 'rows'])
+def test_sharded_training_matches_single_process(tmp_path, mode):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
     r = [np.load(tmp_path / f'rank{i}.npz') for i in range(world)]
     # replicas stay identical
     np.testing.assert_array_equal(r[0]['param'], r[1]['param'])
@@ -147,7 +158,9 @@ def test_row_sharded_training_matches_single_process(tmp_path):
     from invpref_kdd_2022_amd.models import InvPrefExplicit
     from invpref_kdd_2022_amd.train import FlatState
     fs = FlatState(InvPrefExplicit(U, I, E, D).tables(), torch.device('cpu'))
-    for arr, off, shp in zip(tr.tab.arrs, fs.offsets, fs.shapes):
+    if mode == 'users':   # the user tables come first in the flat buffers
+        assert r[0]['offsets'][2] < r[0]['offsets'][1] and fs.offsets[1] < fs.offsets[2]
+    for arr, off, shp in zip(tr.tab.arrs, r[0]['offsets'], fs.shapes):
         got = r[0]['param'][off:off + arr.size].reshape(shp)
         assert np.abs(got - arr).max() < 0.05 * LR
         assert np.quantile(np.abs(got - arr), 0.99) < 5e-6
@@ -158,6 +171,27 @@ def test_row_sharded_training_matches_single_process(tmp_path):
     mism = int((envs != tr.envs).sum())
     assert mism <= 2
     assert abs(int(r[0]['diff']) - diff) <= mism and np.abs(r[0]['counts'] - np.array([cnt[e] for e in range(E)])).sum() <= 2 * mism
+
+
+def test_user_shard_index_arithmetic():
+    rs = np.random.RandomState(0)
+    for n, b, users_n, w in ((1000, 256, 60, 2), (250154, 8192, 15400, 8), (7, 3, 5, 4), (5, 10, 3, 3)):
+        users = rs.randint(0, users_n, n)
+        shards = [UserShard(users, n, b, users_n, r, w) for r in range(w)]
+        allrows = np.concatenate([s.local_rows().numpy() for s in shards])
+        assert sorted(allrows.tolist()) == list(range(n))           # a partition of the rows
+        ranges = [s.user_range(users_n) for s in shards]
+        assert ranges[0][0] == 0 and ranges[-1][1] == users_n and all(ranges[i][1] == ranges[i + 1][0] for i in range(w - 1))
+        for s in shards:
+            lo, hi = s.user_range(users_n)
+            rows = s.local_rows().numpy()
+            assert ((users[rows] >= lo) & (users[rows] < hi)).all()  # only this rank's users
+            assert s.n_local == len(rows)
+            for k in range(s.batch_num):
+                a, c = s.local_batch_bounds(k)
+                g = rows[a:c]
+                assert ((g >= k * b) & (g < min((k + 1) * b, n))).all() and (np.diff(g) > 0).all()   # minibatch order kept
+                np.testing.assert_array_equal(s.select_in_batch(k, np.arange(k * b, k * b + s.global_batch_len(k))), g)
 
 
 def test_row_shard_index_arithmetic():

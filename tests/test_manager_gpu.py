@@ -165,7 +165,8 @@ def _assert_same_run(dlt, lr, name):
 
 def test_sharded_step_sequence_equals_fused_path(monkeypatch):
     """The multi-GPU step sequence (planned gradient pass that overwrites the flat gradient buffer ->
-    RCCL all-reduce with the loss tail -> stand-alone Adam without zeroing) on a 1-rank RCCL group,
+    RCCL all-reduce of the shared range with the loss tail -> stand-alone Adam on this rank's ranges, no zeroing)
+    on a 1-rank RCCL group, in both layouts (user-sharded: user tables first, three Adam ranges; row-sharded),
     against the single-GPU fused path: same loss trace (1e-6) and parameters (ulp-level)."""
     import torch.distributed as dist
     z = np.load(os.path.join(G, 'g4_yahoo_like_traj.npz'))
@@ -177,23 +178,27 @@ def test_sharded_step_sequence_equals_fused_path(monkeypatch):
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=0, world_size=1)
     res = []
-    for forced in ('0', '1'):
+    for forced, mode in (('0', 'users'), ('1', 'users'), ('1', 'rows')):
         monkeypatch.setenv('INVPREF_FORCE_SHARDED_PATH', forced)
+        monkeypatch.setenv('INVPREF_SHARD', mode)
         model = InvPrefImplicit(U, I, E, D, reg_only_embed=False, reg_env_embed=True)
         model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
         np.random.seed(seed)
         mgr = _mgr(ImplicitTrainManager, model, data, z, use_class_re_weight=True, use_recommend_re_weight=True)
+        assert mgr.shard_mode == (mode if forced == '1' else 'rows')
         mgr.stat_envs()
         tr = [mgr.train_a_epoch() for _ in range(3)]
         d = mgr.cluster()
+        mgr.sync_parameters()
         res.append((np.array([[e[k] for k in LOSS_KEYS] for e in tr]), d,
                     {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}))
     dist.destroy_process_group()
-    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-6)
-    assert abs(res[0][1] - res[1][1]) <= 3
-    for k in O.PARAM_NAMES:
-        dlt = np.abs(res[0][2][k] - res[1][2][k])
-        _assert_same_run(dlt, float(z['coefs'][6]), k)
+    for other in res[1:]:
+        np.testing.assert_allclose(res[0][0], other[0], rtol=2e-6)
+        assert abs(res[0][1] - other[1]) <= 3
+        for k in O.PARAM_NAMES:
+            dlt = np.abs(res[0][2][k] - other[2][k])
+            _assert_same_run(dlt, float(z['coefs'][6]), k)
 
 
 def test_train_epochs_single_readback_equals_epoch_by_epoch():

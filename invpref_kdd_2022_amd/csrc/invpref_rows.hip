@@ -144,7 +144,7 @@ struct Eval {
     float gz[EMAX];
     float4 x[NC], gx[NC];   // x = Pu*Qi ; gx = sum_c gz_c W_c
 };
-template <int NC, int EMAX>
+template <int NC, int EMAX, bool HOISTW = false>
 __device__ __forceinline__ void eval_interaction(Eval<NC, EMAX> &o, const float4 (&pu)[NC], const float4 (&qi)[NC],
                                                  const float4 (&pa)[NC], const float4 (&qa)[NC], const float4 (&ev)[NC],
                                                  const float *sW, const float *sb, int E, int e, float y, float cw_rec,
@@ -169,20 +169,44 @@ __device__ __forceinline__ void eval_interaction(Eval<NC, EMAX> &o, const float4
 #pragma unroll
     for (int c = 0; c < NC; c++) o.x[c] = f4mul(pu[c], qi[c]);
     float z[EMAX], mx = -__builtin_inff();
+    // HOISTW (dense tasks, small classifiers): the W rows are read from LDS ONCE, unconditionally and back to
+    // back, and everything after is selects and arithmetic -- with a guarded LDS read per class the E forward
+    // dots and the E backward rows each pay their own LDS round trip in sequence.  Rows c >= E of the staged
+    // area hold other data: they are masked to zero, their logits to -inf (exp -> 0, gz -> 0).
+    constexpr bool HOIST = HOISTW && EMAX * NC <= 4;
+    float4 wrow[HOIST ? EMAX : 1][NC];
+    if (HOIST) {
 #pragma unroll
-    for (int c = 0; c < EMAX; c++) {
-        z[c] = -__builtin_inff();
-        if (c < E) {
-            float4 wr[NC];
-            lds_row<NC>(sW, c, l16, wr);
-            z[c] = dot2<NC>(o.x, wr) + sb[c];
+        for (int c = 0; c < EMAX; c++) {
+            float4 t4[NC];
+            lds_row<NC>(sW, c, l16, t4);
+#pragma unroll
+            for (int jj = 0; jj < NC; jj++) wrow[c][jj] = f4sel(c < E, t4[jj]);
+        }
+#pragma unroll
+        for (int c = 0; c < EMAX; c++) {
+            const float zc = dot2<NC>(o.x, wrow[c]) + sb[c];
+            z[c] = c < E ? zc : -__builtin_inff();
             mx = z[c] > mx ? z[c] : mx;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < EMAX; c++) {
+            z[c] = -__builtin_inff();
+            if (c < E) {
+                float4 wr[NC];
+                lds_row<NC>(sW, c, l16, wr);
+                z[c] = dot2<NC>(o.x, wr) + sb[c];
+                mx = z[c] > mx ? z[c] : mx;
+            }
         }
     }
     float se = 0.f, ze = 0.f;
 #pragma unroll
-    for (int c = 0; c < EMAX; c++)
-        if (c < E) { z[c] = f_exp(z[c] - mx); se += z[c]; }
+    for (int c = 0; c < EMAX; c++) {
+        if (HOIST) { z[c] = f_exp(z[c] - mx); se += z[c]; }   // exp(-inf) = 0 for the padded classes
+        else if (c < E) { z[c] = f_exp(z[c] - mx); se += z[c]; }
+    }
 #pragma unroll
     for (int c = 0; c < EMAX; c++) ze = (c == e) ? z[c] : ze;
     const float rse = f_rcp(se);
@@ -191,13 +215,19 @@ __device__ __forceinline__ void eval_interaction(Eval<NC, EMAX> &o, const float4
     for (int c = 0; c < NC; c++) o.gx[c] = f4zero();
 #pragma unroll
     for (int c = 0; c < EMAX; c++) {
-        o.gz[c] = 0.f;
-        if (c < E) {
-            o.gz[c] = k.cc * cw_cls * (z[c] * rse - (c == e ? 1.f : 0.f));
-            float4 wr[NC];
-            lds_row<NC>(sW, c, l16, wr);
+        if (HOIST) {
+            o.gz[c] = c < E ? k.cc * cw_cls * (z[c] * rse - (c == e ? 1.f : 0.f)) : 0.f;
 #pragma unroll
-            for (int jj = 0; jj < NC; jj++) f4fma(o.gx[jj], o.gz[c], wr[jj]);
+            for (int jj = 0; jj < NC; jj++) f4fma(o.gx[jj], o.gz[c], wrow[c][jj]);
+        } else {
+            o.gz[c] = 0.f;
+            if (c < E) {
+                o.gz[c] = k.cc * cw_cls * (z[c] * rse - (c == e ? 1.f : 0.f));
+                float4 wr[NC];
+                lds_row<NC>(sW, c, l16, wr);
+#pragma unroll
+                for (int jj = 0; jj < NC; jj++) f4fma(o.gx[jj], o.gz[c], wr[jj]);
+            }
         }
     }
 }
@@ -503,7 +533,7 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
             float4 ev[NC];
             lds_row<NC>(sEv, e, l16, ev);
             Eval<NC, EMAX> o;
-            eval_interaction<NC, EMAX>(o, pu, qi, pa, qa, ev, sW, sb, t.E, e, y, w_rec * k.invB, w_cls * k.invB, k, implicit, l16);
+            eval_interaction<NC, EMAX, true>(o, pu, qi, pa, qa, ev, sW, sb, t.E, e, y, w_rec * k.invB, w_cls * k.invB, k, implicit, l16);
             // record for the E x D accumulation
 #pragma unroll
             for (int jj = 0; jj < NC; jj++) {

@@ -97,12 +97,16 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     users = np.asarray(users, dtype=np.int64)
     items = np.asarray(items, dtype=np.int64)
     scores = np.asarray(scores, dtype=np.float32)
+    # Defaults follow the minibatch size (measured, tools/kbench.py): a Yahoo step (8 192 interactions) wants many
+    # short tasks -- about one resident set of workgroups, so the step is one latency chain -- while a
+    # MovieLens-sized one (65 536) is throughput-bound and wants fewer, longer ones.
+    scale = max(1, len(users) // 8192)
     if per_slice is None:
-        per_slice = int(os.environ.get('INVPREF_PLAN_PER_SLICE', '2'))
+        per_slice = int(os.environ.get('INVPREF_PLAN_PER_SLICE', str(min(16, 2 * scale))))
     if rounds_per_task is None:
         rounds_per_task = int(os.environ.get('INVPREF_PLAN_ROUNDS', '1'))
     if hot_threshold is None:
-        hot_threshold = int(os.environ.get('INVPREF_PLAN_HOT', '16'))
+        hot_threshold = int(os.environ.get('INVPREF_PLAN_HOT', str(16 if per_slice <= 2 else 16 * per_slice)))
     n = len(users)
     if n and (cnt_max := max(np.bincount(users).max(), np.bincount(items).max())) >= (1 << 23):
         raise ValueError(f'a row with {cnt_max} interactions in one minibatch overflows the job descriptor')
@@ -125,7 +129,7 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
                       skip=hot | (icnt == 0))
     du = _side_rounds(users[pu], items[pu], pu, scores[pu], user_num, per_slice, 1, skip=(ucnt == 0))
     return dict(batch_users=users.astype(np.int32), batch_items=items.astype(np.int32),
-                dense_per_task=int(os.environ.get('INVPREF_PLAN_DENSE', '32')),
+                dense_per_task=int(os.environ.get('INVPREF_PLAN_DENSE', str(min(128, 32 * scale)))),
                 stream_rows=np.concatenate([stream_u, stream_i]), n_stream_user=len(stream_u),
                 n_stream_item=len(stream_i), rows_per_stream_task=int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', '64')),n=n, n_item_rounds=len(di), rounds_per_task=rounds_per_task, desc=np.concatenate([di, du]),
                 other_user=items[pu].astype(np.int32), pos_user=pu.astype(np.int32),

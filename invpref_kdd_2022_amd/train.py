@@ -176,12 +176,13 @@ class _InvPrefTrainManager:
         # atomic-free planned M-step (plan.py) unless INVPREF_NO_PLAN=1 (then: float-atomic scatter-add)
         self.use_plan = os.environ.get('INVPREF_NO_PLAN', '0') != '1'
         if 'INVPREF_NO_PLAN' not in os.environ:
-            # round-1 heuristic: the planned kernel keeps the E x D partials in per-wave LDS areas only while
-            # E*D is small (E <= 4, D <= 64); beyond that it falls back to LDS atomics and the plan-free
-            # scatter-add kernel is currently the faster of the two
+            # measured (tools/kbench.py): the planned kernel wins up to MovieLens-class shapes (E = 8, D = 128:
+            # 122 us against 181 us per 65 536-interaction step); at MIND-class E*D (E = 16, D = 256) every
+            # interaction's three evaluations cost more than the shaped atomics of the plan-free kernel
+            # (2.2 ms against 1.66 ms), which is then used instead
             emax = 4 if model.env_num <= 4 else (8 if model.env_num <= 8 else 16)
             nc = 4 if model.factor_num % 4 else (1 if model.factor_num <= 64 else (2 if model.factor_num <= 128 else 4))
-            self.use_plan = emax * nc <= 4
+            self.use_plan = emax * nc <= 16
         self._plans = None
         # whole epochs as one HIP graph launch (single GPU, planned path, fixed alpha); INVPREF_NO_GRAPH=1 disables
         self.use_graph = os.environ.get('INVPREF_NO_GRAPH', '0') != '1'

@@ -276,3 +276,34 @@ def test_rows_path_mind_shape_g5():
             ref, got = z['g_' + k], g
         tol = 2e-5 if 'embed_' in k and 'env.' not in k else 3e-4
         assert np.abs(got - ref).max() < tol * np.abs(ref).max() + 1e-9, k
+
+
+def test_rows_path_movielens_shape_default_plan():
+    """MovieLens-class step (U=6 040, I=3 706, E=8, D=128, B=65 536) through the planned fused
+    pass with the DEFAULT plan parameters for that minibatch size (16 interactions per slice, hot rows above 256,
+    128 interactions per dense task) against oracle gradient + oracle Adam."""
+    U, I, E, D, B = 6040, 3706, 8, 128, 65536
+    data = synth.interactions(31, U, I, B, implicit=True, zipf=False)
+    tabs = synth.tables(32, U, I, E, D, std=0.1)
+    envs = np.random.RandomState(33).randint(0, E, B).astype(np.int64)
+    pl = planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I)
+    assert pl['dense_per_task'] == 128 and pl['n_item_rounds'] > 0
+    dp = planlib.upload(pl, DEV)
+    P = dev_params(tabs)
+    P2, M, V = ([torch.zeros_like(p) for p in P] for _ in range(3))
+    ws = ops.Workspace(DEV)
+    _, _, sw = ops.stat_envs(t64(envs), E, ws)
+    coefs = (3.35, 9.99, 9.06, 3.13, 0.49, 1.9)
+    flags = ops.flags_of(True, True, True, False, True)
+    losses = torch.zeros(6, device=DEV)
+    lr = 0.005
+    ops.mstep_rows_adam(P, P2, M, V, dp, t64(envs), t32(data[:, 2]), sw, B, coefs, flags, losses, 1, lr, ws)
+    tab = O.Tables(tabs)
+    _, _, osw = O.stat_envs(envs, E)
+    og, ol = O.mstep(tab, data[:, 0], data[:, 1], envs, data[:, 2], osw, coefs, O.flags_of(True, True, True, False, True))
+    np.testing.assert_allclose(losses.cpu().numpy(), ol, rtol=1e-5)
+    for k, p0, g, p2 in zip(O.PARAM_NAMES, tab.arrs, og, P2):
+        po = p0.reshape(-1).copy()
+        O.adam(po, g.reshape(-1), np.zeros_like(po), np.zeros_like(po), 1, lr)
+        dlt = np.abs(p2.cpu().numpy().reshape(-1) - po)
+        assert dlt.max() < 0.05 * lr and np.quantile(dlt, 0.99) < 1e-5, k

@@ -71,7 +71,8 @@ def graph_time(fn, inner=20, reps=20):
 print('graph: atomic grad %.1f us, adam %.1f us' % (
     graph_time(lambda: ops.mstep_grad(P, G, u, v, e, y, w, B, coefs, flags, losses, ws)),
     graph_time(lambda: ops.adam_(flat, flat, flat, flat, 1, 0.005))))
-for per_slice, rpt, hot in ((1, 1, 16), (2, 1, 16), (2, 1, 10 ** 9)):
+combos = [tuple(int(x) for x in c.split(':')) for c in os.environ['KB_COMBOS'].split(',')] if os.environ.get('KB_COMBOS') else ((1, 1, 16), (2, 1, 16), (2, 1, 10 ** 9))
+for per_slice, rpt, hot in combos:
     pl = planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, per_slice=per_slice, rounds_per_task=rpt,
                                 hot_threshold=hot)
     dp = planlib.upload(pl, dev)

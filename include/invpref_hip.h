@@ -168,14 +168,17 @@ int invpref_mstep_rows_adam_hip(const InvPrefTables *tables, const InvPrefTables
 int invpref_set_profile_event(void *event);
 
 /* ---- the same pass for HIP-graph replay.  A captured launch freezes its kernel arguments, so the
- * per-step Adam scalars cannot be passed by value: they live in one of two device slots, picked by the
+ * per-step scalars cannot be passed by value: they live in one of two device slots, picked by the
  * frozen argument `slot` = (step & 1).  A pass for step s reads slot s&1 and fills the other slot with
  * step s+1 and table[s+1 - base] for its successor (no ticket, no ordering between workgroups: nobody
  * reads that slot before the next launch).
- *   state: device int32[16], slot p at state + 8p = {step (1-based), base = step that table[0] belongs to,
- *          table[step - base] (6 floats)}.  Before the first pass (and after a refill / rebase) the caller
+ *   table: device float[n][8], one row per step: the six Adam scalars (invpref_adam_schedule_fill() computes them on
+ *          the host), then the gradient-reversal alpha of that step -- NaN, as the fill leaves it, means "the alpha of
+ *          the call's coefficient block"; a caller running the alpha schedule of train.py:214-217 writes it here --
+ *          then one unused float.
+ *   state: device int32[32], slot p at state + 16p = {step (1-based), base = step that table[0] belongs to,
+ *          table[step - base] (8 floats), unused...}.  Before the first pass (and after a refill / rebase) the caller
  *          writes slot (step & 1) for the step about to run.
- *   table: device float[n][6], filled on the host by invpref_adam_schedule_fill() and uploaded.
  *   slot : parity of the step this call performs; consecutive calls alternate.
  * The caller keeps step - base inside [0, n). */
 typedef struct InvPrefAdamSchedule {

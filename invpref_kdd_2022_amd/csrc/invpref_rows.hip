@@ -43,6 +43,16 @@ namespace {
 constexpr int kReplicas = REPLICAS;   // replica slabs for the E x D gradients / loss sums
 constexpr int kGroups = 16;     // 16-lane groups per 256-thread workgroup
 
+// one row of the device-side schedule (include/invpref_hip.h: InvPrefAdamSchedule)
+struct SchedRow {
+    AdamScalars ad;
+    float alpha;   // gradient-reversal alpha of the step; NaN: use the one of the call's coefficient block
+    float pad;
+};
+__device__ __forceinline__ const SchedRow *sched_slot_ptr(const int *state, int slot) {
+    return reinterpret_cast<const SchedRow *>(state + 16 * slot + 2);
+}
+
 struct RowsArgs {
     const int4 *desc;             // [n_rounds][16][2]: see InvPrefRowPlan in include/invpref_hip.h
     int n_rounds, n_item_rounds, rounds_per_task;
@@ -65,8 +75,8 @@ struct RowsArgs {
     int n, dense_per_task, n_dense_tasks;
     const int *item_hot_index;    // [item_num]: scratch row of an item whose gradient goes through atomics, or -1
     float *hot_scratch;           // [n_hot][2][DP] gradient accumulators of those rows (zero on entry, re-zeroed by finish)
-    int *sched_state;             // optional device int32[16]: two slots {step, base, AdamScalars}, see InvPrefAdamSchedule
-    const AdamScalars *sched_table;  // optional device table of per-step Adam scalars (graph replay)
+    int *sched_state;             // optional device int32[32]: two slots {step, base, SchedRow}, see InvPrefAdamSchedule
+    const SchedRow *sched_table;  // optional device table of per-step scalars (graph replay)
     int sched_n, sched_slot;
     int stamps_nodrain;           // diagnostic: do not drain memory operations before a stamp
     unsigned long long *stamps;   // diagnostic builds only (INVPREF_STAMPS): [n_tasks][8] s_memrealtime ticks
@@ -257,13 +267,17 @@ __device__ __forceinline__ void rows_task(const DevTables &t, const RowsArgs &a,
     // PureMF (INVPREF_PURE_MF): the env-aware tables, embed_env and the classifier are absent -- their
     // rows stay the zeros they are initialised to below and are neither loaded nor stored
     const bool pure = a.flags & INVPREF_PURE_MF;
-    const StepScalars k = a.k;
+    StepScalars k = a.k;
+    if (a.sched_state) {  // scheduled alpha (train.py:214-217) under graph replay
+        const float al = sched_slot_ptr(a.sched_state, a.sched_slot)->alpha;
+        if (al == al) k.alpha = al;
+    }
     const int *oth_ids = a.oth[side], *pos = a.pos[side];
     const float *T_own_inv = USER ? t.Pu : t.Qi, *T_own_env = USER ? t.Pa : t.Qa;
     const float *T_oth_inv = USER ? t.Qi : t.Pu, *T_oth_env = USER ? t.Qa : t.Pa;
     // Adam scalars of this step: by value, or (graph replay: kernel arguments are frozen) looked up
     // by the device-side step counter that rows_finish_kernel advances
-    const AdamScalars ad = a.sched_state ? *reinterpret_cast<const AdamScalars *>(a.sched_state + 8 * a.sched_slot + 2) : a.ad;
+    const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
 
     STAMP(0);
     // the first round's descriptor goes out before anything else: every gather below hangs on it
@@ -459,7 +473,11 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
     const bool rw_rec = a.flags & INVPREF_REWEIGHT_REC, rw_cls = a.flags & INVPREF_REWEIGHT_CLS;
     const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
     const bool pure = a.flags & INVPREF_PURE_MF;
-    const StepScalars k = a.k;
+    StepScalars k = a.k;
+    if (a.sched_state) {
+        const float al = sched_slot_ptr(a.sched_state, a.sched_slot)->alpha;
+        if (al == al) k.alpha = al;
+    }
     STAMP(0);
     // The ids and the four rows of an iteration are requested one phase early.  First iteration: the ids go
     // out before the staging loads (both fly together), the rows before the barrier that makes the staged
@@ -665,7 +683,7 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
 template <int NC, bool VEC>
 __device__ __forceinline__ void stream_task(const DevTables &t, const RowsArgs &a, int side, const int *rows, int n) {
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const AdamScalars ad = a.sched_state ? *reinterpret_cast<const AdamScalars *>(a.sched_state + 8 * a.sched_slot + 2) : a.ad;
+    const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
     const float *Tinv = side == 0 ? t.Pu : t.Qi, *Tenv = side == 0 ? t.Pa : t.Qa;
     const bool pure = a.flags & INVPREF_PURE_MF;
     for (int i = grp; i < n; i += 2 * kGroups) {
@@ -808,18 +826,18 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
                                                            int nslabs, int DP, int EMAX, StepScalars k, float l2,
                                                            float l1, int64_t Bnorm, uint32_t flags, int fused,
                                                            AdamScalars ad_in, int *sched_state,
-                                                           const AdamScalars *sched_table, int sched_n, int sched_slot,
+                                                           const SchedRow *sched_table, int sched_n, int sched_slot,
                                                            float *__restrict__ losses6, HotRows hot, int nc, int vec) {
-    const AdamScalars ad = sched_state ? *reinterpret_cast<const AdamScalars *>(sched_state + 8 * sched_slot + 2) : ad_in;
+    const AdamScalars ad = sched_state ? sched_slot_ptr(sched_state, sched_slot)->ad : ad_in;
     // the device-side schedule moves on: one thread fills the OTHER slot with the next step's number and
     // Adam scalars.  Nobody reads that slot before the next launch, so no ordering between blocks is needed.
     if (sched_state && blockIdx.x == 0 && threadIdx.x == 0) {
-        const int *cur = sched_state + 8 * sched_slot;
-        int *nxt = sched_state + 8 * (sched_slot ^ 1);
+        const int *cur = sched_state + 16 * sched_slot;
+        int *nxt = sched_state + 16 * (sched_slot ^ 1);
         const int next = cur[0] + 1, base = cur[1], idx = next - base;
         nxt[0] = next;
         nxt[1] = base;
-        if (idx >= 0 && idx < sched_n) *reinterpret_cast<AdamScalars *>(nxt + 2) = sched_table[idx];
+        if (idx >= 0 && idx < sched_n) *reinterpret_cast<SchedRow *>(nxt + 2) = sched_table[idx];
     }
     if ((int)blockIdx.x >= hot.slab_blocks) {
         // trailing blocks: 64 groups of 16 lanes, one hot item row each
@@ -1015,7 +1033,7 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a.item_hot_index = plan->n_hot > 0 ? plan->item_hot_index : nullptr;
     a.hot_scratch = (float *)workspace + (size_t)slab_len * kReplicas;
     a.sched_state = sched ? sched->state : nullptr;
-    a.sched_table = sched ? reinterpret_cast<const AdamScalars *>(sched->table) : nullptr;
+    a.sched_table = sched ? reinterpret_cast<const SchedRow *>(sched->table) : nullptr;
     a.sched_n = sched ? sched->n : 0;
     a.sched_slot = sched ? (sched->slot & 1) : 0;
     // diagnostics: INVPREF_STAMPS=<device pointer, hex> makes the kernel write phase time stamps there
@@ -1117,13 +1135,15 @@ int invpref_adam_schedule_fill(float *host_table, int64_t first_step, int64_t n,
     for (int64_t i = 0; i < n; i++) {
         const double step = (double)(first_step + i);
         const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
-        float *r = host_table + 6 * i;
+        float *r = host_table + 8 * i;
         r[0] = (float)(lr / bc1);
         r[1] = (float)sqrt(bc2);
         r[2] = (float)(1.0 - beta1);
         r[3] = (float)beta2;
         r[4] = (float)(1.0 - beta2);
         r[5] = (float)eps;
+        r[6] = __builtin_nanf("");   // alpha: the call's coefficient block, unless the caller writes one here
+        r[7] = 0.f;
     }
     return 0;
 }

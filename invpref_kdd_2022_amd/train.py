@@ -184,7 +184,7 @@ class _InvPrefTrainManager:
             nc = 4 if model.factor_num % 4 else (1 if model.factor_num <= 64 else (2 if model.factor_num <= 128 else 4))
             self.use_plan = emax * nc <= 16
         self._plans = None
-        # whole epochs as one HIP graph launch (single GPU, planned path, fixed alpha); INVPREF_NO_GRAPH=1 disables
+        # runs of whole epochs as one HIP graph launch (single GPU, planned path); INVPREF_NO_GRAPH=1 disables
         self.use_graph = os.environ.get('INVPREF_NO_GRAPH', '0') != '1'
         # testing aid: run the multi-GPU step sequence (gradient pass -> all-reduce -> stand-alone Adam) on one rank
         self._force_sharded_path = os.environ.get('INVPREF_FORCE_SHARDED_PATH', '0') == '1'
@@ -386,34 +386,46 @@ class _InvPrefTrainManager:
 
     def _alpha_for(self, k: int) -> float:
         if self.update_alpha:  # train.py:214-217
-            p = float(k + (self.epoch_cnt + 1) * self.batch_num) / float((self.epoch_cnt + 1) * self.batch_num)
-            self.alpha = 2. / (1. + np.exp(-10. * p)) - 1.
+            self.alpha = self._scheduled_alpha(self.epoch_cnt, k)
         return self.alpha
 
     # ---- device-side Adam schedule for graph replay (include/invpref_hip.h: InvPrefAdamSchedule)
     _SCHED_N = 8192
 
+    def _scheduled_alpha(self, epoch_cnt: int, k: int) -> float:
+        """train.py:214-217 for minibatch k of the epoch that follows `epoch_cnt` completed ones"""
+        p = float(k + (epoch_cnt + 1) * self.batch_num) / float((epoch_cnt + 1) * self.batch_num)
+        return 2. / (1. + np.exp(-10. * p)) - 1.
+
     def _sched_prepare(self, steps_ahead: int):
+        """Device-side schedule for graph replay (InvPrefAdamSchedule): one row per optimiser step with the Adam
+        scalars and, under the alpha schedule of train.py:214-217, that step's alpha.  Called at an epoch
+        boundary: row j belongs to minibatch j % batch_num of epoch epoch_cnt + j // batch_num."""
         st, L = self.state, _capi.lib()
         if self._sched is None:
-            table = torch.zeros(self._SCHED_N, 6, dtype=torch.float32, device=self.device)
-            state = torch.zeros(16, dtype=torch.int32, device=self.device)
+            table = torch.zeros(self._SCHED_N, 8, dtype=torch.float32, device=self.device)
+            state = torch.zeros(32, dtype=torch.int32, device=self.device)
             self._sched = dict(table=table, state=state, base=-(10 ** 9), host=None,
                                struct=_capi.AdamSchedule(state.data_ptr(), table.data_ptr(), self._SCHED_N))
         sc = self._sched
         first = st.step + 1
-        if first < sc['base'] or first + steps_ahead > sc['base'] + self._SCHED_N:
-            host = np.zeros((self._SCHED_N, 6), np.float32)
+        stale_alpha = self.update_alpha and not self._sched_synced   # the step -> (epoch, minibatch) mapping moved
+        if first < sc['base'] or first + steps_ahead > sc['base'] + self._SCHED_N or stale_alpha:
+            host = np.zeros((self._SCHED_N, 8), np.float32)
             _capi.check(L.invpref_adam_schedule_fill(host.ctypes.data, first, self._SCHED_N, self.lr, 0.9, 0.999, 1e-8),
                         'invpref_adam_schedule_fill')
+            if self.update_alpha:
+                j = np.arange(self._SCHED_N)
+                e1 = (self.epoch_cnt + j // self.batch_num + 1).astype(np.float64) * self.batch_num
+                host[:, 6] = (2. / (1. + np.exp(-10. * ((j % self.batch_num) + e1) / e1)) - 1.).astype(np.float32)
             sc['table'].copy_(torch.from_numpy(host))
             sc['base'], sc['host'] = first, host
             self._sched_synced = False
         if not self._sched_synced:  # the device counter follows the host's after eager steps / refills
-            st16, o = np.zeros(16, np.int32), 8 * (first & 1)  # the slot of the step about to run
-            st16[o:o + 2] = first, sc['base']
-            st16[o + 2:o + 8] = sc['host'][first - sc['base']].view(np.int32)
-            sc['state'].copy_(torch.from_numpy(st16))
+            st32, o = np.zeros(32, np.int32), 16 * (first & 1)  # the slot of the step about to run
+            st32[o:o + 2] = first, sc['base']
+            st32[o + 2:o + 10] = sc['host'][first - sc['base']].view(np.int32)
+            sc['state'].copy_(torch.from_numpy(st32))
             self._sched_synced = True
 
     def _issue_epochs(self, stream, sched: bool, n: int):
@@ -456,7 +468,7 @@ class _InvPrefTrainManager:
             self._raw_setup()
             self._graphs.clear()
         st = self.state
-        graph_ok = self.use_graph and self.use_plan and self.world_size == 1 and not self.update_alpha \
+        graph_ok = self.use_graph and self.use_plan and self.world_size == 1 \
             and not self._force_sharded_path and self.batch_num <= self._SCHED_N // 2
         if graph_ok and self._graph_warm:
             n = min(want, self._graph_epochs)
@@ -467,6 +479,8 @@ class _InvPrefTrainManager:
             st.step += steps
             if steps % 2:
                 st.swap()
+            if self.update_alpha:   # what the reference's loop leaves in self.alpha after these epochs
+                self.alpha = self._scheduled_alpha(self.epoch_cnt + n - 1, self.batch_num - 1)
         else:
             n = 1
             self._issue_epochs(torch.cuda.current_stream().cuda_stream, False, 1)

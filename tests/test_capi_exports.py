@@ -53,9 +53,10 @@ def test_argument_validation_without_a_device(lib):
     lib.invpref_forward_hip.argtypes = [C.POINTER(_capi.Tables)] + [C.c_void_p] * 3 + [C.c_int64, C.c_uint32] + [C.c_void_p] * 4
     assert lib.invpref_forward_hip(C.byref(t), None, None, None, 0, 0, None, None, None, None) == -2    # EUNSUPPORTED
     lib.invpref_adam_schedule_fill.argtypes = [C.c_void_p, C.c_int64, C.c_int64] + [C.c_double] * 4
-    buf = (C.c_float * 12)()
+    buf = (C.c_float * 16)()   # two rows of 8 floats: six Adam scalars, alpha (NaN = the call's), unused
     assert lib.invpref_adam_schedule_fill(buf, 1, 2, 0.01, 0.9, 0.999, 1e-8) == 0
-    assert abs(buf[0] - 0.01 / (1 - 0.9)) < 1e-6 and abs(buf[6] - 0.01 / (1 - 0.81)) < 1e-6
+    assert abs(buf[0] - 0.01 / (1 - 0.9)) < 1e-6 and abs(buf[8] - 0.01 / (1 - 0.81)) < 1e-6
+    assert buf[6] != buf[6] and buf[14] != buf[14] and buf[7] == 0.0
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -249,6 +249,47 @@ def test_train_epochs_single_readback_equals_epoch_by_epoch():
     assert abs(diffs2[0] - diffs[0]) <= 3 and all(abs(cnts2[0][e] - cnts[0][e]) <= 3 for e in cnts[0])
 
 
+def test_alpha_schedule_under_graph_replay(monkeypatch):
+    """alpha=None (train.py:214-217: alpha follows the training progress, as MovieLens_InvPref.py and
+    Yahoo_InvPref_explicit.py run it): the graph-replayed epochs read every step's alpha from the device-side
+    schedule and must reproduce the eagerly issued loop, including the manager's `alpha` attribute."""
+    z = np.load(os.path.join(G, 'g4_yahoo_like_traj.npz'))
+    U, I, E, D, bs, epochs, seed = [int(x) for x in z['meta']]
+    data = synth.yahoo_like(seed)[:40000]
+    tabs = synth.tables(seed + 7, U, I, E, D, std=0.05)
+    res = []
+    for no_graph in ('1', '0'):
+        monkeypatch.setenv('INVPREF_NO_GRAPH', no_graph)
+        model = InvPrefImplicit(U, I, E, D, reg_only_embed=False, reg_env_embed=True)
+        model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+        np.random.seed(seed)
+        cf = z['coefs']
+        mgr = ImplicitTrainManager(model=model, evaluator=StubEvaluator(), device=DEV, training_data=torch.from_numpy(data).to(DEV),
+                                   batch_size=bs, epochs=9, cluster_interval=100, evaluate_interval=10 ** 9, lr=float(cf[6]),
+                                   invariant_coe=float(cf[0]), env_aware_coe=float(cf[1]), env_coe=float(cf[2]),
+                                   L2_coe=float(cf[3]), L1_coe=float(cf[4]), alpha=None, use_class_re_weight=True,
+                                   use_recommend_re_weight=True, cluster_use_random_sort=False)
+        assert mgr.update_alpha
+        mgr.stat_envs()
+        tr = mgr.train_epochs(2) + [mgr.train_a_epoch()] + mgr.train_epochs(3)
+        assert bool(mgr._graphs) == (no_graph == '0')
+        res.append((np.array([[e[k] for k in LOSS_KEYS] for e in tr]), mgr.alpha,
+                    {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-6)
+    assert res[0][1] == res[1][1] and 0.99 < res[0][1] < 1.0
+    for k in O.PARAM_NAMES:
+        _assert_same_run(np.abs(res[0][2][k] - res[1][2][k]), float(z['coefs'][6]), k)
+    # the alpha really matters for the trajectory: a fixed alpha of 0.5 gives a different loss trace
+    model = InvPrefImplicit(U, I, E, D, reg_only_embed=False, reg_env_embed=True)
+    model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+    np.random.seed(seed)
+    mgr = _mgr(ImplicitTrainManager, model, data, z, use_class_re_weight=True, use_recommend_re_weight=True)
+    mgr.alpha = 0.5
+    mgr.stat_envs()
+    other = np.array([[e[k] for k in LOSS_KEYS] for e in mgr.train_epochs(6)])
+    assert np.abs(other[:, 2] / res[0][0][:, 2] - 1).max() > 1e-4
+
+
 # ------------------------------------------------------------------ evaluation (SURVEY §8 f1)
 def test_implicit_evaluator_matches_reference_and_oracle():
     from eval_fixture import StubImplicitLoader, eval_fixture

@@ -51,10 +51,10 @@ def graph_time(seq, reps=20):
 import ctypes as C
 from invpref_kdd_2022_amd import _capi
 L = _capi.lib()
-host = np.zeros((8192, 6), np.float32)
+host = np.zeros((8192, 8), np.float32)
 L.invpref_adam_schedule_fill(host.ctypes.data, 1, 8192, 0.005, 0.9, 0.999, 1e-8)
 s_table = torch.from_numpy(host).to(dev)
-st16 = np.zeros(16, np.int32); st16[8:10] = 1; st16[10:16] = host[0].view(np.int32)
+st16 = np.zeros(32, np.int32); st16[16:18] = 1; st16[18:26] = host[0].view(np.int32)
 s_state0 = torch.from_numpy(st16).to(dev); s_state = s_state0.clone()
 s_struct = _capi.AdamSchedule(s_state.data_ptr(), s_table.data_ptr(), 8192)
 tabs_c = {id(P): _capi.make_tables(P), id(P2): _capi.make_tables(P2)}

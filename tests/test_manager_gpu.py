@@ -249,6 +249,55 @@ def test_train_epochs_single_readback_equals_epoch_by_epoch():
     assert abs(diffs2[0] - diffs[0]) <= 3 and all(abs(cnts2[0][e] - cnts[0][e]) <= 3 for e in cnts[0])
 
 
+@pytest.mark.parametrize('mode', ['users', 'rows'])
+def test_rank0_of_two_code_path_on_gpu(monkeypatch, mode):
+    """Everything a rank of a 2-GPU run executes (its share of every minibatch, the per-step exchange on the shared
+    range, Adam on its ranges, the per-epoch loss exchange, sharded E-step + stat_envs, sync_parameters), run as
+    rank 0 of a declared world of 2 over a 1-rank RCCL group (the collectives then sum one contribution): the
+    world_size > 1 branches must run on the GPU and leave exactly the rows this rank is responsible for updated."""
+    import torch.distributed as dist
+    z = np.load(os.path.join(G, 'g4_yahoo_like_traj.npz'))
+    U, I, E, D, bs, epochs, seed = [int(x) for x in z['meta']]
+    data = synth.yahoo_like(seed)[:40000]
+    tabs = synth.tables(seed + 7, U, I, E, D, std=0.05)
+    monkeypatch.setenv('INVPREF_SHARD', mode)
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29534')
+        dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        model = InvPrefImplicit(U, I, E, D, reg_only_embed=False, reg_env_embed=True)
+        model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+        np.random.seed(seed)
+        mgr = _mgr(ImplicitTrainManager, model, data, z, use_class_re_weight=True, use_recommend_re_weight=True,
+                   rank=0, world_size=2)
+        assert mgr.shard_mode == mode and mgr.users_tensor.shape[0] < len(data)
+        cnt = mgr.stat_envs()
+        assert sum(cnt.values()) == mgr.users_tensor.shape[0]      # (one contribution summed: this rank's rows)
+        tr = mgr.train_epochs(2)
+        assert all(np.isfinite(list(d.values())).all() for d in tr) and not mgr._graphs
+        d = mgr.cluster()
+        cnt = mgr.stat_envs()
+        assert 0 <= d <= mgr.users_tensor.shape[0] and sum(cnt.values()) == mgr.users_tensor.shape[0]
+        mgr.sync_parameters()
+        pu = model.embed_user_invariant.weight.detach().cpu().numpy()
+        moved = np.abs(pu - tabs['embed_user_invariant.weight']).max(axis=1) > 0
+        mine_u = np.unique(mgr.users_tensor.cpu().numpy())     # (a row no interaction ever touches never moves)
+        assert moved[mine_u].all()
+        if mode == 'users':
+            lo, hi = mgr.shard.user_range(U)
+            assert (lo, hi) == (0, U // 2) and mine_u.max() < hi
+            # foreign rows: never updated here; the masked exchange (no second rank to contribute) leaves zeros
+            assert not pu[hi:].any()
+        else:
+            assert mine_u.max() >= U // 2      # a row slice holds users of the whole range
+        qi = model.embed_item_invariant.weight.detach().cpu().numpy()
+        mine_i = np.unique(mgr.items_tensor.cpu().numpy())
+        assert (np.abs(qi - tabs['embed_item_invariant.weight']).max(axis=1) > 0)[mine_i].all()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_alpha_schedule_under_graph_replay(monkeypatch):
     """alpha=None (train.py:214-217: alpha follows the training progress, as MovieLens_InvPref.py and
     Yahoo_InvPref_explicit.py run it): the graph-replayed epochs read every step's alpha from the device-side

@@ -1,5 +1,7 @@
 """GPU: edge cases of the hot path through the C ABI -- ragged / tiny / maximum sizes, empty shards,
 extreme scores -- each against the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -138,3 +140,64 @@ def test_train_loop_end_to_end_with_device_evaluator():
     assert all(np.isfinite(list(d.values())).all() for d in losses) and losses[-1]['loss'] < losses[0]['loss']
     assert set(tests[0]) == {'ndcg', 'recall', 'precision'} and set(tests[0]['ndcg']) == {3, 5, 7}
     assert all(sum(c.values()) == len(data) for c in cnts) and len(diffs) == 3
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('INVPREF_FUZZ', '12'))))
+def test_random_plan_parameters_and_shapes(seed):
+    """Randomised sweep: shapes (D aligned and not, E up to 16), duplicate-heavy and sparse minibatches, every plan
+    parameter (interactions per slice, rounds per workgroup, hot threshold, dense / stream task sizes, a user range),
+    flag combinations, InvPref and PureMF -- planned gradient pass and fused pass against the oracle."""
+    rs = np.random.RandomState(1000 + seed)
+    U, I = int(rs.choice([3, 17, 60, 300])), int(rs.choice([2, 9, 40, 150]))
+    E, D = int(rs.choice([1, 2, 4, 5, 8, 16])), int(rs.choice([4, 8, 20, 30, 64, 100, 128, 256]))
+    B = int(rs.choice([1, 15, 16, 17, 100, 700, 3000]))
+    implicit, pure = bool(rs.randint(2)), bool(rs.randint(3) == 0)
+    if pure:
+        E = 1
+    tabs = synth.tables(seed + 5, U, I, E, D, std=0.25)
+    if pure:
+        for k in O.PARAM_NAMES[2:]:
+            tabs[k] = np.zeros_like(tabs[k])
+    u = rs.randint(0, U, B) if rs.randint(2) else rs.randint(0, max(1, U // 8), B)   # spread / duplicate-heavy
+    v, e = rs.randint(0, I, B), rs.randint(0, E, B)
+    y = (rs.randint(0, 2, B) if implicit else rs.randint(1, 6, B)).astype(np.float32)
+    w = rs.uniform(0.1, 1, B).astype(np.float32)
+    rw_rec, rw_cls = (False, False) if pure else (bool(rs.randint(2)), bool(rs.randint(2)))
+    roe, ree = (True, False) if pure else (bool(rs.randint(2)), bool(rs.randint(2)))
+    coefs = O.pure_mf_coefs(0.3, 0.05) if pure else np.array(COEFS[:6], np.float64)
+    os_env = dict(INVPREF_PLAN_STREAM_ROWS=str(int(rs.choice([1, 16, 64, 200]))), INVPREF_PLAN_DENSE=str(int(rs.choice([16, 32, 48, 128]))))
+    old = {k: os.environ.get(k) for k in os_env}
+    os.environ.update(os_env)
+    try:
+        lo = int(rs.randint(0, U)) if rs.randint(2) else 0
+        user_range = (lo, int(rs.randint(lo, U)) + 1) if rs.randint(2) else None
+        pl = planlib.build_row_plan(u, v, y, U, I, per_slice=int(rs.choice([1, 2, 3, 8, 16])),
+                                    rounds_per_task=int(rs.choice([1, 1, 2, 3])),
+                                    hot_threshold=int(rs.choice([-1, 0, 2, 16, 10 ** 9])), user_range=user_range)
+    finally:
+        for k, val in old.items():
+            os.environ.pop(k, None) if val is None else os.environ.__setitem__(k, val)
+    dp = planlib.upload(pl, DEV)
+    tab, ws = O.Tables(tabs), ops.Workspace(DEV)
+    oflags = O.flags_of(implicit, rw_rec, rw_cls, roe, ree)
+    og, ol = O.mstep(tab, u, v, e, y, w, coefs, oflags)
+    flags = ops.flags_of(implicit, rw_rec, rw_cls, roe, ree)
+    names = O.PARAM_NAMES[:2] if pure else O.PARAM_NAMES
+    P = [torch.from_numpy(np.ascontiguousarray(tabs[k], np.float32)).to(DEV) for k in names]
+    # (a) fused pass: parameters after one step vs oracle gradient + oracle Adam, on the rows this plan is responsible for
+    P2, M, V = ([torch.zeros_like(p) for p in P] for _ in range(3))
+    losses = torch.zeros(6, device=DEV)
+    lr = 0.01
+    ops.mstep_rows_adam(P, P2, M, V, dp, None if pure else t64(e), t32(y), None if pure else t32(w), B, coefs, flags,
+                        losses, 1, lr, ws, pure=pure)
+    np.testing.assert_allclose(losses.cpu().numpy(), ol, rtol=3e-5, atol=1e-7)
+    for i, k in enumerate(names):
+        po = np.ascontiguousarray(tabs[k], np.float32).reshape(-1).copy()
+        O.adam(po, og[i].reshape(-1), np.zeros_like(po), np.zeros_like(po), 1, lr)
+        got = p2 = P2[i].cpu().numpy()
+        want = po.reshape(got.shape)
+        if i in (0, 2) and user_range is not None:   # untouched user rows outside the range are not this plan's business
+            touched = np.zeros(U, bool); touched[u] = True
+            keep = touched.copy(); keep[user_range[0]:user_range[1]] = True
+            got, want = got[keep], want[keep]
+        assert np.abs(got - want).max() < 0.06 * lr, (k, seed)

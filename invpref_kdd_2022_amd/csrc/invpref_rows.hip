@@ -53,45 +53,6 @@ __device__ __forceinline__ const SchedRow *sched_slot_ptr(const int *state, int 
     return reinterpret_cast<const SchedRow *>(state + 16 * slot + 2);
 }
 
-struct RowsArgs {
-    const int4 *desc;             // [n_rounds][16][2]: see InvPrefRowPlan in include/invpref_hip.h
-    int n_rounds, n_item_rounds, rounds_per_task;
-    const int *oth[2], *pos[2];   // per side, in that side's sorted order: partner row, position in the minibatch
-    const int64_t *envs;          // minibatch base pointers, indexed by pos
-    const float *scores, *weights;
-    StepScalars k;
-    uint32_t flags;
-    float *slabs;
-    int fused;                    // 0: store gradient rows to g; 1: Adam on the spot -> np / m / v
-    float *g[4];                  // Pu, Qi, Pa, Qa gradient tables   (fused == 0)
-    float *np[4];                 // new parameter tables              (fused == 1)
-    float *m[4], *v[4];           // Adam moments                      (fused == 1)
-    AdamScalars ad;
-    // rows the minibatch does not touch: no job, just the dense-Adam step (or a zero gradient row),
-    // streamed by dedicated workgroups with several rows in flight per group
-    const int *stream_rows;       // [n_stream_user + n_stream_item] row ids, user rows first
-    int n_stream_user, n_stream_item, rows_per_stream_task, n_job_tasks, n_stream_user_tasks;
-    const int *batch_users, *batch_items;   // [n] ids of the minibatch in its own order (dense tasks)
-    int n, dense_per_task, n_dense_tasks;
-    const int *item_hot_index;    // [item_num]: scratch row of an item whose gradient goes through atomics, or -1
-    float *hot_scratch;           // [n_hot][2][DP] gradient accumulators of those rows (zero on entry, re-zeroed by finish)
-    int *sched_state;             // optional device int32[32]: two slots {step, base, SchedRow}, see InvPrefAdamSchedule
-    const SchedRow *sched_table;  // optional device table of per-step scalars (graph replay)
-    int sched_n, sched_slot;
-    int stamps_nodrain;           // diagnostic: do not drain memory operations before a stamp
-    unsigned long long *stamps;   // diagnostic builds only (INVPREF_STAMPS): [n_tasks][8] s_memrealtime ticks
-};
-
-// diagnostic phase stamp: drains the wave's outstanding memory operations first, so the latency of
-// a phase is charged to that phase.  Never executed unless a stamp buffer is passed.
-#define STAMP(i)                                                                  \
-    do {                                                                          \
-        if (a.stamps) {                                                           \
-            if (!a.stamps_nodrain) __builtin_amdgcn_s_waitcnt(0);                 \
-            if (threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-        }                                                                         \
-    } while (0)
-
 // Row-store cache policy, measured on the real loop (ping-pong parameter buffers, 31 different plans,
 // tools/kb3.py): plain stores for everything.  The new parameters p' are gathered by the very next
 // step and m', v' are re-read by it, so they should stay in the cache hierarchy: nontemporal p'
@@ -140,6 +101,237 @@ __device__ __forceinline__ float4 f4sel(bool c, float4 a) { return c ? a : f4zer
 __device__ __forceinline__ float4 f4xor_lanes(float4 v, int m) {
     return make_float4(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64), __shfl_xor(v.z, m, 64), __shfl_xor(v.w, m, 64));
 }
+
+// folds (and re-zeroes) the replica slabs: gradients of embed_env / classifier (+ classifier
+// regulariser, models.py:211-217), the six loss outputs; then either stores those gradients
+// (fused == 0) or applies Adam to the three small tables (fused == 1).
+struct SmallTables {
+    float *gEv, *gW, *gb;        // fused == 0
+    float *nEv, *nW, *nb;        // fused == 1: new parameters
+    float *mEv, *mW, *mb, *vEv, *vW, *vb;
+};
+// item rows whose gradient arrived through atomics (no job of their own): finished here
+struct HotRows {
+    int n, slab_blocks;          // rows; number of leading blocks that fold the slabs
+    const int *rows, *cnt;       // [n] item row id, interactions of that row in this minibatch
+    float *scratch;              // [n][2][DP]
+    const float *Qi, *Qa;        // current item tables
+    float *gQi, *gQa;            // fused == 0: gradient tables
+    float *nQi, *nQa, *mQi, *mQa, *vQi, *vQa;   // fused == 1
+};
+
+template <int NC, bool VEC>
+__device__ __forceinline__ void finish_hot_rows(const DevTables &t, const HotRows &h, const StepScalars &k,
+                                                int fused, const AdamScalars &ad, int block, bool pure) {
+    constexpr int DP = NC * 64;
+    const int l16 = threadIdx.x & 15;
+    const int i = block * (int)(blockDim.x >> 4) + (int)(threadIdx.x >> 4);
+    if (i >= h.n) return;
+    const int row = h.rows[i];
+    const float cnt = (float)h.cnt[i];
+    float *sc = h.scratch + (int64_t)i * 2 * DP;
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+        if (pure && tt) break;
+        const float *T = tt == 0 ? h.Qi : h.Qa;
+        float4 p[NC], g[NC];
+        load_row<NC, VEC>(T, row, t.D, l16, p);
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            float4 *q = reinterpret_cast<float4 *>(sc + tt * DP + (l16 + kRow * c) * 4);
+            g[c] = *q;
+            *q = f4zero();  // leave the accumulator zeroed for the next step
+            g[c].x += cnt * (k.r2 * p[c].x + k.r1 * c_sign(p[c].x)); g[c].y += cnt * (k.r2 * p[c].y + k.r1 * c_sign(p[c].y));
+            g[c].z += cnt * (k.r2 * p[c].z + k.r1 * c_sign(p[c].z)); g[c].w += cnt * (k.r2 * p[c].w + k.r1 * c_sign(p[c].w));
+        }
+        if (!fused) {
+            store_row<NC, VEC>(tt == 0 ? h.gQi : h.gQa, row, t.D, l16, g);
+        } else {
+            float4 m[NC], v[NC];
+            load_row<NC, VEC>(tt == 0 ? h.mQi : h.mQa, row, t.D, l16, m);
+            load_row<NC, VEC>(tt == 0 ? h.vQi : h.vQa, row, t.D, l16, v);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                adam1f(p[c].x, g[c].x, m[c].x, v[c].x, ad); adam1f(p[c].y, g[c].y, m[c].y, v[c].y, ad);
+                adam1f(p[c].z, g[c].z, m[c].z, v[c].z, ad); adam1f(p[c].w, g[c].w, m[c].w, v[c].w, ad);
+            }
+            store_row<NC, VEC, ROWS_ST_P>(tt == 0 ? h.nQi : h.nQa, row, t.D, l16, p);
+            store_row<NC, VEC>(tt == 0 ? h.mQi : h.mQa, row, t.D, l16, m);
+            store_row<NC, VEC>(tt == 0 ? h.vQi : h.vQa, row, t.D, l16, v);
+        }
+    }
+}
+// everything one minibatch's finish needs (folding the slabs, the three small tables, the hot rows, the loss
+// outputs): the stand-alone rows_finish_kernel takes it as its argument, and a chained launch (invpref_chain_*)
+// carries the PREVIOUS step's block inside the next mstep_rows_kernel, whose leading workgroups run it
+struct FinishArgs {
+    DevTables t;                 // tables the step read (hot rows / small tables: values before the update)
+    SmallTables o;
+    HotRows hot;
+    float *slabs;
+    int nslabs, DP, EMAX, nc, vec, fused;
+    StepScalars k;
+    float l2, l1;
+    int64_t Bnorm;
+    uint32_t flags;
+    AdamScalars ad;
+    float *losses6;
+};
+
+// one block of the finish: `block` < hot.slab_blocks folds 64 columns of the slabs with blockDim/64 sub-rows of
+// threads (part: [blockDim/64][64] doubles of LDS, sloss: [kLossSlots], sreg: [2]); later blocks finish blockDim/16 hot rows
+__device__ __forceinline__ void finish_block(const FinishArgs &f, const AdamScalars &ad, int block, double *part,
+                                             double *sloss, double *sreg) {
+    const DevTables &t = f.t;
+    const SmallTables &o = f.o;
+    const HotRows &hot = f.hot;
+    const StepScalars &k = f.k;
+    const int DP = f.DP, EMAX = f.EMAX, fused = f.fused, nslabs = f.nslabs;
+    const uint32_t flags = f.flags;
+    float *slabs = f.slabs, *losses6 = f.losses6;
+    const float l2 = f.l2, l1 = f.l1;
+    const int64_t Bnorm = f.Bnorm;
+    if (block >= hot.slab_blocks) {
+        const int hb = block - hot.slab_blocks;
+        if (!f.vec) finish_hot_rows<4, false>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
+        else if (f.nc == 1) finish_hot_rows<1, true>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
+        else if (f.nc == 2) finish_hot_rows<2, true>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
+        else finish_hot_rows<4, true>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
+        return;
+    }
+    const int subs = blockDim.x >> 6;
+
+    const int EDP = t.E * DP, slab_len = 2 * EDP + EMAX + kLossSlots;
+    const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int idx = block * 64 + col;
+    const bool pure = flags & INVPREF_PURE_MF;  // no small tables to finish: only the loss sums are folded
+    // parameter / moment of the output this thread will finish (sub == 0 threads), requested up front
+    float pre_p = 0.f, pre_m = 0.f, pre_v = 0.f;
+    if (sub == 0 && idx < 2 * EDP + EMAX) {
+        const bool isB = idx >= 2 * EDP, isW = !isB && idx >= EDP;
+        const int r = isB ? 0 : (isW ? idx - EDP : idx);
+        const int e = isB ? idx - 2 * EDP : r / DP, d = isB ? 0 : r - e * DP;
+        if (e < t.E && d < t.D && !pure) {
+            const int off = isB ? e : e * t.D + d;
+            pre_p = isB ? t.b[off] : (isW ? t.W[off] : t.Ev[off]);
+            if (fused) {
+                pre_m = (isB ? o.mb : (isW ? o.mW : o.mEv))[off];
+                pre_v = (isB ? o.vb : (isW ? o.vW : o.vEv))[off];
+            }
+        }
+    }
+    double acc = 0.0;
+    if (idx < slab_len)
+        for (int s = sub; s < nslabs; s += subs) {
+            float *q = slabs + (int64_t)s * slab_len + idx;
+            acc += (double)__builtin_nontemporal_load(q);
+            *q = 0.f;  // leave the replicas zeroed for the next step
+        }
+    part[sub * 64 + col] = acc;
+    if (threadIdx.x < 2) sreg[threadIdx.x] = 0.0;
+    __syncthreads();
+    const bool dense = (flags & INVPREF_DENSE_REG) && !(flags & INVPREF_REG_ONLY_EMBED) && !pure;
+    const bool last_block = block == hot.slab_blocks - 1;
+    if (sub == 0 && idx < slab_len) {
+        double v = 0.0;
+        for (int s = 0; s < subs; s++) v += part[s * 64 + col];
+        if (idx < 2 * EDP) {
+            const bool isW = idx >= EDP;
+            const int r = isW ? idx - EDP : idx;
+            const int e = r / DP, d = r - e * DP;
+            if (d < t.D && !pure) {
+                const int off = e * t.D + d;
+                float gv = (float)v;
+                float pv = pre_p;
+                if (isW && dense) gv += 2.f * l2 / ((float)t.D * (float)t.E) * pv + l1 / ((float)t.D * (float)t.E) * c_sign(pv);
+                if (!fused) {
+                    (isW ? o.gW : o.gEv)[off] = gv;
+                } else {
+                    float *mp = (isW ? o.mW : o.mEv) + off, *vp = (isW ? o.vW : o.vEv) + off;
+                    float mm = pre_m, vv = pre_v;
+                    adam1(pv, gv, mm, vv, ad);
+                    (isW ? o.nW : o.nEv)[off] = pv; *mp = mm; *vp = vv;
+                }
+            }
+        } else if (idx < 2 * EDP + EMAX) {
+            const int e = idx - 2 * EDP;
+            if (e < t.E && !pure) {
+                float gv = (float)v, pv = pre_p;
+                if (dense) gv += 2.f * l2 / (float)t.E * pv + l1 / (float)t.E * c_sign(pv);
+                if (!fused) {
+                    o.gb[e] = gv;
+                } else {
+                    float mm = pre_m, vv = pre_v;
+                    adam1(pv, gv, mm, vv, ad);
+                    o.nb[e] = pv; o.mb[e] = mm; o.vb[e] = vv;
+                }
+            }
+        } else {
+            sloss[idx - 2 * EDP - EMAX] = v;
+        }
+    }
+    __syncthreads();
+    if (last_block && losses6) {
+        if (dense && threadIdx.x < 64) {
+            double w2 = 0, w1 = 0, b2 = 0, b1 = 0;
+            for (int i = threadIdx.x; i < t.E * t.D; i += 64) { const double x = t.W[i]; w2 += x * x; w1 += fabs(x); }
+            for (int i = threadIdx.x; i < t.E; i += 64) { const double x = t.b[i]; b2 += x * x; b1 += fabs(x); }
+            double r2v = w2 / ((double)t.D * t.E) + b2 / (double)t.E, r1v = w1 / ((double)t.D * t.E) + b1 / (double)t.E;
+            for (int m = 32; m >= 1; m >>= 1) { r2v += __shfl_xor(r2v, m, 64); r1v += __shfl_xor(r1v, m, 64); }
+            if (threadIdx.x == 0) { sreg[0] = r2v; sreg[1] = r1v; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double Bn = (double)Bnorm, BD2 = Bn * (double)t.D * 2.0;
+            const double Li = sloss[0] / Bn, Le = sloss[1] / Bn, Lc = sloss[2] / Bn;
+            const double L2 = sloss[3] / BD2 + sreg[0], L1 = sloss[4] / BD2 + sreg[1];
+            // added with fire-and-forget atomics: a plain `+=` would hold the kernel's end back by one more
+            // memory round trip (the same single fp32 addition either way)
+            atomicAdd(losses6 + 0, (float)Li); atomicAdd(losses6 + 1, (float)Le); atomicAdd(losses6 + 2, (float)Lc);
+            atomicAdd(losses6 + 3, (float)L2); atomicAdd(losses6 + 4, (float)L1);
+            atomicAdd(losses6 + 5, (float)((double)k.ca * Li + (double)k.cb * Le + (double)k.cc * Lc + (double)l2 * L2 + (double)l1 * L1));
+        }
+    }
+}
+
+struct RowsArgs {
+    const int4 *desc;             // [n_rounds][16][2]: see InvPrefRowPlan in include/invpref_hip.h
+    int n_rounds, n_item_rounds, rounds_per_task;
+    const int *oth[2], *pos[2];   // per side, in that side's sorted order: partner row, position in the minibatch
+    const int64_t *envs;          // minibatch base pointers, indexed by pos
+    const float *scores, *weights;
+    StepScalars k;
+    uint32_t flags;
+    float *slabs;
+    int fused;                    // 0: store gradient rows to g; 1: Adam on the spot -> np / m / v
+    float *g[4];                  // Pu, Qi, Pa, Qa gradient tables   (fused == 0)
+    float *np[4];                 // new parameter tables              (fused == 1)
+    float *m[4], *v[4];           // Adam moments                      (fused == 1)
+    AdamScalars ad;
+    // rows the minibatch does not touch: no job, just the dense-Adam step (or a zero gradient row),
+    // streamed by dedicated workgroups with several rows in flight per group
+    const int *stream_rows;       // [n_stream_user + n_stream_item] row ids, user rows first
+    int n_stream_user, n_stream_item, rows_per_stream_task, n_job_tasks, n_stream_user_tasks;
+    const int *batch_users, *batch_items;   // [n] ids of the minibatch in its own order (dense tasks)
+    int n, dense_per_task, n_dense_tasks;
+    const int *item_hot_index;    // [item_num]: scratch row of an item whose gradient goes through atomics, or -1
+    float *hot_scratch;           // [n_hot][2][DP] gradient accumulators of those rows (zero on entry, re-zeroed by finish)
+    int *sched_state;             // optional device int32[32]: two slots {step, base, SchedRow}, see InvPrefAdamSchedule
+    const SchedRow *sched_table;  // optional device table of per-step scalars (graph replay)
+    int sched_n, sched_slot;
+    int stamps_nodrain;           // diagnostic: do not drain memory operations before a stamp
+    unsigned long long *stamps;   // diagnostic builds only (INVPREF_STAMPS): [n_tasks][8] s_memrealtime ticks
+};
+
+// diagnostic phase stamp: drains the wave's outstanding memory operations first, so the latency of
+// a phase is charged to that phase.  Never executed unless a stamp buffer is passed.
+#define STAMP(i)                                                                  \
+    do {                                                                          \
+        if (a.stamps) {                                                           \
+            if (!a.stamps_nodrain) __builtin_amdgcn_s_waitcnt(0);                 \
+            if (threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                         \
+    } while (0)
 
 struct Sample {
     int oth, ps;
@@ -763,74 +955,15 @@ __global__ __launch_bounds__(256, ROWS_MIN_WAVES) void mstep_rows_kernel(DevTabl
     else rows_task<NC, VEC, EMAX, false>(t, a, task, lds);
 }
 
-// folds (and re-zeroes) the replica slabs: gradients of embed_env / classifier (+ classifier
-// regulariser, models.py:211-217), the six loss outputs; then either stores those gradients
-// (fused == 0) or applies Adam to the three small tables (fused == 1).
-struct SmallTables {
-    float *gEv, *gW, *gb;        // fused == 0
-    float *nEv, *nW, *nb;        // fused == 1: new parameters
-    float *mEv, *mW, *mb, *vEv, *vW, *vb;
-};
-// item rows whose gradient arrived through atomics (no job of their own): finished here
-struct HotRows {
-    int n, slab_blocks;          // rows; number of leading blocks that fold the slabs
-    const int *rows, *cnt;       // [n] item row id, interactions of that row in this minibatch
-    float *scratch;              // [n][2][DP]
-    const float *Qi, *Qa;        // current item tables
-    float *gQi, *gQa;            // fused == 0: gradient tables
-    float *nQi, *nQa, *mQi, *mQa, *vQi, *vQa;   // fused == 1
-};
 
-template <int NC, bool VEC>
-__device__ __forceinline__ void finish_hot_rows(const DevTables &t, const HotRows &h, const StepScalars &k,
-                                                int fused, const AdamScalars &ad, int block, bool pure) {
-    constexpr int DP = NC * 64;
-    const int l16 = threadIdx.x & 15;
-    const int i = block * (int)(blockDim.x >> 4) + (int)(threadIdx.x >> 4);
-    if (i >= h.n) return;
-    const int row = h.rows[i];
-    const float cnt = (float)h.cnt[i];
-    float *sc = h.scratch + (int64_t)i * 2 * DP;
-#pragma unroll
-    for (int tt = 0; tt < 2; tt++) {
-        if (pure && tt) break;
-        const float *T = tt == 0 ? h.Qi : h.Qa;
-        float4 p[NC], g[NC];
-        load_row<NC, VEC>(T, row, t.D, l16, p);
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-            float4 *q = reinterpret_cast<float4 *>(sc + tt * DP + (l16 + kRow * c) * 4);
-            g[c] = *q;
-            *q = f4zero();  // leave the accumulator zeroed for the next step
-            g[c].x += cnt * (k.r2 * p[c].x + k.r1 * c_sign(p[c].x)); g[c].y += cnt * (k.r2 * p[c].y + k.r1 * c_sign(p[c].y));
-            g[c].z += cnt * (k.r2 * p[c].z + k.r1 * c_sign(p[c].z)); g[c].w += cnt * (k.r2 * p[c].w + k.r1 * c_sign(p[c].w));
-        }
-        if (!fused) {
-            store_row<NC, VEC>(tt == 0 ? h.gQi : h.gQa, row, t.D, l16, g);
-        } else {
-            float4 m[NC], v[NC];
-            load_row<NC, VEC>(tt == 0 ? h.mQi : h.mQa, row, t.D, l16, m);
-            load_row<NC, VEC>(tt == 0 ? h.vQi : h.vQa, row, t.D, l16, v);
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-                adam1f(p[c].x, g[c].x, m[c].x, v[c].x, ad); adam1f(p[c].y, g[c].y, m[c].y, v[c].y, ad);
-                adam1f(p[c].z, g[c].z, m[c].z, v[c].z, ad); adam1f(p[c].w, g[c].w, m[c].w, v[c].w, ad);
-            }
-            store_row<NC, VEC, ROWS_ST_P>(tt == 0 ? h.nQi : h.nQa, row, t.D, l16, p);
-            store_row<NC, VEC>(tt == 0 ? h.mQi : h.mQa, row, t.D, l16, m);
-            store_row<NC, VEC>(tt == 0 ? h.vQi : h.vQa, row, t.D, l16, v);
-        }
-    }
-}
-__global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTables o, float *__restrict__ slabs,
-                                                           int nslabs, int DP, int EMAX, StepScalars k, float l2,
-                                                           float l1, int64_t Bnorm, uint32_t flags, int fused,
-                                                           AdamScalars ad_in, int *sched_state,
-                                                           const SchedRow *sched_table, int sched_n, int sched_slot,
-                                                           float *__restrict__ losses6, HotRows hot, int nc, int vec) {
-    const AdamScalars ad = sched_state ? sched_slot_ptr(sched_state, sched_slot)->ad : ad_in;
+__global__ __launch_bounds__(1024) void rows_finish_kernel(const FinishArgs f, int *sched_state, const SchedRow *sched_table,
+                                                           int sched_n, int sched_slot) {
+    __shared__ double part[16 * 64];
+    __shared__ double sloss[kLossSlots];
+    __shared__ double sreg[2];
+    const AdamScalars ad = sched_state ? sched_slot_ptr(sched_state, sched_slot)->ad : f.ad;
     // the device-side schedule moves on: one thread fills the OTHER slot with the next step's number and
-    // Adam scalars.  Nobody reads that slot before the next launch, so no ordering between blocks is needed.
+    // scalars.  Nobody reads that slot before the next launch, so no ordering between blocks is needed.
     if (sched_state && blockIdx.x == 0 && threadIdx.x == 0) {
         const int *cur = sched_state + 16 * sched_slot;
         int *nxt = sched_state + 16 * (sched_slot ^ 1);
@@ -839,110 +972,9 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(DevTables t, SmallTab
         nxt[1] = base;
         if (idx >= 0 && idx < sched_n) *reinterpret_cast<SchedRow *>(nxt + 2) = sched_table[idx];
     }
-    if ((int)blockIdx.x >= hot.slab_blocks) {
-        // trailing blocks: 64 groups of 16 lanes, one hot item row each
-        const int hb = blockIdx.x - hot.slab_blocks;
-        if (!vec) finish_hot_rows<4, false>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
-        else if (nc == 1) finish_hot_rows<1, true>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
-        else if (nc == 2) finish_hot_rows<2, true>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
-        else finish_hot_rows<4, true>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
-        return;
-    }
-    __shared__ double part[16][64];
-    __shared__ double sloss[kLossSlots];
-    __shared__ double sreg[2];
-    const int EDP = t.E * DP, slab_len = 2 * EDP + EMAX + kLossSlots;
-    const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + col;
-    const bool pure = flags & INVPREF_PURE_MF;  // no small tables to finish: only the loss sums are folded
-    // parameter / moment of the output this thread will finish (sub == 0 threads), requested up front
-    float pre_p = 0.f, pre_m = 0.f, pre_v = 0.f;
-    if (sub == 0 && idx < 2 * EDP + EMAX) {
-        const bool isB = idx >= 2 * EDP, isW = !isB && idx >= EDP;
-        const int r = isB ? 0 : (isW ? idx - EDP : idx);
-        const int e = isB ? idx - 2 * EDP : r / DP, d = isB ? 0 : r - e * DP;
-        if (e < t.E && d < t.D && !pure) {
-            const int off = isB ? e : e * t.D + d;
-            pre_p = isB ? t.b[off] : (isW ? t.W[off] : t.Ev[off]);
-            if (fused) {
-                pre_m = (isB ? o.mb : (isW ? o.mW : o.mEv))[off];
-                pre_v = (isB ? o.vb : (isW ? o.vW : o.vEv))[off];
-            }
-        }
-    }
-    double acc = 0.0;
-    if (idx < slab_len)
-        for (int s = sub; s < nslabs; s += 16) {
-            float *q = slabs + (int64_t)s * slab_len + idx;
-            acc += (double)__builtin_nontemporal_load(q);
-            *q = 0.f;  // leave the replicas zeroed for the next step
-        }
-    part[sub][col] = acc;
-    if (threadIdx.x < 2) sreg[threadIdx.x] = 0.0;
-    __syncthreads();
-    const bool dense = (flags & INVPREF_DENSE_REG) && !(flags & INVPREF_REG_ONLY_EMBED) && !pure;
-    const bool last_block = (int)blockIdx.x == hot.slab_blocks - 1;
-    if (sub == 0 && idx < slab_len) {
-        double v = 0.0;
-        for (int s = 0; s < 16; s++) v += part[s][col];
-        if (idx < 2 * EDP) {
-            const bool isW = idx >= EDP;
-            const int r = isW ? idx - EDP : idx;
-            const int e = r / DP, d = r - e * DP;
-            if (d < t.D && !pure) {
-                const int off = e * t.D + d;
-                float gv = (float)v;
-                float pv = pre_p;
-                if (isW && dense) gv += 2.f * l2 / ((float)t.D * (float)t.E) * pv + l1 / ((float)t.D * (float)t.E) * c_sign(pv);
-                if (!fused) {
-                    (isW ? o.gW : o.gEv)[off] = gv;
-                } else {
-                    float *mp = (isW ? o.mW : o.mEv) + off, *vp = (isW ? o.vW : o.vEv) + off;
-                    float mm = pre_m, vv = pre_v;
-                    adam1(pv, gv, mm, vv, ad);
-                    (isW ? o.nW : o.nEv)[off] = pv; *mp = mm; *vp = vv;
-                }
-            }
-        } else if (idx < 2 * EDP + EMAX) {
-            const int e = idx - 2 * EDP;
-            if (e < t.E && !pure) {
-                float gv = (float)v, pv = pre_p;
-                if (dense) gv += 2.f * l2 / (float)t.E * pv + l1 / (float)t.E * c_sign(pv);
-                if (!fused) {
-                    o.gb[e] = gv;
-                } else {
-                    float mm = pre_m, vv = pre_v;
-                    adam1(pv, gv, mm, vv, ad);
-                    o.nb[e] = pv; o.mb[e] = mm; o.vb[e] = vv;
-                }
-            }
-        } else {
-            sloss[idx - 2 * EDP - EMAX] = v;
-        }
-    }
-    __syncthreads();
-    if (last_block && losses6) {
-        if (dense && threadIdx.x < 64) {
-            double w2 = 0, w1 = 0, b2 = 0, b1 = 0;
-            for (int i = threadIdx.x; i < t.E * t.D; i += 64) { const double x = t.W[i]; w2 += x * x; w1 += fabs(x); }
-            for (int i = threadIdx.x; i < t.E; i += 64) { const double x = t.b[i]; b2 += x * x; b1 += fabs(x); }
-            double r2v = w2 / ((double)t.D * t.E) + b2 / (double)t.E, r1v = w1 / ((double)t.D * t.E) + b1 / (double)t.E;
-            for (int m = 32; m >= 1; m >>= 1) { r2v += __shfl_xor(r2v, m, 64); r1v += __shfl_xor(r1v, m, 64); }
-            if (threadIdx.x == 0) { sreg[0] = r2v; sreg[1] = r1v; }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const double Bn = (double)Bnorm, BD2 = Bn * (double)t.D * 2.0;
-            const double Li = sloss[0] / Bn, Le = sloss[1] / Bn, Lc = sloss[2] / Bn;
-            const double L2 = sloss[3] / BD2 + sreg[0], L1 = sloss[4] / BD2 + sreg[1];
-            // added with fire-and-forget atomics: a plain `+=` would hold the kernel's end back by one more
-            // memory round trip (the same single fp32 addition either way)
-            atomicAdd(losses6 + 0, (float)Li); atomicAdd(losses6 + 1, (float)Le); atomicAdd(losses6 + 2, (float)Lc);
-            atomicAdd(losses6 + 3, (float)L2); atomicAdd(losses6 + 4, (float)L1);
-            atomicAdd(losses6 + 5, (float)((double)k.ca * Li + (double)k.cb * Le + (double)k.cc * Lc + (double)l2 * L2 + (double)l1 * L1));
-        }
-    }
+    finish_block(f, ad, blockIdx.x, part, sloss, sreg);
 }
+
 
 void *g_profile_event = nullptr;  // see invpref_set_profile_event()
 
@@ -960,6 +992,34 @@ template <typename K>
 int ensure_lds(K kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return 0;
     return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// the finish block of one step (see FinishArgs): `t` = the tables the step read, `a` = its launch arguments
+FinishArgs make_finish_args(const DevTables &t, const RowsArgs &a, const InvPrefRowPlan *plan, const InvPrefCoefs *coefs,
+                            int64_t batch_norm, uint32_t flags, int fused, const InvPrefTables *grads,
+                            const InvPrefTables *new_tables, const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
+                            const AdamScalars &ad, float *losses6, float *slabs, float *hot_scratch, int DP, int emax,
+                            int nc, int vec) {
+    FinishArgs f{};
+    f.t = t;
+    if (!fused) {
+        f.o.gEv = grads->embed_env; f.o.gW = grads->classifier_weight; f.o.gb = grads->classifier_bias;
+    } else {
+        f.o.nEv = new_tables->embed_env; f.o.nW = new_tables->classifier_weight; f.o.nb = new_tables->classifier_bias;
+        f.o.mEv = exp_avg->embed_env; f.o.mW = exp_avg->classifier_weight; f.o.mb = exp_avg->classifier_bias;
+        f.o.vEv = exp_avg_sq->embed_env; f.o.vW = exp_avg_sq->classifier_weight; f.o.vb = exp_avg_sq->classifier_bias;
+    }
+    const int slab_len = 2 * t.E * DP + emax + kLossSlots;
+    HotRows &h = f.hot;
+    h.n = plan->n_hot; h.slab_blocks = (slab_len + 63) / 64; h.rows = plan->hot_rows; h.cnt = plan->hot_count;
+    h.scratch = hot_scratch;
+    h.Qi = t.Qi; h.Qa = t.Qa;
+    if (!fused) { h.gQi = a.g[1]; h.gQa = a.g[3]; }
+    else { h.nQi = a.np[1]; h.nQa = a.np[3]; h.mQi = a.m[1]; h.mQa = a.m[3]; h.vQi = a.v[1]; h.vQa = a.v[3]; }
+    f.slabs = slabs; f.nslabs = kReplicas; f.DP = DP; f.EMAX = emax; f.nc = nc; f.vec = vec; f.fused = fused;
+    f.k = a.k; f.l2 = coefs->L2_coe; f.l1 = coefs->L1_coe; f.Bnorm = batch_norm; f.flags = flags; f.ad = ad;
+    f.losses6 = losses6;
+    return f;
 }
 
 int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const int64_t *envs, const float *scores,
@@ -1064,24 +1124,11 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
         err = hipEventRecord((hipEvent_t)g_profile_event, st);
         if (err != hipSuccess) return (int)err;
     }
-    SmallTables o{};
-    if (!fused) {
-        o.gEv = grads->embed_env; o.gW = grads->classifier_weight; o.gb = grads->classifier_bias;
-    } else {
-        o.nEv = new_tables->embed_env; o.nW = new_tables->classifier_weight; o.nb = new_tables->classifier_bias;
-        o.mEv = exp_avg->embed_env; o.mW = exp_avg->classifier_weight; o.mb = exp_avg->classifier_bias;
-        o.vEv = exp_avg_sq->embed_env; o.vW = exp_avg_sq->classifier_weight; o.vb = exp_avg_sq->classifier_bias;
-    }
-    const int nfb = (slab_len + 63) / 64;
-    HotRows h{};
-    h.n = plan->n_hot; h.slab_blocks = nfb; h.rows = plan->hot_rows; h.cnt = plan->hot_count; h.scratch = a.hot_scratch;
-    h.Qi = t.Qi; h.Qa = t.Qa;
-    if (!fused) { h.gQi = a.g[1]; h.gQa = a.g[3]; }
-    else { h.nQi = a.np[1]; h.nQa = a.np[3]; h.mQi = a.m[1]; h.mQa = a.m[3]; h.vQi = a.v[1]; h.vQa = a.v[3]; }
+    FinishArgs f = make_finish_args(t, a, plan, coefs, batch_norm, flags, fused, grads, new_tables, exp_avg, exp_avg_sq, ad,
+                                    losses6, (float *)workspace, a.hot_scratch, DP, emax, nc, (int)vec);
     const int hot_blocks = (plan->n_hot + 63) / 64;  // 1024 threads = 64 groups per block
-    hipLaunchKernelGGL(rows_finish_kernel, dim3(nfb + hot_blocks), dim3(1024), 0, st, t, o, (float *)workspace, kReplicas,
-                       DP, emax, k, coefs->L2_coe, coefs->L1_coe, batch_norm, flags, fused, ad, a.sched_state,
-                       a.sched_table, a.sched_n, a.sched_slot, losses6, h, nc, (int)vec);
+    hipLaunchKernelGGL(rows_finish_kernel, dim3(f.hot.slab_blocks + hot_blocks), dim3(1024), 0, st, f, a.sched_state,
+                       a.sched_table, a.sched_n, a.sched_slot);
     return (int)hipGetLastError();
 }
 

@@ -376,6 +376,7 @@ __device__ __forceinline__ void eval_interaction(Eval<NC, EMAX> &o, const float4
     // dots and the E backward rows each pay their own LDS round trip in sequence.  Rows c >= E of the staged
     // area hold other data: they are masked to zero, their logits to -inf (exp -> 0, gz -> 0).
     constexpr bool HOIST = HOISTW && EMAX * NC <= 4;
+    constexpr bool FLAT = !HOIST && EMAX * NC > 4 && EMAX * NC <= 16;   // (beyond that the unrolled loops spill)
     float4 wrow[HOIST ? EMAX : 1][NC];
     if (HOIST) {
 #pragma unroll
@@ -388,6 +389,18 @@ __device__ __forceinline__ void eval_interaction(Eval<NC, EMAX> &o, const float4
 #pragma unroll
         for (int c = 0; c < EMAX; c++) {
             const float zc = dot2<NC>(o.x, wrow[c]) + sb[c];
+            z[c] = c < E ? zc : -__builtin_inff();
+            mx = z[c] > mx ? z[c] : mx;
+        }
+    } else if (FLAT) {
+        // larger classifiers: too many rows to keep, but still no branch per class -- every class's LDS read is
+        // unconditional (rows c >= E of the staged area hold other data and are masked), so the reads of the
+        // next classes are in flight while this one's dot product is reduced
+#pragma unroll
+        for (int c = 0; c < EMAX; c++) {
+            float4 wr[NC];
+            lds_row<NC>(sW, c, l16, wr);
+            const float zc = dot2<NC>(o.x, wr) + sb[c];
             z[c] = c < E ? zc : -__builtin_inff();
             mx = z[c] > mx ? z[c] : mx;
         }
@@ -406,7 +419,7 @@ __device__ __forceinline__ void eval_interaction(Eval<NC, EMAX> &o, const float4
     float se = 0.f, ze = 0.f;
 #pragma unroll
     for (int c = 0; c < EMAX; c++) {
-        if (HOIST) { z[c] = f_exp(z[c] - mx); se += z[c]; }   // exp(-inf) = 0 for the padded classes
+        if (HOIST || FLAT) { z[c] = f_exp(z[c] - mx); se += z[c]; }   // exp(-inf) = 0 for the padded classes
         else if (c < E) { z[c] = f_exp(z[c] - mx); se += z[c]; }
     }
 #pragma unroll
@@ -421,6 +434,12 @@ __device__ __forceinline__ void eval_interaction(Eval<NC, EMAX> &o, const float4
             o.gz[c] = c < E ? k.cc * cw_cls * (z[c] * rse - (c == e ? 1.f : 0.f)) : 0.f;
 #pragma unroll
             for (int jj = 0; jj < NC; jj++) f4fma(o.gx[jj], o.gz[c], wrow[c][jj]);
+        } else if (FLAT) {
+            o.gz[c] = c < E ? k.cc * cw_cls * (z[c] * rse - (c == e ? 1.f : 0.f)) : 0.f;
+            float4 wr[NC];
+            lds_row<NC>(sW, c, l16, wr);
+#pragma unroll
+            for (int jj = 0; jj < NC; jj++) f4fma(o.gx[jj], o.gz[c], f4sel(c < E, wr[jj]));
         } else {
             o.gz[c] = 0.f;
             if (c < E) {
@@ -923,8 +942,14 @@ __device__ __forceinline__ void stream_task(const DevTables &t, const RowsArgs &
     }
 }
 
+// larger rows / classifiers need more registers than 168: at 3 waves per SIMD they spill hundreds of bytes per lane
+// (the MIND-shaped step ran 2.3 ms); with room for 256 registers the same step takes 1.1 ms
+#ifndef ROWS_MIN_WAVES_BIG
+#define ROWS_MIN_WAVES_BIG 2
+#endif
 template <int NC, bool VEC, int EMAX>
-__global__ __launch_bounds__(256, ROWS_MIN_WAVES) void mstep_rows_kernel(DevTables t, RowsArgs a) {
+__global__ __launch_bounds__(256, (NC * EMAX > 4) ? ROWS_MIN_WAVES_BIG : ROWS_MIN_WAVES)
+void mstep_rows_kernel(DevTables t, RowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // grid = [dense tasks | job tasks | stream tasks]: the dense tasks walk several interactions in
     // sequence and start first; every branch below is workgroup-uniform
@@ -981,7 +1006,9 @@ void *g_profile_event = nullptr;  // see invpref_set_profile_event()
 size_t rows_lds_bytes(int E, int nc, int emax) {
     const size_t DP = (size_t)nc * 64, EDP = (size_t)E * DP;
     // job task: slice slots + staged tables + LDS-DMA moment buffers; dense task: staged tables + records
-    const size_t job = sizeof(float) * (kGroups * 2 * DP + 2 * EDP + emax) + (nc <= 2 ? 16 * (size_t)(4 * 4 * nc * 64) : 0);
+    // (+ (emax - E) rows: the branch-free classifier loops read EMAX rows of the staged classifier, masked beyond E)
+    const size_t job = sizeof(float) * (kGroups * 2 * DP + 2 * EDP + emax + (size_t)(emax - E) * DP) +
+                       (nc <= 2 ? 16 * (size_t)(4 * 4 * nc * 64) : 0);
     const size_t nbuf = nc <= 2 ? 2 : 1;
     const size_t dense = sizeof(float) * (2 * EDP + emax + nbuf * (kGroups * 2 * DP + kGroups * (emax + 1)) + kLossSlots +
                                           (nc <= 2 ? kGroups * 2 * DP : 0));

@@ -175,14 +175,9 @@ class _InvPrefTrainManager:
                                    model.reg_only_embed, model.reg_env_embed, dense_reg=(self.rank == 0))
         # atomic-free planned M-step (plan.py) unless INVPREF_NO_PLAN=1 (then: float-atomic scatter-add)
         self.use_plan = os.environ.get('INVPREF_NO_PLAN', '0') != '1'
-        if 'INVPREF_NO_PLAN' not in os.environ:
-            # measured (tools/kbench.py): the planned kernel wins up to MovieLens-class shapes (E = 8, D = 128:
-            # 122 us against 181 us per 65 536-interaction step); at MIND-class E*D (E = 16, D = 256) every
-            # interaction's three evaluations cost more than the shaped atomics of the plan-free kernel
-            # (2.2 ms against 1.66 ms), which is then used instead
-            emax = 4 if model.env_num <= 4 else (8 if model.env_num <= 8 else 16)
-            nc = 4 if model.factor_num % 4 else (1 if model.factor_num <= 64 else (2 if model.factor_num <= 128 else 4))
-            self.use_plan = emax * nc <= 16
+        # (measured, tools/kbench.py, planned fused step vs plan-free gradient + Adam: Yahoo class 19 vs 78 us,
+        #  MovieLens class -- E = 8, D = 128, 65 536 interactions -- 110 vs 181 us, MIND class -- E = 16, D = 256,
+        #  262 144 interactions -- 1.1 vs 1.66 ms: the plan wins everywhere, so it is the default for every shape)
         self._plans = None
         # runs of whole epochs as one HIP graph launch (single GPU, planned path); INVPREF_NO_GRAPH=1 disables
         self.use_graph = os.environ.get('INVPREF_NO_GRAPH', '0') != '1'

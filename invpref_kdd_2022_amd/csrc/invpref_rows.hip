@@ -343,7 +343,8 @@ struct Sample {
 template <int NC, int EMAX>
 struct Eval {
     float g_p, g_q, li, le, lcls;
-    float gz[EMAX];
+    float gz[EMAX];          // EMAX <= 4: every lane holds all classes
+    float gz_lane;           // EMAX > 4: lane l16 of the group holds class l16 (0 beyond E)
     float4 x[NC], gx[NC];   // x = Pu*Qi ; gx = sum_c gz_c W_c
 };
 template <int NC, int EMAX, bool HOISTW = false>
@@ -370,6 +371,41 @@ __device__ __forceinline__ void eval_interaction(Eval<NC, EMAX> &o, const float4
     }
 #pragma unroll
     for (int c = 0; c < NC; c++) o.x[c] = f4mul(pu[c], qi[c]);
+    // (measured per shape, tools/kbench.py: the unrolled branch-free loops below win only at E = 8 with two row chunks)
+    constexpr bool LANEZ = EMAX > 4 && !(EMAX == 8 && NC == 2);
+    if (LANEZ) {
+        // Larger classifiers keep ONE class per lane instead of all classes in every lane: the logit of class c is a
+        // group-uniform value after the row reduction, lane c keeps it; max / sum of the softmax are 16-lane
+        // reductions, one exp per lane instead of E per lane, and the backward fetches gz_c from lane c.  No
+        // per-class register arrays, no per-class branches: the class loops run E times with the next class's LDS
+        // reads issued early.
+        float zmine = -__builtin_inff();
+#pragma unroll 2
+        for (int c = 0; c < E; c++) {
+            float4 wr[NC];
+            lds_row<NC>(sW, c, l16, wr);
+            const float zc = dot2<NC>(o.x, wr) + sb[c];
+            zmine = (l16 == c) ? zc : zmine;
+        }
+        const float mxl = row16_max(zmine);
+        const float ez = l16 < E ? f_exp(zmine - mxl) : 0.f;
+        const float rsel = f_rcp(row16_sum(ez));
+        const float zel = __shfl(ez, e, 16);
+        o.lcls = -f_log(zel * rsel);
+        const float gzl = l16 < E ? k.cc * cw_cls * (ez * rsel - (l16 == e ? 1.f : 0.f)) : 0.f;
+        o.gz_lane = gzl;
+#pragma unroll
+        for (int c = 0; c < NC; c++) o.gx[c] = f4zero();
+#pragma unroll 2
+        for (int c = 0; c < E; c++) {
+            const float g = __shfl(gzl, c, 16);
+            float4 wr[NC];
+            lds_row<NC>(sW, c, l16, wr);
+#pragma unroll
+            for (int jj = 0; jj < NC; jj++) f4fma(o.gx[jj], g, wr[jj]);
+        }
+        return;
+    }
     float z[EMAX], mx = -__builtin_inff();
     // HOISTW (dense tasks, small classifiers): the W rows are read from LDS ONCE, unconditionally and back to
     // back, and everything after is selects and arithmetic -- with a guarded LDS read per class the E forward
@@ -802,8 +838,11 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
             }
             if (l16 < EMAX) {
                 float gsel = 0.f;
+                if (EMAX > 4 && !(EMAX == 8 && NC == 2)) gsel = o.gz_lane;
+                else {
 #pragma unroll
-                for (int c = 0; c < EMAX; c++) gsel = (l16 == c) ? o.gz[c] : gsel;
+                    for (int c = 0; c < EMAX; c++) gsel = (l16 == c) ? o.gz[c] : gsel;
+                }
                 recs[grp * (EMAX + 1) + l16] = gsel;
             }
             if (l16 == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; accLc += o.lcls * w_cls; }

@@ -138,7 +138,7 @@ class _BasicTrainManager(_InvPrefTrainManager):
         self._flags = ops.flags_of(self.implicit, False, False, True, False, dense_reg=False) | _capi.PURE_MF
         self.use_plan, self._plans = True, None
         self.use_graph = os.environ.get('INVPREF_NO_GRAPH', '0') != '1'
-        self._force_sharded_path, self._collective_ok = False, False
+        self._force_sharded_path, self._collective_ok, self._unfused = False, False, False
         self._graphs, self._graph_warm = {}, False
         self._sched, self._sched_synced = None, False
 

@@ -102,7 +102,7 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     # MovieLens-sized one (65 536) is throughput-bound and wants fewer, longer ones.
     scale = max(1, len(users) // 8192)
     if per_slice is None:
-        per_slice = int(os.environ.get('INVPREF_PLAN_PER_SLICE', str(min(16, 2 * scale))))
+        per_slice = int(os.environ.get('INVPREF_PLAN_PER_SLICE', str(min(32, 2 * scale))))
     if rounds_per_task is None:
         rounds_per_task = int(os.environ.get('INVPREF_PLAN_ROUNDS', '1'))
     if hot_threshold is None:
@@ -129,7 +129,7 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
                       skip=hot | (icnt == 0))
     du = _side_rounds(users[pu], items[pu], pu, scores[pu], user_num, per_slice, 1, skip=(ucnt == 0))
     return dict(batch_users=users.astype(np.int32), batch_items=items.astype(np.int32),
-                dense_per_task=int(os.environ.get('INVPREF_PLAN_DENSE', str(min(128, 32 * scale)))),
+                dense_per_task=int(os.environ.get('INVPREF_PLAN_DENSE', str(min(256, 32 * scale)))),
                 stream_rows=np.concatenate([stream_u, stream_i]), n_stream_user=len(stream_u),
                 n_stream_item=len(stream_i), rows_per_stream_task=int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', '64')),n=n, n_item_rounds=len(di), rounds_per_task=rounds_per_task, desc=np.concatenate([di, du]),
                 other_user=items[pu].astype(np.int32), pos_user=pu.astype(np.int32),

@@ -178,6 +178,10 @@ class _InvPrefTrainManager:
         # (measured, tools/kbench.py, planned fused step vs plan-free gradient + Adam: Yahoo class 19 vs 78 us,
         #  MovieLens class -- E = 8, D = 128, 65 536 interactions -- 110 vs 181 us, MIND class -- E = 16, D = 256,
         #  262 144 interactions -- 1.1 vs 1.66 ms: the plan wins everywhere, so it is the default for every shape)
+        # rows of more than 128 floats (four 16-lane chunks): the gradient pass + the flat Adam kernel is faster than
+        # the fused pass there (no LDS-DMA moment prefetch at that row size; MIND class 0.88 vs 0.94 ms per step)
+        self._unfused = self.use_plan and model.factor_num % 4 == 0 and model.factor_num > 128 \
+            and os.environ.get('INVPREF_FUSED', '') != '1'
         self._plans = None
         # runs of whole epochs as one HIP graph launch (single GPU, planned path); INVPREF_NO_GRAPH=1 disables
         self.use_graph = os.environ.get('INVPREF_NO_GRAPH', '0') != '1'
@@ -321,7 +325,7 @@ class _InvPrefTrainManager:
         lo, n, bn = self._raw_batches[k]
         pu, pi, pe, py, pw = self._raw_ptrs
         cf = self._coefs_struct(alpha)
-        multi = self.world_size > 1 or self._force_sharded_path
+        multi = self.world_size > 1 or self._force_sharded_path or self._unfused
         # every step's six loss terms go straight into the epoch's loss buffer (this rank's partial sums in a
         # sharded run: they are all-reduced once per epoch, not per step)
         lp = self._epoch_losses.data_ptr() + 24 * (self._loss_slot * self.batch_num + k)
@@ -463,7 +467,7 @@ class _InvPrefTrainManager:
             self._raw_setup()
             self._graphs.clear()
         st = self.state
-        graph_ok = self.use_graph and self.use_plan and self.world_size == 1 \
+        graph_ok = self.use_graph and self.use_plan and self.world_size == 1 and not self._unfused \
             and not self._force_sharded_path and self.batch_num <= self._SCHED_N // 2
         if graph_ok and self._graph_warm:
             n = min(want, self._graph_epochs)

@@ -298,6 +298,33 @@ def test_rank0_of_two_code_path_on_gpu(monkeypatch, mode):
         dist.destroy_process_group()
 
 
+def test_wide_rows_take_the_unfused_sequence(monkeypatch):
+    """factor_num > 128 (four 16-lane chunks per row): the manager runs gradient pass + flat Adam instead of the fused
+    pass (faster at that row size); INVPREF_FUSED=1 forces the fused pass.  Same trajectory either way."""
+    U, I, E, D, n, bs = 300, 200, 5, 256, 6000, 1024
+    data = synth.interactions(77, U, I, n, implicit=True)
+    tabs = synth.tables(78, U, I, E, D, std=0.05)
+    res = []
+    for fused in ('', '1'):
+        monkeypatch.setenv('INVPREF_FUSED', fused)
+        model = InvPrefImplicit(U, I, E, D, reg_only_embed=False, reg_env_embed=True)
+        model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+        np.random.seed(5)
+        mgr = ImplicitTrainManager(model=model, evaluator=StubEvaluator(), device=DEV, training_data=torch.from_numpy(data).to(DEV),
+                                   batch_size=bs, epochs=4, cluster_interval=2, evaluate_interval=10 ** 9, lr=0.005,
+                                   invariant_coe=3.35, env_aware_coe=9.99, env_coe=9.06, L2_coe=3.13, L1_coe=0.49, alpha=1.9,
+                                   use_class_re_weight=True, use_recommend_re_weight=True, cluster_use_random_sort=False)
+        assert mgr._unfused == (fused == '') and mgr.use_plan
+        (losses, _), _, (diffs, cnts, _) = mgr.train(silent=True)
+        assert bool(mgr._graphs) == (fused == '1')
+        res.append((np.array([[l[k] for k in LOSS_KEYS] for l in losses]), diffs,
+                    {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=5e-5)
+    assert abs(res[0][1][0] - res[1][1][0]) <= 3
+    for k in O.PARAM_NAMES:
+        _assert_same_run(np.abs(res[0][2][k] - res[1][2][k]), 0.005, k)
+
+
 def test_alpha_schedule_under_graph_replay(monkeypatch):
     """alpha=None (train.py:214-217: alpha follows the training progress, as MovieLens_InvPref.py and
     Yahoo_InvPref_explicit.py run it): the graph-replayed epochs read every step's alpha from the device-side

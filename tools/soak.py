@@ -1,0 +1,29 @@
+import os, sys
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import numpy as np, torch
+from invpref_kdd_2022_amd import synth
+from invpref_kdd_2022_amd.models import InvPrefImplicit
+from invpref_kdd_2022_amd.train import ImplicitTrainManager, LOSS_KEYS
+from oracle import oracle as O
+DEV = torch.device('cuda:0')
+U, I, E, D = 2000, 500, 4, 64
+data = synth.interactions(5, U, I, 40000, implicit=True)
+tabs = synth.tables(6, U, I, E, D, std=0.05)
+class Stub:
+    def evaluate(self): return {}
+res = []
+for ng in ('1', '0'):
+    os.environ['INVPREF_NO_GRAPH'] = ng
+    model = InvPrefImplicit(U, I, E, D, reg_only_embed=True, reg_env_embed=False)
+    model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+    np.random.seed(3)
+    mgr = ImplicitTrainManager(model=model, evaluator=Stub(), device=DEV, training_data=torch.from_numpy(data).to(DEV),
+                               batch_size=8192, epochs=1700, cluster_interval=10 ** 9, evaluate_interval=10 ** 9, lr=0.002,
+                               invariant_coe=3.35, env_aware_coe=9.99, env_coe=9.06, L2_coe=3.13, L1_coe=0.49, alpha=1.9,
+                               use_class_re_weight=True, use_recommend_re_weight=False, cluster_use_random_sort=False)
+    (losses, ep), _, (diffs, cnts, ce) = mgr.train(silent=True)
+    tr = np.array([[l[k] for k in LOSS_KEYS] for l in losses])
+    print('no_graph', ng, 'steps', mgr.state.step, 'final', tr[-1], 'diffs', diffs, 'finite', np.isfinite(tr).all())
+    res.append((tr, diffs))
+d = np.abs(res[0][0] / res[1][0] - 1)
+print('max rel loss diff per 100 epochs:', np.round([d[i:i+100].max() for i in range(0, 1700, 100)], 6))

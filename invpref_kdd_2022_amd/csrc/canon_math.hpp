@@ -139,6 +139,14 @@ __device__ __forceinline__ float row16_sum(float x) {
     x = x + dpp_move<0x140>(x);
     return x;
 }
+// the same butterfly with min (E-step argmin over one environment per lane)
+__device__ __forceinline__ float row16_min(float x) {
+    x = __builtin_fminf(x, dpp_move<0xB1>(x));
+    x = __builtin_fminf(x, dpp_move<0x4E>(x));
+    x = __builtin_fminf(x, dpp_move<0x141>(x));
+    x = __builtin_fminf(x, dpp_move<0x140>(x));
+    return x;
+}
 // the same butterfly with max (M-step softmax over one class per lane)
 __device__ __forceinline__ float row16_max(float x) {
     x = __builtin_fmaxf(x, dpp_move<0xB1>(x));

@@ -534,18 +534,25 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
         load_row<NC, VEC>(t.Qa, v, t.D, l16, qa);
         const float p = dot2<NC>(pu, qi);
         const float sp = implicit ? c_sigmoid(p) : p;
-        float best = 0.f;
-        int bi = 0;
+        // One environment per LANE: q_e is a group-uniform value after the row reduction and lane e keeps it; the
+        // sigmoid / BCE chain (canonical, ~100 VALU instructions -- the kernel is ALU-bound, VALUBusy 97 %) then
+        // runs ONCE for all environments instead of once per environment, each lane on its own q.  Same operations on
+        // the same operands as the sequential form, so the distances are bit-identical.
+        float qmine = 0.f;
         for (int c = 0; c < t.E; c++) {
             float4 ev[NC];
             lds_row<NC>(sEv, c, l16, ev);
             const float q = dot3<NC>(pa, qa, ev);
-            float dist;
-            if (implicit) dist = c_bce(sp * c_sigmoid(q), y);
-            else { const float r = (p + q) - y; dist = r * r; }
-            if (eps_rows) dist = dist + eps_rows[s * t.E + c];
-            if (c == 0 || dist < best) { best = dist; bi = c; }
+            qmine = (l16 == c) ? q : qmine;
         }
+        float dist;
+        if (implicit) dist = c_bce(sp * c_sigmoid(qmine), y);
+        else { const float r = (p + qmine) - y; dist = r * r; }
+        if (eps_rows && l16 < t.E) dist = dist + eps_rows[s * t.E + l16];
+        // argmin with the lowest index among equal minima (torch.argmin; the sequential `dist < best` scan)
+        dist = l16 < t.E ? dist : __builtin_inff();
+        const float dmin = row16_min(dist);
+        const int bi = (int)row16_min(dist == dmin ? (float)l16 : 99.f);
         if (l16 == 0) {
             const bool changed = old_envs ? (old_envs[s] != (int64_t)bi) : false;
             new_envs[s] = bi;

@@ -17,7 +17,6 @@ from __future__ import annotations
 import math
 import os
 
-import numpy as np
 import torch
 from torch import nn
 

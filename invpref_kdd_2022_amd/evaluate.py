@@ -14,7 +14,6 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _capi, ops
 from ._capi import check, lib, ptr, stream_ptr
 
 

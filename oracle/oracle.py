@@ -185,6 +185,11 @@ class Trainer:
         self.m = [np.zeros_like(a) for a in self.tab.arrs]
         self.vv = [np.zeros_like(a) for a in self.tab.arrs]
         self.step = 0
+        self.epoch_cnt = 0
+        # alpha = None in the reference (train.py:36-40): alpha follows the training progress (train.py:214-217)
+        self.update_alpha = not np.isfinite(self.coefs[5])
+        if self.update_alpha:
+            self.coefs[5] = 0.0
         self.sample_w = np.zeros(self.N, dt)
         self.counts = None
 
@@ -202,7 +207,14 @@ class Trainer:
         return losses
 
     def train_a_epoch(self):
-        ls = [self.train_a_batch(lo, min(lo + self.bs, self.N)) for lo in range(0, self.N, self.bs)]
+        nb = (self.N + self.bs - 1) // self.bs
+        ls = []
+        for k, lo in enumerate(range(0, self.N, self.bs)):
+            if self.update_alpha:  # train.py:214-217
+                p = float(k + (self.epoch_cnt + 1) * nb) / float((self.epoch_cnt + 1) * nb)
+                self.coefs[5] = 2. / (1. + np.exp(-10. * p)) - 1.
+            ls.append(self.train_a_batch(lo, min(lo + self.bs, self.N)))
+        self.epoch_cnt += 1
         return np.mean(np.stack(ls), axis=0)
 
     def cluster(self):

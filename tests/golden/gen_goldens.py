@@ -18,6 +18,7 @@ What each fixture pins:
   g7    PureMF baselines (Basic*TrainManager)                 -> §8 f2
   g8    data loaders on a small seeded CSV data set           -> §8 f3
   g9    static_pop / final_cluster_stat                       -> §8 f4
+  g10   MovieLens-class trajectory: E=8, D=128, alpha schedule -> §8 a2-a14 at E > 4
 """
 import sys
 import types
@@ -511,8 +512,40 @@ def gen_g9():
     print('g9', out['pop'][0], out['pop'][3])
 
 
+ML_CFG = dict(lr=0.004, invariant_coe=2.2, env_aware_coe=6.1, env_coe=4.3, L2_coe=1.7, L1_coe=0.21, alpha=None)
+
+
+def gen_g10():
+    """MovieLens-class shape and settings (MovieLens_InvPref.py: 8 environments, 128 factors, alpha=None -> the alpha
+    schedule of train.py:214-217, implicit): 6 epochs, E-step after epoch 3, on a small seeded data set."""
+    U, I, E, D, n, bs, seed = 300, 200, 8, 128, 6000, 1024, 4711
+    data = synth.interactions(seed, U, I, n, implicit=True)
+    tabs = synth.tables(seed + 1, U, I, E, D, std=0.05)
+    np.random.seed(seed)
+    model = ref_models.InvPrefImplicit(U, I, E, D, reg_only_embed=False, reg_env_embed=True)
+    load_tables(model, tabs)
+    mgr = make_manager('implicit', model, data, batch_size=bs, cfg=ML_CFG, cls_w=True, rec_w=True, random_sort=False,
+                       epochs=6, cluster_interval=3)
+    assert mgr.update_alpha
+    env0 = mgr.envs.numpy().copy()
+    torch.set_num_threads(1)
+    (losses, _), _, (diffs, cnts, ce) = mgr.train(silent=True, auto=True)
+    keys = ('invariant_loss', 'env_aware_loss', 'envs_loss', 'L2_reg', 'L1_reg', 'loss')
+    trace = np.array([[d[k] for k in keys] for d in losses], dtype=np.float64)
+    print('g10 movielens-like: losses', trace[:, -1], 'diff', diffs, 'alpha', mgr.alpha)
+    fin = model.state_dict()
+    np.savez_compressed(
+        os.path.join(OUT, 'g10_movielens_like_traj.npz'), meta=np.array([U, I, E, D, bs, 6, seed, n]),
+        env0=pack_envs(env0), env_after=pack_envs(mgr.envs.numpy()), loss_trace=trace, diff_num=np.array(diffs),
+        counts=np.array([[c[k] for k in range(E)] for c in cnts]), cluster_epochs=np.array(ce),
+        coefs=np.array([ML_CFG[k] for k in ('invariant_coe', 'env_aware_coe', 'env_coe', 'L2_coe', 'L1_coe')] + [ML_CFG['lr']]),
+        final_alpha=np.array(mgr.alpha), final_env=fin['embed_env.weight'].numpy(),
+        final_W=fin['env_classifier.linear_map.weight'].numpy(), final_b=fin['env_classifier.linear_map.bias'].numpy(),
+        final_user_inv_head=fin['embed_user_invariant.weight'].numpy()[:32])
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10']
     torch.manual_seed(0)
     for name in which:
         globals()['gen_' + name]()

@@ -85,6 +85,43 @@ def test_g4_yahoo_like_trajectory_through_manager():
     assert sum(cnts[0].values()) == len(data)
 
 
+def test_g10_movielens_like_trajectory_through_manager():
+    """MovieLens-class settings (E = 8, D = 128: the one-class-per-lane / branch-free classifier paths, two row chunks;
+    alpha=None: the scheduled alpha read from the device-side schedule under graph replay) through the drop-in
+    manager against the reference's recorded trajectory."""
+    z = np.load(os.path.join(G, 'g10_movielens_like_traj.npz'))
+    U, I, E, D, bs, epochs, seed, n = [int(x) for x in z['meta']]
+    data = synth.interactions(seed, U, I, n, implicit=True)
+    tabs = synth.tables(seed + 1, U, I, E, D, std=0.05)
+    model = InvPrefImplicit(U, I, E, D, reg_only_embed=False, reg_env_embed=True)
+    model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+    np.random.seed(seed)
+    cf = z['coefs']
+    mgr = ImplicitTrainManager(model=model, evaluator=StubEvaluator(), device=DEV, training_data=torch.from_numpy(data).to(DEV),
+                               batch_size=bs, epochs=epochs, cluster_interval=3, evaluate_interval=10 ** 9, lr=float(cf[5]),
+                               invariant_coe=float(cf[0]), env_aware_coe=float(cf[1]), env_coe=float(cf[2]),
+                               L2_coe=float(cf[3]), L1_coe=float(cf[4]), alpha=None, use_class_re_weight=True,
+                               use_recommend_re_weight=True, cluster_use_random_sort=False)
+    np.testing.assert_array_equal(mgr.envs.cpu().numpy(), z['env0'].astype(np.int64))
+    (losses, _), _, (diffs, cnts, ce) = mgr.train(silent=True, auto=True)
+    assert ce == list(z['cluster_epochs']) and mgr._graphs and mgr.use_plan
+    trace = np.array([[d[k] for k in LOSS_KEYS] for d in losses])
+    np.testing.assert_allclose(trace, z['loss_trace'], rtol=3e-5)
+    assert abs(mgr.alpha - float(z['final_alpha'])) < 1e-9
+    # last E-step: HIP == oracle bit-exact on the same tables; vs the reference the near-tie rule (see the oracle test)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    on, _, _, dist = O.estep(O.Tables(sd), data[:, 0], data[:, 1], data[:, 2], True, want_dist=True)
+    got = mgr.envs.cpu().numpy()
+    np.testing.assert_array_equal(got, on)
+    ref = z['env_after'].astype(np.int64)
+    mm = np.nonzero(got != ref)[0]
+    assert len(mm) < 0.05 * n and ((dist[mm, ref[mm]] - dist[mm, got[mm]]) / dist[mm, got[mm]]).max() < 2e-5
+    for key, name in (('final_env', 'embed_env.weight'), ('final_W', 'env_classifier.linear_map.weight'),
+                      ('final_b', 'env_classifier.linear_map.bias')):
+        assert np.abs(sd[name] - z[key]).max() < 2e-3
+    assert np.abs(sd['embed_user_invariant.weight'][:32] - z['final_user_inv_head']).max() < 2e-3
+
+
 @pytest.mark.parametrize('path', G1[::3], ids=[os.path.basename(p)[3:-4] for p in G1[::3]])
 def test_unfused_autograd_surface_matches_reference_grads(path):
     """Build the loss with torch ops exactly like the reference's train_a_batch does, on top of the

@@ -19,6 +19,7 @@ What each fixture pins:
   g8    data loaders on a small seeded CSV data set           -> §8 f3
   g9    static_pop / final_cluster_stat                       -> §8 f4
   g10   MovieLens-class trajectory: E=8, D=128, alpha schedule -> §8 a2-a14 at E > 4
+  g11   cluster() with cluster_use_random_sort=True (eps rows) -> §8 a9, a13
 """
 import sys
 import types
@@ -544,8 +545,33 @@ def gen_g10():
         final_user_inv_head=fin['embed_user_invariant.weight'].numpy()[:32])
 
 
+from random_sort_fixture import random_sort_case  # noqa: E402  (tests/random_sort_fixture.py, shared with the tests)
+
+
+def gen_g11():
+    """cluster() with cluster_use_random_sort=True (the reference's default): the eps permutation table, the
+    np.random.randint stream consumed per minibatch, and argmin over dist + eps."""
+    for E in (4, 5):
+        (U, I, D, n, bs), data, tabs = random_sort_case(E)
+        model = ref_models.InvPrefExplicit(U, I, E, D, reg_only_embed=True, reg_env_embed=False)
+        load_tables(model, tabs)
+        np.random.seed(77 + E)
+        mgr = make_manager('explicit', model, data, batch_size=bs, cfg=YAHOO_CFG, cls_w=True, rec_w=True, random_sort=True,
+                           epochs=1, cluster_interval=1)
+        env0 = mgr.envs.numpy().copy()
+        d1 = mgr.cluster()
+        env1 = mgr.envs.numpy().copy()
+        d2 = mgr.cluster()                                  # a second call keeps consuming the same numpy stream
+        env2 = mgr.envs.numpy().copy()
+        exact = data[:, 0] < U // 2
+        print('g11 E', E, 'diff', d1, d2, 'exact-tie rows moved by the second call:', int((env1 != env2)[exact].sum()),
+              'generic rows moved:', int((env1 != env2)[~exact].sum()))
+        np.savez_compressed(os.path.join(OUT, f'g11_random_sort_E{E}.npz'), meta=np.array([U, I, E, D, n, bs, 77 + E]),
+                            env0=pack_envs(env0), env1=pack_envs(env1), env2=pack_envs(env2), diff=np.array([d1, d2]))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11']
     torch.manual_seed(0)
     for name in which:
         globals()['gen_' + name]()

@@ -85,6 +85,29 @@ def test_g4_yahoo_like_trajectory_through_manager():
     assert sum(cnts[0].values()) == len(data)
 
 
+def test_g11_random_sort_cluster_through_manager():
+    """cluster() with cluster_use_random_sort=True (the reference's default) through the drop-in manager: same numpy
+    stream, same eps permutation rows, same assignments as the reference -- bit for bit, two calls in a row."""
+    from random_sort_fixture import random_sort_case
+    for E in (4, 5):
+        z = np.load(os.path.join(G, f'g11_random_sort_E{E}.npz'))
+        (U, I, D, n, bs), data, tabs = random_sort_case(E)
+        model = InvPrefExplicit(U, I, E, D, reg_only_embed=True, reg_env_embed=False)
+        model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+        np.random.seed(int(z['meta'][6]))
+        mgr = ExplicitTrainManager(model=model, evaluator=StubEvaluator(), device=DEV, training_data=torch.from_numpy(data).to(DEV),
+                                   batch_size=bs, epochs=1, cluster_interval=1, evaluate_interval=10 ** 9, lr=0.005,
+                                   invariant_coe=3.35, env_aware_coe=9.99, env_coe=9.06, L2_coe=3.13, L1_coe=0.49, alpha=1.9,
+                                   use_class_re_weight=True, use_recommend_re_weight=True, cluster_use_random_sort=True)
+        np.testing.assert_array_equal(mgr.envs.cpu().numpy(), z['env0'].astype(np.int64))
+        for j, key in enumerate(('env1', 'env2')):
+            d = mgr.cluster()
+            np.testing.assert_array_equal(mgr.envs.cpu().numpy(), z[key].astype(np.int64))
+            assert d == int(z['diff'][j])
+            cnt = mgr.stat_envs()
+            assert [cnt[e] for e in range(E)] == np.bincount(z[key].astype(np.int64), minlength=E).tolist()
+
+
 def test_g10_movielens_like_trajectory_through_manager():
     """MovieLens-class settings (E = 8, D = 128: the one-class-per-lane / branch-free classifier paths, two row chunks;
     alpha=None: the scheduled alpha read from the device-side schedule under graph replay) through the drop-in

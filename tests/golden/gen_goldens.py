@@ -20,6 +20,7 @@ What each fixture pins:
   g9    static_pop / final_cluster_stat                       -> §8 f4
   g10   MovieLens-class trajectory: E=8, D=128, alpha schedule -> §8 a2-a14 at E > 4
   g11   cluster() with cluster_use_random_sort=True (eps rows) -> §8 a9, a13
+  g12   train() control flow: evaluate / cluster windows        -> §8 a14
 """
 import sys
 import types
@@ -570,8 +571,41 @@ def gen_g11():
                             env0=pack_envs(env0), env1=pack_envs(env1), env2=pack_envs(env2), diff=np.array([d1, d2]))
 
 
+def gen_g12():
+    """train() control flow (train.py:282-342): evaluate_interval / test_begin_epoch, cluster_interval with
+    begin_cluster_epoch / stop_cluster_epoch (diff_num 0 recorded outside the window) -- the epoch lists the reference
+    returns, and the loss trace, for a tiny run."""
+    U, I, E, D, n, bs, seed = 60, 40, 3, 16, 1500, 512, 1212
+    data = synth.interactions(seed, U, I, n, implicit=True)
+    tabs = synth.tables(seed + 1, U, I, E, D, std=0.2)
+    np.random.seed(seed)
+    model = ref_models.InvPrefImplicit(U, I, E, D, reg_only_embed=False, reg_env_embed=True)
+    load_tables(model, tabs)
+
+    class CountingEvaluator:
+        calls = 0
+
+        def evaluate(self):
+            CountingEvaluator.calls += 1
+            return {'calls': CountingEvaluator.calls}
+
+    mgr = ref_train.ImplicitTrainManager(
+        model=model, evaluator=CountingEvaluator(), device=CPU, training_data=torch.from_numpy(data), batch_size=bs, epochs=9,
+        cluster_interval=2, evaluate_interval=3, lr=0.01, invariant_coe=2.0, env_aware_coe=3.0, env_coe=1.5, L2_coe=0.5,
+        L1_coe=0.05, alpha=1.2, use_class_re_weight=True, test_begin_epoch=4, begin_cluster_epoch=3, stop_cluster_epoch=7,
+        cluster_use_random_sort=False, use_recommend_re_weight=True)
+    (losses, loss_epochs), (tests, test_epochs), (diffs, cnts, cluster_epochs) = mgr.train(silent=True, auto=True)
+    keys = ('invariant_loss', 'env_aware_loss', 'envs_loss', 'L2_reg', 'L1_reg', 'loss')
+    print('g12', loss_epochs, test_epochs, cluster_epochs, diffs)
+    np.savez_compressed(os.path.join(OUT, 'g12_train_control_flow.npz'), meta=np.array([U, I, E, D, n, bs, seed]),
+                        loss_trace=np.array([[d[k] for k in keys] for d in losses]), loss_epochs=np.array(loss_epochs),
+                        test_epochs=np.array(test_epochs), test_calls=np.array([t['calls'] for t in tests]),
+                        cluster_epochs=np.array(cluster_epochs), diff_num=np.array(diffs),
+                        counts=np.array([[c[k] for k in range(E)] for c in cnts]))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12']
     torch.manual_seed(0)
     for name in which:
         globals()['gen_' + name]()

@@ -85,6 +85,44 @@ def test_g4_yahoo_like_trajectory_through_manager():
     assert sum(cnts[0].values()) == len(data)
 
 
+def test_g12_train_control_flow_matches_reference():
+    """train()'s outer loop (train.py:282-342): which epochs evaluate (evaluate_interval, test_begin_epoch), which cluster
+    (cluster_interval inside [begin_cluster_epoch, stop_cluster_epoch), diff_num 0 recorded outside) -- the lists the
+    reference returned for the same run, the evaluator called the same number of times, and the loss trace."""
+    z = np.load(os.path.join(G, 'g12_train_control_flow.npz'))
+    U, I, E, D, n, bs, seed = [int(x) for x in z['meta']]
+    data = synth.interactions(seed, U, I, n, implicit=True)
+    tabs = synth.tables(seed + 1, U, I, E, D, std=0.2)
+
+    class CountingEvaluator:
+        def __init__(self):
+            self.calls = 0
+
+        def evaluate(self):
+            self.calls += 1
+            return {'calls': self.calls}
+
+    for silent in (True, False):
+        model = InvPrefImplicit(U, I, E, D, reg_only_embed=False, reg_env_embed=True)
+        model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+        np.random.seed(seed)
+        mgr = ImplicitTrainManager(
+            model=model, evaluator=CountingEvaluator(), device=DEV, training_data=torch.from_numpy(data).to(DEV), batch_size=bs,
+            epochs=9, cluster_interval=2, evaluate_interval=3, lr=0.01, invariant_coe=2.0, env_aware_coe=3.0, env_coe=1.5,
+            L2_coe=0.5, L1_coe=0.05, alpha=1.2, use_class_re_weight=True, test_begin_epoch=4, begin_cluster_epoch=3,
+            stop_cluster_epoch=7, cluster_use_random_sort=False, use_recommend_re_weight=True)
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            (losses, loss_epochs), (tests, test_epochs), (diffs, cnts, cluster_epochs) = mgr.train(silent=silent)
+        assert loss_epochs == list(z['loss_epochs']) and test_epochs == list(z['test_epochs'])
+        assert [t['calls'] for t in tests] == list(z['test_calls'])
+        assert cluster_epochs == list(z['cluster_epochs'])
+        assert diffs[0] == 0 and diffs[3] == 0                       # outside the clustering window
+        assert abs(diffs[1] - int(z['diff_num'][1])) <= 3 and abs(diffs[2] - int(z['diff_num'][2])) <= 6
+        np.testing.assert_allclose(np.array([[d[k] for k in LOSS_KEYS] for d in losses]), z['loss_trace'], rtol=5e-5)
+        assert np.abs(np.array([[c[e] for e in range(E)] for c in cnts]) - z['counts']).sum() <= 24
+
+
 def test_g11_random_sort_cluster_through_manager():
     """cluster() with cluster_use_random_sort=True (the reference's default) through the drop-in manager: same numpy
     stream, same eps permutation rows, same assignments as the reference -- bit for bit, two calls in a row."""

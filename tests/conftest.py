@@ -14,6 +14,15 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built libraries (they are git-ignored): build what the suites load -- the HIP library
+    (hipcc cross-compiles without a GPU), the host-side ingest library and the C oracle -- once, if stale or missing."""
+    from invpref_kdd_2022_amd import build
+    build.build()
+    from oracle import oracle
+    oracle.build()
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN

@@ -17,10 +17,17 @@ def pytest_configure(config):
 def pytest_sessionstart(session):
     """A fresh checkout has no built libraries (they are git-ignored): build what the suites load -- the HIP library
     (hipcc cross-compiles without a GPU), the host-side ingest library and the C oracle -- once, if stale or missing."""
-    from invpref_kdd_2022_amd import build
-    build.build()
-    from oracle import oracle
-    oracle.build()
+    import warnings
+    try:
+        from invpref_kdd_2022_amd import build
+        build.build()
+    except Exception as exc:  # the tests that load the library then fail on their own, with the loader's message
+        warnings.warn(f'could not build the HIP / ingest libraries: {exc}')
+    try:
+        from oracle import oracle
+        oracle.build()
+    except Exception as exc:
+        warnings.warn(f'could not build the CPU oracle: {exc}')
 
 
 @pytest.fixture(scope='session')

@@ -217,7 +217,9 @@ int invpref_predict_hip(const float *user_table, const float *item_table, const 
  *   highlight_items[...] (highlight_ptr may be NULL)  item pool, rating += 1024      (evaluate.py:103-111)
  *   truth_items[truth_ptr[j] .. truth_ptr[j+1])    SORTED ground-truth items         (evaluate.py:11-19)
  * Outputs [n_users, k]: the top-k item ids in descending rating order (lowest id first among equal
- * ratings) and 1.0/0.0 hit labels (get_label).  ratings is not modified.  k <= 64, k <= n_items <= 36864. */
+ * ratings) and 1.0/0.0 hit labels (get_label).  ratings is not modified.  k <= 64, k <= n_items <= 400000
+ * (up to 10 240 items four rating rows are staged in LDS per workgroup; beyond that the row stays in global
+ * memory and LDS holds bit sets over the items -- MIND's 51 283 items included). */
 int invpref_eval_topk_hip(const float *ratings, int64_t n_users, int64_t n_items, const int32_t *mask_ptr,
                           const int32_t *mask_items, const int32_t *highlight_ptr, const int32_t *highlight_items,
                           const int32_t *truth_ptr, const int32_t *truth_items, int32_t k, int32_t *out_items,
@@ -244,7 +246,9 @@ int invpref_static_pop_hip(const int64_t *users, const int64_t *items, const int
 
 /* ---- dense Adam: replaces optimizer.zero_grad() + optimizer.step() of torch.optim.Adam with
  * default betas/eps (train.py:41, :155-157) over one flat fp32 buffer of n parameters.
- * step is 1-based.  zero_grad != 0 also clears grad (the next step's zero_grad()). */
+ * step is 1-based.  zero_grad != 0 also clears grad (the next step's zero_grad()).  The buffers need only be
+ * float-aligned: the float4 body starts at their first common 16-byte boundary (buffers misaligned differently
+ * from one another are processed one float at a time). */
 int invpref_adam_hip(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t n, int64_t step,
                      double lr, double beta1, double beta2, double eps, int zero_grad, void *stream);
 /* The same step over 1..4 pieces [offsets[r], offsets[r] + lengths[r]) of the flat buffers in one launch (host

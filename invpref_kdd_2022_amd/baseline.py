@@ -139,6 +139,7 @@ class _BasicTrainManager(_InvPrefTrainManager):
         self.use_graph = os.environ.get('INVPREF_NO_GRAPH', '0') != '1'
         self._force_sharded_path, self._collective_ok, self._unfused = False, False, False
         self._graphs, self._graph_warm = {}, False
+        self._grad_stale = False
         self._sched, self._sched_synced = None, False
 
     def _coefs(self, alpha):

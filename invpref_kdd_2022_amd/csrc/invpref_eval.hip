@@ -62,6 +62,64 @@ __global__ __launch_bounds__(256) void topk_mask_kernel(const float *__restrict_
     }
 }
 
+// Item counts beyond what four LDS-staged rows allow (16 * n_items bytes <= 160 KB, i.e. n_items <= 10 240): one
+// 256-thread workgroup per test user; the rating row stays in global memory (L2-resident: it is re-read once per
+// pick) and LDS holds three bit sets over the items -- train-item mask, item-pool highlight, already picked --
+// so the same arithmetic (-1024 for a masked item, += 1024 for a highlighted one, picked items out of the race)
+// is applied on the fly.  MIND has 51 283 items (19 KB of bit sets).
+__global__ __launch_bounds__(256) void topk_mask_big_kernel(const float *__restrict__ ratings, int64_t n_users, int n_items,
+                                                            const int *__restrict__ mask_ptr, const int *__restrict__ mask_items,
+                                                            const int *__restrict__ hl_ptr, const int *__restrict__ hl_items,
+                                                            const int *__restrict__ gt_ptr, const int *__restrict__ gt_items,
+                                                            int K, int *__restrict__ out_items, float *__restrict__ out_hits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned bits[];
+    __shared__ float wbest[4];
+    __shared__ int wbi[4];
+    const int words = (n_items + 31) >> 5;
+    unsigned *bm = bits, *bh = bits + words, *bp = bits + 2 * words;
+    const int64_t u = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 3 * words; i += blockDim.x) bits[i] = 0u;
+    __syncthreads();
+    for (int j = mask_ptr[u] + threadIdx.x; j < mask_ptr[u + 1]; j += blockDim.x)
+        atomicOr(bm + (mask_items[j] >> 5), 1u << (mask_items[j] & 31));
+    if (hl_ptr)
+        for (int j = hl_ptr[u] + threadIdx.x; j < hl_ptr[u + 1]; j += blockDim.x)
+            atomicOr(bh + (hl_items[j] >> 5), 1u << (hl_items[j] & 31));
+    __syncthreads();
+    const float *src = ratings + u * (int64_t)n_items;
+    const int g0 = gt_ptr[u], g1 = gt_ptr[u + 1];
+    for (int k = 0; k < K; k++) {
+        float best = -__builtin_inff();
+        int bi = 0x7fffffff;
+        for (int i = threadIdx.x; i < n_items; i += blockDim.x) {
+            const unsigned w = (unsigned)i >> 5, b = 1u << (i & 31);
+            float v = (bm[w] & b) ? -1024.0f : src[i];
+            if (bh[w] & b) v += 1024.0f;
+            if (bp[w] & b) v = -__builtin_inff();
+            if (v > best) { best = v; bi = i; }  // ascending i per thread: the first maximum is the lowest index
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ov = __shfl_xor(best, m, 64);
+            const int oi = __shfl_xor(bi, m, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { wbest[wave] = best; wbi[wave] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; w++)
+                if (wbest[w] > best || (wbest[w] == best && wbi[w] < bi)) { best = wbest[w]; bi = wbi[w]; }
+            int lo = g0, hi = g1;  // binary search in the sorted ground-truth list
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (gt_items[mid] < bi) lo = mid + 1; else hi = mid; }
+            out_items[u * K + k] = bi;
+            out_hits[u * K + k] = (lo < g1 && gt_items[lo] == bi) ? 1.0f : 0.0f;
+            if (bi < n_items) bp[bi >> 5] |= 1u << (bi & 31);
+        }
+        __syncthreads();
+    }
+}
+
 // sum (a-b)^2 and sum |a-b| in double (evaluate.py:199-203: nn.MSELoss / nn.L1Loss over all test pairs)
 __global__ __launch_bounds__(256) void err_sums_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t n,
                                                        double *__restrict__ out2) {
@@ -193,9 +251,21 @@ int invpref_eval_topk_hip(const float *ratings, int64_t n_users, int64_t n_items
                           float *out_hits, void *stream) {
     if (!ratings || !mask_ptr || !truth_ptr || !out_items || !out_hits || n_users < 0 || n_items <= 0 || k <= 0)
         return INVPREF_EINVAL;
-    if (k > kMaxK || k > n_items || n_items > 36 * 1024) return INVPREF_EUNSUPPORTED;  // 4 rows of <= 36K floats in LDS
+    if (k > kMaxK || k > n_items || n_items > 400000) return INVPREF_EUNSUPPORTED;
     if (n_users == 0) return 0;
     const size_t lds = sizeof(float) * 4 * (size_t)n_items;
+    if (lds > 160 * 1024) {   // the four staged rows exceed the CU's LDS: bit-set form, one workgroup per user
+        const size_t lds_bits = sizeof(unsigned) * 3 * (((size_t)n_items + 31) / 32);
+        if (lds_bits > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(topk_mask_big_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bits);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(topk_mask_big_kernel, dim3((unsigned)n_users), dim3(256), lds_bits, (hipStream_t)stream, ratings,
+                           n_users, (int)n_items, mask_ptr, mask_items, highlight_ptr, highlight_items, truth_ptr,
+                           truth_items, (int)k, out_items, out_hits);
+        return (int)hipGetLastError();
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(topk_mask_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

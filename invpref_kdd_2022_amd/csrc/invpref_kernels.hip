@@ -460,24 +460,39 @@ __global__ __launch_bounds__(1024) void mstep_finish_kernel(DevTables t, DevGrad
 // =====================================================================================
 // dense Adam over a flat buffer (torch.optim.Adam single-tensor rule; train.py:41,155-157)
 // =====================================================================================
+__device__ __forceinline__ void adam_scalar_at(float *p, float *g, float *m, float *v, int64_t i, const AdamScalars &a,
+                                               int zero_grad) {
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam1(pp, g[i], mm, vv, a);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+    if (zero_grad) g[i] = 0.f;
+}
+// `head` (0..3, or n for buffers whose addresses are misaligned differently): leading elements handled one
+// float at a time so that the float4 body starts on a 16-byte boundary of all four buffers (a user-sharded
+// rank's row range of a table whose factor_num is not a multiple of 4 starts anywhere)
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
-                                                   float *__restrict__ v, int64_t n, AdamScalars a, int zero_grad) {
-    const int64_t n4 = n >> 2;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        float4 pp = reinterpret_cast<float4 *>(p)[i], gg = reinterpret_cast<float4 *>(g)[i];
-        float4 mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+                                                   float *__restrict__ v, int64_t n, AdamScalars a, int zero_grad,
+                                                   int64_t head) {
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+    if (head >= 4) {  // no common alignment: scalar everywhere
+        for (int64_t i = tid; i < n; i += nthr) adam_scalar_at(p, g, m, v, i, a, zero_grad);
+        return;
+    }
+    const int64_t n4 = (n - head) >> 2;
+    float4 *p4 = reinterpret_cast<float4 *>(p + head), *g4 = reinterpret_cast<float4 *>(g + head);
+    float4 *m4 = reinterpret_cast<float4 *>(m + head), *v4 = reinterpret_cast<float4 *>(v + head);
+    for (int64_t i = tid; i < n4; i += nthr) {
+        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
         adam1(pp.x, gg.x, mm.x, vv.x, a); adam1(pp.y, gg.y, mm.y, vv.y, a);
         adam1(pp.z, gg.z, mm.z, vv.z, a); adam1(pp.w, gg.w, mm.w, vv.w, a);
-        reinterpret_cast<float4 *>(p)[i] = pp; reinterpret_cast<float4 *>(m)[i] = mm;
-        reinterpret_cast<float4 *>(v)[i] = vv;
-        if (zero_grad) reinterpret_cast<float4 *>(g)[i] = f4zero();
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        if (zero_grad) g4[i] = f4zero();
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-        const int64_t i = (n4 << 2) + threadIdx.x;
-        float pp = p[i], mm = m[i], vv = v[i];
-        adam1(pp, g[i], mm, vv, a);
-        p[i] = pp; m[i] = mm; v[i] = vv;
-        if (zero_grad) g[i] = 0.f;
+    if (blockIdx.x == 0) {
+        if ((int64_t)threadIdx.x < head) adam_scalar_at(p, g, m, v, threadIdx.x, a, zero_grad);
+        const int64_t t0 = head + (n4 << 2);
+        if (threadIdx.x >= 4 && t0 + (threadIdx.x - 4) < n && threadIdx.x < 8)
+            adam_scalar_at(p, g, m, v, t0 + (threadIdx.x - 4), a, zero_grad);
     }
 }
 
@@ -512,8 +527,10 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
                                                            const int64_t *__restrict__ items,
                                                            const float *__restrict__ scores, int64_t N, uint32_t flags,
                                                            const float *__restrict__ eps_rows,
-                                                           const int64_t *__restrict__ old_envs,
-                                                           int64_t *__restrict__ new_envs, int *__restrict__ slabs) {
+                                                           const int64_t *old_envs, int64_t *new_envs,
+                                                           int *__restrict__ slabs) {
+    // (old_envs and new_envs may be the SAME buffer -- cluster() updates the assignments in place -- so neither
+    //  is __restrict__; element s is read into a register before it is written)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int DP = NC * 64;
     float *sEv = lds;
@@ -550,11 +567,16 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
         else { const float r = (p + qmine) - y; dist = r * r; }
         if (eps_rows && l16 < t.E) dist = dist + eps_rows[s * t.E + l16];
         // argmin with the lowest index among equal minima (torch.argmin; the sequential `dist < best` scan)
+        // A NaN distance wins, the first one if there are several (torch.argmin's LessOrNan; only reachable with
+        // NaN parameters) -- row16_min ignores NaNs, so the lowest NaN lane is found separately.
         dist = l16 < t.E ? dist : __builtin_inff();
         const float dmin = row16_min(dist);
-        const int bi = (int)row16_min(dist == dmin ? (float)l16 : 99.f);
+        const int bi_num = (int)row16_min(dist == dmin ? (float)l16 : 99.f);
+        const int bi_nan = (int)row16_min(dist != dist ? (float)l16 : 99.f);
+        const int bi = bi_nan < 99 ? bi_nan : bi_num;   // (bi_num == 99 only when every distance is NaN)
         if (l16 == 0) {
-            const bool changed = old_envs ? (old_envs[s] != (int64_t)bi) : false;
+            const int64_t was = old_envs ? old_envs[s] : (int64_t)bi;
+            const bool changed = was != (int64_t)bi;
             new_envs[s] = bi;
             atomicAdd(cnt + bi, 1);
             if (changed) atomicAdd(cnt + t.E, 1);
@@ -860,9 +882,13 @@ int invpref_adam_hip(float *param, float *grad, float *exp_avg, float *exp_avg_s
                      double beta1, double beta2, double eps, int zero_grad, void *stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return INVPREF_EINVAL;
     if (n == 0) return 0;
-    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
-         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15u)
-        return INVPREF_EINVAL;
+    const uintptr_t ap = reinterpret_cast<uintptr_t>(param), ag = reinterpret_cast<uintptr_t>(grad);
+    const uintptr_t am = reinterpret_cast<uintptr_t>(exp_avg), av = reinterpret_cast<uintptr_t>(exp_avg_sq);
+    if ((ap | ag | am | av) & 3u) return INVPREF_EINVAL;   // not even float-aligned
+    // float4 body from the first common 16-byte boundary; buffers misaligned differently go one float at a time
+    int64_t head = ((16u - (ap & 15u)) & 15u) >> 2;
+    if ((ag & 15u) != (ap & 15u) || (am & 15u) != (ap & 15u) || (av & 15u) != (ap & 15u)) head = n > 4 ? n : 4;
+    if (head < 4 && head > n) head = n;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     AdamScalars a;
     a.step_size = (float)(lr / bc1);
@@ -871,11 +897,11 @@ int invpref_adam_hip(float *param, float *grad, float *exp_avg, float *exp_avg_s
     a.b2 = (float)beta2;
     a.w2 = (float)(1.0 - beta2);
     a.eps = (float)eps;
-    int64_t nb = ((n >> 2) + 255) / 256;
+    int64_t nb = (((head >= 4 ? n : n >> 2)) + 255) / 256;
     if (nb < 1) nb = 1;
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, n, a, zero_grad);
+                       exp_avg_sq, n, a, zero_grad, head);
     return (int)hipGetLastError();
 }
 

@@ -44,12 +44,23 @@ def lib():
     return _lib
 
 
-def read_csv(path: str) -> np.ndarray:
-    """``pd.read_csv(path).values`` for an all-numeric file, as float64 [rows, cols]."""
+def read_csv(path: str, header=True) -> np.ndarray:
+    """``pd.read_csv(path).values`` for an all-numeric file, as float64 [rows, cols].
+
+    header=True (default): the first line is the header and is consumed whatever it holds, as ``pd.read_csv``
+    does (the reference loaders call it with default arguments, dataloader.py:124-128); header=False: every line
+    is data; header='auto': the first line is a header iff its first field is not a number.
+    Decimal fields are converted correctly rounded (pandas' default "fast" float parser is not, so a value with
+    many decimal digits can differ from the reference's in the last ulp; ids and integer scores never do)."""
     rows, cols, hdr = C.c_int64(), C.c_int32(), C.c_int32()
     rc = lib().invpref_csv_shape(path.encode(), C.byref(rows), C.byref(cols), C.byref(hdr))
     if rc:
         raise IngestError(f'{path}: cannot read (code {rc})')
+    if header != 'auto':
+        want = 1 if header else 0
+        if want != hdr.value and (rows.value + hdr.value) > 0:   # the shape pass counted with the inferred header
+            rows = C.c_int64(rows.value + hdr.value - want)
+            hdr = C.c_int32(want)
     out = np.empty((rows.value, cols.value), np.float64)
     if out.size == 0:
         return out

@@ -16,7 +16,8 @@ from . import ops
 
 
 class LinearLogSoftMaxEnvClassifier(nn.Module):
-    """Container for the D->E environment classifier (reference models.py:197-220)."""
+    """The D->E environment classifier (reference models.py:197-220).  Inside InvPref*.forward it is fused into
+    the forward / M-step kernels; called on its own it runs on the same HIP kernels (autograd.py)."""
 
     def __init__(self, factor_dim: int, env_num: int):
         super().__init__()
@@ -24,6 +25,18 @@ class LinearLogSoftMaxEnvClassifier(nn.Module):
         nn.init.xavier_uniform_(self.linear_map.weight)
         self.elements_num = float(factor_dim * env_num)
         self.bias_num = float(env_num)
+
+    def forward(self, invariant_preferences: torch.Tensor) -> torch.Tensor:  # models.py:206-209
+        from .autograd import classifier_log_softmax
+        return classifier_log_softmax(invariant_preferences, self.linear_map.weight, self.linear_map.bias)
+
+    def get_L1_reg(self) -> torch.Tensor:  # models.py:211-213
+        from .autograd import classifier_reg
+        return classifier_reg(1, self.linear_map.weight, self.linear_map.bias)
+
+    def get_L2_reg(self) -> torch.Tensor:  # models.py:215-217
+        from .autograd import classifier_reg
+        return classifier_reg(2, self.linear_map.weight, self.linear_map.bias)
 
 
 class _InvPrefBase(nn.Module):

@@ -1,8 +1,9 @@
-"""Operator layer: thin, validated wrappers over the C ABI (include/invpref_hip.h).
+"""Operator layer: convenience wrappers over the ``torch.ops.invpref.*`` custom operators (torch_ops.py),
+which in turn forward to the C ABI (include/invpref_hip.h).
 
 Each function enqueues HIP kernels on torch's current stream and returns without syncing.
 Reference semantics are cited per function; there is no PyTorch-eager implementation behind
-any of them.
+any of them (the operators are registered for the CUDA/HIP dispatch key only).
 """
 from __future__ import annotations
 
@@ -12,6 +13,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _capi
+from . import torch_ops  # noqa: F401  (registers torch.ops.invpref.*)
 from ._capi import (DENSE_REG, IMPLICIT, REG_ENV_EMBED, REG_ONLY_EMBED, REWEIGHT_CLS, REWEIGHT_REC, Coefs,
                     InvPrefError, check, lib, make_tables, ptr, stream_ptr)
 
@@ -54,18 +56,13 @@ class Workspace:
         return z
 
 
+def _o():
+    return torch.ops.invpref
+
+
 def forward(params: Sequence[torch.Tensor], users, items, envs, implicit: bool):
     """InvPref{Implicit,Explicit}.forward (models.py:307-326 / :448-467), values only."""
-    t = make_tables(params)
-    B = users.numel()
-    dev = users.device
-    inv = torch.empty(B, dtype=torch.float32, device=dev)
-    env = torch.empty(B, dtype=torch.float32, device=dev)
-    out = torch.empty(B, t.env_num, dtype=torch.float32, device=dev)
-    check(lib().invpref_forward_hip(C.byref(t), ptr(_ids(users, 'users')), ptr(_ids(items, 'items')),
-                                    ptr(_ids(envs, 'envs')), B, IMPLICIT if implicit else 0, ptr(inv), ptr(env),
-                                    ptr(out), stream_ptr()), 'invpref_forward_hip')
-    return inv, env, out
+    return _o().forward(list(params), users, items, envs, bool(implicit))
 
 
 def mstep_grad(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], users, items, envs, scores,
@@ -73,143 +70,103 @@ def mstep_grad(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], us
                losses6: torch.Tensor, workspace: Workspace) -> None:
     """Forward + losses + regularisers + backward of train_a_batch (train.py:94-156): ADDS the
     gradients into `grads` and the six loss terms into `losses6` (device fp32[6])."""
-    t, g = make_tables(params), make_tables(grads)
-    B = users.numel()
-    _capi._req(scores, torch.float32, 'scores')
-    _capi._req(sample_weights, torch.float32, 'sample_weights')
-    _capi._req(losses6, torch.float32, 'losses6')
-    cf = Coefs(*[float(c) for c in coefs[:6]])
-    need = lib().invpref_mstep_workspace_bytes(C.byref(t), B)
-    ws = workspace.get(need)
-    check(lib().invpref_mstep_grad_hip(C.byref(t), C.byref(g), ptr(_ids(users, 'users')), ptr(_ids(items, 'items')),
-                                       ptr(_ids(envs, 'envs')), ptr(scores), ptr(sample_weights), B, int(batch_norm),
-                                       C.byref(cf), flags, ptr(losses6), ptr(ws), ws.numel(), stream_ptr()),
-          'invpref_mstep_grad_hip')
+    t = make_tables(params)
+    ws = workspace.get(lib().invpref_mstep_workspace_bytes(C.byref(t), users.numel()))
+    _o().train_step_fused(list(params), list(grads), users, items, envs, scores, sample_weights, int(batch_norm),
+                          [float(c) for c in coefs[:6]], int(flags), losses6, ws)
 
 
 def adam_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,
           lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, zero_grad: bool = True) -> None:
     """optimizer.zero_grad() + torch.optim.Adam.step() (train.py:41,155-157) on flat buffers."""
-    for n, t in (('param', param), ('grad', grad), ('exp_avg', exp_avg), ('exp_avg_sq', exp_avg_sq)):
-        _capi._req(t, torch.float32, n)
-    n = param.numel()
-    if not (grad.numel() >= n and exp_avg.numel() == n and exp_avg_sq.numel() == n):
-        raise InvPrefError('adam_: buffer sizes differ')
-    check(lib().invpref_adam_hip(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), n, int(step), float(lr),
-                                 float(beta1), float(beta2), float(eps), int(bool(zero_grad)), stream_ptr()),
-          'invpref_adam_hip')
+    _o().adam_dense_(param, grad, exp_avg, exp_avg_sq, int(step), float(lr), float(beta1), float(beta2), float(eps),
+                     bool(zero_grad))
+
+
+def adam_ranges_(param, grad, exp_avg, exp_avg_sq, offsets, lengths, step: int, lr: float, beta1: float = 0.9,
+                 beta2: float = 0.999, eps: float = 1e-8, zero_grad: bool = True) -> None:
+    """the same rule over up to four (offset, length) pieces of the flat buffers in one launch"""
+    _o().adam_ranges_(param, grad, exp_avg, exp_avg_sq, [int(o) for o in offsets], [int(n) for n in lengths], int(step),
+                      float(lr), float(beta1), float(beta2), float(eps), bool(zero_grad))
 
 
 def estep(params: Sequence[torch.Tensor], users, items, scores, implicit: bool, old_envs: Optional[torch.Tensor],
           workspace: Workspace, eps_rows: Optional[torch.Tensor] = None, new_envs: Optional[torch.Tensor] = None,
           want_weights: bool = True):
     """cluster() + stat_envs() (train.py:235-259, :268-280) over all given interactions.
-    Returns (new_envs int64[N], counts int64[E], diff int64[1], class_w fp32[E], sample_w fp32[N])."""
+    Returns (new_envs int64[N], counts int64[E], diff int64[1], class_w fp32[E], sample_w fp32[N]).
+    new_envs may be the same tensor as old_envs (in-place update, `estep_assign_`)."""
     t = make_tables(params)
-    N = users.numel()
-    dev = users.device
-    _capi._req(scores, torch.float32, 'scores')
-    _capi._req(eps_rows, torch.float32, 'eps_rows')
-    if old_envs is not None:
-        _ids(old_envs, 'old_envs')
-    if new_envs is None:
-        new_envs = torch.empty(N, dtype=torch.int64, device=dev)
-    counts = torch.empty(t.env_num, dtype=torch.int64, device=dev)
-    diff = torch.zeros(1, dtype=torch.int64, device=dev)
-    cw = torch.empty(t.env_num, dtype=torch.float32, device=dev) if want_weights else None
-    sw = torch.empty(N, dtype=torch.float32, device=dev) if want_weights else None
-    ws = workspace.get(lib().invpref_estep_workspace_bytes(C.byref(t), N))
-    check(lib().invpref_estep_hip(C.byref(t), ptr(_ids(users, 'users')), ptr(_ids(items, 'items')), ptr(scores), N,
-                                  IMPLICIT if implicit else 0, ptr(eps_rows), ptr(old_envs), ptr(new_envs),
-                                  ptr(counts), ptr(diff), ptr(cw), ptr(sw), ptr(ws), ws.numel(), stream_ptr()),
-          'invpref_estep_hip')
-    return new_envs, counts, diff, cw, sw
+    ws = workspace.get(lib().invpref_estep_workspace_bytes(C.byref(t), users.numel()))
+    if new_envs is not None and old_envs is not None and new_envs.data_ptr() == old_envs.data_ptr():
+        counts, diff, cw, sw = _o().estep_assign_(list(params), users, items, scores, new_envs, bool(implicit), eps_rows,
+                                                  bool(want_weights), ws)
+        return new_envs, counts, diff, (cw if want_weights else None), (sw if want_weights else None)
+    out, counts, diff = _o().estep_assign(list(params), users, items, scores, old_envs, bool(implicit), eps_rows, ws)
+    if new_envs is not None:
+        new_envs.copy_(out)
+        out = new_envs
+    cw = sw = None
+    if want_weights:
+        cw, sw = _o().sample_weights(out, counts, users.numel(), t.env_num)
+    return out, counts, diff, cw, sw
 
 
 def stat_envs(envs: torch.Tensor, env_num: int, workspace: Workspace, want_sample_weights: bool = True):
     """stat_envs() (train.py:268-280): (counts int64[E], class_w fp32[E], sample_w fp32[N])."""
-    N = envs.numel()
-    dev = envs.device
-    counts = torch.empty(env_num, dtype=torch.int64, device=dev)
-    cw = torch.empty(env_num, dtype=torch.float32, device=dev)
-    sw = torch.empty(N, dtype=torch.float32, device=dev) if want_sample_weights else None
     ws = workspace.get(4 * (env_num + 1) * 2048)
-    check(lib().invpref_stat_envs_hip(ptr(_ids(envs, 'envs')), N, env_num, ptr(counts), ptr(cw), ptr(sw), ptr(ws),
-                                      ws.numel(), stream_ptr()), 'invpref_stat_envs_hip')
-    return counts, cw, sw
+    counts, cw, sw = _o().stat_envs(envs, int(env_num), bool(want_sample_weights), ws)
+    return counts, cw, (sw if want_sample_weights else None)
 
 
 def sample_weights(envs: torch.Tensor, counts: torch.Tensor, n_total: int, env_num: int):
     """Weight half of stat_envs (train.py:274-278) from global counts: (class_w[E], sample_w[N_local])."""
-    N = envs.numel()
-    dev = envs.device
-    _capi._req(counts, torch.int64, 'counts')
-    cw = torch.empty(env_num, dtype=torch.float32, device=dev)
-    sw = torch.empty(N, dtype=torch.float32, device=dev)
-    check(lib().invpref_sample_weights_hip(ptr(_ids(envs, 'envs')), N, ptr(counts), int(n_total), env_num, ptr(cw),
-                                           ptr(sw), stream_ptr()), 'invpref_sample_weights_hip')
-    return cw, sw
+    return _o().sample_weights(envs, counts, int(n_total), int(env_num))
 
 
 def backward(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], users, items, envs, implicit: bool,
              alpha: float, d_inv, d_env, d_out, workspace: Workspace) -> None:
     """Backward of forward() incl. the gradient-reversal layer (functions.py:7-16): ADDS into grads."""
-    t, g = make_tables(params), make_tables(grads)
-    B = users.numel()
-    for n, x in (('d_inv', d_inv), ('d_env', d_env), ('d_out', d_out)):
-        _capi._req(x, torch.float32, n)
-    ws = workspace.get(lib().invpref_mstep_workspace_bytes(C.byref(t), B))
-    check(lib().invpref_backward_hip(C.byref(t), C.byref(g), ptr(_ids(users, 'users')), ptr(_ids(items, 'items')),
-                                     ptr(_ids(envs, 'envs')), B, IMPLICIT if implicit else 0, float(alpha), ptr(d_inv),
-                                     ptr(d_env), ptr(d_out), ptr(ws), ws.numel(), stream_ptr()),
-          'invpref_backward_hip')
+    t = make_tables(params)
+    ws = workspace.get(lib().invpref_mstep_workspace_bytes(C.byref(t), users.numel()))
+    _o().backward(list(params), list(grads), users, items, envs, bool(implicit), float(alpha), d_inv, d_env, d_out, ws)
 
 
 def predict(user_table: torch.Tensor, item_table: torch.Tensor, users: torch.Tensor, sigmoid: bool) -> torch.Tensor:
     """InvPrefImplicit.predict (models.py:393-407): [n_users, item_num] scores."""
-    _capi._req(user_table, torch.float32, 'user_table')
-    _capi._req(item_table, torch.float32, 'item_table')
-    n, (I, D) = users.numel(), item_table.shape
-    out = torch.empty(n, I, dtype=torch.float32, device=users.device)
-    check(lib().invpref_predict_hip(ptr(user_table), ptr(item_table), ptr(_ids(users, 'users')), n, I, D,
-                                    int(bool(sigmoid)), ptr(out), stream_ptr()), 'invpref_predict_hip')
-    return out
+    return _o().predict(user_table, item_table, users, bool(sigmoid))
+
+
+def rows_workspace(params, dplan, workspace: Workspace, pure: bool = False) -> torch.Tensor:
+    """the zero-initialised scratch of the planned M-step (replica slabs + hot-row accumulators)"""
+    t = (_capi.make_pure_tables if pure else make_tables)(params)
+    return workspace.get_zeroed(lib().invpref_rows_workspace_bytes(C.byref(t), C.byref(dplan.struct)))
 
 
 def mstep_rows_grad(params, grads, dplan, envs, scores, sample_weights, batch_norm: int, coefs, flags: int,
                      losses6: torch.Tensor, workspace: Workspace) -> None:
     """Planned, atomic-free M-step gradient of one minibatch (plan.py): OVERWRITES every row of grads."""
-    t, g = make_tables(params), make_tables(grads)
-    _capi._req(scores, torch.float32, 'scores')
-    _capi._req(sample_weights, torch.float32, 'sample_weights')
-    cf = Coefs(*[float(c) for c in coefs[:6]])
-    ws = workspace.get_zeroed(lib().invpref_rows_workspace_bytes(C.byref(t), C.byref(dplan.struct)))
-    check(lib().invpref_mstep_rows_grad_hip(C.byref(t), C.byref(g), C.byref(dplan.struct), ptr(_ids(envs, 'envs')),
-                                             ptr(scores), ptr(sample_weights), int(batch_norm), C.byref(cf), flags,
-                                             ptr(losses6), ptr(ws), ws.numel(), stream_ptr()),
-          'invpref_mstep_rows_grad_hip')
+    ws = rows_workspace(params, dplan, workspace)
+    _o().train_step_planned_grad_(list(params), list(grads), dplan.buf, dplan.meta, envs, scores, sample_weights,
+                                  int(batch_norm), [float(c) for c in coefs[:6]], int(flags), losses6, ws)
 
 
 def mstep_rows_adam(params, new_params, exp_avg, exp_avg_sq, dplan, envs, scores, sample_weights, batch_norm: int,
                     coefs, flags: int, losses6: torch.Tensor, step: int, lr: float, workspace: Workspace,
-                    beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, pure: bool = False) -> None:
+                    beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, pure: bool = False,
+                    sched=None) -> None:
     """M-step + Adam in one pass: reads params, writes new_params, updates the moments in place.
     pure=True: PureMF step (INVPREF_PURE_MF): the table lists hold [user table, item table] only, envs /
-    sample_weights may be None."""
-    mk = _capi.make_pure_tables if pure else make_tables
-    t, tn = mk(params), mk(new_params)
-    tm, tv = mk(exp_avg), mk(exp_avg_sq)
-    _capi._req(scores, torch.float32, 'scores')
-    _capi._req(sample_weights, torch.float32, 'sample_weights')
+    sample_weights may be None.  sched = (state int32[32], table fp32[n, 8], slot): per-step scalars from the
+    device-side schedule (graph replay) instead of (step, lr, betas, eps)."""
     if pure:
         flags |= _capi.PURE_MF
-    cf = Coefs(*[float(c) for c in coefs[:6]])
-    ws = workspace.get_zeroed(lib().invpref_rows_workspace_bytes(C.byref(t), C.byref(dplan.struct)))
-    check(lib().invpref_mstep_rows_adam_hip(C.byref(t), C.byref(tn), C.byref(tm), C.byref(tv), C.byref(dplan.struct),
-                                             ptr(None if envs is None else _ids(envs, 'envs')), ptr(scores),
-                                             ptr(sample_weights), int(batch_norm), C.byref(cf), flags, ptr(losses6),
-                                             int(step), float(lr), float(beta1), float(beta2), float(eps), ptr(ws),
-                                             ws.numel(), stream_ptr()), 'invpref_mstep_rows_adam_hip')
+    ws = rows_workspace(params, dplan, workspace, pure)
+    s_state, s_table, s_slot = sched if sched is not None else (None, None, 0)
+    _o().train_step_planned_adam_(list(params), list(new_params), list(exp_avg), list(exp_avg_sq), dplan.buf, dplan.meta,
+                                  envs, scores, sample_weights, int(batch_norm), [float(c) for c in coefs[:6]],
+                                  int(flags), losses6, int(step), float(lr), float(beta1), float(beta2), float(eps),
+                                  s_state, s_table, int(s_slot), ws)
 
 
 POP_KEYS = ['users_cnt_weight_result', 'items_cnt_weight_result', 'users_normalize_cnt_weight_result',

@@ -143,6 +143,26 @@ class DevicePlan:
     arrays: list  # keeps the device tensors alive
     n_tasks: int
     n_rounds: int
+    buf: torch.Tensor = None    # the one int32 device buffer behind every array of the plan
+    meta: torch.Tensor = None   # CPU int64[len(_fields_)]: struct fields in order, pointers as int32 offsets into buf
+
+
+_PTR_FIELDS = [i for i, (_, ty) in enumerate(RowPlanStruct._fields_) if ty is C.c_void_p]
+
+
+def struct_from_meta(buf: torch.Tensor, meta: torch.Tensor) -> RowPlanStruct:
+    """The InvPrefRowPlan of a plan that travels as (device buffer, CPU meta tensor) -- the form in which
+    ``torch.ops.invpref.train_step_planned_*`` take it."""
+    if buf.dtype != torch.int32 or not buf.is_contiguous() or meta.dtype != torch.int64 or meta.is_cuda \
+            or meta.numel() != len(RowPlanStruct._fields_):
+        raise ValueError('row plan: int32 device buffer + CPU int64 meta tensor expected')
+    vals = meta.tolist()
+    base, n = buf.data_ptr(), buf.numel()
+    for i in _PTR_FIELDS:
+        if not 0 <= vals[i] <= n:
+            raise ValueError('row plan: array offset outside the buffer')
+        vals[i] = base + 4 * vals[i]
+    return RowPlanStruct(*vals)
 
 
 def upload(plan: dict, device) -> DevicePlan:
@@ -156,6 +176,7 @@ def upload(plan: dict, device) -> DevicePlan:
         ptrs[k] = off
         off += len(a) + pad
     buf = torch.from_numpy(np.concatenate(parts)).to(device)
+    offs = dict(ptrs)
     ptrs = {k: buf.data_ptr() + 4 * o for k, o in ptrs.items()}
     nr, rpt = len(plan['desc']), plan['rounds_per_task']
     st = RowPlanStruct(nr, plan['n_item_rounds'], rpt, plan['n'], ptrs['desc'], ptrs['other_user'],
@@ -166,4 +187,7 @@ def upload(plan: dict, device) -> DevicePlan:
     spt = plan['rows_per_stream_task']
     n_tasks = -(-nr // rpt) + -(-plan['n_stream_user'] // spt) + -(-plan['n_stream_item'] // spt) \
         + -(-plan['n'] // plan['dense_per_task'])
-    return DevicePlan(st, [buf], n_tasks, nr)
+    meta = [getattr(st, name) for name, _ in RowPlanStruct._fields_]
+    for i in _PTR_FIELDS:
+        meta[i] = offs[RowPlanStruct._fields_[i][0]]
+    return DevicePlan(st, [buf], n_tasks, nr, buf, torch.tensor(meta, dtype=torch.int64))

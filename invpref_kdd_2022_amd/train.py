@@ -22,6 +22,7 @@ from __future__ import annotations
 import itertools
 import math
 import os
+import time
 from typing import Optional
 
 import numpy as np
@@ -190,6 +191,7 @@ class _InvPrefTrainManager:
         import torch.distributed as _dist
         self._collective_ok = _dist.is_available() and _dist.is_initialized()
         self._graphs, self._graph_warm = {}, False
+        self._grad_stale = False
         self._sched = None
         self._sched_synced = False
 
@@ -227,13 +229,6 @@ class _InvPrefTrainManager:
         """the one exchange of an optimiser step: the shared part of the flat gradient + the loss tail"""
         all_reduce_sum_(self.state.grad_ext[self._ar_lo:], self.process_group)
 
-    def _coefs_struct(self, alpha):
-        """ctypes coefficient block for `alpha` (cached: alpha is usually fixed)"""
-        c = getattr(self, '_cf_cache', None)
-        if c is None or c[0] != alpha:
-            c = self._cf_cache = (alpha, _capi.Coefs(*self._coefs(alpha)))
-        return c[1]
-
     # ------------------------------------------------------------------ M-step
     def _coefs(self, alpha):
         return (self.invariant_coe, self.env_aware_coe, self.env_coe, self.L2_coe, self.L1_coe, alpha)
@@ -245,6 +240,11 @@ class _InvPrefTrainManager:
         if losses6 is None:
             losses6 = st.losses6
             losses6.zero_()
+        if self._grad_stale:
+            # a planned gradient pass (multi-GPU / D > 128 path) OVERWRITES its rows and its Adam does not zero
+            # them: the buffer still holds that step's (all-reduced) gradient, and the plan-free kernel below ADDS
+            st.grad.zero_()
+            self._grad_stale = False
         ops.mstep_grad(st.p_views, st.g_views, users, items, envs, scores, weights, batch_norm, self._coefs(alpha),
                        self._flags, losses6, self.workspace)
         if self.world_size > 1:
@@ -272,16 +272,12 @@ class _InvPrefTrainManager:
         vals = self.state.losses6.tolist()
         return dict(zip(LOSS_KEYS, vals))
 
-    # ---- the epoch loop issues raw C-ABI calls with every argument prepared once: per step the host
-    #      does two (three with a collective) foreign calls and nothing else
+    # ---- the epoch loop: every per-minibatch argument (views of the resident interaction arrays, the row plan,
+    #      the zero-initialised scratch) is prepared once; a step is one or two torch.ops.invpref.* calls
+    #      (+ the collective in a sharded run) and nothing is read back
     def _raw_setup(self):
         st = self.state
         L = _capi.lib()
-        mk = self._make_tables
-        self._raw_t = mk(st.p_views)
-        self._raw_g = mk(st.g_views)
-        if not self._pure:
-            self._raw_ws = self.workspace.get(L.invpref_mstep_workspace_bytes(C.byref(self._raw_t), self.batch_size))
         # one graph replays up to _graph_epochs epochs (fewer, longer launches: the GPU idles ~60 us
         # between two replays); each epoch of a replay writes its own [batch_num, 6] slice of the loss buffer
         self._graph_epochs = max(1, min(8, 2048 // self.batch_num))
@@ -292,76 +288,54 @@ class _InvPrefTrainManager:
         self._raw_batches = []
         for k in range(self.batch_num):
             lo, hi = self.shard.local_batch_bounds(k)
-            self._raw_batches.append((lo, hi - lo, self.shard.global_batch_len(k)))
-        self._raw_mstep, self._raw_adam = L.invpref_mstep_grad_hip, L.invpref_adam_hip
-        self._raw_adam_ranges = L.invpref_adam_ranges_hip
+            v = None if self._pure else (self.envs[lo:hi], self.sample_weights[lo:hi])
+            self._raw_batches.append((lo, hi - lo, self.shard.global_batch_len(k), self.users_tensor[lo:hi],
+                                      self.items_tensor[lo:hi], self.scores_tensor[lo:hi],
+                                      None if self._pure else v[0], None if self._pure else v[1]))
         rg = getattr(self, '_adam_ranges', [(0, st.n)])
-        self._adam_ranges_c = None
-        if len(rg) > 1 and len(rg) <= 4 and all(o % 4 == 0 and n % 4 == 0 for o, n in rg):
-            self._adam_ranges_c = ((C.c_int64 * len(rg))(*[o for o, _ in rg]), (C.c_int64 * len(rg))(*[n for _, n in rg]),
-                                   len(rg))
-        self._raw_rows_grad, self._raw_rows_adam = L.invpref_mstep_rows_grad_hip, L.invpref_mstep_rows_adam_hip
-        self._raw_rows_adam_sched = L.invpref_mstep_rows_adam_sched_hip
+        self._adam_ranges_one = len(rg) > 1 and len(rg) <= 4 and all(o % 4 == 0 and n % 4 == 0 for o, n in rg)
         if self.use_plan and self._plans is None:
+            t0 = time.perf_counter()
             u, v = self.users_tensor.cpu().numpy(), self.items_tensor.cpu().numpy()
             y = self.scores_tensor.cpu().numpy()
             self._plans = []
-            for lo, n, _ in self._raw_batches:
+            for lo, n, *_ in self._raw_batches:
                 pl = planlib.build_row_plan(u[lo:lo + n], v[lo:lo + n], y[lo:lo + n], self.model.user_num,
                                             self.model.item_num,
                                             user_range=None if self._pure else self.shard.user_range(self.model.user_num))
                 self._plans.append(planlib.upload(pl, self.device))
+            self.plan_build_s = time.perf_counter() - t0     # host-side, once per run (reported by bench.py)
         if self.use_plan:
-            self._raw_ows = self.workspace.get_zeroed(
-                max(L.invpref_rows_workspace_bytes(C.byref(self._raw_t), C.byref(dp.struct)) for dp in self._plans))
-        # ctypes views of both parameter buffers / moments for the fused pass
-        self._raw_tabs = {id(st.p_views): mk(st.p_views), id(st.p_views_alt): mk(st.p_views_alt)}
-        self._raw_m, self._raw_v = mk(st.m_views), mk(st.v_views)
+            # every plan shares ONE zero-initialised scratch (each step leaves it zeroed): size it for the largest
+            t = self._make_tables(st.p_views)
+            self.workspace.get_zeroed(max(L.invpref_rows_workspace_bytes(C.byref(t), C.byref(dp.struct))
+                                          for dp in self._plans))
 
-    def _raw_step(self, k: int, alpha: float, stream, mid_event=None, sched=False):
+    def _raw_step(self, k: int, alpha: float, stream=None, mid_event=None, sched=False):
         st = self.state
         if not sched:
             self._sched_synced = False
-        lo, n, bn = self._raw_batches[k]
-        pu, pi, pe, py, pw = self._raw_ptrs
-        cf = self._coefs_struct(alpha)
+        lo, n, bn, bu, bi, by, be, bw = self._raw_batches[k]
+        coefs = self._coefs(alpha)
         multi = self.world_size > 1 or self._force_sharded_path or self._unfused
         # every step's six loss terms go straight into the epoch's loss buffer (this rank's partial sums in a
         # sharded run: they are all-reduced once per epoch, not per step)
-        lp = self._epoch_losses.data_ptr() + 24 * (self._loss_slot * self.batch_num + k)
-        t_cur = self._raw_tabs[id(st.p_views)]
+        lp = self._epoch_losses[self._loss_slot, k]
         if self.use_plan and not multi:
             # fused M-step + Adam: one pass, gradient never stored, parameters ping-pong
             st.step += 1
-            if sched:  # graph capture: Adam scalars come from the device-side schedule
-                self._sched['struct'].slot = st.step & 1
-                rc = self._raw_rows_adam_sched(
-                    C.byref(t_cur), C.byref(self._raw_tabs[id(st.p_views_alt)]), C.byref(self._raw_m),
-                    C.byref(self._raw_v), C.byref(self._plans[k].struct), pe + 8 * lo, py + 4 * lo, pw + 4 * lo, bn,
-                    C.byref(cf), self._flags, lp, C.byref(self._sched['struct']), self._raw_ows.data_ptr(),
-                    self._raw_ows.numel(), stream)
-            else:
-                rc = self._raw_rows_adam(
-                    C.byref(t_cur), C.byref(self._raw_tabs[id(st.p_views_alt)]), C.byref(self._raw_m),
-                    C.byref(self._raw_v), C.byref(self._plans[k].struct), pe + 8 * lo, py + 4 * lo, pw + 4 * lo, bn,
-                    C.byref(cf), self._flags, lp, st.step, self.lr, 0.9, 0.999, 1e-8, self._raw_ows.data_ptr(),
-                    self._raw_ows.numel(), stream)
-            if rc:
-                _capi.check(rc, 'invpref_mstep_rows_adam_hip')
+            sc = (self._sched['state'], self._sched['table'], st.step & 1) if sched else None
+            ops.mstep_rows_adam(st.p_views, st.p_views_alt, st.m_views, st.v_views, self._plans[k], be, by, bw, bn,
+                                coefs, self._flags, lp, st.step, self.lr, self.workspace, pure=self._pure, sched=sc)
             st.swap()
             if mid_event is not None:
                 mid_event.record()
             return
         if self.use_plan:
-            rc = self._raw_rows_grad(C.byref(t_cur), C.byref(self._raw_g), C.byref(self._plans[k].struct),
-                                      pe + 8 * lo, py + 4 * lo, pw + 4 * lo, bn, C.byref(cf), self._flags, lp,
-                                      self._raw_ows.data_ptr(), self._raw_ows.numel(), stream)
+            ops.mstep_rows_grad(st.p_views, st.g_views, self._plans[k], be, by, bw, bn, coefs, self._flags, lp,
+                                self.workspace)
         else:
-            rc = self._raw_mstep(C.byref(t_cur), C.byref(self._raw_g), pu + 8 * lo, pi + 8 * lo, pe + 8 * lo,
-                                 py + 4 * lo, pw + 4 * lo, n, bn, C.byref(cf), self._flags, lp,
-                                 self._raw_ws.data_ptr(), self._raw_ws.numel(), stream)
-        if rc:
-            _capi.check(rc, 'invpref_mstep_(rows_)grad_hip')
+            ops.mstep_grad(st.p_views, st.g_views, bu, bi, be, by, bw, bn, coefs, self._flags, lp, self.workspace)
         if multi:
             if self.world_size > 1 or self._collective_ok:
                 all_reduce_sum_(st.grad[self._ar_lo:], self.process_group)   # the step's one exchange
@@ -369,19 +343,16 @@ class _InvPrefTrainManager:
             mid_event.record()
         st.step += 1
         # the planned gradient pass overwrites every row it is responsible for, so the gradient buffer needs no zeroing
-        pp, pg, pm, pv = st.param.data_ptr(), st.grad.data_ptr(), st.exp_avg.data_ptr(), st.exp_avg_sq.data_ptr()
-        zero = 0 if self.use_plan else 1
-        if self._adam_ranges_c is not None:   # every piece in one launch
-            offs, lens, cnt = self._adam_ranges_c
-            rc = self._raw_adam_ranges(pp, pg, pm, pv, offs, lens, cnt, st.step, self.lr, 0.9, 0.999, 1e-8, zero, stream)
-            if rc:
-                _capi.check(rc, 'invpref_adam_ranges_hip')
+        zero = not self.use_plan
+        if self.use_plan:
+            self._grad_stale = True   # see _step()
+        if self._adam_ranges_one:   # every piece in one launch
+            ops.adam_ranges_(st.param, st.grad, st.exp_avg, st.exp_avg_sq, [o for o, _ in self._adam_ranges],
+                             [ln for _, ln in self._adam_ranges], st.step, self.lr, zero_grad=zero)
         else:
-            for o, n in self._adam_ranges:
-                rc = self._raw_adam(pp + 4 * o, pg + 4 * o, pm + 4 * o, pv + 4 * o, n, st.step, self.lr, 0.9, 0.999, 1e-8,
-                                    zero, stream)
-                if rc:
-                    _capi.check(rc, 'invpref_adam_hip')
+            for o, ln in self._adam_ranges:
+                ops.adam_(st.param[o:o + ln], st.grad[o:o + ln], st.exp_avg[o:o + ln], st.exp_avg_sq[o:o + ln], st.step,
+                          self.lr, zero_grad=zero)
 
     def _alpha_for(self, k: int) -> float:
         if self.update_alpha:  # train.py:214-217
@@ -482,7 +453,7 @@ class _InvPrefTrainManager:
                 self.alpha = self._scheduled_alpha(self.epoch_cnt + n - 1, self.batch_num - 1)
         else:
             n = 1
-            self._issue_epochs(torch.cuda.current_stream().cuda_stream, False, 1)
+            self._issue_epochs(None, False, 1)
             if self.world_size > 1:
                 all_reduce_sum_(self._epoch_losses[:1], self.process_group)   # per-rank loss partials -> totals
             self._graph_warm = True
@@ -499,7 +470,7 @@ class _InvPrefTrainManager:
             step0, views0 = st.step, st.p_views
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._issue_epochs(torch.cuda.current_stream().cuda_stream, True, n)
+                self._issue_epochs(None, True, n)
             # capture records, it does not run: put the host-side bookkeeping back
             st.step = step0
             if st.p_views is not views0:

@@ -356,7 +356,8 @@ void FN(oracle_estep)(const oracle_tables *t, const int64_t *u, const int64_t *v
             else { real r = (p + q) - y[i]; dist = r * r; }
             if (eps_rows) dist = dist + eps_rows[i * E + c];
             if (dist_out) dist_out[i * E + c] = dist;
-            if (c == 0 || dist < best) { best = dist; bi = c; }
+            /* torch.argmin: lowest index among equal minima; a NaN wins, the first one if several (LessOrNan) */
+            if (c == 0 || dist < best || (dist != dist && best == best)) { best = dist; bi = c; }
         }
         new_envs[i] = bi;
         counts[bi]++;

@@ -108,8 +108,16 @@ def test_csv_edge_cases(tmp_path):
         p.write_bytes(text.encode())
         return str(p)
     # no header, CRLF, no trailing newline, blank lines, negative / fractional / exponent fields, spaces
-    a = dl.read_csv(w('a.csv', '1,2,3\r\n\r\n-4, 5.25 ,6e2\n7,8,+9'))
+    a = dl.read_csv(w('a.csv', '1,2,3\r\n\r\n-4, 5.25 ,6e2\n7,8,+9'), header=False)
     np.testing.assert_array_equal(a, [[1, 2, 3], [-4, 5.25, 600], [7, 8, 9]])
+    np.testing.assert_array_equal(dl.read_csv(str(tmp_path / 'a.csv'), header='auto'), a)
+    # the default mirrors pd.read_csv: the first line is the header even when it is numeric
+    np.testing.assert_array_equal(dl.read_csv(str(tmp_path / 'a.csv')), a[1:])
+    import pandas as pd
+    np.testing.assert_array_equal(pd.read_csv(str(tmp_path / 'a.csv'), skipinitialspace=True).values, a[1:])
+    assert dl.read_csv(w('one.csv', '1,2\n')).shape == (0, 2)
+    with pytest.raises(dl.IngestError):
+        dl.read_csv(w('hh.csv', 'u,i\n1,2\n'), header=False)                  # the header line is not data
     assert dl.read_csv(w('h.csv', 'user_id,item_id\n')).shape == (0, 2)       # header only
     assert dl.read_csv(w('e.csv', '')).shape == (0, 0)                         # empty file
     with pytest.raises(dl.IngestError):
@@ -126,7 +134,7 @@ def test_csv_edge_cases(tmp_path):
     # exact decimal conversion (same doubles as python's float())
     vals = ['0.1', '3.14159', '123456.789012', '1e-5', '-2.5E+3', '0.000001', '99999999999999']
     p = w('f.csv', '\n'.join(vals) + '\n')
-    np.testing.assert_array_equal(dl.read_csv(p)[:, 0], [float(v) for v in vals])
+    np.testing.assert_array_equal(dl.read_csv(p, header=False)[:, 0], [float(v) for v in vals])
     # CSR: duplicates collapse, users without pairs get empty sets, bad ids are refused
     ptr, idx = dl.csr_sets(np.array([2, 0, 2, 2, 0]), np.array([5, 1, 5, 3, 0]), 4)
     assert ptr.tolist() == [0, 2, 2, 4, 4] and idx.tolist() == [0, 1, 3, 5]

@@ -129,3 +129,27 @@ def test_stat_envs_rule():
     np.testing.assert_array_equal(sw, cw[envs])
     counts, cw, _ = O.stat_envs(np.zeros(8, np.int64), 2)
     assert cw[0] == np.float32(7 / 8)  # min(cnt+1, N-1)/N   train.py:274
+
+
+@pytest.mark.parametrize('implicit', [True, False])
+def test_oracle_estep_nan_rows_follow_torch_argmin(implicit):
+    """torch.argmin (train.py:199) picks the first NaN of a row of distances; so does the oracle's scan."""
+    import torch
+    from invpref_kdd_2022_amd import synth
+    U, I, E, D, B = 30, 20, 5, 16, 400
+    rs = np.random.RandomState(8)
+    tabs = synth.tables(9, U, I, E, D, std=0.3)
+    tabs['embed_env.weight'][2, 1] = np.nan                 # env 2: NaN distance everywhere
+    tabs['embed_user_env_aware.weight'][4, :] = np.nan      # user 4: every distance NaN
+    u, v = rs.randint(0, U, B), rs.randint(0, I, B)
+    y = (rs.randint(0, 2, B) if implicit else rs.randint(1, 6, B)).astype(np.float32)
+    new, counts, _, dist = O.estep(O.Tables(tabs), u, v, y, implicit, want_dist=True)
+    np.testing.assert_array_equal(new, torch.argmin(torch.from_numpy(dist), dim=1).numpy())
+    assert counts.sum() == B and new.min() >= 0 and new.max() < E
+    if implicit:
+        # the aten BCE clamps max(log(s), -100) swallow a NaN score (the distance becomes 100; the reference itself
+        # refuses NaN inputs to BCELoss with "all elements of input should be between 0 and 1")
+        assert (dist[:, 2] == 100).all() and (dist[u == 4] == 100).all()
+    else:
+        assert np.isnan(dist[:, 2]).all() and np.isnan(dist[u == 4]).all()
+        assert (new[u != 4] == 2).all() and (new[u == 4] == 0).all()

@@ -1,46 +1,62 @@
 #!/usr/bin/env python3
 """bench.py -- training interactions/sec of the InvPref hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1: spawns its own N ranks, see below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): Yahoo!R3-implicit-shaped synthetic data,
-U=15 400, I=1 000, 250 154 interactions PER GPU, E=4, D=64, minibatch 8 192 rows PER GPU (weak
-scaling: the global minibatch is 8 192*N rows; every rank takes the interactions of the users it owns and
-one RCCL all-reduce per step carries the shared -- item-side -- part of the flat gradient buffer, DESIGN.md
-§6), reference Yahoo hyper-parameters (Yahoo_InvPref_Implicit.py:17-41).
+Workload (BASELINE.json configs[1] at N = 1, configs[3] at N > 1): Yahoo!R3-implicit-shaped
+synthetic data, U=15 400, I=1 000, 250 154 interactions PER GPU, E=4, D=64, minibatch 8 192 rows PER GPU (weak
+scaling: the global minibatch is 8 192*N rows), reference Yahoo hyper-parameters (Yahoo_InvPref_Implicit.py:17-41).
+N > 1 runs the configuration BASELINE.json names -- interactions ROW-sharded, one RCCL all-reduce of the flat
+gradient buffer per optimiser step -- and reports the user-sharded layout beside it in `detail`.
 
-A "step" is one optimiser step of the M-step (fused gradient kernel + dense Adam) on one minibatch;
-every 155 steps (= cluster_interval 5 epochs x 31 minibatches) the E-step (+ stat_envs) over all
-interactions runs inside the timed region, as in the reference loop.  Inputs are resident in HBM
-before the timed region.  value = interactions processed by all ranks / max-over-ranks time.
+A "step" is one optimiser step of the M-step (fused gradient kernel + dense Adam) on one minibatch; every 155 steps
+(= cluster_interval 5 epochs x 31 minibatches) the E-step (+ stat_envs) over all interactions runs inside the
+timed region, as in the reference loop.  The timed region is always WHOLE cluster intervals (so the replayed HIP
+graphs and the E-step are inside it) and at least MIN_TIMED_S long: --steps / --warmup are rounded up accordingly
+and the line reports both (`steps_requested`, `steps` = timed).  Inputs are resident in HBM before the timed region;
+nothing is read back inside it.  value = interactions processed by all ranks / max-over-ranks time.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 U, I, E, D, N_PER_GPU, B_PER_GPU = 15400, 1000, 4, 64, 250154, 8192
 SEED = 17373331
 YAHOO = dict(lr=0.005, invariant_coe=3.351991776096847, env_aware_coe=9.988658447411407,
              env_coe=9.06447753571379, L2_coe=3.1351402017943117, L1_coe=0.4935216278026648,
              alpha=1.9053711444718746)
-ESTEP_EVERY = 155  # cluster_interval (5 epochs) x 31 minibatches
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+CLUSTER_INTERVAL = 5          # epochs (Yahoo_InvPref_Implicit.py:27)
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
+MIN_TIMED_S = 0.5
+MAX_TIMED_S = 30.0
 
 
 class StubEvaluator:
     def evaluate(self):
         return {}
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes
+    (torch.distributed.run) before this process has touched the GPU, and return their exit code."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.call(cmd, env=env)
 
 
 def pmc_traffic_bytes(kernel_name: str):
@@ -73,57 +89,58 @@ def rocprof_avg_ms(kernel_name: str):
     return None
 
 
-def cpu_baseline(seconds_budget: float = 12.0):
-    """The oracle (C port, one thread) on the same Yahoo-shaped workload, bounded sample."""
+def cpu_baseline():
+    """The oracle's all-core (OpenMP) loops on the same Yahoo-shaped workload on this box's host cores: M-step
+    (gradient + dense Adam) epochs and the E-step, all cores and one core, min of N (SURVEY.md §8(d);
+    the reference's CPU path is train.py:204-259).  `kind: port` -- the reference is Python and cannot travel."""
+    import numpy as np
     from invpref_kdd_2022_amd import synth
     from oracle import oracle as O
     data = synth.interactions(SEED, U, I, N_PER_GPU, implicit=True)
     tabs = synth.tables(SEED + 7, U, I, E, D)
     env0 = np.random.RandomState(SEED).randint(0, E, N_PER_GPU)
     cf = [YAHOO[k] for k in ('invariant_coe', 'env_aware_coe', 'env_coe', 'L2_coe', 'L1_coe', 'alpha')]
-    tr = O.Trainer(tabs, data, env0, implicit=True, batch_size=B_PER_GPU, coefs=cf, lr=YAHOO['lr'],
-                   reweight_rec=False, reweight_cls=True, reg_only_embed=True, reg_env_embed=False)
-    tr.stat_envs()
-    nb = (N_PER_GPU + B_PER_GPU - 1) // B_PER_GPU
-    done, t0 = 0, time.perf_counter()
-    k = 0
-    while True:
-        lo = (k % nb) * B_PER_GPU
-        hi = min(lo + B_PER_GPU, N_PER_GPU)
-        tr.train_a_batch(lo, hi)
-        done += hi - lo
-        k += 1
-        if time.perf_counter() - t0 > seconds_budget and k % nb == 0:
-            break
-    t_m = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    tr.cluster()
-    t_e = time.perf_counter() - t1
-    return {'value': done / t_m, 'unit': 'interactions/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{k} M-step minibatches ({done} interactions, {t_m:.1f} s) of the same Yahoo-shaped workload '
-                      f'through oracle/invpref_oracle.c, single thread; E-step alone {N_PER_GPU / t_e:.0f} interactions/s',
-            'estep_value': N_PER_GPU / t_e}
+    cores = O.omp_max_threads()
+    res = {}
+    for th, n_ep, n_es in ((cores, 5, 3), (1, 2, 1)):
+        tr = O.ParallelTrainer(tabs, data, env0, implicit=True, batch_size=B_PER_GPU, coefs=cf, lr=YAHOO['lr'],
+                               reweight_rec=False, reweight_cls=True, reg_only_embed=True, reg_env_embed=False,
+                               threads=th)
+        tr.stat_envs()
+        if th > 1:
+            tr.train_a_epoch()          # thread pool / page warm-up, not timed
+        tm, te = [], []
+        for _ in range(n_ep):
+            t0 = time.perf_counter()
+            tr.train_a_epoch()
+            tm.append(time.perf_counter() - t0)
+        for _ in range(n_es):
+            t0 = time.perf_counter()
+            tr.cluster()
+            te.append(time.perf_counter() - t0)
+            tr.stat_envs()
+        res[th] = (min(tm), min(te), n_ep, n_es)
+    tm, te, n_ep, n_es = res[cores]
+    blended = CLUSTER_INTERVAL * N_PER_GPU / (CLUSTER_INTERVAL * tm + te)
+    tm1, te1 = res[1][0], res[1][1]
+    return {'value': blended, 'unit': 'interactions/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle/invpref_oracle.c OpenMP loops, {cores} threads: min of {n_ep} M-step epochs '
+                      f'({N_PER_GPU} interactions, 31 minibatches, gradient + dense Adam) and min of {n_es} E-steps of '
+                      f'the same Yahoo-shaped workload, blended at the reference cadence (5 epochs : 1 E-step); '
+                      f'one-thread figures from {res[1][2]} epochs / {res[1][3]} E-step',
+            'mstep_all_cores': N_PER_GPU / tm, 'estep_all_cores': N_PER_GPU / te,
+            'mstep_one_core': N_PER_GPU / tm1, 'estep_one_core': N_PER_GPU / te1,
+            'value_one_core': CLUSTER_INTERVAL * N_PER_GPU / (CLUSTER_INTERVAL * tm1 + te1)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=620)
-    ap.add_argument('--warmup', type=int, default=62)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
-
-    from invpref_kdd_2022_amd import parallel, synth
+def build_manager(dev, rank, world, shard_mode=None):
+    import numpy as np
+    import torch
+    from invpref_kdd_2022_amd import synth
     from invpref_kdd_2022_amd.models import InvPrefImplicit
     from invpref_kdd_2022_amd.train import ImplicitTrainManager
-
-    rank, local, world = parallel.init_from_env('nccl')
-    if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-
+    if shard_mode is not None:
+        os.environ['INVPREF_SHARD'] = shard_mode
     data = synth.interactions(SEED, U, I, N_PER_GPU * world, implicit=True)
     tabs = synth.tables(SEED + 7, U, I, E, D)
     model = InvPrefImplicit(U, I, E, D, reg_only_embed=True, reg_env_embed=False)
@@ -131,144 +148,296 @@ def main():
     np.random.seed(SEED)
     mgr = ImplicitTrainManager(
         model=model, evaluator=StubEvaluator(), device=dev, training_data=torch.from_numpy(data).to(dev),
-        batch_size=B_PER_GPU * world, epochs=10 ** 9, cluster_interval=5, evaluate_interval=10 ** 9,
+        batch_size=B_PER_GPU * world, epochs=10 ** 9, cluster_interval=CLUSTER_INTERVAL, evaluate_interval=10 ** 9,
         use_class_re_weight=True, use_recommend_re_weight=False, cluster_use_random_sort=False,
         rank=rank, world_size=world, **YAHOO)
     mgr.stat_envs()
-    nb = mgr.batch_num
-    # one-time setup outside the timed region: an eager epoch, then capture of the epoch graphs the loop
-    # below replays (runs of 1..5 epochs between two E-steps, both parameter buffers)
-    mgr.train_epochs(1)
-    if mgr._graph_warm and mgr.use_plan and world == 1 and mgr.use_graph:
-        mgr.prepare_graphs(range(1, ESTEP_EVERY // nb + 1))
-    state = {'pos': 0, 'done': 0}
-    pending = []  # device-side results (epoch losses, diff_num, env counts): read back after the timed region
+    return mgr
 
-    def run(n_steps):
-        """n_steps optimiser steps of the training loop: whole epochs go through train_epochs() (on a single
-        GPU one HIP graph launch per run of epochs), a partial epoch through the same per-step calls issued
-        eagerly; the E-step + stat_envs run every ESTEP_EVERY steps as in the reference loop.  Nothing is
-        read back to the host inside the loop: the results stay on the device and are fetched (and
-        checked) after the timed region."""
-        left = n_steps
+
+def timed_run(mgr, world, steps_req, warmup_req):
+    """Warm-up + the timed region, both in whole cluster intervals (5 epochs + E-step + stat_envs).
+    Returns (seconds max-over-ranks, steps timed, steps of warm-up, pending device results)."""
+    import torch
+    nb = mgr.batch_num
+    per = CLUSTER_INTERVAL * nb
+    pending = []
+
+    def interval():
+        left = CLUSTER_INTERVAL
         while left > 0:
-            if state['pos'] == 0 and left >= nb:
-                # whole epochs up to the next E-step: enqueued back to back, losses read back once
-                n_ep = max(1, min(left, ESTEP_EVERY - state['done'] % ESTEP_EVERY) // nb)
-                pending.append(mgr.train_epochs(n_ep, sync=False))
-                left -= nb * n_ep
-                state['done'] += nb * n_ep
-            else:
-                if getattr(mgr, '_raw_ptrs', None) is None:
-                    mgr._raw_setup()
-                mgr._raw_step(state['pos'], mgr.alpha, torch.cuda.current_stream().cuda_stream)
-                state['pos'] = (state['pos'] + 1) % nb
-                left -= 1
-                state['done'] += 1
-            if state['done'] % ESTEP_EVERY == 0 and state['pos'] == 0:
-                pending.append(mgr.cluster(sync=False))
-                pending.append(mgr.stat_envs(sync=False))
+            out = mgr.train_epochs(left, sync=False)
+            pending.append(out)
+            left -= out.shape[0]
+        pending.append(mgr.cluster(sync=False))
+        pending.append(mgr.stat_envs(sync=False))
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
 
-    run(args.warmup)
+    # one-time set-up outside everything: an eager epoch, then capture of the epoch graphs the loop replays
+    mgr.train_epochs(1)
+    graphs = mgr._graph_warm and mgr.use_plan and world == 1 and mgr.use_graph
+    if graphs:
+        mgr.prepare_graphs(range(1, CLUSTER_INTERVAL + 1))
+    n_warm = max(1, -(-warmup_req // per))
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.steps)
+    for _ in range(n_warm):
+        interval()
+    torch.cuda.synchronize(); barrier()
+    est = (time.perf_counter() - t0) / n_warm                     # seconds per interval (first replays included)
+    if world > 1:
+        t = torch.tensor([est], dtype=torch.float64, device=mgr.device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        est = float(t.item())
+    n_int = max(-(-steps_req // per), int(MIN_TIMED_S / est) + 1)
+    n_int = max(1, min(n_int, max(-(-steps_req // per), int(MAX_TIMED_S / est))))
+    pending.clear()
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_int):
+        interval()
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     for p in pending:  # every epoch's losses, every E-step's diff_num and env counts were really produced
         assert bool(torch.isfinite(p.double()).all()), 'non-finite training result'
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=mgr.device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    return dt, n_int * per, n_warm * per, bool(graphs and mgr._graphs)
 
-    # per-launch device time of the step's kernels: HIP events on the launch stream around the same
-    # calls issued eagerly (events cannot be read back from inside a replayed graph), one epoch's worth
+
+def device_step_times(mgr, world):
+    """Device time of the M-step and the E-step alone, HIP events on the launch stream (torch's current stream
+    is the stream every kernel of this package is enqueued on): whole epochs -- one graph replay per run of epochs
+    on a single GPU -- so the figure is the step as the training loop really runs it, kernel boundaries included."""
+    import torch
+    nb, reps = mgr.batch_num, 6
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    mgr.train_epochs(CLUSTER_INTERVAL, sync=False)
+    torch.cuda.synchronize()
+    ev[0].record()
+    for r in range(reps):
+        mgr.train_epochs(CLUSTER_INTERVAL, sync=False)
+        ev[r + 1].record()
+    torch.cuda.synchronize()
+    ms_step = min(a.elapsed_time(b) for a, b in zip(ev[:-1], ev[1:])) / (CLUSTER_INTERVAL * nb)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    mgr.cluster(sync=False); mgr.stat_envs(sync=False)
+    e1.record()
+    torch.cuda.synchronize()
+    return ms_step, e0.elapsed_time(e1)
+
+
+def eager_kernel_times(mgr):
+    """Per-launch time of the step's kernels from HIP events around EAGER launches (one epoch): the interval from
+    the end of the previous kernel to the end of this one, i.e. kernel + launch gap.  The stream is kept backlogged
+    so that the stamps are taken by the GPU, not while it waits for the host."""
+    import numpy as np
+    import torch
+    from invpref_kdd_2022_amd import _capi
     if getattr(mgr, '_raw_ptrs', None) is None:
         mgr._raw_setup()
-    from invpref_kdd_2022_amd import _capi
+    nb = mgr.batch_num
     ev = {'m0': [], 'mk': [], 'm1': [], 'a1': []}
-    stream = torch.cuda.current_stream().cuda_stream
-    fused = mgr.use_plan and world == 1
-    # keep the stream backlogged while the instrumented steps are enqueued, so that an event's time stamp is
-    # taken right before the next kernel starts and not while the GPU waits for the host
+    fused = mgr.use_plan and mgr.world_size == 1 and not mgr._unfused
     torch.cuda._sleep(int(4e6))
     for k in range(nb):
         e0, ek, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
-        if fused:  # the library records ek between mstep_rows_kernel and rows_finish_kernel
-            ek.record()  # (creates the underlying hipEvent_t)
+        if fused:  # the library records ek behind the main kernel of the step (before a separate finish kernel, if any)
+            ek.record()
             _capi.lib().invpref_set_profile_event(ek.cuda_event)
         e0.record()
-        mgr._raw_step(k, mgr.alpha, stream, mid_event=e1)
+        mgr._raw_step(k, mgr.alpha, mid_event=e1)
         e2.record()
         ev['m0'].append(e0); ev['mk'].append(ek); ev['m1'].append(e1); ev['a1'].append(e2)
     _capi.lib().invpref_set_profile_event(None)
     torch.cuda.synchronize()
+    med = lambda a, b: float(np.median([x.elapsed_time(y) for x, y in zip(ev[a], ev[b])]))  # noqa: E731
+    out = {'step_ms_eager_events': med('m0', 'a1')}
+    if fused:
+        out['main_kernel_ms_eager_events'] = med('m0', 'mk')
+    else:
+        out['mstep_ms_eager_events'], out['adam_ms_eager_events'] = med('m0', 'm1'), med('m1', 'a1')
+    return out
 
-    # M-step-only and E-step-only rates (SURVEY §8(d): report them separately from the blended figure)
-    a0, a1, a2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-    a0.record()
-    mgr.train_epochs(3, sync=False)
-    a1.record()
-    mgr.cluster(sync=False); mgr.stat_envs(sync=False)
-    a2.record()
+
+def roofline_large(dev):
+    """The same fused kernel on ONE cache-exceeding launch (SURVEY.md §8(d) "Roofline launch"): 2^20 uniformly random
+    interactions over tables of 400 000 users x 100 000 items, D=64, E=4 -- 256 MB per flat buffer, five buffers, far
+    beyond the 256 MiB Infinity Cache, so this is the HBM figure; the Yahoo-sized step above is cache-resident."""
+    import numpy as np
+    import torch
+    from invpref_kdd_2022_amd import ops, plan as planlib, synth
+    Ul, Il, Bl = 400000, 100000, 1 << 20
+    rs = np.random.RandomState(5)
+    u, v = rs.randint(0, Ul, Bl), rs.randint(0, Il, Bl)
+    y = (rs.random_sample(Bl) < 0.5).astype(np.float32)
+    tabs = synth.tables(6, Ul, Il, E, D)
+    P = [torch.from_numpy(tabs[k]).to(dev) for k in ops.PARAM_NAMES]
+    P2 = [torch.zeros_like(p) for p in P]
+    M = [torch.zeros_like(p) for p in P]
+    V = [torch.zeros_like(p) for p in P]
+    t0 = time.perf_counter()
+    dp = planlib.upload(planlib.build_row_plan(u, v, y, Ul, Il), dev)
+    plan_s = time.perf_counter() - t0
+    e = torch.from_numpy(rs.randint(0, E, Bl).astype(np.int64)).to(dev)
+    yt, w = torch.from_numpy(y).to(dev), torch.rand(Bl, device=dev)
+    ws = ops.Workspace(dev)
+    losses = torch.zeros(6, device=dev)
+    cf = [YAHOO[k] for k in ('invariant_coe', 'env_aware_coe', 'env_coe', 'L2_coe', 'L1_coe', 'alpha')]
+    flags = ops.flags_of(True, False, True, True, False)
+    times = []
+    a, b = P, P2
+    for it in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.mstep_rows_adam(a, b, M, V, dp, e, yt, w, Bl, cf, flags, losses, it + 1, 0.005, ws)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+        a, b = b, a
+    ms = min(times[1:])
+    Pn = sum(p.numel() for p in P)
+    nbytes = Bl * (32 + 16 * D) + 24 * Pn
+    return {'bound': 'hbm', 'achieved': nbytes / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None, 'cache_resident': False,
+            'kernel': 'the fused M-step + Adam step (same kernels as the headline), one launch',
+            'launch_ms': ms, 'algorithmic_bytes_per_launch': nbytes,
+            'workload': f'{Bl} uniform interactions, {Ul} x {Il} tables, D={D}, E={E}: {4 * Pn / 1e6:.0f} MB per flat '
+                        f'buffer (p, p\', m, v: {16 * Pn / 1e6:.0f} MB)', 'plan_build_s': plan_s}
+
+
+def eval_timing(dev):
+    """ImplicitTestManager.evaluate() on the Yahoo test shape (5 400 test users x 1 000 items,
+    top-k 3/5/7, test batch 1 024: Yahoo_InvPref_Implicit.py:43-48); the reference's CPU path took 4.8 s per call in
+    the survey container."""
+    import numpy as np
+    import torch
+    from invpref_kdd_2022_amd.evaluate import ImplicitTestManager
+    from invpref_kdd_2022_amd.models import InvPrefImplicit
+    rs = np.random.RandomState(11)
+    users = sorted(rs.choice(U, 5400, replace=False).tolist())
+    mask = {u: set(rs.choice(I, rs.randint(1, 33), replace=False).tolist()) for u in users}
+    truth = {u: set(rs.choice(I, 10, replace=False).tolist()) for u in users}
+
+    class Loader:
+        all_test_users_by_sorted_list = users
+        get_sorted_all_test_users_ground_truth = [truth[u] for u in users]
+
+        @staticmethod
+        def user_mask_items(u):
+            return mask[u]
+    model = InvPrefImplicit(U, I, E, D).to(dev)
+    tm = ImplicitTestManager(model, Loader(), test_batch_size=1024, top_k_list=[3, 5, 7], use_item_pool=False)
+    tm.evaluate()                       # builds the CSR arrays from the python sets once
     torch.cuda.synchronize()
-    detail = {'mstep_interactions_per_s_per_gpu': 3 * mgr.users_tensor.shape[0] / (a0.elapsed_time(a1) * 1e-3),
-              'estep_interactions_per_s_per_gpu': mgr.users_tensor.shape[0] / (a1.elapsed_time(a2) * 1e-3),
-              'estep_ms': a1.elapsed_time(a2)}
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        res = tm.evaluate()
+        ts.append(time.perf_counter() - t0)
+    assert 0.0 <= res['ndcg'][5] <= 1.0
+    return {'evaluate_s': min(ts), 'test_users': len(users), 'items': I, 'top_k': [3, 5, 7],
+            'reference_cpu_s_survey_container': 4.8}
 
-    inter = args.steps * B_PER_GPU * world
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=1550)
+    ap.add_argument('--warmup', type=int, default=155)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip roofline_large / eval timing (profiling runs)')
+    args = ap.parse_args()
+
+    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))      # (nothing in this process has touched the GPU)
+
+    import numpy as np  # noqa: F401
+    import torch
+    from invpref_kdd_2022_amd import parallel
+
+    rank, local, world = parallel.init_from_env('nccl')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    # N > 1: BASELINE.json configs[3] as written -- row-sharded, whole flat gradient all-reduced
+    mgr = build_manager(dev, rank, world, 'rows' if world > 1 else None)
+    dt, steps, warm_steps, graphs = timed_run(mgr, world, args.steps, args.warmup)
+    inter = steps * B_PER_GPU * world
     value = inter / dt
-    # per-op device time from HIP events recorded on the launch stream inside the timed region
-    ms_m = float(np.median([a.elapsed_time(b) for a, b in zip(ev['m0'], ev['m1'])]))
-    ms_a = float(np.median([a.elapsed_time(b) for a, b in zip(ev['m1'], ev['a1'])]))
+    ms_step_dev, ms_estep = device_step_times(mgr, world)
+    n_local = mgr.users_tensor.shape[0]
+    detail = {'mstep_interactions_per_s_per_gpu': B_PER_GPU / (ms_step_dev * 1e-3),
+              'estep_interactions_per_s_per_gpu': n_local / (ms_estep * 1e-3), 'estep_ms': ms_estep,
+              'timed_seconds': dt}
+    detail.update(eager_kernel_times(mgr))
+
     P = mgr.state.n
+    fused = mgr.use_plan and world == 1 and not mgr._unfused
     # Algorithmic bytes (DESIGN.md §5).  SURVEY §8(d) prices the un-fused pair: M-step B*(32+32D) (ids/labels,
     # 4 row reads, 4 gradient-row adds) + Adam 32P (28 B/param + 4 B zeroing).  The fused owner pass never
     # stores the gradient, so it is priced at what it must move: B*(32+16D) + 24P (p,m,v read; p',m',v' written).
-    bytes_m_survey, bytes_a_survey = B_PER_GPU * (32 + 32 * D), 32 * P
+    bytes_survey = B_PER_GPU * (32 + 32 * D) + 32 * P
     if fused:
-        # dominant kernel alone: mstep_rows_kernel (M-step + Adam of the four big tables); the three small
-        # tables (E*D + E*D + E parameters) are finished by rows_finish_kernel and are not counted here
-        ms_k = float(np.median([a.elapsed_time(b) for a, b in zip(ev['m0'], ev['mk'])]))
-        nbytes = B_PER_GPU * (32 + 16 * D) + 24 * (P - 2 * E * D - 64)
-        roof = {'kernel': 'mstep_rows_kernel (M-step with fused Adam)', 'bytes': nbytes, 'ms': ms_k}
-        other = {'rows_plus_finish_ms_events': ms_m, 'rows_kernel_ms_events': ms_k,
-                 'GBs_of_pair_at_survey_unfused_pricing': (bytes_m_survey + bytes_a_survey) / (ms_m * 1e-3) / 1e9}
+        nbytes = B_PER_GPU * (32 + 16 * D) + 24 * P
+        kname = 'mstep_rows_kernel'
+        what = 'the whole optimiser step: mstep_rows_kernel (M-step + fused dense Adam; finish included)'
     else:
-        bytes_m = bytes_m_survey
-        if ms_a >= ms_m:
-            roof = {'kernel': 'adam_kernel', 'bytes': bytes_a_survey, 'ms': ms_a}
-        else:
-            roof = {'kernel': 'mstep kernel (+finish)', 'bytes': bytes_m, 'ms': ms_m}
-        other = {'mstep_ms': ms_m, 'mstep_GBs': bytes_m / (ms_m * 1e-3) / 1e9, 'adam_ms': ms_a,
-                 'adam_GBs': bytes_a_survey / (ms_a * 1e-3) / 1e9}
-    achieved = roof['bytes'] / (roof['ms'] * 1e-3) / 1e9
-    traffic = pmc_traffic_bytes(roof['kernel'].split()[0])
+        nbytes = bytes_survey
+        kname = 'mstep_rows_kernel' if mgr.use_plan else 'mstep_atomic_kernel'
+        what = 'the whole optimiser step: gradient pass + all-reduce + stand-alone Adam'
+    achieved = nbytes / (ms_step_dev * 1e-3) / 1e9
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/)',
-                'kernel': roof['kernel'],
-                'avg_launch_ms': roof['ms'], 'algorithmic_bytes_per_launch': roof['bytes'],
-                'rocprofv3_avg_launch_ms': rocprof_avg_ms(roof['kernel'].split()[0]), 'other': other}
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(kname),
+                'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/)', 'kernel': what,
+                'avg_launch_ms': ms_step_dev, 'algorithmic_bytes_per_launch': nbytes,
+                'timing': 'HIP events on the launch stream around replays of whole-epoch graphs, per step '
+                          '(kernel boundaries included)' if graphs else 'HIP events on the launch stream around '
+                          'whole eagerly issued epochs, per step',
+                'cache_resident': True,
+                'cache_note': 'all five flat buffers (42 MB) sit in the 256 MiB Infinity Cache at this size: the 8 TB/s '
+                              'HBM peak is the yardstick north_star names, not the level that serves the bytes; '
+                              'roofline_large is the cache-exceeding launch',
+                'rocprofv3_avg_launch_ms': rocprof_avg_ms(kname),
+                'GBs_at_survey_unfused_pricing': bytes_survey / (ms_step_dev * 1e-3) / 1e9}
     out = {
         'metric': 'training interactions/sec, Yahoo-implicit InvPref', 'value': value, 'unit': 'interactions/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+        'n_gpus': world, 'steps': steps, 'steps_requested': args.steps, 'warmup': warm_steps,
+        'warmup_requested': args.warmup, 'ms_per_step': dt / steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'yahoo_r3_implicit_shaped', 'users': U, 'items': I, 'envs': E, 'factor_num': D,
                    'interactions_per_gpu': N_PER_GPU, 'batch_per_gpu': B_PER_GPU, 'global_batch': B_PER_GPU * world,
-                   'estep_every_steps': ESTEP_EVERY, 'parallelism': (f'{mgr.shard_mode}-sharded x{world}, 1 all-reduce/step ({4 * (mgr.state.n - mgr._ar_lo)} B)' if world > 1 else 'single GPU'),
-                   'hip_graph_epochs': bool(mgr._graphs)},
+                   'estep_every_steps': CLUSTER_INTERVAL * mgr.batch_num,
+                   'parallelism': (f'{mgr.shard_mode}-sharded x{world}, 1 all-reduce/step '
+                                   f'({4 * (mgr.state.n + 8 - mgr._ar_lo)} B)' if world > 1 else 'single GPU')},
+        'timed_path': 'graph' if graphs else 'eager', 'plan_build_s': getattr(mgr, 'plan_build_s', None),
         'roofline': roofline, 'detail': detail,
     }
+    if world > 1:
+        # the xGMI-first layout beside the configuration BASELINE.json names (DESIGN.md §6)
+        del mgr
+        torch.cuda.empty_cache()
+        mgr_u = build_manager(dev, rank, world, 'users')
+        dt_u, steps_u, _, _ = timed_run(mgr_u, world, args.steps, args.warmup)
+        out['detail']['user_sharded'] = {'value': steps_u * B_PER_GPU * world / dt_u, 'ms_per_step': dt_u / steps_u * 1e3,
+                                         'steps': steps_u, 'all_reduce_bytes': 4 * (mgr_u.state.n + 8 - mgr_u._ar_lo)}
+    if rank == 0 and world == 1 and not args.no_extras:
+        out['roofline_large'] = roofline_large(dev)
+        out['detail']['evaluation'] = eval_timing(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

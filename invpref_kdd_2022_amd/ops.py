@@ -60,8 +60,18 @@ def _o():
     return torch.ops.invpref
 
 
+def _gpu(*tensors):
+    """The operators exist for the CUDA/HIP dispatch key only; say so in this package's own words before the
+    dispatcher does ("no kernel for the CPU backend")."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise InvPrefError(f'tensor on {t.device}: the InvPref operators run on the GPU only '
+                               '(the HIP path has no CPU fallback)')
+
+
 def forward(params: Sequence[torch.Tensor], users, items, envs, implicit: bool):
     """InvPref{Implicit,Explicit}.forward (models.py:307-326 / :448-467), values only."""
+    _gpu(users, *params)
     return _o().forward(list(params), users, items, envs, bool(implicit))
 
 
@@ -70,6 +80,7 @@ def mstep_grad(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], us
                losses6: torch.Tensor, workspace: Workspace) -> None:
     """Forward + losses + regularisers + backward of train_a_batch (train.py:94-156): ADDS the
     gradients into `grads` and the six loss terms into `losses6` (device fp32[6])."""
+    _gpu(users, *params)
     t = make_tables(params)
     ws = workspace.get(lib().invpref_mstep_workspace_bytes(C.byref(t), users.numel()))
     _o().train_step_fused(list(params), list(grads), users, items, envs, scores, sample_weights, int(batch_norm),
@@ -79,6 +90,7 @@ def mstep_grad(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], us
 def adam_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: int,
           lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, zero_grad: bool = True) -> None:
     """optimizer.zero_grad() + torch.optim.Adam.step() (train.py:41,155-157) on flat buffers."""
+    _gpu(param, grad, exp_avg, exp_avg_sq)
     _o().adam_dense_(param, grad, exp_avg, exp_avg_sq, int(step), float(lr), float(beta1), float(beta2), float(eps),
                      bool(zero_grad))
 
@@ -96,6 +108,7 @@ def estep(params: Sequence[torch.Tensor], users, items, scores, implicit: bool, 
     """cluster() + stat_envs() (train.py:235-259, :268-280) over all given interactions.
     Returns (new_envs int64[N], counts int64[E], diff int64[1], class_w fp32[E], sample_w fp32[N]).
     new_envs may be the same tensor as old_envs (in-place update, `estep_assign_`)."""
+    _gpu(users, *params)
     t = make_tables(params)
     ws = workspace.get(lib().invpref_estep_workspace_bytes(C.byref(t), users.numel()))
     if new_envs is not None and old_envs is not None and new_envs.data_ptr() == old_envs.data_ptr():
@@ -114,6 +127,7 @@ def estep(params: Sequence[torch.Tensor], users, items, scores, implicit: bool, 
 
 def stat_envs(envs: torch.Tensor, env_num: int, workspace: Workspace, want_sample_weights: bool = True):
     """stat_envs() (train.py:268-280): (counts int64[E], class_w fp32[E], sample_w fp32[N])."""
+    _gpu(envs)
     ws = workspace.get(4 * (env_num + 1) * 2048)
     counts, cw, sw = _o().stat_envs(envs, int(env_num), bool(want_sample_weights), ws)
     return counts, cw, (sw if want_sample_weights else None)
@@ -134,6 +148,7 @@ def backward(params: Sequence[torch.Tensor], grads: Sequence[torch.Tensor], user
 
 def predict(user_table: torch.Tensor, item_table: torch.Tensor, users: torch.Tensor, sigmoid: bool) -> torch.Tensor:
     """InvPrefImplicit.predict (models.py:393-407): [n_users, item_num] scores."""
+    _gpu(user_table, item_table, users)
     return _o().predict(user_table, item_table, users, bool(sigmoid))
 
 

@@ -387,3 +387,228 @@ float oracle_clog1p(float x) { return r_log1p(x); }
 float oracle_cdot2(const float *a, const float *b, int64_t D) { return dot2(a, b, D); }
 float oracle_cdot3(const float *a, const float *b, const float *c, int64_t D) { return dot3(a, b, c, D); }
 #endif
+
+#if !defined(ORACLE_F64) && defined(_OPENMP)
+/* ==================================================================================================
+ * All-core forms of the three timed loops, for the `cpu_baseline` leg of bench.py ("OpenMP over
+ * all host cores").  Same arithmetic per interaction as the serial functions above; the scatter is
+ * owner-computes, so the four big gradient tables come out BIT-IDENTICAL to the serial oracle whatever the
+ * thread count (each row's interactions are added in minibatch order by one thread); the E x D tables and the
+ * loss sums are reduced from per-thread double partials (differences at the 1e-16 level).
+ * ================================================================================================== */
+#include <omp.h>
+
+int oracle_omp_max_threads(void) { return omp_get_max_threads(); }
+
+typedef struct { float g_p, g_q, gz[16]; } omp_rec;
+
+void oracle_mstep_omp_f32(const oracle_tables *t, const oracle_grads *g, const int64_t *u, const int64_t *v,
+                          const int64_t *e, const float *y, const float *w, int64_t B, int64_t Bnorm,
+                          const double *coefs, uint32_t flags, int include_dense_reg, double *losses, int nthreads) {
+    const int64_t D = t->D, E = t->E;
+    if (E > 16 || nthreads < 1) return;
+    const float ca = (float)coefs[0], cb = (float)coefs[1], cc = (float)coefs[2];
+    const float l2 = (float)coefs[3], l1 = (float)coefs[4], alpha = (float)coefs[5];
+    const float invB = 1.0f / (float)Bnorm;
+    const float r2 = l2 / ((float)Bnorm * (float)D), r1 = l1 / (2.0f * (float)Bnorm * (float)D);
+    omp_rec *rec = (omp_rec *)malloc(sizeof(omp_rec) * (size_t)(B > 0 ? B : 1));
+    const size_t ED = (size_t)(E * D);
+    const size_t slab = 2 * ED + (size_t)E + 8;     /* aEv | aW | ab | 7 loss partials */
+    double *part = (double *)calloc(slab * (size_t)nthreads, sizeof(double));
+    /* ---- pass 1: per-interaction forward + the scalar part of the backward; E x D partials per thread */
+#pragma omp parallel num_threads(nthreads)
+    {
+        const int tid = omp_get_thread_num();
+        double *aEv = part + slab * (size_t)tid, *aW = aEv + ED, *ab = aW + ED, *L = ab + E;
+        float *x = (float *)malloc(sizeof(float) * (size_t)D), z[16];
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < B; i++) {
+            const int64_t ui = u[i], vi = v[i], ei = e[i];
+            const float *pu = t->Pu + ui * D, *qi = t->Qi + vi * D;
+            const float *pa = t->Pa + ui * D, *qa = t->Qa + vi * D, *ev = t->Ev + ei * D;
+            const float wi = w ? w[i] : 1.0f;
+            const float cw_rec = ((flags & F_REWEIGHT_REC) ? wi : 1.0f) * invB;
+            const float cw_cls = ((flags & F_REWEIGHT_CLS) ? wi : 1.0f) * invB;
+            float p = dot2(pu, qi, D), q = dot3(pa, qa, ev, D), g_p, g_q, li, le;
+            if (flags & F_IMPLICIT) {
+                float sp = r_sigmoid(p), sq = r_sigmoid(q), se = sp * sq;
+                li = r_bce(sp, y[i]);
+                le = r_bce(se, y[i]);
+                float d_inv = ca * cw_rec * r_dbce(sp, y[i]);
+                float d_env = cb * cw_rec * r_dbce(se, y[i]);
+                g_p = (d_inv + d_env * sq) * (sp * (1.0f - sp));
+                g_q = d_env * sp * (sq * (1.0f - sq));
+            } else {
+                float s2 = p + q;
+                li = (p - y[i]) * (p - y[i]);
+                le = (s2 - y[i]) * (s2 - y[i]);
+                float d_env = cb * cw_rec * 2.0f * (s2 - y[i]);
+                g_p = ca * cw_rec * 2.0f * (p - y[i]) + d_env;
+                g_q = d_env;
+            }
+            L[0] += (double)(li * ((flags & F_REWEIGHT_REC) ? wi : 1.0f));
+            L[1] += (double)(le * ((flags & F_REWEIGHT_REC) ? wi : 1.0f));
+            for (int64_t d = 0; d < D; d++) x[d] = pu[d] * qi[d];
+            float mx = -INFINITY;
+            for (int64_t c = 0; c < E; c++) { z[c] = dot2(x, t->W + c * D, D) + t->b[c]; mx = r_max(mx, z[c]); }
+            float se = 0;
+            for (int64_t c = 0; c < E; c++) se += r_exp(z[c] - mx);
+            float lse = r_log(se);
+            L[2] += (double)(-((z[ei] - mx) - lse) * ((flags & F_REWEIGHT_CLS) ? wi : 1.0f));
+            rec[i].g_p = g_p;
+            rec[i].g_q = g_q;
+            for (int64_t c = 0; c < E; c++) {
+                float sm = r_exp((z[c] - mx) - lse);
+                float gzc = cc * cw_cls * (sm - (float)(c == ei));
+                rec[i].gz[c] = gzc;
+                ab[c] += (double)gzc;
+                for (int64_t d = 0; d < D; d++) aW[c * D + d] += (double)(gzc * x[d]);
+            }
+            for (int64_t d = 0; d < D; d++) {
+                float gev = g_q * (pa[d] * qa[d]);
+                if (flags & F_REG_ENV_EMBED) gev += 2.0f * r2 * ev[d] + 2.0f * r1 * r_sign(ev[d]);
+                aEv[ei * D + d] += (double)gev;
+                L[3] += (double)(pu[d] * pu[d]) + (double)(pa[d] * pa[d]) + (double)(qi[d] * qi[d]) +
+                        (double)(qa[d] * qa[d]);
+                L[4] += fabs((double)pu[d]) + fabs((double)pa[d]) + fabs((double)qi[d]) + fabs((double)qa[d]);
+                if (flags & F_REG_ENV_EMBED) { L[5] += (double)(ev[d] * ev[d]); L[6] += fabs((double)ev[d]); }
+            }
+        }
+        free(x);
+    }
+    /* ---- pass 2: owner-computes scatter.  side 0: user rows (Pu, Pa), side 1: item rows (Qi, Qa) */
+    for (int side = 0; side < 2; side++) {
+        const int64_t R = side == 0 ? t->U : t->I;
+        const int64_t *own = side == 0 ? u : v;
+        int64_t *ptr = (int64_t *)calloc((size_t)R + 1, sizeof(int64_t));
+        int64_t *ord = (int64_t *)malloc(sizeof(int64_t) * (size_t)(B > 0 ? B : 1));
+        for (int64_t i = 0; i < B; i++) ptr[own[i] + 1]++;
+        for (int64_t r = 0; r < R; r++) ptr[r + 1] += ptr[r];
+        int64_t *fill = (int64_t *)malloc(sizeof(int64_t) * (size_t)(R > 0 ? R : 1));
+        memcpy(fill, ptr, sizeof(int64_t) * (size_t)R);
+        for (int64_t i = 0; i < B; i++) ord[fill[own[i]]++] = i;     /* stable: minibatch order inside a row */
+        free(fill);
+#pragma omp parallel num_threads(nthreads)
+        {
+            float *gx = (float *)malloc(sizeof(float) * (size_t)D);
+#pragma omp for schedule(dynamic, 64)
+            for (int64_t r = 0; r < R; r++) {
+                for (int64_t j = ptr[r]; j < ptr[r + 1]; j++) {
+                    const int64_t i = ord[j], ui = u[i], vi = v[i], ei = e[i];
+                    const float *pu = t->Pu + ui * D, *qi = t->Qi + vi * D;
+                    const float *pa = t->Pa + ui * D, *qa = t->Qa + vi * D, *ev = t->Ev + ei * D;
+                    const float g_p = rec[i].g_p, g_q = rec[i].g_q;
+                    for (int64_t d = 0; d < D; d++) gx[d] = 0;
+                    for (int64_t c = 0; c < E; c++)
+                        for (int64_t d = 0; d < D; d++) gx[d] += rec[i].gz[c] * t->W[c * D + d];
+                    if (side == 0) {
+                        for (int64_t d = 0; d < D; d++) {
+                            float gip = g_p - alpha * gx[d];
+                            g->Pu[ui * D + d] += gip * qi[d] + r2 * pu[d] + r1 * r_sign(pu[d]);
+                            g->Pa[ui * D + d] += g_q * (qa[d] * ev[d]) + r2 * pa[d] + r1 * r_sign(pa[d]);
+                        }
+                    } else {
+                        for (int64_t d = 0; d < D; d++) {
+                            float gip = g_p - alpha * gx[d];
+                            g->Qi[vi * D + d] += gip * pu[d] + r2 * qi[d] + r1 * r_sign(qi[d]);
+                            g->Qa[vi * D + d] += g_q * (pa[d] * ev[d]) + r2 * qa[d] + r1 * r_sign(qa[d]);
+                        }
+                    }
+                }
+            }
+            free(gx);
+        }
+        free(ptr);
+        free(ord);
+    }
+    /* ---- fold the per-thread partials (thread order: deterministic for a given thread count) */
+    double *tot = (double *)calloc(slab, sizeof(double));
+    for (int th = 0; th < nthreads; th++)
+        for (size_t k = 0; k < slab; k++) tot[k] += part[slab * (size_t)th + k];
+    for (size_t k = 0; k < ED; k++) { g->Ev[k] += (float)tot[k]; g->W[k] += (float)tot[ED + k]; }
+    for (int64_t c = 0; c < E; c++) g->b[c] += (float)tot[2 * ED + (size_t)c];
+    const double *L = tot + 2 * ED + E;
+    double L2 = L[3] / ((double)Bnorm * (double)D * 2.0) + L[5] / ((double)Bnorm * (double)D);
+    double L1 = L[4] / ((double)Bnorm * (double)D * 2.0) + L[6] / ((double)Bnorm * (double)D);
+    if (include_dense_reg && !(flags & F_REG_ONLY_EMBED)) {
+        double w2 = 0, w1 = 0, b2 = 0, b1 = 0;
+        const float kw2 = 2.0f * l2 / ((float)D * (float)E), kw1 = l1 / ((float)D * (float)E);
+        const float kb2 = 2.0f * l2 / (float)E, kb1 = l1 / (float)E;
+        for (int64_t k = 0; k < E * D; k++) {
+            w2 += (double)(t->W[k] * t->W[k]);
+            w1 += fabs((double)t->W[k]);
+            g->W[k] += kw2 * t->W[k] + kw1 * r_sign(t->W[k]);
+        }
+        for (int64_t c = 0; c < E; c++) {
+            b2 += (double)(t->b[c] * t->b[c]);
+            b1 += fabs((double)t->b[c]);
+            g->b[c] += kb2 * t->b[c] + kb1 * r_sign(t->b[c]);
+        }
+        L2 += w2 / ((double)D * (double)E) + b2 / (double)E;
+        L1 += w1 / ((double)D * (double)E) + b1 / (double)E;
+    }
+    losses[0] += L[0] / (double)Bnorm;
+    losses[1] += L[1] / (double)Bnorm;
+    losses[2] += L[2] / (double)Bnorm;
+    losses[3] += L2;
+    losses[4] += L1;
+    losses[5] = coefs[0] * losses[0] + coefs[1] * losses[1] + coefs[2] * losses[2] + coefs[3] * losses[3] +
+                coefs[4] * losses[4];
+    free(tot); free(part); free(rec);
+}
+
+/* oracle_adam_f32 over n parameters, split over threads (element-wise: bit-identical), zeroing g like
+ * optimizer.zero_grad() does before the next step */
+void oracle_adam_omp_f32(float *p, float *g, float *m, float *vv, int64_t n, int64_t step, double lr, double beta1,
+                         double beta2, double eps, int zero_grad, int nthreads) {
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1), bc2s = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2), epsr = (float)eps;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t i = 0; i < n; i++) {
+        float gi = g[i];
+        float mi = m[i] + w1 * (gi - m[i]);
+        float vi = vv[i] * b2 + (w2 * gi) * gi;
+        float denom = sqrtf(vi) / bc2s + epsr;
+        p[i] = p[i] + ((-step_size) * mi) / denom;
+        m[i] = mi;
+        vv[i] = vi;
+        if (zero_grad) g[i] = 0.0f;
+    }
+}
+
+/* oracle_estep_f32 with the rows split over threads (integers out: identical to the serial form) */
+void oracle_estep_omp_f32(const oracle_tables *t, const int64_t *u, const int64_t *v, const float *y, int64_t N,
+                          uint32_t flags, const int64_t *old_envs, int64_t *new_envs, int64_t *counts, int64_t *diff,
+                          int nthreads) {
+    const int64_t D = t->D, E = t->E;
+    int64_t nd = 0;
+    int64_t cnt[64] = {0};
+#pragma omp parallel num_threads(nthreads) reduction(+ : nd)
+    {
+        int64_t mine[64] = {0};
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < N; i++) {
+            const float *pu = t->Pu + u[i] * D, *qi = t->Qi + v[i] * D;
+            const float *pa = t->Pa + u[i] * D, *qa = t->Qa + v[i] * D;
+            float p = dot2(pu, qi, D);
+            float sp = (flags & F_IMPLICIT) ? r_sigmoid(p) : p;
+            float best = 0;
+            int64_t bi = 0;
+            for (int64_t c = 0; c < E; c++) {
+                float q = dot3(pa, qa, t->Ev + c * D, D), dist;
+                if (flags & F_IMPLICIT) dist = r_bce(sp * r_sigmoid(q), y[i]);
+                else { float r = (p + q) - y[i]; dist = r * r; }
+                if (c == 0 || dist < best || (dist != dist && best == best)) { best = dist; bi = c; }
+            }
+            new_envs[i] = bi;
+            mine[bi]++;
+            if (old_envs && old_envs[i] != bi) nd++;
+        }
+#pragma omp critical
+        for (int64_t c = 0; c < E; c++) cnt[c] += mine[c];
+    }
+    for (int64_t c = 0; c < E; c++) counts[c] = cnt[c];
+    if (diff) *diff = nd;
+}
+#endif

@@ -256,3 +256,76 @@ def pure_mf_trainer(user_emb, item_emb, data, *, implicit: bool, batch_size: int
     return Trainer(pure_mf_params(user_emb, item_emb), data, np.zeros(len(data), np.int64), implicit=implicit,
                    batch_size=batch_size, coefs=pure_mf_coefs(L2_coe, L1_coe), lr=lr, reweight_rec=False,
                    reweight_cls=False, reg_only_embed=True, reg_env_embed=False, prec=prec)
+
+
+# ---------------------------------------------------------------------------------------------
+# All-core (OpenMP) forms of the timed loops: the `cpu_baseline` leg of bench.py.
+# Same arithmetic as the serial functions; the big-table gradients are bit-identical to them.
+def omp_max_threads() -> int:
+    return int(lib().oracle_omp_max_threads())
+
+
+def mstep_omp(tab: Tables, u, v, e, y, w, coefs, flags: int, threads: int, bnorm: int | None = None,
+              include_dense_reg=True, grads=None, losses=None):
+    assert tab.prec == 'f32'
+    u, v, e = _ids(u), _ids(v), _ids(e)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    w = None if w is None else np.ascontiguousarray(w, dtype=np.float32)
+    B = len(u)
+    if grads is None:
+        grads = [np.zeros_like(a) for a in tab.arrs]
+    if losses is None:
+        losses = np.zeros(6, np.float64)
+    ts = tab.cstruct()
+    gs = _Grads(*[_ptr(a) for a in grads])
+    cf = np.ascontiguousarray(coefs[:6], dtype=np.float64)
+    lib().oracle_mstep_omp_f32(C.byref(ts), C.byref(gs), _ptr(u), _ptr(v), _ptr(e), _ptr(y), _ptr(w), C.c_int64(B),
+                               C.c_int64(B if bnorm is None else bnorm), _ptr(cf), C.c_uint32(flags),
+                               C.c_int(bool(include_dense_reg)), _ptr(losses), C.c_int(int(threads)))
+    return grads, losses
+
+
+def adam_omp(p, g, m, v, step: int, lr: float, threads: int, zero_grad=True, beta1=0.9, beta2=0.999, eps=1e-8):
+    lib().oracle_adam_omp_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), C.c_int64(p.size), C.c_int64(step), C.c_double(lr),
+                              C.c_double(beta1), C.c_double(beta2), C.c_double(eps), C.c_int(bool(zero_grad)),
+                              C.c_int(int(threads)))
+
+
+def estep_omp(tab: Tables, u, v, y, implicit: bool, threads: int, old_envs=None):
+    assert tab.prec == 'f32'
+    u, v = _ids(u), _ids(v)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    N = len(u)
+    new = np.empty(N, np.int64)
+    counts = np.zeros(tab.E, np.int64)
+    diff = np.zeros(1, np.int64)
+    old = None if old_envs is None else _ids(old_envs)
+    ts = tab.cstruct()
+    lib().oracle_estep_omp_f32(C.byref(ts), _ptr(u), _ptr(v), _ptr(y), C.c_int64(N),
+                               C.c_uint32(F_IMPLICIT if implicit else 0), _ptr(old), _ptr(new), _ptr(counts), _ptr(diff),
+                               C.c_int(int(threads)))
+    return new, counts, int(diff[0])
+
+
+class ParallelTrainer(Trainer):
+    """Trainer on the all-core functions, with persistent gradient buffers zeroed by the Adam pass (as
+    optimizer.zero_grad() + step() do): what bench.py times as the CPU baseline."""
+
+    def __init__(self, *args, threads: int, **kw):
+        super().__init__(*args, **kw)
+        self.threads = int(threads)
+        self.grads = [np.zeros_like(a) for a in self.tab.arrs]
+
+    def train_a_batch(self, lo, hi):
+        sl = slice(lo, hi)
+        _, losses = mstep_omp(self.tab, self.u[sl], self.v[sl], self.envs[sl], self.y[sl], self.sample_w[sl],
+                              self.coefs, self.flags, self.threads, grads=self.grads)
+        self.step += 1
+        for p, g, m, v in zip(self.tab.arrs, self.grads, self.m, self.vv):
+            adam_omp(p.reshape(-1), g.reshape(-1), m.reshape(-1), v.reshape(-1), self.step, self.lr, self.threads)
+        return losses
+
+    def cluster(self):
+        new, counts, diff = estep_omp(self.tab, self.u, self.v, self.y, self.implicit, self.threads, old_envs=self.envs)
+        self.envs = new
+        return diff

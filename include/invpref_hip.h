@@ -196,6 +196,20 @@ int invpref_mstep_rows_adam_sched_hip(const InvPrefTables *tables, const InvPref
                                       uint32_t flags, float *losses6, const InvPrefAdamSchedule *sched,
                                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* The gradient-pass + stand-alone-Adam sequence (multi-GPU: an all-reduce sits between the two; single GPU: rows of
+ * more than 128 floats) for HIP-graph replay.  invpref_mstep_rows_grad_sched_hip reads the step's slot (a scheduled
+ * gradient-reversal alpha, train.py:214-217) and leaves the schedule where it is; invpref_adam_ranges_sched_hip --
+ * the step's last launch -- takes its Adam scalars from the slot and fills the other slot for the next step.  Same
+ * contracts otherwise as invpref_mstep_rows_grad_hip / invpref_adam_ranges_hip below. */
+int invpref_mstep_rows_grad_sched_hip(const InvPrefTables *tables, const InvPrefTables *grads, const InvPrefRowPlan *plan,
+                                      const int64_t *envs, const float *scores, const float *sample_weights,
+                                      int64_t batch_norm, const InvPrefCoefs *coefs, uint32_t flags, float *losses6,
+                                      const InvPrefAdamSchedule *sched, void *workspace, size_t workspace_bytes,
+                                      void *stream);
+int invpref_adam_ranges_sched_hip(float *param, float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *offsets,
+                                  const int64_t *lengths, int32_t n_ranges, const InvPrefAdamSchedule *sched,
+                                  int zero_grad, void *stream);
+
 /* ---- backward of forward(): replaces autograd through InvPref*.forward + ReverseLayerF
  * (models.py:307-326 / :448-467, functions.py:7-16) for callers that build their own loss on the
  * unfused outputs (e.g. the reference's untouched train.py).  Upstream gradients d_* have the shapes

@@ -23,7 +23,8 @@ EXPORTS = [
     'invpref_rows_workspace_bytes', 'invpref_mstep_rows_grad_hip', 'invpref_mstep_rows_adam_hip',
     'invpref_adam_schedule_fill', 'invpref_mstep_rows_adam_sched_hip', 'invpref_eval_topk_hip',
     'invpref_eval_error_sums_hip', 'invpref_set_profile_event', 'invpref_static_pop_workspace_bytes',
-    'invpref_static_pop_hip', 'invpref_adam_ranges_hip',
+    'invpref_static_pop_hip', 'invpref_adam_ranges_hip', 'invpref_mstep_rows_grad_sched_hip',
+    'invpref_adam_ranges_sched_hip',
 ]
 
 
@@ -86,6 +87,10 @@ def lib():
                                                    i64, f64, f64, f64, f64, vp, C.c_size_t, vp]
         L.invpref_adam_ranges_hip.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32, i64, f64, f64, f64, f64, C.c_int, vp]
         L.invpref_adam_schedule_fill.argtypes = [vp, i64, i64, f64, f64, f64, f64]
+        L.invpref_mstep_rows_grad_sched_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), vp, vp, vp, vp, i64,
+                                                         C.POINTER(Coefs), u32, vp, C.POINTER(AdamSchedule), vp,
+                                                         C.c_size_t, vp]
+        L.invpref_adam_ranges_sched_hip.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32, C.POINTER(AdamSchedule), C.c_int, vp]
         L.invpref_mstep_rows_adam_sched_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), C.POINTER(Tables),
                                                         C.POINTER(Tables), vp, vp, vp, vp, i64, C.POINTER(Coefs), u32,
                                                         vp, C.POINTER(AdamSchedule), vp, C.c_size_t, vp]

@@ -502,8 +502,29 @@ struct AdamRanges {
     int64_t off4[4], end4[4];   // piece r covers float4 indices [off4[r], off4[r] + len4[r]); end4 = running total
     int n;
 };
+// one row of the device-side schedule, as laid out in include/invpref_hip.h (InvPrefAdamSchedule)
+struct SchedRowK {
+    AdamScalars ad;
+    float alpha, pad;
+};
+// sched_state != nullptr (HIP-graph replay: kernel arguments are frozen): the Adam scalars are read from slot
+// `sched_slot` of the device-side schedule, and one thread fills the other slot for the step after this one
+// (in the gradient-pass + stand-alone-Adam sequence THIS kernel is the step's last, so it moves the schedule on).
 __global__ __launch_bounds__(256) void adam_ranges_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
-                                                          float *__restrict__ v, AdamRanges r, AdamScalars a, int zero_grad) {
+                                                          float *__restrict__ v, AdamRanges r, AdamScalars a, int zero_grad,
+                                                          int *sched_state, const SchedRowK *sched_table, int sched_n,
+                                                          int sched_slot) {
+    if (sched_state) {
+        a = reinterpret_cast<const SchedRowK *>(sched_state + 16 * sched_slot + 2)->ad;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const int *cur = sched_state + 16 * sched_slot;
+            int *nxt = sched_state + 16 * (sched_slot ^ 1);
+            const int next = cur[0] + 1, base = cur[1], idx = next - base;
+            nxt[0] = next;
+            nxt[1] = base;
+            if (idx >= 0 && idx < sched_n) *reinterpret_cast<SchedRowK *>(nxt + 2) = sched_table[idx];
+        }
+    }
     const int64_t total = r.end4[r.n - 1];
     for (int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
         int q = 0;
@@ -905,14 +926,15 @@ int invpref_adam_hip(float *param, float *grad, float *exp_avg, float *exp_avg_s
     return (int)hipGetLastError();
 }
 
-int invpref_adam_ranges_hip(float *param, float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *offsets,
-                            const int64_t *lengths, int32_t n_ranges, int64_t step, double lr, double beta1, double beta2,
-                            double eps, int zero_grad, void *stream) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || !offsets || !lengths || n_ranges < 1 || n_ranges > 4 || step < 1)
+static int adam_ranges_launch(float *param, float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *offsets,
+                              const int64_t *lengths, int32_t n_ranges, const AdamScalars &a, int zero_grad,
+                              const InvPrefAdamSchedule *sched, void *stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !offsets || !lengths || n_ranges < 1 || n_ranges > 4)
         return INVPREF_EINVAL;
     if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
          reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15u)
         return INVPREF_EINVAL;
+    if (sched && (!sched->state || !sched->table || sched->n <= 0)) return INVPREF_EINVAL;
     AdamRanges r{};
     int64_t total = 0;
     for (int i = 0; i < n_ranges; i++) {
@@ -922,6 +944,19 @@ int invpref_adam_ranges_hip(float *param, float *grad, float *exp_avg, float *ex
         r.end4[i] = total;
     }
     r.n = n_ranges;
+    int64_t nb = (total + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(adam_ranges_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, r, a, zero_grad, sched ? sched->state : nullptr,
+                       sched ? reinterpret_cast<const SchedRowK *>(sched->table) : nullptr, sched ? sched->n : 0,
+                       sched ? (sched->slot & 1) : 0);
+    return (int)hipGetLastError();
+}
+
+int invpref_adam_ranges_hip(float *param, float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *offsets,
+                            const int64_t *lengths, int32_t n_ranges, int64_t step, double lr, double beta1, double beta2,
+                            double eps, int zero_grad, void *stream) {
+    if (step < 1) return INVPREF_EINVAL;
     const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     AdamScalars a;
     a.step_size = (float)(lr / bc1);
@@ -930,11 +965,15 @@ int invpref_adam_ranges_hip(float *param, float *grad, float *exp_avg, float *ex
     a.b2 = (float)beta2;
     a.w2 = (float)(1.0 - beta2);
     a.eps = (float)eps;
-    int64_t nb = (total + 255) / 256;
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(adam_ranges_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                       exp_avg_sq, r, a, zero_grad);
-    return (int)hipGetLastError();
+    return adam_ranges_launch(param, grad, exp_avg, exp_avg_sq, offsets, lengths, n_ranges, a, zero_grad, nullptr, stream);
+}
+
+int invpref_adam_ranges_sched_hip(float *param, float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *offsets,
+                                  const int64_t *lengths, int32_t n_ranges, const InvPrefAdamSchedule *sched,
+                                  int zero_grad, void *stream) {
+    if (!sched) return INVPREF_EINVAL;
+    return adam_ranges_launch(param, grad, exp_avg, exp_avg_sq, offsets, lengths, n_ranges, AdamScalars{}, zero_grad,
+                              sched, stream);
 }
 
 size_t invpref_estep_workspace_bytes(const InvPrefTables *tables, int64_t N) {

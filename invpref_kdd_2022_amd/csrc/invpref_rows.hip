@@ -130,34 +130,42 @@ __device__ __forceinline__ void finish_hot_rows(const DevTables &t, const HotRow
     const int row = h.rows[i];
     const float cnt = (float)h.cnt[i];
     float *sc = h.scratch + (int64_t)i * 2 * DP;
+    // every load of both tables goes out before the first store (the scratch rows are re-zeroed below, and a store
+    // the compiler cannot prove disjoint would otherwise split the loads into dependent round trips)
+    float4 p[2][NC], g[2][NC], m[2][NC], v[2][NC];
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
         if (pure && tt) break;
-        const float *T = tt == 0 ? h.Qi : h.Qa;
-        float4 p[NC], g[NC];
-        load_row<NC, VEC>(T, row, t.D, l16, p);
+        load_row<NC, VEC>(tt == 0 ? h.Qi : h.Qa, row, t.D, l16, p[tt]);
+#pragma unroll
+        for (int c = 0; c < NC; c++) g[tt][c] = *reinterpret_cast<const float4 *>(sc + tt * DP + (l16 + kRow * c) * 4);
+        if (fused) {
+            load_row<NC, VEC>(tt == 0 ? h.mQi : h.mQa, row, t.D, l16, m[tt]);
+            load_row<NC, VEC>(tt == 0 ? h.vQi : h.vQa, row, t.D, l16, v[tt]);
+        }
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+        if (pure && tt) break;
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            float4 *q = reinterpret_cast<float4 *>(sc + tt * DP + (l16 + kRow * c) * 4);
-            g[c] = *q;
-            *q = f4zero();  // leave the accumulator zeroed for the next step
-            g[c].x += cnt * (k.r2 * p[c].x + k.r1 * c_sign(p[c].x)); g[c].y += cnt * (k.r2 * p[c].y + k.r1 * c_sign(p[c].y));
-            g[c].z += cnt * (k.r2 * p[c].z + k.r1 * c_sign(p[c].z)); g[c].w += cnt * (k.r2 * p[c].w + k.r1 * c_sign(p[c].w));
+            *reinterpret_cast<float4 *>(sc + tt * DP + (l16 + kRow * c) * 4) = f4zero();  // zeroed for the next step
+            float4 &gg = g[tt][c];
+            const float4 pp = p[tt][c];
+            gg.x += cnt * (k.r2 * pp.x + k.r1 * c_sign(pp.x)); gg.y += cnt * (k.r2 * pp.y + k.r1 * c_sign(pp.y));
+            gg.z += cnt * (k.r2 * pp.z + k.r1 * c_sign(pp.z)); gg.w += cnt * (k.r2 * pp.w + k.r1 * c_sign(pp.w));
         }
         if (!fused) {
-            store_row<NC, VEC>(tt == 0 ? h.gQi : h.gQa, row, t.D, l16, g);
+            store_row<NC, VEC>(tt == 0 ? h.gQi : h.gQa, row, t.D, l16, g[tt]);
         } else {
-            float4 m[NC], v[NC];
-            load_row<NC, VEC>(tt == 0 ? h.mQi : h.mQa, row, t.D, l16, m);
-            load_row<NC, VEC>(tt == 0 ? h.vQi : h.vQa, row, t.D, l16, v);
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                adam1f(p[c].x, g[c].x, m[c].x, v[c].x, ad); adam1f(p[c].y, g[c].y, m[c].y, v[c].y, ad);
-                adam1f(p[c].z, g[c].z, m[c].z, v[c].z, ad); adam1f(p[c].w, g[c].w, m[c].w, v[c].w, ad);
+                adam1f(p[tt][c].x, g[tt][c].x, m[tt][c].x, v[tt][c].x, ad); adam1f(p[tt][c].y, g[tt][c].y, m[tt][c].y, v[tt][c].y, ad);
+                adam1f(p[tt][c].z, g[tt][c].z, m[tt][c].z, v[tt][c].z, ad); adam1f(p[tt][c].w, g[tt][c].w, m[tt][c].w, v[tt][c].w, ad);
             }
-            store_row<NC, VEC, ROWS_ST_P>(tt == 0 ? h.nQi : h.nQa, row, t.D, l16, p);
-            store_row<NC, VEC>(tt == 0 ? h.mQi : h.mQa, row, t.D, l16, m);
-            store_row<NC, VEC>(tt == 0 ? h.vQi : h.vQa, row, t.D, l16, v);
+            store_row<NC, VEC, ROWS_ST_P>(tt == 0 ? h.nQi : h.nQa, row, t.D, l16, p[tt]);
+            store_row<NC, VEC>(tt == 0 ? h.mQi : h.mQa, row, t.D, l16, m[tt]);
+            store_row<NC, VEC>(tt == 0 ? h.vQi : h.vQa, row, t.D, l16, v[tt]);
         }
     }
 }
@@ -1028,7 +1036,9 @@ __global__ __launch_bounds__(1024) void rows_finish_kernel(const FinishArgs f, i
     const AdamScalars ad = sched_state ? sched_slot_ptr(sched_state, sched_slot)->ad : f.ad;
     // the device-side schedule moves on: one thread fills the OTHER slot with the next step's number and
     // scalars.  Nobody reads that slot before the next launch, so no ordering between blocks is needed.
-    if (sched_state && blockIdx.x == 0 && threadIdx.x == 0) {
+    // (in the gradient-pass form -- fused == 0 -- the stand-alone Adam kernel that follows is the step's last
+    //  launch and moves the schedule on; here the slot is only read, for a scheduled alpha)
+    if (sched_state && f.fused && blockIdx.x == 0 && threadIdx.x == 0) {
         const int *cur = sched_state + 16 * sched_slot;
         int *nxt = sched_state + 16 * (sched_slot ^ 1);
         const int next = cur[0] + 1, base = cur[1], idx = next - base;
@@ -1219,6 +1229,16 @@ int invpref_mstep_rows_grad_hip(const InvPrefTables *tables, const InvPrefTables
                                 void *workspace, size_t workspace_bytes, void *stream) {
     return launch_rows(tables, plan, envs, scores, sample_weights, batch_norm, coefs, flags, losses6, workspace,
                        workspace_bytes, (hipStream_t)stream, 0, grads, nullptr, nullptr, nullptr, AdamScalars{});
+}
+
+int invpref_mstep_rows_grad_sched_hip(const InvPrefTables *tables, const InvPrefTables *grads, const InvPrefRowPlan *plan,
+                                      const int64_t *envs, const float *scores, const float *sample_weights,
+                                      int64_t batch_norm, const InvPrefCoefs *coefs, uint32_t flags, float *losses6,
+                                      const InvPrefAdamSchedule *sched, void *workspace, size_t workspace_bytes,
+                                      void *stream) {
+    if (!sched) return INVPREF_EINVAL;
+    return launch_rows(tables, plan, envs, scores, sample_weights, batch_norm, coefs, flags, losses6, workspace,
+                       workspace_bytes, (hipStream_t)stream, 0, grads, nullptr, nullptr, nullptr, AdamScalars{}, sched);
 }
 
 int invpref_mstep_rows_adam_hip(const InvPrefTables *tables, const InvPrefTables *new_tables,

@@ -96,10 +96,12 @@ def adam_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_av
 
 
 def adam_ranges_(param, grad, exp_avg, exp_avg_sq, offsets, lengths, step: int, lr: float, beta1: float = 0.9,
-                 beta2: float = 0.999, eps: float = 1e-8, zero_grad: bool = True) -> None:
-    """the same rule over up to four (offset, length) pieces of the flat buffers in one launch"""
+                 beta2: float = 0.999, eps: float = 1e-8, zero_grad: bool = True, sched=None) -> None:
+    """the same rule over up to four (offset, length) pieces of the flat buffers in one launch.
+    sched = (state, table, slot): scalars from the device-side schedule (graph replay); the launch moves it on."""
+    s_state, s_table, s_slot = sched if sched is not None else (None, None, 0)
     _o().adam_ranges_(param, grad, exp_avg, exp_avg_sq, [int(o) for o in offsets], [int(n) for n in lengths], int(step),
-                      float(lr), float(beta1), float(beta2), float(eps), bool(zero_grad))
+                      float(lr), float(beta1), float(beta2), float(eps), bool(zero_grad), s_state, s_table, int(s_slot))
 
 
 def estep(params: Sequence[torch.Tensor], users, items, scores, implicit: bool, old_envs: Optional[torch.Tensor],
@@ -159,11 +161,14 @@ def rows_workspace(params, dplan, workspace: Workspace, pure: bool = False) -> t
 
 
 def mstep_rows_grad(params, grads, dplan, envs, scores, sample_weights, batch_norm: int, coefs, flags: int,
-                     losses6: torch.Tensor, workspace: Workspace) -> None:
-    """Planned, atomic-free M-step gradient of one minibatch (plan.py): OVERWRITES every row of grads."""
+                     losses6: torch.Tensor, workspace: Workspace, sched=None) -> None:
+    """Planned, atomic-free M-step gradient of one minibatch (plan.py): OVERWRITES every row of grads.
+    sched = (state, table, slot): a scheduled alpha is read from the device-side schedule (graph replay)."""
     ws = rows_workspace(params, dplan, workspace)
+    s_state, s_table, s_slot = sched if sched is not None else (None, None, 0)
     _o().train_step_planned_grad_(list(params), list(grads), dplan.buf, dplan.meta, envs, scores, sample_weights,
-                                  int(batch_norm), [float(c) for c in coefs[:6]], int(flags), losses6, ws)
+                                  int(batch_norm), [float(c) for c in coefs[:6]], int(flags), losses6, s_state, s_table,
+                                  int(s_slot), ws)
 
 
 def mstep_rows_adam(params, new_params, exp_avg, exp_avg_sq, dplan, envs, scores, sample_weights, batch_norm: int,

@@ -153,16 +153,32 @@ def _train_step_fused_fake(tables, grads, users, items, envs, scores, sample_wei
 
 _define('train_step_planned_grad_(Tensor[] tables, Tensor(a!)[] grads, Tensor plan_buf, Tensor plan_meta, Tensor? envs, '
         'Tensor scores, Tensor? sample_weights, int batch_norm, float[] coefs, int flags, Tensor(b!) losses6, '
-        'Tensor(c!) workspace) -> ()')
+        'Tensor? sched_state, Tensor? sched_table, int sched_slot, Tensor(c!) workspace) -> ()')
+
+
+def _sched_struct(sched_state, sched_table, sched_slot):
+    _capi._req(sched_state, torch.int32, 'sched_state')
+    _f32(sched_table, 'sched_table')
+    if sched_table is None or sched_state.numel() < 32 or sched_table.dim() != 2 or sched_table.shape[1] != 8:
+        raise InvPrefError('sched_state int32[32] and sched_table float32[n, 8] go together')
+    return _capi.AdamSchedule(sched_state.data_ptr(), sched_table.data_ptr(), sched_table.shape[0], int(sched_slot) & 1)
 
 
 @_impl('train_step_planned_grad_')
 def _planned_grad(tables, grads, plan_buf, plan_meta, envs, scores, sample_weights, batch_norm, coefs, flags, losses6,
-                  workspace):
+                  sched_state, sched_table, sched_slot, workspace):
     t, g = _tables(tables), _tables(grads)
     _f32(scores, 'scores'); _f32(sample_weights, 'sample_weights'); _f32(losses6, 'losses6')
     cf = _coefs(coefs)
     ps = _plan_struct(plan_buf, plan_meta)
+    if sched_state is not None:   # graph replay: a scheduled alpha comes from the device-side schedule
+        sc = _sched_struct(sched_state, sched_table, sched_slot)
+        check(lib().invpref_mstep_rows_grad_sched_hip(C.byref(t), C.byref(g), C.byref(ps),
+                                                      ptr(None if envs is None else _ids(envs, 'envs')), ptr(scores),
+                                                      ptr(sample_weights), int(batch_norm), C.byref(cf), int(flags),
+                                                      ptr(losses6), C.byref(sc), ptr(workspace), workspace.numel(),
+                                                      stream_ptr()), 'invpref_mstep_rows_grad_sched_hip')
+        return
     check(lib().invpref_mstep_rows_grad_hip(C.byref(t), C.byref(g), C.byref(ps),
                                              ptr(None if envs is None else _ids(envs, 'envs')), ptr(scores),
                                              ptr(sample_weights), int(batch_norm), C.byref(cf), int(flags),
@@ -172,7 +188,7 @@ def _planned_grad(tables, grads, plan_buf, plan_meta, envs, scores, sample_weigh
 
 @_fake('train_step_planned_grad_')
 def _planned_grad_fake(tables, grads, plan_buf, plan_meta, envs, scores, sample_weights, batch_norm, coefs, flags,
-                       losses6, workspace):
+                       losses6, sched_state, sched_table, sched_slot, workspace):
     return None
 
 
@@ -193,11 +209,7 @@ def _planned_adam(tables, new_tables, exp_avg, exp_avg_sq, plan_buf, plan_meta, 
     pe = ptr(None if envs is None else _ids(envs, 'envs'))
     if sched_state is not None:
         # Adam scalars (and a scheduled alpha) come from the device-side schedule: graph replay freezes arguments
-        _capi._req(sched_state, torch.int32, 'sched_state')
-        _f32(sched_table, 'sched_table')
-        if sched_table is None or sched_state.numel() < 32 or sched_table.dim() != 2 or sched_table.shape[1] != 8:
-            raise InvPrefError('sched_state int32[32] and sched_table float32[n, 8] go together')
-        sc = _capi.AdamSchedule(sched_state.data_ptr(), sched_table.data_ptr(), sched_table.shape[0], int(sched_slot) & 1)
+        sc = _sched_struct(sched_state, sched_table, sched_slot)
         check(lib().invpref_mstep_rows_adam_sched_hip(C.byref(t), C.byref(tn), C.byref(tm), C.byref(tv), C.byref(ps), pe,
                                                       ptr(scores), ptr(sample_weights), int(batch_norm), C.byref(cf),
                                                       int(flags), ptr(losses6), C.byref(sc), ptr(workspace),
@@ -246,23 +258,32 @@ def _adam_dense_fake(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, e
 
 
 _define('adam_ranges_(Tensor(a!) param, Tensor(b!) grad, Tensor(c!) exp_avg, Tensor(d!) exp_avg_sq, int[] offsets, '
-        'int[] lengths, int step, float lr, float beta1, float beta2, float eps, bool zero_grad) -> ()')
+        'int[] lengths, int step, float lr, float beta1, float beta2, float eps, bool zero_grad, '
+        'Tensor(e!)? sched_state, Tensor? sched_table, int sched_slot) -> ()')
 
 
 @_impl('adam_ranges_')
-def _adam_ranges(param, grad, exp_avg, exp_avg_sq, offsets, lengths, step, lr, beta1, beta2, eps, zero_grad):
+def _adam_ranges(param, grad, exp_avg, exp_avg_sq, offsets, lengths, step, lr, beta1, beta2, eps, zero_grad,
+                 sched_state, sched_table, sched_slot):
     n = _adam_check(param, grad, exp_avg, exp_avg_sq)
     k = len(offsets)
     if k != len(lengths) or not 1 <= k <= 4 or any(o < 0 or ln <= 0 or o + ln > n for o, ln in zip(offsets, lengths)):
         raise InvPrefError('adam_ranges_: 1..4 (offset, length) pieces inside the buffers')
     offs, lens = (C.c_int64 * k)(*offsets), (C.c_int64 * k)(*lengths)
+    if sched_state is not None:   # graph replay: scalars from the device-side schedule, which this launch moves on
+        sc = _sched_struct(sched_state, sched_table, sched_slot)
+        check(lib().invpref_adam_ranges_sched_hip(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), offs, lens, k,
+                                                  C.byref(sc), int(bool(zero_grad)), stream_ptr()),
+              'invpref_adam_ranges_sched_hip')
+        return
     check(lib().invpref_adam_ranges_hip(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), offs, lens, k, int(step),
                                         float(lr), float(beta1), float(beta2), float(eps), int(bool(zero_grad)),
                                         stream_ptr()), 'invpref_adam_ranges_hip')
 
 
 @_fake('adam_ranges_')
-def _adam_ranges_fake(param, grad, exp_avg, exp_avg_sq, offsets, lengths, step, lr, beta1, beta2, eps, zero_grad):
+def _adam_ranges_fake(param, grad, exp_avg, exp_avg_sq, offsets, lengths, step, lr, beta1, beta2, eps, zero_grad,
+                      sched_state, sched_table, sched_slot):
     return None
 
 

@@ -191,6 +191,7 @@ class _InvPrefTrainManager:
         import torch.distributed as _dist
         self._collective_ok = _dist.is_available() and _dist.is_initialized()
         self._graphs, self._graph_warm = {}, False
+        self._estep_graphs = {}
         self._grad_stale = False
         self._sched = None
         self._sched_synced = False
@@ -292,8 +293,11 @@ class _InvPrefTrainManager:
             self._raw_batches.append((lo, hi - lo, self.shard.global_batch_len(k), self.users_tensor[lo:hi],
                                       self.items_tensor[lo:hi], self.scores_tensor[lo:hi],
                                       None if self._pure else v[0], None if self._pure else v[1]))
-        rg = getattr(self, '_adam_ranges', [(0, st.n)])
-        self._adam_ranges_one = len(rg) > 1 and len(rg) <= 4 and all(o % 4 == 0 and n % 4 == 0 for o, n in rg)
+        if not hasattr(self, '_adam_ranges'):
+            self._adam_ranges = [(0, st.n)]
+        rg = self._adam_ranges
+        self._adam_ranges_ok = len(rg) <= 4 and all(o % 4 == 0 and n % 4 == 0 for o, n in rg)   # one ranged launch can do it
+        self._adam_ranges_one = len(rg) > 1 and self._adam_ranges_ok
         if self.use_plan and self._plans is None:
             t0 = time.perf_counter()
             u, v = self.users_tensor.cpu().numpy(), self.items_tensor.cpu().numpy()
@@ -331,9 +335,13 @@ class _InvPrefTrainManager:
             if mid_event is not None:
                 mid_event.record()
             return
+        st.step += 1
+        # graph capture: per-step scalars (Adam bias corrections, a scheduled alpha) come from the device-side
+        # schedule, read by the gradient pass and moved on by the ranged Adam launch that ends the step
+        sc = (self._sched['state'], self._sched['table'], st.step & 1) if sched else None
         if self.use_plan:
             ops.mstep_rows_grad(st.p_views, st.g_views, self._plans[k], be, by, bw, bn, coefs, self._flags, lp,
-                                self.workspace)
+                                self.workspace, sched=sc)
         else:
             ops.mstep_grad(st.p_views, st.g_views, bu, bi, be, by, bw, bn, coefs, self._flags, lp, self.workspace)
         if multi:
@@ -341,14 +349,13 @@ class _InvPrefTrainManager:
                 all_reduce_sum_(st.grad[self._ar_lo:], self.process_group)   # the step's one exchange
         if mid_event is not None:
             mid_event.record()
-        st.step += 1
         # the planned gradient pass overwrites every row it is responsible for, so the gradient buffer needs no zeroing
         zero = not self.use_plan
         if self.use_plan:
             self._grad_stale = True   # see _step()
-        if self._adam_ranges_one:   # every piece in one launch
+        if self._adam_ranges_one or sched:   # every piece in one launch
             ops.adam_ranges_(st.param, st.grad, st.exp_avg, st.exp_avg_sq, [o for o, _ in self._adam_ranges],
-                             [ln for _, ln in self._adam_ranges], st.step, self.lr, zero_grad=zero)
+                             [ln for _, ln in self._adam_ranges], st.step, self.lr, zero_grad=zero, sched=sc)
         else:
             for o, ln in self._adam_ranges:
                 ops.adam_(st.param[o:o + ln], st.grad[o:o + ln], st.exp_avg[o:o + ln], st.exp_avg_sq[o:o + ln], st.step,
@@ -438,8 +445,10 @@ class _InvPrefTrainManager:
             self._raw_setup()
             self._graphs.clear()
         st = self.state
-        graph_ok = self.use_graph and self.use_plan and self.world_size == 1 and not self._unfused \
-            and not self._force_sharded_path and self.batch_num <= self._SCHED_N // 2
+        # the fused single-GPU step, and the gradient-pass -> [all-reduce] -> ranged-Adam sequence of sharded runs and
+        # wide rows (RCCL collectives record into a HIP graph like kernels do), are replayed as whole-epoch graphs
+        fused_seq = self._fused_seq()
+        graph_ok = self.graphs_enabled()
         if graph_ok and self._graph_warm:
             n = min(want, self._graph_epochs)
             steps = n * self.batch_num
@@ -447,8 +456,10 @@ class _InvPrefTrainManager:
             g = self._graph_for(n)
             g.replay()
             st.step += steps
-            if steps % 2:
+            if steps % 2 and fused_seq:
                 st.swap()
+            if self.world_size > 1:
+                all_reduce_sum_(self._epoch_losses[:n], self.process_group)   # per-rank loss partials -> totals
             if self.update_alpha:   # what the reference's loop leaves in self.alpha after these epochs
                 self.alpha = self._scheduled_alpha(self.epoch_cnt + n - 1, self.batch_num - 1)
         else:
@@ -461,6 +472,28 @@ class _InvPrefTrainManager:
         self.epoch_cnt += n
         return self._epoch_losses[:n].mean(dim=1)
 
+    def _fused_seq(self) -> bool:
+        """one fused M-step + Adam launch per step (single GPU, rows of at most 128 floats), parameters ping-pong"""
+        return self.world_size == 1 and not self._unfused and not self._force_sharded_path
+
+    def graphs_enabled(self) -> bool:
+        """Are whole epochs replayed as HIP graphs?  (after the first, eagerly issued, epoch)"""
+        if getattr(self, '_raw_ptrs', None) is None:
+            self._raw_setup()
+        return bool(self.use_graph and self.use_plan and self.users_tensor.is_cuda
+                    and self.batch_num <= self._SCHED_N // 2
+                    and (self._fused_seq() or (self._adam_ranges_ok and self._graph_collectives())))
+
+    def _graph_collectives(self) -> bool:
+        """May the step's all-reduce be captured?  Yes on the RCCL backend (or when there is none to capture);
+        INVPREF_NO_COLLECTIVE_GRAPH=1 keeps the sharded loop eager."""
+        if os.environ.get('INVPREF_NO_COLLECTIVE_GRAPH', '0') == '1':
+            return False
+        if self.world_size == 1 and not self._collective_ok:
+            return True
+        import torch.distributed as dist
+        return dist.get_backend(self.process_group) == 'nccl'
+
     def _graph_for(self, n: int):
         """The HIP graph of n epochs starting from the current parameter buffer (captured on first use)."""
         st = self.state
@@ -469,7 +502,8 @@ class _InvPrefTrainManager:
         if g is None:
             step0, views0 = st.step, st.p_views
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # (thread-local capture mode: the RCCL watchdog thread of a process group may query events meanwhile)
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 self._issue_epochs(None, True, n)
             # capture records, it does not run: put the host-side bookkeeping back
             st.step = step0
@@ -489,7 +523,8 @@ class _InvPrefTrainManager:
             step0 = self.state.step
             for _ in range(2):  # a fused step swaps the buffers and flips the schedule slot: both move together
                 self._graph_for(n)
-                self.state.swap()
+                if self._fused_seq():
+                    self.state.swap()
                 self.state.step += 1
             self.state.step = step0
 
@@ -528,6 +563,13 @@ class _InvPrefTrainManager:
         sync=False: no read-back, returns diff_num as a device int64[1] tensor."""
         self.model.eval()
         eps = self._eps_rows(self.users_tensor.shape[0]) if self.cluster_use_random_sort else None
+        if self.world_size == 1 and self.use_graph and self.envs.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # one HIP-graph replay instead of a handful of eager launches behind the Python operator layer (the
+            # host-side cost of those was several times the 40 us the kernels take); the per-row eps rows of
+            # train.py:192-196 are host random numbers: they are copied into the buffer the graph reads
+            counts, diff, cw, sw = self._cluster_replay(eps)
+            self._pending_stat = (counts, cw, sw)
+            return int(diff.item()) if sync else diff.clone()
         # new assignments overwrite self.envs in place (the kernel reads old_envs[i] before writing i)
         new, counts, diff, cw, sw = ops.estep(self.state.p_views, self.users_tensor, self.items_tensor,
                                               self.scores_tensor, self.implicit, self.envs, self.workspace,
@@ -540,6 +582,36 @@ class _InvPrefTrainManager:
             cw, sw = ops.sample_weights(self.envs, counts, self.n_total, self.envs_num)
         self._pending_stat = (counts, cw, sw)
         return int(diff.item()) if sync else diff.clone()
+
+    def _cluster_replay(self, eps):
+        """The E-step + the count / weight half of stat_envs as a captured graph, one per parameter buffer (the
+        fused M-step ping-pongs between two) and per interaction-array set; outputs live in the graph's pool."""
+        key = (id(self.state.p_views), self.envs.data_ptr(), self.users_tensor.data_ptr(), eps is not None)
+        ent = self._estep_graphs.get(key)
+        if ent is None:
+            eps_buf = None if eps is None else torch.empty_like(eps)
+
+            def run():
+                _, counts, diff, cw, sw = ops.estep(self.state.p_views, self.users_tensor, self.items_tensor,
+                                                    self.scores_tensor, self.implicit, self.envs, self.workspace,
+                                                    eps_rows=eps_buf, new_envs=self.envs, want_weights=True)
+                return counts, diff, cw, sw
+            # sizes the workspace outside the capture (envs is restored: the warm-up is not an E-step)
+            keep = self.envs.clone()
+            if eps_buf is not None:
+                eps_buf.copy_(eps)
+            run()
+            self.envs.copy_(keep)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = run()
+            ent = self._estep_graphs[key] = (g, eps_buf, outs)
+        g, eps_buf, outs = ent
+        if eps_buf is not None:
+            eps_buf.copy_(eps)
+        g.replay()
+        return outs
 
     def cluster_a_batch(self, batch_users_tensor, batch_items_tensor, batch_scores_tensor) -> torch.Tensor:
         """train.py:169-202 for one batch (single-rank semantics)."""

@@ -373,7 +373,8 @@ def test_rank0_of_two_code_path_on_gpu(monkeypatch, mode):
         cnt = mgr.stat_envs()
         assert sum(cnt.values()) == mgr.users_tensor.shape[0]      # (one contribution summed: this rank's rows)
         tr = mgr.train_epochs(2)
-        assert all(np.isfinite(list(d.values())).all() for d in tr) and not mgr._graphs
+        # the second epoch is a replayed HIP graph with the step's RCCL all-reduce captured inside it
+        assert all(np.isfinite(list(d.values())).all() for d in tr) and mgr._graphs
         d = mgr.cluster()
         cnt = mgr.stat_envs()
         assert 0 <= d <= mgr.users_tensor.shape[0] and sum(cnt.values()) == mgr.users_tensor.shape[0]
@@ -396,6 +397,48 @@ def test_rank0_of_two_code_path_on_gpu(monkeypatch, mode):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('mode', ['rows', 'users'])
+def test_sharded_epochs_graph_vs_eager(monkeypatch, mode):
+    """The sharded epoch (planned gradient pass -> RCCL all-reduce -> ranged Adam per step) captured ONCE into a HIP
+    graph and replayed, against the same sequence issued eagerly (INVPREF_NO_COLLECTIVE_GRAPH=1), on a 1-rank RCCL
+    group: mechanics of capture / replay with the collective inside, the device-side schedule (Adam scalars moved on
+    by the ranged Adam launch), the scheduled alpha."""
+    import torch.distributed as dist
+    z = np.load(os.path.join(G, 'g4_yahoo_like_traj.npz'))
+    U, I, E, D, bs, epochs, seed = [int(x) for x in z['meta']]
+    data = synth.yahoo_like(seed)[:30000]
+    tabs = synth.tables(seed + 7, U, I, E, D, std=0.05)
+    monkeypatch.setenv('INVPREF_FORCE_SHARDED_PATH', '1')
+    monkeypatch.setenv('INVPREF_SHARD', mode)
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29535')
+        dist.init_process_group('nccl', rank=0, world_size=1)
+    res = []
+    try:
+        for eager in ('1', '0'):
+            monkeypatch.setenv('INVPREF_NO_COLLECTIVE_GRAPH', eager)
+            model = InvPrefImplicit(U, I, E, D, reg_only_embed=False, reg_env_embed=True)
+            model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+            np.random.seed(seed)
+            kw = dict(use_class_re_weight=True, use_recommend_re_weight=True)
+            mgr = _mgr(ImplicitTrainManager, model, data, z, **kw)
+            mgr.alpha, mgr.update_alpha = 0., True          # the alpha schedule of train.py:214-217
+            mgr.stat_envs()
+            tr = mgr.train_epochs(5)
+            d = mgr.cluster()
+            tr += mgr.train_epochs(2)
+            assert bool(mgr._graphs) == (eager == '0')
+            res.append((np.array([[e[k] for k in LOSS_KEYS] for e in tr]), d,
+                        {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}))
+    finally:
+        dist.destroy_process_group()
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-6)
+    assert abs(res[0][1] - res[1][1]) <= 3
+    for k in O.PARAM_NAMES:
+        _assert_same_run(np.abs(res[0][2][k] - res[1][2][k]), float(z['coefs'][6]), k)
+
+
 def test_wide_rows_take_the_unfused_sequence(monkeypatch):
     """factor_num > 128 (four 16-lane chunks per row): the manager runs gradient pass + flat Adam instead of the fused
     pass (faster at that row size); INVPREF_FUSED=1 forces the fused pass.  Same trajectory either way."""
@@ -414,7 +457,7 @@ def test_wide_rows_take_the_unfused_sequence(monkeypatch):
                                    use_class_re_weight=True, use_recommend_re_weight=True, cluster_use_random_sort=False)
         assert mgr._unfused == (fused == '') and mgr.use_plan
         (losses, _), _, (diffs, cnts, _) = mgr.train(silent=True)
-        assert bool(mgr._graphs) == (fused == '1')
+        assert bool(mgr._graphs)   # both sequences are replayed as whole-epoch HIP graphs
         res.append((np.array([[l[k] for k in LOSS_KEYS] for l in losses]), diffs,
                     {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}))
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=5e-5)

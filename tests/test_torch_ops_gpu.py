@@ -28,7 +28,7 @@ def _setup(implicit=True, seed=0):
     return data, tabs, envs, w, P, t
 
 
-def _ws(nbytes=1 << 22, zero=False):
+def _ws(nbytes=1 << 26, zero=False):
     return (torch.zeros if zero else torch.empty)(nbytes, dtype=torch.uint8, device=DEV)
 
 
@@ -133,7 +133,8 @@ def test_planned_ops_vs_oracle():
     G = [torch.full_like(p, 7.0) for p in P]      # every row is overwritten
     losses = torch.zeros(6, device=DEV)
     ws = _ws(zero=True)
-    torch.ops.invpref.train_step_planned_grad_(P, G, dp.buf, dp.meta, t['e'], t['y'], t['w'], B, COEFS, flags, losses, ws)
+    torch.ops.invpref.train_step_planned_grad_(P, G, dp.buf, dp.meta, t['e'], t['y'], t['w'], B, COEFS, flags, losses,
+                                               None, None, 0, ws)
     np.testing.assert_allclose(losses.cpu().numpy(), ol, rtol=1e-5)
     for k, g, o in zip(ops.PARAM_NAMES, G, og):
         assert _relerr(g.cpu().numpy(), o) < 2e-5, k
@@ -170,13 +171,14 @@ def test_opcheck():
         1, 0.01, 0.9, 0.999, 1e-8, True))
     oc(torch.ops.invpref.adam_ranges_.default,
        (torch.randn(n, device=DEV), torch.randn(n, device=DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV),
-        [0, 512], [256, 128], 1, 0.01, 0.9, 0.999, 1e-8, False))
+        [0, 512], [256, 128], 1, 0.01, 0.9, 0.999, 1e-8, False, None, None, 0))
     oc(torch.ops.invpref.forward.default, (P, t['u'], t['v'], t['e'], True))
     oc(torch.ops.invpref.stat_envs.default, (t['e'], E, True, _ws()))
     oc(torch.ops.invpref.predict.default, (P[0], P[1], t['u'][:16], True))
     dp = planlib.upload(planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I), DEV)
     oc(torch.ops.invpref.train_step_planned_grad_.default,
-       (P, G, dp.buf, dp.meta, t['e'], t['y'], t['w'], B, COEFS, flags, torch.zeros(6, device=DEV), _ws(zero=True)))
+       (P, G, dp.buf, dp.meta, t['e'], t['y'], t['w'], B, COEFS, flags, torch.zeros(6, device=DEV), None, None, 0,
+        _ws(zero=True)))
     oc(torch.ops.invpref.train_step_planned_adam_.default,
        (P, [torch.zeros_like(p) for p in P], [torch.zeros_like(p) for p in P], [torch.zeros_like(p) for p in P],
         dp.buf, dp.meta, t['e'], t['y'], t['w'], B, COEFS, flags, torch.zeros(6, device=DEV), 1, 0.005, 0.9, 0.999,

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic: phase time stamps of mstep_rows_kernel (GPU box).  Not part of the product or tests."""
+"""Diagnostic: phase time stamps of mstep_rows_kernel (GPU box).  Not part of the product or tests.
+The stamped launch is the LAST of a run of steps over different minibatch plans with ping-pong parameter buffers
+(the cache state of the training loop), STAMPS_STEPS of them (default 12)."""
 import os
 import sys
 
@@ -13,48 +15,57 @@ os.environ['INVPREF_STAMPS'] = hex(stamps.data_ptr())
 from invpref_kdd_2022_amd import ops, plan as planlib, synth
 
 U, I, E, D, B = 15400, 1000, 4, 64, 8192
-data = synth.interactions(1, U, I, B, implicit=True)
+nsteps = int(os.environ.get('STAMPS_STEPS', '12'))
+data = synth.yahoo_like()[:nsteps * B]
 tabs = synth.tables(2, U, I, E, D)
 P = [torch.from_numpy(tabs[k]).to(dev) for k in ops.PARAM_NAMES]
 P2 = [torch.zeros_like(p) for p in P]
 M = [torch.zeros_like(p) for p in P]
 V = [torch.zeros_like(p) for p in P]
 y = torch.from_numpy(data[:, 2].astype(np.float32)).to(dev)
-e = torch.from_numpy(np.random.RandomState(3).randint(0, E, B).astype(np.int64)).to(dev)
-w = torch.rand(B, device=dev)
+e = torch.from_numpy(np.random.RandomState(3).randint(0, E, len(data)).astype(np.int64)).to(dev)
+w = torch.rand(len(data), device=dev)
 ws = ops.Workspace(dev)
 losses = torch.zeros(6, device=dev)
 coefs = (3.35, 9.99, 9.06, 3.13, 0.49, 1.9)
 flags = ops.flags_of(True, False, True, True, False)
 if os.environ.get('STAMPS_DRAIN') != '1':
     os.environ['INVPREF_STAMPS_NODRAIN'] = '1'
-for per_slice, rpt, hot, dense in ((2, 1, 16, 32), (2, 1, 16, 16), (1, 1, 16, 32)):
+combos = [tuple(int(x) for x in c.split(',')) for c in os.environ.get('STAMPS_COMBOS', '2,1,16,32').split(';')]
+for per_slice, rpt, hot, dense in combos:
     os.environ['INVPREF_PLAN_DENSE'] = str(dense)
-    pl = planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, per_slice=per_slice, rounds_per_task=rpt,
-                                hot_threshold=hot)
-    dp = planlib.upload(pl, dev)
-    for _ in range(5):
-        stamps.zero_()
-        ops.mstep_rows_adam(P, P2, M, V, dp, e, y, w, B, coefs, flags, losses, 5, 0.005, ws)
+    pls = [planlib.build_row_plan(data[k * B:(k + 1) * B, 0], data[k * B:(k + 1) * B, 1], data[k * B:(k + 1) * B, 2], U, I,
+                                  per_slice=per_slice, rounds_per_task=rpt, hot_threshold=hot) for k in range(nsteps)]
+    dps = [planlib.upload(pl, dev) for pl in pls]
+    for rep in range(3):
+        a, b = P, P2
+        for k in range(nsteps):
+            if k == nsteps - 1:
+                stamps.zero_()
+            sl = slice(k * B, (k + 1) * B)
+            ops.mstep_rows_adam(a, b, M, V, dps[k], e[sl], y[sl], w[sl], B, coefs, flags, losses, 5 + k, 0.005, ws)
+            a, b = b, a
     torch.cuda.synchronize()
+    pl, dp = pls[-1], dps[-1]
     st = stamps.cpu().numpy().reshape(-1, 8)[:dp.n_tasks].astype(np.int64)
     nd = -(-B // dense)
     ni = pl['n_item_rounds'] // rpt
     njob = -(-dp.n_rounds // rpt)
     t0 = st[:, 0].min()
     end = np.where(st[:, 7] > 0, st[:, 7], st[:, 6])
-    print(f'== per_slice={per_slice} hot>{hot} dense/task={dense}: tasks {dp.n_tasks} = dense {nd} + item {ni} + user {njob - ni} + stream {dp.n_tasks - njob - nd}; span {(end.max() - t0) / 100:.2f} us')
+    print(f'== per_slice={per_slice} hot>{hot} dense/task={dense}: tasks {dp.n_tasks} = dense {nd} + item {ni} + user {njob - ni} + stream {dp.n_tasks - njob - nd}, n_hot {len(pl["hot_rows"])}; span {(end.max() - t0) / 100:.2f} us')
     for name, sl in (('dense', slice(0, nd)), ('item', slice(nd, nd + ni)), ('user', slice(nd + ni, nd + njob)), ('stream', slice(nd + njob, None))):
         s0, e0 = (st[sl, 0] - t0) / 100, (end[sl] - t0) / 100
         if len(s0) == 0:
             continue
         life = e0 - s0
-        print(f'  {name:6s} n={len(s0):4d} start med {np.median(s0):5.2f} p90 {np.quantile(s0, .9):5.2f} max {s0.max():5.2f} | life med {np.median(life):5.2f} p90 {np.quantile(life, .9):5.2f} max {life.max():5.2f} | end med {np.median(e0):5.2f} max {e0.max():5.2f}')
+        print(f'  {name:6s} n={len(s0):4d} start med {np.median(s0):5.2f} p90 {np.quantile(s0, .9):5.2f} max {s0.max():5.2f} | life med {np.median(life):5.2f} p90 {np.quantile(life, .9):5.2f} max {life.max():5.2f} | end med {np.median(e0):5.2f} p90 {np.quantile(e0, .9):5.2f} max {e0.max():5.2f}')
 
     for name, sl in (('item', slice(nd, nd + ni)), ('user', slice(nd + ni, nd + njob))):
         j = st[sl].astype(np.float64)
         ph = np.diff(j[:, :7], axis=1) / 100
         print('  %s job phases (us, median): stage issue %.2f | descriptor %.2f | gathers+sync %.2f | interactions %.2f | slice meet %.2f | adam+store %.2f' % ((name,) + tuple(np.median(ph, axis=0))))
     d = st[:nd].astype(np.float64)
-    ph = np.diff(d[:, [0, 1, 2, 3, 4, 5, 6, 7]], axis=1) / 100
-    print('  dense phases (us, median): stage+sync %.2f | ids+gather %.2f | eval %.2f | records+sync %.2f | accumulate %.2f | hot atomics + 2nd iteration %.2f | epilogue %.2f' % tuple(np.median(ph, axis=0)))
+    ph = np.diff(d, axis=1) / 100
+    print('  dense phases (us, median / max): stage+sync %.2f/%.2f | first eval %.2f/%.2f | rest of loop %.2f/%.2f | slab atomics + drain + sync %.2f/%.2f | arrival counters %.2f/%.2f | hot rows finished here %.2f/%.2f | slab fold (last task only) %.2f/%.2f'
+          % tuple(x for c in range(7) for x in (np.median(ph[:, c]), ph[:, c].max())))

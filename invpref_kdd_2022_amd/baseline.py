@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from . import _capi, ops, plan as planlib
-from .parallel import RowShard
+from .parallel import RowShard, UserShard
 from .train import FlatState, _InvPrefTrainManager, transfer_loss_dict_to_line_str
 
 PURE_LOSS_KEYS = ['score_loss', 'L2_reg', 'L1_reg', 'loss']  # train.py:399-404
@@ -110,15 +110,31 @@ class _BasicTrainManager(_InvPrefTrainManager):
 
     def __init__(self, model, evaluator, device: torch.device, training_data: torch.Tensor, batch_size: int,
                  epochs: int, evaluate_interval: int, lr: float, L2_coe: float, L1_coe: float,
-                 test_begin_epoch: int = 0):
+                 test_begin_epoch: int = 0, *, rank=None, world_size=None, process_group=None):
+        """rank / world_size / process_group (keyword-only, beyond the reference's signature): one process per GPU,
+        sharded like the InvPref managers (parallel.py; INVPREF_SHARD=users|rows): every rank keeps its share of
+        every minibatch, one all-reduce per optimiser step, every mean() over the GLOBAL minibatch."""
         if model.implicit != self.implicit:
             raise TypeError(f'{type(self).__name__} needs an {"implicit" if self.implicit else "explicit"} model')
         self.model, self.evaluator, self.device = model, evaluator, torch.device(device)
-        self.rank, self.world_size, self.process_group = 0, 1, None
+        self.process_group = process_group
+        if world_size is None:
+            import torch.distributed as dist
+            world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+            rank = dist.get_rank(process_group) if world_size > 1 else 0
+        self.rank, self.world_size = int(rank or 0), int(world_size)
         n_total = training_data.shape[0]
         self.n_total, self.batch_size = n_total, batch_size
         self.batch_num = math.ceil(n_total / batch_size)
-        self.shard = RowShard(n_total, batch_size, 0, 1)
+        forced = os.environ.get('INVPREF_FORCE_SHARDED_PATH', '0') == '1'
+        self.shard_mode = os.environ.get('INVPREF_SHARD', 'users') if (self.world_size > 1 or forced) else 'rows'
+        if self.shard_mode == 'users':
+            self.shard = UserShard(training_data[:, 0].cpu().numpy(), n_total, batch_size, model.user_num, self.rank,
+                                   self.world_size)
+        else:
+            self.shard = RowShard(n_total, batch_size, self.rank, self.world_size)
+        if self.world_size > 1:
+            training_data = training_data.index_select(0, self.shard.local_rows().to(training_data.device))
         self.users_tensor = training_data[:, 0].contiguous().to(self.device)
         self.items_tensor = training_data[:, 1].contiguous().to(self.device)
         self.scores_tensor = training_data[:, 2].float().contiguous().to(self.device)
@@ -132,12 +148,15 @@ class _BasicTrainManager(_InvPrefTrainManager):
         self.alpha, self.update_alpha = 0., False
         self.cluster_interval = 1 << 62
         self.model.to(self.device)
-        self.state = FlatState(model.tables(), self.device)
+        self.state = FlatState(model.tables(), self.device)     # [user table | item table]: the shared part is last
+        self._setup_ranges(model)
         self.workspace = ops.Workspace(self.device)
         self._flags = ops.flags_of(self.implicit, False, False, True, False, dense_reg=False) | _capi.PURE_MF
         self.use_plan, self._plans = True, None
         self.use_graph = os.environ.get('INVPREF_NO_GRAPH', '0') != '1'
-        self._force_sharded_path, self._collective_ok, self._unfused = False, False, False
+        import torch.distributed as _dist
+        self._force_sharded_path, self._unfused = forced, False
+        self._collective_ok = _dist.is_available() and _dist.is_initialized()
         self._graphs, self._graph_warm = {}, False
         self._grad_stale = False
         self._sched, self._sched_synced = None, False
@@ -152,7 +171,10 @@ class _BasicTrainManager(_InvPrefTrainManager):
 
     def train_a_batch(self, batch_users_tensor, batch_items_tensor, batch_scores_tensor, *args) -> dict:
         """train.py:379-405 on caller-supplied tensors: the row plan of this one minibatch is built on the
-        host first (the epoch loop uses the plans prepared once for the static minibatches instead)."""
+        host first (the epoch loop uses the plans prepared once for the static minibatches instead).
+        Single-process form; sharded runs go through train_epochs() / train()."""
+        if self.world_size > 1:
+            raise NotImplementedError('train_a_batch on caller-supplied tensors is single-process; use train_epochs()')
         u = batch_users_tensor.detach().cpu().numpy()
         v = batch_items_tensor.detach().cpu().numpy()
         y = batch_scores_tensor.detach().float().contiguous()
@@ -173,6 +195,7 @@ class _BasicTrainManager(_InvPrefTrainManager):
         test_result_list, test_epoch_list, loss_result_list, train_epoch_index_list = [], [], [], []
 
         def evaluate():
+            self.sync_parameters()
             res = self.evaluator.evaluate()
             test_result_list.append(res)
             test_epoch_list.append(self.epoch_cnt)
@@ -193,6 +216,7 @@ class _BasicTrainManager(_InvPrefTrainManager):
                     print(transfer_loss_dict_to_line_str(run[i]))
             if (self.epoch_cnt % self.evaluate_interval) == 0 and self.epoch_cnt >= self.test_begin_epoch:
                 evaluate()
+        self.sync_parameters()
         if defer and loss_result_list:
             loss_result_list = self.loss_dicts(torch.stack(loss_result_list))
         return (loss_result_list, train_epoch_index_list), (test_result_list, test_epoch_list)

@@ -201,12 +201,14 @@ class _InvPrefTrainManager:
         gradient that is all-reduced (through the loss tail), `_adam_ranges` = (offset, length) pieces of the
         flat buffers this rank applies Adam to."""
         st = self.state
+        # tables indexed by user: InvPref keeps two (invariant, env-aware), PureMF one
+        self._user_tables = (0,) if self._pure else (0, 2)
         if self.shard_mode == 'users':
             lo, hi = self.shard.user_range(model.user_num)
             D = model.factor_num
-            self._ar_lo = st.offsets[1]                      # embed_item_invariant: start of the replicated part
-            self._adam_ranges = [(st.offsets[0] + lo * D, (hi - lo) * D), (st.offsets[2] + lo * D, (hi - lo) * D),
-                                 (self._ar_lo, st.n - self._ar_lo)]
+            self._ar_lo = st.offsets[1]                      # the item table that follows the user tables: start of the replicated part
+            self._adam_ranges = [(st.offsets[i] + lo * D, (hi - lo) * D) for i in self._user_tables] + \
+                                [(self._ar_lo, st.n - self._ar_lo)]
             self._adam_ranges = [r for r in self._adam_ranges if r[1] > 0]
         else:
             self._ar_lo = 0
@@ -219,7 +221,7 @@ class _InvPrefTrainManager:
         if self.world_size == 1 or self.shard_mode != 'users':
             return
         lo, hi = self.shard.user_range(self.model.user_num)
-        for i in (0, 2):
+        for i in self._user_tables:
             view = self.state.p_views[i]
             tmp = torch.zeros_like(view)
             tmp[lo:hi] = view[lo:hi]
@@ -306,10 +308,10 @@ class _InvPrefTrainManager:
             for lo, n, *_ in self._raw_batches:
                 pl = planlib.build_row_plan(u[lo:lo + n], v[lo:lo + n], y[lo:lo + n], self.model.user_num,
                                             self.model.item_num,
-                                            user_range=None if self._pure else self.shard.user_range(self.model.user_num))
+                                            user_range=self.shard.user_range(self.model.user_num))
                 self._plans.append(planlib.upload(pl, self.device))
             self.plan_build_s = time.perf_counter() - t0     # host-side, once per run (reported by bench.py)
-        if self.use_plan:
+        if self.use_plan and self.users_tensor.is_cuda:
             # every plan shares ONE zero-initialised scratch (each step leaves it zeroed): size it for the largest
             t = self._make_tables(st.p_views)
             self.workspace.get_zeroed(max(L.invpref_rows_workspace_bytes(C.byref(t), C.byref(dp.struct))

@@ -66,7 +66,12 @@ def _oracle_ops(monkey_target):
         cw = (np.minimum(c + 1, n_total - 1) / n_total).astype(np.float32)
         return torch.from_numpy(cw), torch.from_numpy(cw[envs.numpy()])
 
-    for name, fn in dict(mstep_grad=mstep_grad, adam_=adam_, estep=estep, stat_envs=stat_envs,
+    def adam_ranges_(param, grad, m, v, offsets, lengths, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, zero_grad=True,
+                     sched=None):
+        for o, n in zip(offsets, lengths):
+            adam_(param[o:o + n], grad[o:o + n], m[o:o + n], v[o:o + n], step, lr, zero_grad=zero_grad)
+
+    for name, fn in dict(mstep_grad=mstep_grad, adam_=adam_, adam_ranges_=adam_ranges_, estep=estep, stat_envs=stat_envs,
                          sample_weights=sample_weights).items():
         setattr(monkey_target, name, fn)
 
@@ -208,3 +213,155 @@ def test_row_shard_index_arithmetic():
                 lo, hi = s.local_batch_bounds(k)
                 g0, g1 = s.global_rows_of_batch(k)
                 np.testing.assert_array_equal(s.local_rows().numpy()[lo:hi], np.arange(g0, g1))
+
+
+# ---- Yahoo-shaped runs through the EPOCH loop (train_epochs -> _raw_step: what bench.py and train() use), world 4 / 8:
+# BASELINE.json configs[3] -- 15 400 x 1 000, 250 154 interactions, global minibatch 8 192 cut `world` ways (1 024 rows per
+# rank at world 8), 31 minibatches of which the last is ragged (4 394 rows: uneven slices) -- both shard layouts.
+YU, YI, YE, YD, YN, YB = 15400, 1000, 4, 16, 250154, 8192
+
+
+def _yahoo_worker(rank, world, port, out_dir, mode):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), INVPREF_SHARD=mode, INVPREF_NO_PLAN='1',
+                      OMP_NUM_THREADS='1')
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        _oracle_ops(ops)
+        from invpref_kdd_2022_amd.models import InvPrefImplicit
+        from invpref_kdd_2022_amd.train import ImplicitTrainManager, LOSS_KEYS
+
+        class Stub:
+            def evaluate(self):
+                return {}
+        data = synth.interactions(17373331, YU, YI, YN, implicit=True)
+        tabs = synth.tables(8, YU, YI, YE, YD, std=0.1)
+        model = InvPrefImplicit(YU, YI, YE, YD, reg_only_embed=True, reg_env_embed=False)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in tabs.items()})
+        np.random.seed(5)
+        mgr = ImplicitTrainManager(model=model, evaluator=Stub(), device=torch.device('cpu'),
+                                   training_data=torch.from_numpy(data), batch_size=YB, epochs=2, cluster_interval=1,
+                                   evaluate_interval=10 ** 9, lr=0.005, use_class_re_weight=True,
+                                   use_recommend_re_weight=False, cluster_use_random_sort=False, rank=rank,
+                                   world_size=world, invariant_coe=3.35, env_aware_coe=9.99, env_coe=9.06, L2_coe=3.13,
+                                   L1_coe=0.49, alpha=1.9)
+        assert mgr.batch_num == 31 and mgr.shard.global_batch_len(30) == YN - 30 * YB
+        if mode == 'rows':   # the ragged last minibatch: slices differ by at most one row and tile it exactly
+            lens = [RowShard(YN, YB, r, world).slice_in_batch(30) for r in range(world)]
+            assert lens[0][0] == 0 and lens[-1][1] == YN - 30 * YB and max(b - a for a, b in lens) - min(b - a for a, b in lens) <= 1
+        mgr.stat_envs()
+        l1 = mgr.train_epochs(1)[0]
+        diff = mgr.cluster()
+        cnt = mgr.stat_envs()
+        l2 = mgr.train_epochs(1)[0]
+        mgr.sync_parameters()
+        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), param=mgr.state.param.numpy(),
+                 offsets=np.array(mgr.state.offsets), losses=np.array([[l[k] for k in LOSS_KEYS] for l in (l1, l2)]),
+                 diff=diff, counts=np.array([cnt[e] for e in range(YE)]), envs=mgr.envs.numpy(),
+                 rows=mgr.shard.local_rows().numpy(), ar_floats=mgr.state.n + 8 - mgr._ar_lo)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('world,mode', [(4, 'rows'), (8, 'rows'), (8, 'users')])
+def test_yahoo_shaped_epochs_world_4_and_8(tmp_path, world, mode):
+    mp.spawn(_yahoo_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
+    r = [np.load(tmp_path / f'rank{i}.npz') for i in range(world)]
+    for x in r[1:]:   # replicas agree
+        np.testing.assert_array_equal(r[0]['param'], x['param'])
+        np.testing.assert_array_equal(r[0]['losses'], x['losses'])
+        assert int(r[0]['diff']) == int(x['diff'])
+    P = 2 * (YU + YI) * YD + 2 * YE * YD + YE
+    if mode == 'rows':
+        assert int(r[0]['ar_floats']) >= P + 8            # the whole flat gradient + the loss tail, one all-reduce
+    else:
+        assert int(r[0]['ar_floats']) < 2 * YI * YD + 2 * YE * YD + YE + 8 + 5 * 64   # item side + small tables only
+    # single process: the oracle's own loop over the whole data
+    data = synth.interactions(17373331, YU, YI, YN, implicit=True)
+    tabs = synth.tables(8, YU, YI, YE, YD, std=0.1)
+    np.random.seed(5)
+    env0 = np.random.randint(0, YE, YN)
+    tr = O.Trainer(tabs, data, env0, implicit=True, batch_size=YB, coefs=[3.35, 9.99, 9.06, 3.13, 0.49, 1.9], lr=0.005,
+                   reweight_rec=False, reweight_cls=True, reg_only_embed=True, reg_env_embed=False)
+    tr.stat_envs()
+    ref = [tr.train_a_epoch()]
+    diff = tr.cluster()
+    cnt = tr.stat_envs()
+    ref.append(tr.train_a_epoch())
+    np.testing.assert_allclose(r[0]['losses'], np.array(ref), rtol=2e-5)
+    envs = np.empty(YN, np.int64)
+    for x in r:
+        envs[x['rows']] = x['envs']
+    mism = int((envs != tr.envs).sum())
+    assert mism <= 8 and abs(int(r[0]['diff']) - diff) <= mism
+    assert np.abs(r[0]['counts'] - np.array([cnt[e] for e in range(YE)])).sum() <= 2 * mism
+    from invpref_kdd_2022_amd.models import InvPrefImplicit
+    from invpref_kdd_2022_amd.train import FlatState
+    fs = FlatState(InvPrefImplicit(YU, YI, YE, YD).tables(), torch.device('cpu'))
+    for arr, off, shp in zip(tr.tab.arrs, r[0]['offsets'], fs.shapes):
+        got = r[0]['param'][off:off + arr.size].reshape(shp)
+        assert np.abs(got - arr).max() < 2.5 * 0.005       # (a noise-level gradient may step the other way, twice)
+        if arr.size > 4096:   # the big tables; the E x D ones are sums over every interaction, re-associated 8 ways
+            assert np.quantile(np.abs(got - arr), 0.99) < 5e-5
+        else:
+            assert np.abs(got - arr).max() < 1e-3
+
+
+# ---- PureMF managers sharded: the planned gradient pass (HIP-only) is stood in for by the oracle
+def _pure_worker(rank, world, port, out_dir, mode):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), INVPREF_SHARD=mode)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        _oracle_ops(ops)
+        from invpref_kdd_2022_amd import plan as planlib
+        from invpref_kdd_2022_amd.baseline import BasicImplicitTrainManager, PureMatrixFactorization
+
+        def mstep_rows_grad(params, grads, dplan, envs, scores, weights, batch_norm, coefs, flags, losses6, ws, sched=None):
+            names = [f for f, _ in planlib.RowPlanStruct._fields_]
+            meta = dict(zip(names, dplan.meta.tolist()))
+            buf, n = dplan.buf.numpy(), meta['n']
+            u = buf[meta['batch_users']:meta['batch_users'] + n].astype(np.int64)
+            v = buf[meta['batch_items']:meta['batch_items'] + n].astype(np.int64)
+            tab = O.Tables(O.pure_mf_params(params[0].detach().numpy(), params[1].detach().numpy()))
+            g, l = O.mstep(tab, u, v, np.zeros(n, np.int64), scores.numpy(), None, np.asarray(coefs, np.float64),
+                           O.flags_of(bool(flags & 1), False, False, True, False), bnorm=batch_norm, include_dense_reg=False)
+            grads[0].copy_(torch.from_numpy(g[0]))     # the planned pass OVERWRITES every row
+            grads[1].copy_(torch.from_numpy(g[1]))
+            losses6 += torch.from_numpy(l.astype(np.float32))
+        ops.mstep_rows_grad = mstep_rows_grad
+
+        class Stub:
+            def evaluate(self):
+                return {}
+        data = synth.interactions(3, U, I, N, implicit=True, zipf=False)
+        rs = np.random.RandomState(4)
+        model = PureMatrixFactorization(U, I, D)
+        model.load_state_dict({'user_emb.weight': torch.from_numpy((rs.randn(U, D) * 0.2).astype(np.float32)),
+                               'item_emb.weight': torch.from_numpy((rs.randn(I, D) * 0.2).astype(np.float32))})
+        mgr = BasicImplicitTrainManager(model, Stub(), torch.device('cpu'), torch.from_numpy(data), B, 3, 10 ** 9, LR,
+                                        0.01, 0.001, rank=rank, world_size=world)
+        assert mgr.shard_mode == mode and mgr.users_tensor.shape[0] < N
+        (losses, _), _ = mgr.train(silent=True)
+        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), pu=model.user_emb.weight.detach().numpy(),
+                 qi=model.item_emb.weight.detach().numpy(), losses=np.array([[l[k] for k in l] for l in losses]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('mode', ['users', 'rows'])
+def test_pure_mf_manager_sharded(tmp_path, mode):
+    world = 2
+    mp.spawn(_pure_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
+    r = [np.load(tmp_path / f'rank{i}.npz') for i in range(world)]
+    np.testing.assert_array_equal(r[0]['pu'], r[1]['pu'])       # after sync_parameters every rank holds the model
+    np.testing.assert_array_equal(r[0]['qi'], r[1]['qi'])
+    np.testing.assert_array_equal(r[0]['losses'], r[1]['losses'])
+    data = synth.interactions(3, U, I, N, implicit=True, zipf=False)
+    rs = np.random.RandomState(4)
+    pu0, qi0 = (rs.randn(U, D) * 0.2).astype(np.float32), (rs.randn(I, D) * 0.2).astype(np.float32)
+    tr = O.pure_mf_trainer(pu0, qi0, data, implicit=True, batch_size=B, lr=LR, L2_coe=0.01, L1_coe=0.001)
+    ref = O.pure_mf_losses(np.stack([tr.train_a_epoch() for _ in range(3)]))
+    np.testing.assert_allclose(r[0]['losses'], ref, rtol=2e-5)
+    assert np.abs(r[0]['pu'] - tr.tab.arrs[0]).max() < 0.05 * LR and np.abs(r[0]['qi'] - tr.tab.arrs[1]).max() < 0.05 * LR

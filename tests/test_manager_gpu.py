@@ -433,7 +433,8 @@ def test_sharded_epochs_graph_vs_eager(monkeypatch, mode):
                         {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}))
     finally:
         dist.destroy_process_group()
-    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-6)
+    # two runs of the same sequence differ through the order of the float atomics (hot rows, E x D slabs): 1e-5
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-5)
     assert abs(res[0][1] - res[1][1]) <= 3
     for k in O.PARAM_NAMES:
         _assert_same_run(np.abs(res[0][2][k] - res[1][2][k]), float(z['coefs'][6]), k)

@@ -83,6 +83,35 @@ def test_manager_trajectory_vs_reference(kind):
     np.testing.assert_allclose([got[k] for k in PURE_LOSS_KEYS], want, rtol=5e-5)
 
 
+@pytest.mark.parametrize('mode', ['rows', 'users'])
+def test_manager_sharded_sequence_vs_reference(monkeypatch, mode):
+    """The PureMF managers on the multi-GPU step sequence (planned gradient pass -> RCCL all-reduce -> ranged Adam,
+    whole epochs replayed as HIP graphs), run on a 1-rank RCCL group: the reference's trajectory (g7)."""
+    import torch.distributed as dist
+    monkeypatch.setenv('INVPREF_FORCE_SHARDED_PATH', '1')
+    monkeypatch.setenv('INVPREF_SHARD', mode)
+    z = np.load(os.path.join(G, 'g7_pure_mf_implicit.npz'))
+    (U, I, D, n, bs, epochs), data, init, cfg = pure_mf_inputs('implicit')
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29536')
+        dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        model = _model('implicit', init, U, I, D)
+        mgr = BasicImplicitTrainManager(model=model, evaluator=StubEvaluator(), device=DEV,
+                                        training_data=torch.from_numpy(data).to(DEV), batch_size=bs, epochs=epochs,
+                                        evaluate_interval=10 ** 9, lr=cfg['lr'], L2_coe=cfg['L2_coe'], L1_coe=cfg['L1_coe'])
+        assert mgr.shard_mode == mode and not mgr._fused_seq()
+        (losses, _), _ = mgr.train(silent=True)
+        assert mgr._graphs
+        np.testing.assert_allclose([[d[k] for k in PURE_LOSS_KEYS] for d in losses], z['traj'], rtol=2e-5)
+        sd = model.state_dict()
+        for k in sd:
+            assert np.abs(sd[k].cpu().numpy() - z['final_' + k]).max() < 1e-3, k
+    finally:
+        dist.destroy_process_group()
+
+
 def test_train_a_batch_and_unfused_surface():
     """train_a_batch on caller-supplied tensors (plan built on the fly) equals the first step of the
     reference; the module's unfused surface (forward / get_L*_reg / autograd / predict) matches g7."""

@@ -156,7 +156,7 @@ def predict(user_table: torch.Tensor, item_table: torch.Tensor, users: torch.Ten
 
 def rows_workspace(params, dplan, workspace: Workspace, pure: bool = False) -> torch.Tensor:
     """the zero-initialised scratch of the planned M-step (replica slabs + hot-row accumulators)"""
-    t = (_capi.make_pure_tables if pure else make_tables)(params)
+    t = (_capi.make_pure_tables if (pure or len(params) == 2) else make_tables)(params)
     return workspace.get_zeroed(lib().invpref_rows_workspace_bytes(C.byref(t), C.byref(dplan.struct)))
 
 

@@ -21,6 +21,9 @@ What each fixture pins:
   g10   MovieLens-class trajectory: E=8, D=128, alpha schedule -> §8 a2-a14 at E > 4
   g11   cluster() with cluster_use_random_sort=True (eps rows) -> §8 a9, a13
   g12   train() control flow: evaluate / cluster windows        -> §8 a14
+  g13   MIND-shaped trajectory: E=16, D=256, B=262144, 3 steps + E-step (1 and 8 reference threads)
+  g14   MovieLens at full size: 6040 x 3706, B=65536, 2 epochs + E-step (1 and 8 reference threads)
+  g15   the reference's own 1-thread vs 8-thread spread on the g4 / g10 runs
 """
 import sys
 import types
@@ -604,8 +607,141 @@ def gen_g12():
                         counts=np.array([[c[k] for k in range(E)] for c in cnts]))
 
 
+KEYS6 = ('invariant_loss', 'env_aware_loss', 'envs_loss', 'L2_reg', 'L1_reg', 'loss')
+
+
+def _large_run(shape, cfg, n, bs, E, D, seed, epochs, threads, roe, ree, std):
+    """`epochs` epochs + one E-step + stat_envs of the reference manager on a seeded synthetic data set, with the
+    given torch thread count.  E > 10: the E! eps table cannot be built (train.py:86-92) -> overridden, random sort off."""
+    U, I = shape['user_num'], shape['item_num']
+    data = synth.interactions(seed, U, I, n, implicit=True, zipf=True)
+    tabs = synth.tables(seed + 1, U, I, E, D, std=std)
+    np.random.seed(seed)
+    model = ref_models.InvPrefImplicit(U, I, E, D, reg_only_embed=roe, reg_env_embed=ree)
+    load_tables(model, tabs)
+    mgr = make_manager('implicit', model, data, batch_size=bs, cfg=cfg, cls_w=True, rec_w=True, random_sort=False,
+                       epochs=epochs, cluster_interval=epochs, no_eps=E > 10)
+    env0 = mgr.envs.numpy().copy()
+    torch.set_num_threads(threads)
+    mgr.stat_envs()
+    per_step = []
+    orig = mgr.train_a_batch
+
+    def spy(*a, **kw):
+        d = orig(*a, **kw)
+        per_step.append([d[k] for k in KEYS6])
+        return d
+    mgr.train_a_batch = spy
+    ep = [mgr.train_a_epoch() for _ in range(epochs)]
+    diff = mgr.cluster()
+    cnt = mgr.stat_envs()
+    return dict(tabs=tabs, env0=env0, steps=np.array(per_step, np.float64),
+                epochs=np.array([[d[k] for k in KEYS6] for d in ep], np.float64), diff=diff,
+                counts=np.array([cnt[e] for e in range(E)]), envs=mgr.envs.numpy().copy(), sd=model.state_dict(),
+                alpha=mgr.alpha)
+
+
+def _save_large(name, r1, r8, meta, cfg):
+    rs = np.random.RandomState(3)
+    U, I = meta[0], meta[1]
+    urows, irows = rs.randint(0, U, 64), rs.randint(0, I, 64)
+    out = dict(meta=np.array(meta), table_hash=np.array(sd_hash(r1['tabs'])), env0=pack_envs(r1['env0']),
+               env_after=pack_envs(r1['envs']), step_losses=r1['steps'], epoch_losses=r1['epochs'],
+               diff_num=np.array(r1['diff']), counts=r1['counts'], urows=urows, irows=irows,
+               coefs=np.array([np.nan if cfg[k] is None else cfg[k] for k in
+                               ('invariant_coe', 'env_aware_coe', 'env_coe', 'L2_coe', 'L1_coe', 'alpha', 'lr')]),
+               # the reference's own run-to-run spread: the same run with 8 torch threads instead of 1
+               step_losses_t8=r8['steps'], epoch_losses_t8=r8['epochs'], diff_num_t8=np.array(r8['diff']),
+               counts_t8=r8['counts'], envs_mismatch_t8=np.array(int((r1['envs'] != r8['envs']).sum())))
+    for k in PARAM_NAMES:
+        a1, a8 = r1['sd'][k].numpy(), r8['sd'][k].numpy()
+        out['spread_' + k] = np.array([np.abs(a1 - a8).max(), np.quantile(np.abs(a1 - a8), 0.99)])
+        if 'user' in k:
+            out['final_' + k] = a1[urows]
+        elif 'item' in k:
+            out['final_' + k] = a1[irows]
+        else:
+            out['final_' + k] = a1.copy()
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, 'step losses', r1['steps'][:, -1], 'diff', r1['diff'], 'vs 8 threads', r8['diff'],
+          'max rel loss spread', np.abs(r1['steps'] / r8['steps'] - 1).max(), 'envs mismatch', out['envs_mismatch_t8'])
+
+
+def gen_g13():
+    """MIND-shaped trajectory (MIND_InvPref.py: 16 environments, 256 factors, minibatch 262 144): three optimiser
+    steps (one epoch over 3 x 262 144 interactions), then the E-step over all of them and stat_envs."""
+    E, D, bs, seed = 16, 256, 262144, 1313
+    n = 3 * bs
+    kw = dict(shape=synth.MIND_SHAPE, cfg=YAHOO_CFG, n=n, bs=bs, E=E, D=D, seed=seed, epochs=1, roe=False, ree=True, std=0.05)
+    r1, r8 = _large_run(threads=1, **kw), _large_run(threads=8, **kw)
+    _save_large('g13_mind_like_traj.npz', r1, r8,
+                [synth.MIND_SHAPE['user_num'], synth.MIND_SHAPE['item_num'], E, D, bs, 1, seed, n], YAHOO_CFG)
+
+
+def gen_g14():
+    """MovieLens at full size (6 040 x 3 706, minibatch 65 536 -- MovieLens_InvPref.py:26 -- 8 environments, 128 factors,
+    alpha=None: the alpha schedule): two epochs over 2^20 interactions, then the E-step and stat_envs."""
+    E, D, bs, seed = 8, 128, 65536, 1414
+    n = 1 << 20
+    kw = dict(shape=dict(user_num=6040, item_num=3706), cfg=ML_CFG, n=n, bs=bs, E=E, D=D, seed=seed, epochs=2, roe=False,
+              ree=True, std=0.05)
+    r1, r8 = _large_run(threads=1, **kw), _large_run(threads=8, **kw)
+    _save_large('g14_movielens_full_traj.npz', r1, r8, [6040, 3706, E, D, bs, 2, seed, n], ML_CFG)
+
+
+def gen_g15():
+    """The reference's own 1-thread vs 8-thread spread on the multi-epoch fixtures whose tests carry tolerances above
+    1e-5 (g4 Yahoo-shaped, g10 MovieLens-class, g3 Coat): the same runs as gen_g4 / gen_g10 / gen_g3 with
+    torch.set_num_threads(8), stored beside nothing else -- the tests bound their tolerances by these numbers."""
+    out = {}
+    # g4
+    U, I = synth.YAHOO_SHAPE['user_num'], synth.YAHOO_SHAPE['item_num']
+    E, D, seed = 4, 64, 17373331
+    res = {}
+    for th in (1, 8):
+        data = synth.yahoo_like(seed)
+        tabs = synth.tables(seed + 7, U, I, E, D, std=0.01)
+        np.random.seed(seed)
+        model = ref_models.InvPrefImplicit(U, I, E, D, reg_only_embed=True, reg_env_embed=False)
+        load_tables(model, tabs)
+        mgr = make_manager('implicit', model, data, batch_size=8192, cfg=YAHOO_CFG, cls_w=True, rec_w=False,
+                           random_sort=False, epochs=5, cluster_interval=5)
+        torch.set_num_threads(th)
+        (losses, _), _, (diffs, cnts, _) = mgr.train(silent=True, auto=True)
+        res[th] = (np.array([[d[k] for k in KEYS6] for d in losses]), diffs[0], mgr.envs.numpy().copy(),
+                   {k: v.numpy().copy() for k, v in model.state_dict().items()})
+    out['g4_loss_t1'], out['g4_loss_t8'] = res[1][0], res[8][0]
+    out['g4_diff'] = np.array([res[1][1], res[8][1]])
+    out['g4_envs_mismatch'] = np.array(int((res[1][2] != res[8][2]).sum()))
+    for k in PARAM_NAMES:
+        out['g4_spread_' + k] = np.array([np.abs(res[1][3][k] - res[8][3][k]).max()])
+    # g10
+    U, I, E, D, n, bs, seed = 300, 200, 8, 128, 6000, 1024, 4711
+    res = {}
+    for th in (1, 8):
+        data = synth.interactions(seed, U, I, n, implicit=True)
+        tabs = synth.tables(seed + 1, U, I, E, D, std=0.05)
+        np.random.seed(seed)
+        model = ref_models.InvPrefImplicit(U, I, E, D, reg_only_embed=False, reg_env_embed=True)
+        load_tables(model, tabs)
+        mgr = make_manager('implicit', model, data, batch_size=bs, cfg=ML_CFG, cls_w=True, rec_w=True, random_sort=False,
+                           epochs=6, cluster_interval=3)
+        torch.set_num_threads(th)
+        (losses, _), _, (diffs, cnts, _) = mgr.train(silent=True, auto=True)
+        res[th] = (np.array([[d[k] for k in KEYS6] for d in losses]), diffs, mgr.envs.numpy().copy())
+    out['g10_loss_t1'], out['g10_loss_t8'] = res[1][0], res[8][0]
+    out['g10_diff'] = np.array([res[1][1], res[8][1]])
+    out['g10_envs_mismatch'] = np.array(int((res[1][2] != res[8][2]).sum()))
+    for tag in ('g4', 'g10'):
+        a, b = out[tag + '_loss_t1'], out[tag + '_loss_t8']
+        print(tag, 'max rel loss spread 1 vs 8 threads per term:', np.abs(a / b - 1).max(axis=0), 'diff', out[tag + '_diff'],
+              'envs mismatch', out[tag + '_envs_mismatch'])
+    np.savez_compressed(os.path.join(OUT, 'g15_reference_thread_spread.npz'), **out)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12']
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14',
+                             'g15']
     torch.manual_seed(0)
     for name in which:
         globals()['gen_' + name]()

@@ -52,8 +52,9 @@ def test_g3_coat_explicit_trajectory_through_manager():
     sd = model.state_dict()
     for k in O.PARAM_NAMES:
         # 210 Adam steps: hardware exp/log/rcp in the M-step (~1 ulp each) drift a little further from the
-        # reference than the oracle's canonical arithmetic does (2e-4); weights are O(0.1-1)
-        assert np.abs(sd[k].cpu().numpy() - z['final_' + k]).max() < 1e-3, k
+        # reference than the oracle's canonical arithmetic does (2e-4); weights are O(0.1-1).  Measured
+        # (tools/tol_probe.py): 3.5e-4 in embed_user_env_aware, <= 5e-5 in every other table
+        assert np.abs(sd[k].cpu().numpy() - z['final_' + k]).max() < (7e-4 if k == 'embed_user_env_aware.weight' else 1.5e-4), k
 
 
 def test_g4_yahoo_like_trajectory_through_manager():
@@ -69,7 +70,16 @@ def test_g4_yahoo_like_trajectory_through_manager():
     (losses, _), _, (diffs, cnts, _) = mgr.train(silent=True, auto=True)
     trace = np.array([[d[k] for k in LOSS_KEYS] for d in losses])
     np.testing.assert_allclose(trace[:, [0, 1, 2, 5]], z['loss_trace'][:, [0, 1, 2, 5]], rtol=1e-5)
-    np.testing.assert_allclose(trace[:, [3, 4]], z['loss_trace'][:, [3, 4]], rtol=5e-5)  # see oracle test
+    # L2_reg / L1_reg REPORTS: the reference's fp32 norm() over 524 288 terms moves with its own thread count -- golden g15
+    # holds the same run with 8 torch threads: L1 differs by 2.45e-5 between the two.  Against the 8-thread (chunked, more
+    # accurate) sums this implementation is at 1e-5 (measured: L2 9.8e-6, L1 8e-7); against the 1-thread run it is held
+    # to 1e-5 or 1.5x the reference's own spread on that term
+    s15 = np.load(os.path.join(G, 'g15_reference_thread_spread.npz'))
+    np.testing.assert_array_equal(s15['g4_loss_t1'], z['loss_trace'])
+    np.testing.assert_allclose(trace[:, [3, 4]], s15['g4_loss_t8'][:, [3, 4]], rtol=1.5e-5)
+    spread = np.abs(s15['g4_loss_t1'] / s15['g4_loss_t8'] - 1).max(axis=0)
+    for col in (3, 4):
+        np.testing.assert_allclose(trace[:, col], z['loss_trace'][:, col], rtol=max(1.5e-5, 1.5 * spread[col]))
     # E-step in the tie-heavy regime: HIP == oracle bit-exact on the SAME tables; vs the reference every
     # disagreeing row has a relative distance gap < 2e-5
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
@@ -119,7 +129,8 @@ def test_g12_train_control_flow_matches_reference():
         assert cluster_epochs == list(z['cluster_epochs'])
         assert diffs[0] == 0 and diffs[3] == 0                       # outside the clustering window
         assert abs(diffs[1] - int(z['diff_num'][1])) <= 3 and abs(diffs[2] - int(z['diff_num'][2])) <= 6
-        np.testing.assert_allclose(np.array([[d[k] for k in LOSS_KEYS] for d in losses]), z['loss_trace'], rtol=5e-5)
+        # (measured, tools/tol_probe.py: 1.3e-6)
+        np.testing.assert_allclose(np.array([[d[k] for k in LOSS_KEYS] for d in losses]), z['loss_trace'], rtol=1e-5)
         assert np.abs(np.array([[c[e] for e in range(E)] for c in cnts]) - z['counts']).sum() <= 24
 
 
@@ -167,7 +178,7 @@ def test_g10_movielens_like_trajectory_through_manager():
     (losses, _), _, (diffs, cnts, ce) = mgr.train(silent=True, auto=True)
     assert ce == list(z['cluster_epochs']) and mgr._graphs and mgr.use_plan
     trace = np.array([[d[k] for k in LOSS_KEYS] for d in losses])
-    np.testing.assert_allclose(trace, z['loss_trace'], rtol=3e-5)
+    np.testing.assert_allclose(trace, z['loss_trace'], rtol=1e-5)     # (measured, tools/tol_probe.py: 1.8e-6)
     assert abs(mgr.alpha - float(z['final_alpha'])) < 1e-9
     # last E-step: HIP == oracle bit-exact on the same tables; vs the reference the near-tie rule (see the oracle test)
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}

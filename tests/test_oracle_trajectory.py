@@ -70,9 +70,14 @@ def test_g4_yahoo_like_trajectory():
     trace = np.stack([tr.train_a_epoch() for _ in range(epochs)])
     # the three data-loss terms and the total loss: 1e-5 relative (north_star tolerance)
     np.testing.assert_allclose(trace[:, [0, 1, 2, 5]], z['loss_trace'][:, [0, 1, 2, 5]], rtol=1e-5)
-    # L2_reg / L1_reg: the reference sums 524 288 fp32 terms per norm() in fp32 and is itself
-    # ~2e-5 away from the exact sum (the oracle accumulates loss REPORTS in double)
-    np.testing.assert_allclose(trace[:, [3, 4]], z['loss_trace'][:, [3, 4]], rtol=5e-5)
+    # L2_reg / L1_reg: the reference sums 524 288 fp32 terms per norm() in fp32 and moves with its own thread count
+    # (golden g15: the same run with 8 torch threads; L1 differs by 2.45e-5).  The oracle accumulates loss REPORTS in
+    # double: 1e-5 of the 8-thread (chunked, more accurate) sums, and of the 1-thread run within that run's own spread
+    s15 = np.load(os.path.join(G, 'g15_reference_thread_spread.npz'))
+    np.testing.assert_allclose(trace[:, [3, 4]], s15['g4_loss_t8'][:, [3, 4]], rtol=1.5e-5)
+    spread = np.abs(s15['g4_loss_t1'] / s15['g4_loss_t8'] - 1).max(axis=0)
+    for col in (3, 4):
+        np.testing.assert_allclose(trace[:, col], z['loss_trace'][:, col], rtol=max(1.5e-5, 1.5 * spread[col]))
     # collapsed / tie-heavy regime (SURVEY §7 "hard parts"): strong L1 drives the env-aware branch to
     # sigma(q)~0.5 for every env, so the top-2 distances tie at fp32 rounding level on most rows and
     # the reference itself changes ~50 assignments between 1 and 8 threads.  Contract: every row

@@ -382,9 +382,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=155)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip roofline_large / eval timing (profiling runs)')
+    ap.add_argument('--spawn', action='store_true', help='launch the ranks as child processes even for --gpus 1 (checks the launcher path)')
     args = ap.parse_args()
 
-    if args.gpus > 1 and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
+    if (args.gpus > 1 or args.spawn) and 'RANK' not in os.environ and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))      # (nothing in this process has touched the GPU)
 
     import numpy as np  # noqa: F401

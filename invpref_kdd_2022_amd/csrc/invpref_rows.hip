@@ -70,7 +70,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 template <int MODE>
 __device__ __forceinline__ void store4(float *p, float4 r) {
     if (MODE == 0) *reinterpret_cast<float4 *>(p) = r;
-    else {
+    else if (MODE == 2) {   // write-through (sc1): leaves the XCD's L2 at once instead of at the end of the kernel
+        v4f val = {r.x, r.y, r.z, r.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(val) : "memory");
+    } else if (MODE == 3) {
+        v4f val = {r.x, r.y, r.z, r.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(val) : "memory");
+    } else {
         v4f val = {r.x, r.y, r.z, r.w};
         __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(p));
     }

@@ -202,7 +202,11 @@ def timed_run(mgr, world, steps_req, warmup_req):
     mgr.train_epochs(1)
     graphs = mgr._graph_warm and mgr.graphs_enabled()
     if graphs:
-        mgr.prepare_graphs(range(1, CLUSTER_INTERVAL + 1))
+        try:
+            mgr.prepare_graphs(range(1, CLUSTER_INTERVAL + 1))
+        except Exception as exc:   # (e.g. a collective that cannot be captured on this node): eager launches
+            print(f'bench: graph capture failed ({exc!r}); timing the eager loop', file=sys.stderr)
+            mgr.use_graph, graphs = False, False
     n_warm = max(1, -(-warmup_req // per))
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()

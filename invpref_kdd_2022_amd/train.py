@@ -451,11 +451,19 @@ class _InvPrefTrainManager:
         # wide rows (RCCL collectives record into a HIP graph like kernels do), are replayed as whole-epoch graphs
         fused_seq = self._fused_seq()
         graph_ok = self.graphs_enabled()
+        g = None
         if graph_ok and self._graph_warm:
             n = min(want, self._graph_epochs)
             steps = n * self.batch_num
             self._sched_prepare(steps)
-            g = self._graph_for(n)
+            try:
+                g = self._graph_for(n)
+            except Exception as exc:   # e.g. a collective library that cannot record into a graph: stay eager
+                import warnings
+                warnings.warn(f'HIP-graph capture of the epoch failed ({exc!r}); continuing with eager launches')
+                self.use_graph = False
+                self._loss_slot = 0
+        if g is not None:
             g.replay()
             st.step += steps
             if steps % 2 and fused_seq:
@@ -504,13 +512,15 @@ class _InvPrefTrainManager:
         if g is None:
             step0, views0 = st.step, st.p_views
             g = torch.cuda.CUDAGraph()
-            # (thread-local capture mode: the RCCL watchdog thread of a process group may query events meanwhile)
-            with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                self._issue_epochs(None, True, n)
-            # capture records, it does not run: put the host-side bookkeeping back
-            st.step = step0
-            if st.p_views is not views0:
-                st.swap()
+            try:
+                # (thread-local capture mode: the RCCL watchdog thread of a process group may query events meanwhile)
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    self._issue_epochs(None, True, n)
+            finally:
+                # capture records, it does not run: put the host-side bookkeeping back
+                st.step = step0
+                if st.p_views is not views0:
+                    st.swap()
             self._graphs[key] = g
         return g
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define INVPREF_ABI_VERSION 1
+#define INVPREF_ABI_VERSION 2
 
 /* error codes */
 #define INVPREF_OK 0
@@ -137,6 +137,15 @@ typedef struct InvPrefRowPlan {
      * sums, the hot rows' atomics) is computed by workgroups that walk the minibatch in its own order,
      * dense_per_task interactions each: the ids of the minibatch as int32. */
     const int32_t *batch_users, *batch_items; /* [n] */
+    /* XCD-affine task order (speed only; any order gives the same results).  n_classes = 8 (the XCDs of an MI355X), or
+     * 1 / 0 for the plain order.  Table rows are dealt to the classes in blocks of 64 rows, class(row) =
+     * (row >> 6) % n_classes; the rounds in `desc` and the rows in `stream_rows` are grouped by class, and workgroup b of
+     * the launch runs tasks of class b % n_classes only -- under the round-robin placement of workgroups over the XCDs
+     * that is the same XCD step after step, so a row's parameters and Adam moments are still in that XCD's L2 when the
+     * next step reads them.  cls[c] = { first item round, item rounds, first user round, user rounds, first streamed
+     * user row (index into stream_rows), streamed user rows, first streamed item row, streamed item rows } of class c. */
+    int32_t n_classes, reserved2;
+    int32_t cls[8][8];
 } InvPrefRowPlan;
 
 /* The rows-path workspace must be ZERO-FILLED before its first use; every call leaves it zero-filled. */

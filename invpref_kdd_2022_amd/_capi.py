@@ -101,7 +101,7 @@ def lib():
         L.invpref_static_pop_workspace_bytes.restype = C.c_size_t
         L.invpref_static_pop_hip.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
         L.invpref_device_name.argtypes = [C.c_char_p, C.c_size_t]
-        if L.invpref_abi_version() != 1:
+        if L.invpref_abi_version() != 2:
             raise InvPrefError('libinvpref_hip.so ABI version mismatch')
         _lib = L
     return _lib

@@ -26,6 +26,7 @@
 // per-group register partials -> workgroup reduction -> float atomics into a few replica slabs
 // (~2 KB per workgroup, 256-byte contiguous instructions) folded by rows_finish_kernel.
 #include <stdlib.h>
+#include <string.h>
 
 #include "kernel_common.hpp"
 
@@ -326,6 +327,8 @@ struct RowsArgs {
     // streamed by dedicated workgroups with several rows in flight per group
     const int *stream_rows;       // [n_stream_user + n_stream_item] row ids, user rows first
     int n_stream_user, n_stream_item, rows_per_stream_task, n_job_tasks, n_stream_user_tasks;
+    int n_cls;                    // XCD-affine task order: workgroup b runs tasks of class b % n_cls (InvPrefRowPlan)
+    int cls[8][8];
     const int *batch_users, *batch_items;   // [n] ids of the minibatch in its own order (dense tasks)
     int n, dense_per_task, n_dense_tasks;
     const int *item_hot_index;    // [item_num]: scratch row of an item whose gradient goes through atomics, or -1
@@ -943,53 +946,57 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
 }
 
 // Untouched rows: gradient exactly zero, so m' = m + (1-b1)(0-m), v' = b2 v, p' = p - step*m'/(sqrt(v')/bc+eps)
-// (the same adam1f as everywhere, fed g = 0).  Each 16-lane group keeps two rows (12 float4 loads) in flight.
+// (the same adam1f as everywhere, fed g = 0).  Each 16-lane group keeps R = 2 rows of both tables in flight (12 float4
+// loads; R = 3 was tried for 96-row tasks: 159 VGPRs, or 40 spilled at the 128 a one-wave step needs).
 template <int NC, bool VEC>
 __device__ __forceinline__ void stream_task(const DevTables &t, const RowsArgs &a, int side, const int *rows, int n) {
+    constexpr int R = 2;
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
     const float *Tinv = side == 0 ? t.Pu : t.Qi, *Tenv = side == 0 ? t.Pa : t.Qa;
     const bool pure = a.flags & INVPREF_PURE_MF;
-    for (int i = grp; i < n; i += 2 * kGroups) {
-        const int r0 = rows[i];
-        const bool two = i + kGroups < n;
-        const int r1 = two ? rows[i + kGroups] : r0;
+    for (int i = grp; i < n; i += R * kGroups) {
+        int row[R];
+        bool on[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            on[q] = i + q * kGroups < n;
+            row[q] = rows[on[q] ? i + q * kGroups : i];
+        }
         if (!a.fused) {
             float4 z[NC];
 #pragma unroll
             for (int c = 0; c < NC; c++) z[c] = f4zero();
-            store_row<NC, VEC>(a.g[side], r0, t.D, l16, z);
-            if (!pure) store_row<NC, VEC>(a.g[2 + side], r0, t.D, l16, z);
-            if (two) {
-                store_row<NC, VEC>(a.g[side], r1, t.D, l16, z);
-                if (!pure) store_row<NC, VEC>(a.g[2 + side], r1, t.D, l16, z);
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                if (!on[q]) continue;
+                store_row<NC, VEC>(a.g[side], row[q], t.D, l16, z);
+                if (!pure) store_row<NC, VEC>(a.g[2 + side], row[q], t.D, l16, z);
             }
             continue;
         }
-        float4 p[4][NC], m[4][NC], v[4][NC];  // {r0 inv, r0 env, r1 inv, r1 env}
+        float4 p[2 * R][NC], m[2 * R][NC], v[2 * R][NC];  // {row 0 inv, row 0 env, row 1 inv, ...}
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int row = q < 2 ? r0 : r1;
+        for (int q = 0; q < 2 * R; q++) {
             const int ti = (q & 1) * 2 + side;
             if (!(pure && (q & 1))) {
-                load_row<NC, VEC>((q & 1) ? Tenv : Tinv, row, t.D, l16, p[q]);
-                load_row<NC, VEC>(a.m[ti], row, t.D, l16, m[q]);
-                load_row<NC, VEC>(a.v[ti], row, t.D, l16, v[q]);
+                load_row<NC, VEC>((q & 1) ? Tenv : Tinv, row[q >> 1], t.D, l16, p[q]);
+                load_row<NC, VEC>(a.m[ti], row[q >> 1], t.D, l16, m[q]);
+                load_row<NC, VEC>(a.v[ti], row[q >> 1], t.D, l16, v[q]);
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int row = q < 2 ? r0 : r1;
+        for (int q = 0; q < 2 * R; q++) {
             const int ti = (q & 1) * 2 + side;
-            if ((q < 2 || two) && !(pure && (q & 1))) {
+            if (on[q >> 1] && !(pure && (q & 1))) {
 #pragma unroll
                 for (int c = 0; c < NC; c++) {
                     adam1f(p[q][c].x, 0.f, m[q][c].x, v[q][c].x, ad); adam1f(p[q][c].y, 0.f, m[q][c].y, v[q][c].y, ad);
                     adam1f(p[q][c].z, 0.f, m[q][c].z, v[q][c].z, ad); adam1f(p[q][c].w, 0.f, m[q][c].w, v[q][c].w, ad);
                 }
-                store_row<NC, VEC, ROWS_ST_P>(a.np[ti], row, t.D, l16, p[q]);
-                store_row<NC, VEC>(a.m[ti], row, t.D, l16, m[q]);
-                store_row<NC, VEC>(a.v[ti], row, t.D, l16, v[q]);
+                store_row<NC, VEC, ROWS_ST_P>(a.np[ti], row[q >> 1], t.D, l16, p[q]);
+                store_row<NC, VEC>(a.m[ti], row[q >> 1], t.D, l16, m[q]);
+                store_row<NC, VEC>(a.v[ti], row[q >> 1], t.D, l16, v[q]);
             }
         }
     }
@@ -1004,33 +1011,43 @@ template <int NC, bool VEC, int EMAX>
 __global__ __launch_bounds__(256, (NC * EMAX > 4) ? ROWS_MIN_WAVES_BIG : ROWS_MIN_WAVES)
 void mstep_rows_kernel(DevTables t, RowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // grid = [dense tasks | job tasks | stream tasks]: the dense tasks walk several interactions in
-    // sequence and start first; every branch below is workgroup-uniform
-    int b = blockIdx.x;
-    if (b < a.n_dense_tasks) {
-        const int s0 = b * a.dense_per_task;
+    // Workgroup b runs the tasks of class c = b % n_cls (XCD-affine order, InvPrefRowPlan), the j-th of them with
+    // j = b / n_cls: the class's share of the dense tasks first (they walk several interactions in sequence), then its
+    // item jobs, user jobs, streamed user rows, streamed item rows.  Every branch below is workgroup-uniform.
+    const int ncls = a.n_cls;
+    const int c = (int)blockIdx.x % ncls;
+    int j = (int)blockIdx.x / ncls;
+    const int nd = a.n_dense_tasks > c ? (a.n_dense_tasks - c + ncls - 1) / ncls : 0;
+    if (j < nd) {
+        const int s0 = (c + ncls * j) * a.dense_per_task;
         dense_task<NC, VEC, EMAX>(t, a, s0, min(s0 + a.dense_per_task, a.n), lds);
         return;
     }
-    b -= a.n_dense_tasks;
-    if (b >= a.n_job_tasks) {  // trailing workgroups: untouched rows
-        STAMP(0);
-        const int sb = b - a.n_job_tasks;
-        const bool us = sb < a.n_stream_user_tasks;
-        const int first = (us ? sb : sb - a.n_stream_user_tasks) * a.rows_per_stream_task;
-        const int total = us ? a.n_stream_user : a.n_stream_item;
-        const int *list = a.stream_rows + (us ? 0 : a.n_stream_user) + first;
-        stream_task<NC, VEC>(t, a, us ? 0 : 1, list, min(a.rows_per_stream_task, total - first));
-        STAMP(7);
+    j -= nd;
+    const int rpt = a.rounds_per_task, spt = a.rows_per_stream_task;
+    const int i_base = a.cls[c][0], i_n = a.cls[c][1], u_base = a.cls[c][2], u_n = a.cls[c][3];
+    const int su_base = a.cls[c][4], su_n = a.cls[c][5], si_base = a.cls[c][6], si_n = a.cls[c][7];
+    const int ti = (i_n + rpt - 1) / rpt, tu = (u_n + rpt - 1) / rpt;
+    if (j < ti) {
+        rows_task<NC, VEC, EMAX, false>(t, a, make_int4(1, i_base + j * rpt, min(rpt, i_n - j * rpt), 0), lds);
         return;
     }
-    // job workgroup b runs rounds [b*rpt, (b+1)*rpt); the item-side rounds come first (they hold the longer
-    // jobs) and are padded to a multiple of rpt, so a workgroup never mixes sides
-    const int r0 = b * a.rounds_per_task;
-    const int nr = min(a.rounds_per_task, a.n_rounds - r0);
-    const int4 task = make_int4(r0 < a.n_item_rounds ? 1 : 0, r0, nr, 0);
-    if (task.x == 0) rows_task<NC, VEC, EMAX, true>(t, a, task, lds);
-    else rows_task<NC, VEC, EMAX, false>(t, a, task, lds);
+    j -= ti;
+    if (j < tu) {
+        rows_task<NC, VEC, EMAX, true>(t, a, make_int4(0, u_base + j * rpt, min(rpt, u_n - j * rpt), 0), lds);
+        return;
+    }
+    j -= tu;
+    const int tsu = (su_n + spt - 1) / spt, tsi = (si_n + spt - 1) / spt;
+    if (j < tsu + tsi) {  // untouched rows
+        STAMP(0);
+        const bool us = j < tsu;
+        const int first = (us ? j : j - tsu) * spt;
+        stream_task<NC, VEC>(t, a, us ? 0 : 1, a.stream_rows + (us ? su_base : si_base) + first,
+                             min(spt, (us ? su_n : si_n) - first));
+        STAMP(7);
+    }
+    // (a class with fewer tasks than the longest one: nothing to do)
 }
 
 
@@ -1165,8 +1182,30 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a.batch_users = plan->batch_users; a.batch_items = plan->batch_items; a.n = plan->n;
     a.dense_per_task = plan->dense_per_task;
     a.n_dense_tasks = (plan->n + plan->dense_per_task - 1) / plan->dense_per_task;
-    const int n_tasks = a.n_dense_tasks + n_job_tasks + a.n_stream_user_tasks +
-                        (plan->n_stream_item + plan->rows_per_stream_task - 1) / plan->rows_per_stream_task;
+    // XCD-affine order: the grid holds n_cls interleaved task lists, padded to the longest
+    a.n_cls = plan->n_classes > 0 ? plan->n_classes : 1;
+    if (a.n_cls > 8) return INVPREF_EINVAL;
+    if (plan->n_classes > 0) {
+        memcpy(a.cls, plan->cls, sizeof(a.cls));
+    } else {  // the plain order as one class
+        const int tmp[8] = {0, plan->n_item_rounds, plan->n_item_rounds, plan->n_rounds - plan->n_item_rounds, 0,
+                            plan->n_stream_user, plan->n_stream_user, plan->n_stream_item};
+        memset(a.cls, 0, sizeof(a.cls));
+        memcpy(a.cls[0], tmp, sizeof(tmp));
+    }
+    int per_class = 0;
+    for (int c = 0; c < a.n_cls; c++) {
+        const int *q = a.cls[c];
+        if (q[0] < 0 || q[1] < 0 || q[2] < 0 || q[3] < 0 || q[4] < 0 || q[5] < 0 || q[6] < 0 || q[7] < 0 ||
+            q[0] + q[1] > plan->n_item_rounds || q[2] < plan->n_item_rounds || q[2] + q[3] > plan->n_rounds ||
+            q[4] + q[5] > plan->n_stream_user + plan->n_stream_item || q[6] + q[7] > plan->n_stream_user + plan->n_stream_item)
+            return INVPREF_EINVAL;
+        const int rpt = plan->rounds_per_task, spt = plan->rows_per_stream_task;
+        const int nd = a.n_dense_tasks > c ? (a.n_dense_tasks - c + a.n_cls - 1) / a.n_cls : 0;
+        const int tot = nd + (q[1] + rpt - 1) / rpt + (q[3] + rpt - 1) / rpt + (q[5] + spt - 1) / spt + (q[7] + spt - 1) / spt;
+        per_class = tot > per_class ? tot : per_class;
+    }
+    const int n_tasks = per_class * a.n_cls;
     if (n_tasks <= 0) return INVPREF_EINVAL;
     a.oth[0] = plan->other_user; a.pos[0] = plan->pos_user;
     a.oth[1] = plan->other_item; a.pos[1] = plan->pos_item;

@@ -28,7 +28,20 @@ class RowPlanStruct(C.Structure):
                 ('hot_rows', C.c_void_p), ('hot_count', C.c_void_p), ('item_hot_index', C.c_void_p),
                 ('n_stream_user', C.c_int32), ('n_stream_item', C.c_int32), ('rows_per_stream_task', C.c_int32),
                 ('dense_per_task', C.c_int32), ('stream_rows', C.c_void_p), ('batch_users', C.c_void_p),
-                ('batch_items', C.c_void_p)]
+                ('batch_items', C.c_void_p), ('n_classes', C.c_int32), ('reserved2', C.c_int32),
+                ('cls', C.c_int32 * 64)]
+
+N_CLASSES = 8          # XCDs of an MI355X: blocks b and b + 8 of a launch share one (round-robin placement)
+CLASS_SHIFT = 6        # rows are dealt to the classes in blocks of 64
+
+
+def stream_rows_default(factor_num: int) -> int:
+    """untouched rows per stream task: two iterations of a workgroup (2 rows per 16-lane group in flight)"""
+    return 64
+
+
+def row_class(rows: np.ndarray, n_classes: int) -> np.ndarray:
+    return (np.asarray(rows) >> CLASS_SHIFT) % n_classes
 
 
 def _side_rounds(own, oth, pos, y, n_rows: int, per_slice: int, pad_to: int, skip=None):
@@ -88,12 +101,19 @@ def _side_rounds(own, oth, pos, y, n_rows: int, per_slice: int, pad_to: int, ski
 
 def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, user_num: int, item_num: int,
                    per_slice: int | None = None, rounds_per_task: int | None = None,
-                   hot_threshold: int | None = None, user_range=None) -> dict:
+                   hot_threshold: int | None = None, user_range=None, n_classes: int | None = None,
+                   rows_per_stream_task: int | None = None) -> dict:
     """users/items/scores: ONE minibatch (or this rank's slice of it); scores as the fp32 labels.
     hot_threshold: item rows with MORE interactions than this get no job; their gradient is added with
     float atomics by the user-side jobs and completed by the finish kernel (-1: every item row).
     user_range: (lo, hi) user rows this rank is responsible for (user-sharded runs): untouched user rows
-    outside it are not streamed (nobody reads their gradient or updates them here)."""
+    outside it are not streamed (nobody reads their gradient or updates them here).
+    n_classes: XCD-affine task order (default 8 = the XCDs of an MI355X; INVPREF_PLAN_CLASSES): table rows are dealt
+    to the classes in blocks of 64 rows, and every job / streamed row of class c is run by a workgroup with
+    blockIdx.x % n_classes == c -- under the round-robin placement of workgroups the SAME XCD step after step, so
+    the row's parameters and Adam moments are still in that XCD's L2 when the next step reads them (measured,
+    tools/xcd_probe.py: a pure streaming step takes 8.4 us with a stable assignment and 11.5 us when the assignment
+    moves to another XCD every step).  Speed only: any order gives the same results."""
     users = np.asarray(users, dtype=np.int64)
     items = np.asarray(items, dtype=np.int64)
     scores = np.asarray(scores, dtype=np.float32)
@@ -106,7 +126,9 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     if rounds_per_task is None:
         rounds_per_task = int(os.environ.get('INVPREF_PLAN_ROUNDS', '1'))
     if hot_threshold is None:
-        hot_threshold = int(os.environ.get('INVPREF_PLAN_HOT', str(16 if per_slice <= 2 else 16 * per_slice)))
+        # (Yahoo-class plans: 10 -- measured with the XCD-affine order, tools/ab2.sh: the per-class padding of the
+        #  job rounds must not push the launch beyond one residency wave of 1 024 workgroups)
+        hot_threshold = int(os.environ.get('INVPREF_PLAN_HOT', str(10 if per_slice <= 2 else 16 * per_slice)))
     n = len(users)
     if n and (cnt_max := max(np.bincount(users).max(), np.bincount(items).max())) >= (1 << 23):
         raise ValueError(f'a row with {cnt_max} interactions in one minibatch overflows the job descriptor')
@@ -125,13 +147,39 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         untouched_u[user_range[1]:] = False
     stream_u = np.flatnonzero(untouched_u).astype(np.int32)     # untouched rows: streamed, no job
     stream_i = np.flatnonzero(icnt == 0).astype(np.int32)
-    di = _side_rounds(items[pi], users[pi], pi, scores[pi], item_num, per_slice, rounds_per_task,
-                      skip=hot | (icnt == 0))
-    du = _side_rounds(users[pu], items[pu], pu, scores[pu], user_num, per_slice, 1, skip=(ucnt == 0))
+    if n_classes is None:
+        n_classes = int(os.environ.get('INVPREF_PLAN_CLASSES', str(N_CLASSES)))
+    n_classes = max(1, min(8, n_classes))
+    ucls, icls = row_class(np.arange(user_num), n_classes), row_class(np.arange(item_num), n_classes)
+    di_parts, du_parts, su_parts, si_parts = [], [], [], []
+    cls = np.zeros((8, 8), np.int32)
+    for c in range(n_classes):
+        # per class: item rounds (padded to whole tasks), user rounds, untouched user rows, untouched item rows
+        di_parts.append(_side_rounds(items[pi], users[pi], pi, scores[pi], item_num, per_slice, rounds_per_task,
+                                     skip=hot | (icnt == 0) | (icls != c)))
+        du_parts.append(_side_rounds(users[pu], items[pu], pu, scores[pu], user_num, per_slice, 1,
+                                     skip=(ucnt == 0) | (ucls != c)))
+        su_parts.append(stream_u[ucls[stream_u] == c])
+        # (the few untouched item rows are not worth one tiny task per class: class 0 streams them all)
+        si_parts.append(stream_i if c == 0 else stream_i[:0])
+    n_item_rounds = sum(len(d) for d in di_parts)
+    ib, ub, sb = 0, n_item_rounds, 0
+    for c in range(n_classes):
+        cls[c, 0], cls[c, 1] = ib, len(di_parts[c]); ib += len(di_parts[c])
+        cls[c, 2], cls[c, 3] = ub, len(du_parts[c]); ub += len(du_parts[c])
+    for c in range(n_classes):
+        cls[c, 4], cls[c, 5] = sb, len(su_parts[c]); sb += len(su_parts[c])
+    for c in range(n_classes):
+        cls[c, 6], cls[c, 7] = sb, len(si_parts[c]); sb += len(si_parts[c])
+    stream_u, stream_i = np.concatenate(su_parts), np.concatenate(si_parts)
+    di, du = np.concatenate(di_parts), np.concatenate(du_parts)
     return dict(batch_users=users.astype(np.int32), batch_items=items.astype(np.int32),
                 dense_per_task=int(os.environ.get('INVPREF_PLAN_DENSE', str(min(256, 32 * scale)))),
-                stream_rows=np.concatenate([stream_u, stream_i]), n_stream_user=len(stream_u),
-                n_stream_item=len(stream_i), rows_per_stream_task=int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', '64')),n=n, n_item_rounds=len(di), rounds_per_task=rounds_per_task, desc=np.concatenate([di, du]),
+                stream_rows=np.concatenate([stream_u, stream_i]).astype(np.int32), n_stream_user=len(stream_u),
+                n_stream_item=len(stream_i),
+                rows_per_stream_task=int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', str(rows_per_stream_task or 64))),
+                n_classes=n_classes, cls=cls,
+                n=n, n_item_rounds=len(di), rounds_per_task=rounds_per_task, desc=np.concatenate([di, du]),
                 other_user=items[pu].astype(np.int32), pos_user=pu.astype(np.int32),
                 other_item=users[pi].astype(np.int32), pos_item=pi.astype(np.int32),
                 hot_rows=hot_rows, hot_count=icnt[hot_rows].astype(np.int32), item_hot_index=hot_index)
@@ -147,22 +195,31 @@ class DevicePlan:
     meta: torch.Tensor = None   # CPU int64[len(_fields_)]: struct fields in order, pointers as int32 offsets into buf
 
 
-_PTR_FIELDS = [i for i, (_, ty) in enumerate(RowPlanStruct._fields_) if ty is C.c_void_p]
+_META_LEN = sum(64 if name == 'cls' else 1 for name, _ in RowPlanStruct._fields_)
 
 
 def struct_from_meta(buf: torch.Tensor, meta: torch.Tensor) -> RowPlanStruct:
     """The InvPrefRowPlan of a plan that travels as (device buffer, CPU meta tensor) -- the form in which
     ``torch.ops.invpref.train_step_planned_*`` take it."""
     if buf.dtype != torch.int32 or not buf.is_contiguous() or meta.dtype != torch.int64 or meta.is_cuda \
-            or meta.numel() != len(RowPlanStruct._fields_):
+            or meta.numel() != _META_LEN:
         raise ValueError('row plan: int32 device buffer + CPU int64 meta tensor expected')
     vals = meta.tolist()
     base, n = buf.data_ptr(), buf.numel()
-    for i in _PTR_FIELDS:
-        if not 0 <= vals[i] <= n:
-            raise ValueError('row plan: array offset outside the buffer')
-        vals[i] = base + 4 * vals[i]
-    return RowPlanStruct(*vals)
+    args, i = [], 0
+    for name, ty in RowPlanStruct._fields_:
+        if name == 'cls':
+            args.append((C.c_int32 * 64)(*vals[i:i + 64]))
+            i += 64
+            continue
+        v = vals[i]
+        i += 1
+        if ty is C.c_void_p:
+            if not 0 <= v <= n:
+                raise ValueError('row plan: array offset outside the buffer')
+            v = base + 4 * v
+        args.append(v)
+    return RowPlanStruct(*args)
 
 
 def upload(plan: dict, device) -> DevicePlan:
@@ -179,15 +236,39 @@ def upload(plan: dict, device) -> DevicePlan:
     offs = dict(ptrs)
     ptrs = {k: buf.data_ptr() + 4 * o for k, o in ptrs.items()}
     nr, rpt = len(plan['desc']), plan['rounds_per_task']
+    ncls = int(plan.get('n_classes', 1))
+    cls = np.asarray(plan['cls'], np.int32) if 'cls' in plan else np.zeros((8, 8), np.int32)
+    if 'cls' not in plan:   # the plain order as one class
+        cls[0] = [0, plan['n_item_rounds'], plan['n_item_rounds'], nr - plan['n_item_rounds'], 0, plan['n_stream_user'],
+                  plan['n_stream_user'], plan['n_stream_item']]
     st = RowPlanStruct(nr, plan['n_item_rounds'], rpt, plan['n'], ptrs['desc'], ptrs['other_user'],
                        ptrs['pos_user'], ptrs['other_item'], ptrs['pos_item'], len(plan['hot_rows']), 0,
                        ptrs['hot_rows'], ptrs['hot_count'], ptrs['item_hot_index'], plan['n_stream_user'],
                        plan['n_stream_item'], plan['rows_per_stream_task'], plan['dense_per_task'],
-                       ptrs['stream_rows'], ptrs['batch_users'], ptrs['batch_items'])
-    spt = plan['rows_per_stream_task']
-    n_tasks = -(-nr // rpt) + -(-plan['n_stream_user'] // spt) + -(-plan['n_stream_item'] // spt) \
-        + -(-plan['n'] // plan['dense_per_task'])
-    meta = [getattr(st, name) for name, _ in RowPlanStruct._fields_]
-    for i in _PTR_FIELDS:
-        meta[i] = offs[RowPlanStruct._fields_[i][0]]
+                       ptrs['stream_rows'], ptrs['batch_users'], ptrs['batch_items'], ncls, 0,
+                       (C.c_int32 * 64)(*cls.reshape(-1).tolist()))
+    n_tasks = ncls * max(class_tasks(plan, cls, c) for c in range(ncls))
+    meta = _meta_of(st, offs)
     return DevicePlan(st, [buf], n_tasks, nr, buf, torch.tensor(meta, dtype=torch.int64))
+
+
+def class_tasks(plan: dict, cls: np.ndarray, c: int) -> int:
+    """workgroups of class c: its share of the dense tasks, its item / user job tasks, its stream tasks"""
+    ncls, rpt, spt = int(plan.get('n_classes', 1)), plan['rounds_per_task'], plan['rows_per_stream_task']
+    nd = -(-plan['n'] // plan['dense_per_task'])
+    return (max(0, -(-(nd - c) // ncls)) + -(-int(cls[c, 1]) // rpt) + -(-int(cls[c, 3]) // rpt)
+            + -(-int(cls[c, 5]) // spt) + -(-int(cls[c, 7]) // spt))
+
+
+def _meta_of(st: RowPlanStruct, offs: dict) -> list:
+    """the struct as a flat list of integers (array fields expanded), pointers as int32 offsets into the buffer"""
+    meta = []
+    for name, ty in RowPlanStruct._fields_:
+        v = getattr(st, name)
+        if ty is C.c_void_p:
+            meta.append(offs[name])
+        elif hasattr(v, '__len__'):
+            meta.extend(list(v))
+        else:
+            meta.append(v)
+    return meta

@@ -308,7 +308,8 @@ class _InvPrefTrainManager:
             for lo, n, *_ in self._raw_batches:
                 pl = planlib.build_row_plan(u[lo:lo + n], v[lo:lo + n], y[lo:lo + n], self.model.user_num,
                                             self.model.item_num,
-                                            user_range=self.shard.user_range(self.model.user_num))
+                                            user_range=self.shard.user_range(self.model.user_num),
+                                            rows_per_stream_task=planlib.stream_rows_default(self.model.factor_num))
                 self._plans.append(planlib.upload(pl, self.device))
             self.plan_build_s = time.perf_counter() - t0     # host-side, once per run (reported by bench.py)
         if self.use_plan and self.users_tensor.is_cuda:

@@ -16,8 +16,27 @@ def check_plan(users, items, U, I, **kw):
     assert p['dense_per_task'] > 0
     su, si = p['stream_rows'][:p['n_stream_user']], p['stream_rows'][p['n_stream_user']:]
     assert len(si) == p['n_stream_item']
-    np.testing.assert_array_equal(su, np.flatnonzero(np.bincount(users, minlength=U) == 0))
-    np.testing.assert_array_equal(si, np.flatnonzero(np.bincount(items, minlength=I) == 0))
+    np.testing.assert_array_equal(np.sort(su), np.flatnonzero(np.bincount(users, minlength=U) == 0))
+    np.testing.assert_array_equal(np.sort(si), np.flatnonzero(np.bincount(items, minlength=I) == 0))
+    # XCD-affine order: rounds and streamed rows are grouped by class = (row >> 6) % n_classes, cls[c] delimits them
+    ncls, cls = p['n_classes'], p['cls']
+    assert 1 <= ncls <= 8
+    ib, ub, sb = 0, nir, 0
+    for c in range(ncls):
+        assert cls[c, 0] == ib and cls[c, 2] == ub and cls[c, 1] % rpt == 0
+        for lo, cnt_ in ((cls[c, 0], cls[c, 1]), (cls[c, 2], cls[c, 3])):
+            rows = desc[lo:lo + cnt_, :, 0].reshape(-1)
+            rows = rows[rows >= 0]
+            assert (planlib.row_class(rows, ncls) == c).all()
+        ib += cls[c, 1]
+        ub += cls[c, 3]
+    assert ib == nir and ub == len(desc)
+    for c in range(ncls):
+        assert cls[c, 4] == sb
+        seg = p['stream_rows'][sb:sb + cls[c, 5]]
+        assert (planlib.row_class(seg, ncls) == c).all() and (np.diff(seg) > 0).all()
+        sb += cls[c, 5]
+    assert sb == p['n_stream_user'] and cls[0, 6] == sb and cls[:ncls, 7].sum() == p['n_stream_item']
     hot = set(p['hot_rows'].tolist())
     icnt = np.bincount(items, minlength=I)
     np.testing.assert_array_equal(p['hot_count'], icnt[p['hot_rows']])
@@ -74,6 +93,12 @@ def test_plan_parameters(per_slice, rpt, hot):
     rs = np.random.RandomState(per_slice)
     u, v = rs.randint(0, 37, 500), rs.randint(0, 5, 500)  # item rows with ~100 interactions each
     check_plan(u, v, 40, 7, per_slice=per_slice, rounds_per_task=rpt, hot_threshold=hot)
+
+
+def test_plan_single_class_is_the_plain_order():
+    d = synth.yahoo_like()[:8192]
+    p = check_plan(d[:, 0], d[:, 1], 15400, 1000, n_classes=1)
+    np.testing.assert_array_equal(p['stream_rows'][:p['n_stream_user']], np.flatnonzero(np.bincount(d[:, 0], minlength=15400) == 0))
 
 
 def test_plan_empty_and_single():

@@ -160,8 +160,8 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         du_parts.append(_side_rounds(users[pu], items[pu], pu, scores[pu], user_num, per_slice, 1,
                                      skip=(ucnt == 0) | (ucls != c)))
         su_parts.append(stream_u[ucls[stream_u] == c])
-        # (the few untouched item rows are not worth one tiny task per class: class 0 streams them all)
-        si_parts.append(stream_i if c == 0 else stream_i[:0])
+        # (a few untouched item rows are not worth one tiny task per class: class 0 streams them all then)
+        si_parts.append(stream_i[icls[stream_i] == c] if len(stream_i) > 8 * 64 else (stream_i if c == 0 else stream_i[:0]))
     n_item_rounds = sum(len(d) for d in di_parts)
     ib, ub, sb = 0, n_item_rounds, 0
     for c in range(n_classes):

@@ -37,6 +37,9 @@ def check_plan(users, items, U, I, **kw):
         assert (planlib.row_class(seg, ncls) == c).all() and (np.diff(seg) > 0).all()
         sb += cls[c, 5]
     assert sb == p['n_stream_user'] and cls[0, 6] == sb and cls[:ncls, 7].sum() == p['n_stream_item']
+    for c in range(ncls):   # untouched item rows: by class when there are many, all in class 0 otherwise
+        seg = p['stream_rows'][cls[c, 6]:cls[c, 6] + cls[c, 7]]
+        assert (np.diff(seg) > 0).all() and (len(si) <= 512 or (planlib.row_class(seg, ncls) == c).all())
     hot = set(p['hot_rows'].tolist())
     icnt = np.bincount(items, minlength=I)
     np.testing.assert_array_equal(p['hot_count'], icnt[p['hot_rows']])

@@ -29,7 +29,7 @@ w = torch.ones(1, device=dev)
 
 
 def plan_rot(rot):
-    pl = planlib.build_row_plan(np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32), U, I)
+    pl = planlib.build_row_plan(np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32), U, I, n_classes=1)
     nu = pl['n_stream_user']
     su, si = pl['stream_rows'][:nu], pl['stream_rows'][nu:]
     pl['stream_rows'] = np.concatenate([np.roll(su, 64 * rot), np.roll(si, 64 * rot)])

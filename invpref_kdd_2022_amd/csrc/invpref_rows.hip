@@ -1025,8 +1025,18 @@ void mstep_rows_kernel(DevTables t, RowsArgs a) {
     }
     j -= nd;
     const int rpt = a.rounds_per_task, spt = a.rows_per_stream_task;
-    const int i_base = a.cls[c][0], i_n = a.cls[c][1], u_base = a.cls[c][2], u_n = a.cls[c][3];
-    const int su_base = a.cls[c][4], su_n = a.cls[c][5], si_base = a.cls[c][6], si_n = a.cls[c][7];
+    // (a masked sum over the eight rows instead of a dynamic index -- or of selects, which the optimiser turns back
+    //  into one: indexing a by-value kernel argument with a run-time value can make the compiler copy the whole
+    //  argument block to scratch memory -- seen with a larger argument block: 1.1 KB per lane, 80 us per launch)
+    int q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int on = (c == k) ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) q[i] += a.cls[k][i] * on;
+    }
+    const int i_base = q[0], i_n = q[1], u_base = q[2], u_n = q[3];
+    const int su_base = q[4], su_n = q[5], si_base = q[6], si_n = q[7];
     const int ti = (i_n + rpt - 1) / rpt, tu = (u_n + rpt - 1) / rpt;
     if (j < ti) {
         rows_task<NC, VEC, EMAX, false>(t, a, make_int4(1, i_base + j * rpt, min(rpt, i_n - j * rpt), 0), lds);

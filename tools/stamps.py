@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 dev = torch.device('cuda:0')
-stamps = torch.zeros(8192 * 8, dtype=torch.int64, device=dev)
+stamps = torch.zeros(16384 * 8, dtype=torch.int64, device=dev)
 os.environ['INVPREF_STAMPS'] = hex(stamps.data_ptr())
 from invpref_kdd_2022_amd import ops, plan as planlib, synth
 
@@ -47,25 +47,38 @@ for per_slice, rpt, hot, dense in combos:
             a, b = b, a
     torch.cuda.synchronize()
     pl, dp = pls[-1], dps[-1]
-    st = stamps.cpu().numpy().reshape(-1, 8)[:dp.n_tasks].astype(np.int64)
-    nd = -(-B // dense)
-    ni = pl['n_item_rounds'] // rpt
-    njob = -(-dp.n_rounds // rpt)
-    t0 = st[:, 0].min()
+    ncls, cls, spt = pl['n_classes'], pl['cls'], pl['rows_per_stream_task']
+    nd_all = -(-B // dense)
+    per_class = dp.n_tasks // ncls
+    nfin = 0   # (blocks beyond the task grid: an experiment carried the finish in the last blocks of the launch)
+    st = stamps.cpu().numpy().reshape(-1, 8)[:dp.n_tasks + nfin].astype(np.int64)
+    kind = np.full(dp.n_tasks + nfin, 'pad   ', dtype=object)
+    for b in range(dp.n_tasks):          # the kernel's own dispatch arithmetic
+        c, j = b % ncls, b // ncls
+        ndc = max(0, -(-(nd_all - c) // ncls))
+        ti, tu = -(-int(cls[c, 1]) // rpt), -(-int(cls[c, 3]) // rpt)
+        ts = -(-int(cls[c, 5]) // spt) + -(-int(cls[c, 7]) // spt)
+        kind[b] = 'dense' if j < ndc else 'item' if j < ndc + ti else 'user' if j < ndc + ti + tu else 'stream' if j < ndc + ti + tu + ts else 'pad'
+    kind[dp.n_tasks:] = 'finish'
+    live = st[:, 0] > 0
+    t0 = st[live, 0].min()
     end = np.where(st[:, 7] > 0, st[:, 7], st[:, 6])
-    print(f'== per_slice={per_slice} hot>{hot} dense/task={dense}: tasks {dp.n_tasks} = dense {nd} + item {ni} + user {njob - ni} + stream {dp.n_tasks - njob - nd}, n_hot {len(pl["hot_rows"])}; span {(end.max() - t0) / 100:.2f} us')
-    for name, sl in (('dense', slice(0, nd)), ('item', slice(nd, nd + ni)), ('user', slice(nd + ni, nd + njob)), ('stream', slice(nd + njob, None))):
-        s0, e0 = (st[sl, 0] - t0) / 100, (end[sl] - t0) / 100
-        if len(s0) == 0:
+    print(f'== per_slice={per_slice} hot>{hot} dense/task={dense}: grid {dp.n_tasks} + {nfin} finish blocks; ' + ', '.join(f'{k} {int((kind == k).sum())}' for k in ('dense', 'item', 'user', 'stream', 'pad', 'finish')) + f'; n_hot {len(pl["hot_rows"])}; span {(end[live].max() - t0) / 100:.2f} us')
+    for name in ('dense', 'item', 'user', 'stream', 'finish'):
+        sel = (kind == name) & live
+        if not sel.any():
             continue
+        s0, e0 = (st[sel, 0] - t0) / 100, (end[sel] - t0) / 100
         life = e0 - s0
-        print(f'  {name:6s} n={len(s0):4d} start med {np.median(s0):5.2f} p90 {np.quantile(s0, .9):5.2f} max {s0.max():5.2f} | life med {np.median(life):5.2f} p90 {np.quantile(life, .9):5.2f} max {life.max():5.2f} | end med {np.median(e0):5.2f} p90 {np.quantile(e0, .9):5.2f} max {e0.max():5.2f}')
-
-    for name, sl in (('item', slice(nd, nd + ni)), ('user', slice(nd + ni, nd + njob))):
-        j = st[sl].astype(np.float64)
+        print(f'  {name:6s} n={sel.sum():4d} start med {np.median(s0):5.2f} p90 {np.quantile(s0, .9):5.2f} max {s0.max():5.2f} | life med {np.median(life):5.2f} p90 {np.quantile(life, .9):5.2f} max {life.max():5.2f} | end med {np.median(e0):5.2f} p90 {np.quantile(e0, .9):5.2f} max {e0.max():5.2f}')
+    for name in ('item', 'user'):
+        j = st[(kind == name) & live].astype(np.float64)
         ph = np.diff(j[:, :7], axis=1) / 100
         print('  %s job phases (us, median): stage issue %.2f | descriptor %.2f | gathers+sync %.2f | interactions %.2f | slice meet %.2f | adam+store %.2f' % ((name,) + tuple(np.median(ph, axis=0))))
-    d = st[:nd].astype(np.float64)
-    ph = np.diff(d, axis=1) / 100
-    print('  dense phases (us, median / max): stage+sync %.2f/%.2f | first eval %.2f/%.2f | rest of loop %.2f/%.2f | slab atomics + drain + sync %.2f/%.2f | arrival counters %.2f/%.2f | hot rows finished here %.2f/%.2f | slab fold (last task only) %.2f/%.2f'
-          % tuple(x for c in range(7) for x in (np.median(ph[:, c]), ph[:, c].max())))
+    d = st[(kind == 'dense') & live].astype(np.float64)
+    print('  dense (us, median / max): start -> staged %.2f/%.2f | staged -> end of loop %.2f/%.2f | end of loop -> arrived %.2f/%.2f'
+          % tuple(x for a_, b_ in ((0, 1), (1, 6), (6, 7)) for x in (np.median(d[:, b_] - d[:, a_]) / 100, (d[:, b_] - d[:, a_]).max() / 100)))
+    f = st[(kind == 'finish') & live].astype(np.float64)
+    if len(f):
+        print('  finish blocks (us, median / max): waiting %.2f/%.2f | finish work %.2f/%.2f | counters %.2f/%.2f'
+              % tuple(x for a_, b_ in ((0, 1), (1, 6), (6, 7)) for x in (np.median(f[:, b_] - f[:, a_]) / 100, (f[:, b_] - f[:, a_]).max() / 100)))

@@ -182,6 +182,24 @@ def build_manager(dev, rank, world, shard_mode=None):
     return mgr
 
 
+def sync_or_die(world, seconds=120.0):
+    """torch.cuda.synchronize() that gives up: in a multi-rank run a collective that never completes (e.g. a captured
+    all-reduce the library cannot replay) must end the bench with an error, not hang the node."""
+    import torch
+    if world == 1:
+        torch.cuda.synchronize()
+        return
+    ev = torch.cuda.Event()
+    ev.record()
+    t0 = time.perf_counter()
+    while not ev.query():
+        if time.perf_counter() - t0 > seconds:
+            print(json.dumps({'error': f'GPU work did not complete within {seconds:.0f} s (rank {os.environ.get("RANK")}): '
+                                       'set INVPREF_NO_COLLECTIVE_GRAPH=1 to keep the sharded loop eager'}), flush=True)
+            os._exit(3)
+        time.sleep(0.0005)
+
+
 def timed_run(mgr, world, steps_req, warmup_req):
     """Warm-up + the timed region, both in whole cluster intervals (5 epochs + E-step + stat_envs).
     Returns (seconds max-over-ranks, steps timed, steps of warm-up, pending device results)."""
@@ -213,11 +231,11 @@ def timed_run(mgr, world, steps_req, warmup_req):
             print(f'bench: graph capture failed ({exc!r}); timing the eager loop', file=sys.stderr)
             mgr.use_graph, graphs = False, False
     n_warm = max(1, -(-warmup_req // per))
-    barrier(); torch.cuda.synchronize()
+    barrier(); sync_or_die(world)
     t0 = time.perf_counter()
     for _ in range(n_warm):
         interval()
-    torch.cuda.synchronize(); barrier()
+    sync_or_die(world); barrier()
     est = (time.perf_counter() - t0) / n_warm                     # seconds per interval (first replays included)
     if world > 1:
         t = torch.tensor([est], dtype=torch.float64, device=mgr.device)

@@ -146,6 +146,11 @@ typedef struct InvPrefRowPlan {
      * user row (index into stream_rows), streamed user rows, first streamed item row, streamed item rows } of class c. */
     int32_t n_classes, reserved2;
     int32_t cls[8][8];
+    /* optional (NULL: not used): [item_num] interactions of the item in this minibatch if the item is in the hot-row list,
+     * 0 otherwise.  With it, and an item table of at most 2 048 rows, the hot rows' accumulators are indexed by the item id
+     * and the finish kernel handles every item row with loads that depend on nothing but its thread index (one memory
+     * round trip instead of two on the step's critical path); the workspace holds item_num accumulator rows then. */
+    const int32_t *item_hot_count;
 } InvPrefRowPlan;
 
 /* The rows-path workspace must be ZERO-FILLED before its first use; every call leaves it zero-filled. */

@@ -42,6 +42,15 @@ namespace {
 #endif
 
 constexpr int kReplicas = REPLICAS;   // replica slabs for the E x D gradients / loss sums
+// item tables up to this many rows use the direct hot-row form (HotRows::item_cnt): the finish reads every item
+// row speculatively, which is only worth it while that is a few MB
+constexpr int kHotDirectMaxItems = 2048;
+inline bool hot_direct(const InvPrefTables *tables, const InvPrefRowPlan *plan) {
+    return plan->n_hot > 0 && plan->item_hot_count && tables->item_num <= kHotDirectMaxItems;
+}
+inline size_t hot_scratch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan) {
+    return hot_direct(tables, plan) ? (size_t)tables->item_num : (size_t)plan->n_hot;
+}
 constexpr int kGroups = 16;     // 16-lane groups per 256-thread workgroup
 
 // one row of the device-side schedule (include/invpref_hip.h: InvPrefAdamSchedule)
@@ -121,12 +130,43 @@ struct SmallTables {
 struct HotRows {
     int n, slab_blocks;          // rows; number of leading blocks that fold the slabs
     const int *rows, *cnt;       // [n] item row id, interactions of that row in this minibatch
+    // direct form (small item tables): scratch row = item id, item_cnt[item] = interactions of a hot item (0: not hot);
+    // one group per ITEM, so that nothing the group loads depends on an earlier load (n = item_num then)
+    const int *item_cnt;
+    unsigned long long *stamps;  // diagnostic
     float *scratch;              // [n][2][DP]
     const float *Qi, *Qa;        // current item tables
     float *gQi, *gQa;            // fused == 0: gradient tables
     float *nQi, *nQa, *mQi, *mQa, *vQi, *vQa;   // fused == 1
 };
 
+// The finish kernel is one short dependent chain (kernel arguments -> loads -> Adam -> stores) on the critical path of
+// every step, so its loads are written to leave in ONE burst: pointers are picked with selects, addresses are clamped
+// instead of guarded, and nothing is loaded under a branch (a load under a branch is waited for at the join -- measured:
+// the branchy form of this kernel spent 3.7 us of work per step, each `cond ? a[i] : b[i]` a memory round trip of its own).
+// Touches every 64-byte line of the kernel-argument segment in ONE burst of scalar loads at the top of a kernel.  The
+// compiler fetches arguments lazily, branch by branch; on a cold scalar cache each level is a round trip of its own
+// (measured with phase stamps: 1.8 us from the entry of rows_finish_kernel to its first data), after this they all hit.
+template <int BYTES>
+__device__ __forceinline__ void warm_kernargs() {
+    typedef const __attribute__((address_space(4))) unsigned *kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int LINES = (BYTES + 63) / 64;
+#pragma unroll
+    for (int i0 = 0; i0 < LINES; i0 += 8) {
+        unsigned x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = ka[(i0 + j < LINES ? i0 + j : LINES - 1) * 16];
+        asm volatile("" ::"s"(x[0]), "s"(x[1]), "s"(x[2]), "s"(x[3]), "s"(x[4]), "s"(x[5]), "s"(x[6]), "s"(x[7]));
+    }
+}
+// a kernel-argument pointer made resident in scalar registers HERE: without it the compiler fetches each argument
+// lazily inside the branch that first needs it (one scalar-cache round trip per branch level, in sequence)
+template <typename T>
+__device__ __forceinline__ T *pinned(T *p) {
+    asm volatile("" ::"s"(p));   // (input only: the pointer keeps its inferred address space)
+    return p;
+}
 template <int NC, bool VEC>
 __device__ __forceinline__ void finish_hot_rows(const DevTables &t, const HotRows &h, const StepScalars &k,
                                                 int fused, const AdamScalars &ad, int block, bool pure) {
@@ -134,23 +174,51 @@ __device__ __forceinline__ void finish_hot_rows(const DevTables &t, const HotRow
     const int l16 = threadIdx.x & 15;
     const int i = block * (int)(blockDim.x >> 4) + (int)(threadIdx.x >> 4);
     if (i >= h.n) return;
-    const int row = h.rows[i];
-    const float cnt = (float)h.cnt[i];
-    float *sc = h.scratch + (int64_t)i * 2 * DP;
-    // every load of both tables goes out before the first store (the scratch rows are re-zeroed below, and a store
-    // the compiler cannot prove disjoint would otherwise split the loads into dependent round trips)
+    const int *item_cnt = pinned(h.item_cnt), *rows = pinned(h.rows), *cnts = pinned(h.cnt);
+    const float *qi = pinned(h.Qi), *qa = pinned(h.Qa), *mqi = pinned(h.mQi), *mqa = pinned(h.mQa);
+    const float *vqi = pinned(h.vQi), *vqa = pinned(h.vQa);
+    float *nqi = pinned(h.nQi), *nqa = pinned(h.nQa), *gqi = pinned(h.gQi), *gqa = pinned(h.gQa);
+    float *sc = pinned(h.scratch) + (int64_t)i * 2 * DP;
+    int row = i, icnt;
+    if (item_cnt) {
+        icnt = item_cnt[i];             // direct form: the row is the group's index, nothing below waits for this load
+    } else {
+        row = rows[i];                  // indexed form: the row loads below depend on this one
+        icnt = cnts[i];
+    }
+    const float *Q[2] = {qi, pure ? qi : qa};                       // (PureMF: the second table is absent; its loads
+    const float *M[2] = {fused ? mqi : qi, fused ? (pure ? mqi : mqa) : qi};   //  repeat the first's and are never
+    const float *V[2] = {fused ? vqi : qi, fused ? (pure ? vqi : vqa) : qi};   //  used)
     float4 p[2][NC], g[2][NC], m[2][NC], v[2][NC];
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
-        if (pure && tt) break;
-        load_row<NC, VEC>(tt == 0 ? h.Qi : h.Qa, row, t.D, l16, p[tt]);
 #pragma unroll
         for (int c = 0; c < NC; c++) g[tt][c] = *reinterpret_cast<const float4 *>(sc + tt * DP + (l16 + kRow * c) * 4);
-        if (fused) {
-            load_row<NC, VEC>(tt == 0 ? h.mQi : h.mQa, row, t.D, l16, m[tt]);
-            load_row<NC, VEC>(tt == 0 ? h.vQi : h.vQa, row, t.D, l16, v[tt]);
+        if (VEC) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const int i0 = (l16 + kRow * c) * 4;
+                const int64_t off = (int64_t)row * t.D + (i0 < t.D ? i0 : 0);   // clamped, not guarded
+                p[tt][c] = *reinterpret_cast<const float4 *>(Q[tt] + off);
+                m[tt][c] = *reinterpret_cast<const float4 *>(M[tt] + off);
+                v[tt][c] = *reinterpret_cast<const float4 *>(V[tt] + off);
+            }
+        } else {
+            load_row<NC, VEC>(Q[tt], row, t.D, l16, p[tt]);
+            load_row<NC, VEC>(M[tt], row, t.D, l16, m[tt]);
+            load_row<NC, VEC>(V[tt], row, t.D, l16, v[tt]);
         }
     }
+    // direct form: a group whose item is not a hot row of this minibatch stops here -- its loads were speculative.  The
+    // opaque statement keeps them so: without it the compiler sinks the row loads below this test, i.e. behind the
+    // round trip of the count they were meant to fly with.
+    asm volatile("" : "+v"(icnt)::"memory");
+    if (h.stamps) {   // diagnostic: the loads have landed
+        __builtin_amdgcn_s_waitcnt(0);
+        if (threadIdx.x == 0) h.stamps[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (item_cnt && icnt == 0) return;
+    const float cnt = (float)icnt;
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
         if (pure && tt) break;
@@ -163,16 +231,16 @@ __device__ __forceinline__ void finish_hot_rows(const DevTables &t, const HotRow
             gg.z += cnt * (k.r2 * pp.z + k.r1 * c_sign(pp.z)); gg.w += cnt * (k.r2 * pp.w + k.r1 * c_sign(pp.w));
         }
         if (!fused) {
-            store_row<NC, VEC>(tt == 0 ? h.gQi : h.gQa, row, t.D, l16, g[tt]);
+            store_row<NC, VEC>(tt == 0 ? gqi : gqa, row, t.D, l16, g[tt]);
         } else {
 #pragma unroll
             for (int c = 0; c < NC; c++) {
                 adam1f(p[tt][c].x, g[tt][c].x, m[tt][c].x, v[tt][c].x, ad); adam1f(p[tt][c].y, g[tt][c].y, m[tt][c].y, v[tt][c].y, ad);
                 adam1f(p[tt][c].z, g[tt][c].z, m[tt][c].z, v[tt][c].z, ad); adam1f(p[tt][c].w, g[tt][c].w, m[tt][c].w, v[tt][c].w, ad);
             }
-            store_row<NC, VEC, ROWS_ST_P>(tt == 0 ? h.nQi : h.nQa, row, t.D, l16, p[tt]);
-            store_row<NC, VEC>(tt == 0 ? h.mQi : h.mQa, row, t.D, l16, m[tt]);
-            store_row<NC, VEC>(tt == 0 ? h.vQi : h.vQa, row, t.D, l16, v[tt]);
+            store_row<NC, VEC, ROWS_ST_P>(tt == 0 ? nqi : nqa, row, t.D, l16, p[tt]);
+            store_row<NC, VEC>(const_cast<float *>(tt == 0 ? mqi : mqa), row, t.D, l16, m[tt]);
+            store_row<NC, VEC>(const_cast<float *>(tt == 0 ? vqi : vqa), row, t.D, l16, v[tt]);
         }
     }
 }
@@ -188,15 +256,31 @@ struct FinishArgs {
     StepScalars k;
     float l2, l1;
     int64_t Bnorm;
+    double inv_B, inv_BD2;       // 1 / Bnorm, 1 / (2 Bnorm D): the loss epilogue multiplies (fp64 divisions are ~0.1 us each,
+                                 // at the very end of the step's chain)
     uint32_t flags;
     AdamScalars ad;
     float *losses6;
+    unsigned long long *stamps;  // diagnostic (INVPREF_STAMPS): [block][8] s_memrealtime ticks
 };
+// diagnostic phase stamp of the finish kernel (drains the wave's memory operations first); never executed unless a
+// stamp buffer is passed
+#define FSTAMP(i)                                                                                         \
+    do {                                                                                                  \
+        if (f.stamps) {                                                                                   \
+            __builtin_amdgcn_s_waitcnt(0);                                                                \
+            if (threadIdx.x == 0) f.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();      \
+        }                                                                                                 \
+    } while (0)
 
-// one block of the finish: `block` < hot.slab_blocks folds 64 columns of the slabs with blockDim/64 sub-rows of
-// threads (part: [blockDim/64][64] doubles of LDS, sloss: [kLossSlots], sreg: [2]); later blocks finish blockDim/16 hot rows
+// one block of the finish: `block` < hot.slab_blocks folds 64 columns of the slabs with kFinishSubs sub-rows of threads
+// (part: [kFinishSubs][64] doubles of LDS, sloss: [kLossSlots]); later blocks finish blockDim/16 hot rows.
+// 512 threads: the fold wants many threads with few loads each (one wave per block with 32 loads per thread measured
+// 0.5 us slower: a wave issues its loads one after the other), and 512 leave every instance its registers.
+constexpr int kFinishThreads = 512, kFinishSubs = kFinishThreads / 64;
+template <int NC, bool VEC>
 __device__ __forceinline__ void finish_block(const FinishArgs &f, const AdamScalars &ad, int block, double *part,
-                                             double *sloss, double *sreg) {
+                                             double *sloss) {
     const DevTables &t = f.t;
     const SmallTables &o = f.o;
     const HotRows &hot = f.hot;
@@ -205,51 +289,70 @@ __device__ __forceinline__ void finish_block(const FinishArgs &f, const AdamScal
     const uint32_t flags = f.flags;
     float *slabs = f.slabs, *losses6 = f.losses6;
     const float l2 = f.l2, l1 = f.l1;
-    const int64_t Bnorm = f.Bnorm;
+    FSTAMP(0);
     if (block >= hot.slab_blocks) {
-        const int hb = block - hot.slab_blocks;
-        if (!f.vec) finish_hot_rows<4, false>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
-        else if (f.nc == 1) finish_hot_rows<1, true>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
-        else if (f.nc == 2) finish_hot_rows<2, true>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
-        else finish_hot_rows<4, true>(t, hot, k, fused, ad, hb, flags & INVPREF_PURE_MF);
+        finish_hot_rows<NC, VEC>(t, hot, k, fused, ad, block - hot.slab_blocks, flags & INVPREF_PURE_MF);
+        FSTAMP(3);
         return;
     }
-    const int subs = blockDim.x >> 6;
-
     const int EDP = t.E * DP, slab_len = 2 * EDP + EMAX + kLossSlots;
-    const int col = threadIdx.x & 63, sub = threadIdx.x >> 6;
-    const int idx = block * 64 + col;
+    const int colx = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int idx = block * 64 + colx;
     const bool pure = flags & INVPREF_PURE_MF;  // no small tables to finish: only the loss sums are folded
-    // parameter / moment of the output this thread will finish (sub == 0 threads), requested up front
+    const bool dense = (flags & INVPREF_DENSE_REG) && !(flags & INVPREF_REG_ONLY_EMBED) && !pure;
+    const bool last_block = block == hot.slab_blocks - 1;
+    // parameter / moments of the output this thread will finish (sub == 0 threads), requested up front: the table is
+    // picked with selects and the offset clamped, so the three loads leave together (see finish_hot_rows)
     float pre_p = 0.f, pre_m = 0.f, pre_v = 0.f;
     if (sub == 0 && idx < 2 * EDP + EMAX) {
         const bool isB = idx >= 2 * EDP, isW = !isB && idx >= EDP;
         const int r = isB ? 0 : (isW ? idx - EDP : idx);
         const int e = isB ? idx - 2 * EDP : r / DP, d = isB ? 0 : r - e * DP;
-        if (e < t.E && d < t.D && !pure) {
-            const int off = isB ? e : e * t.D + d;
-            pre_p = isB ? t.b[off] : (isW ? t.W[off] : t.Ev[off]);
-            if (fused) {
-                pre_m = (isB ? o.mb : (isW ? o.mW : o.mEv))[off];
-                pre_v = (isB ? o.vb : (isW ? o.vW : o.vEv))[off];
-            }
-        }
+        const bool live = e < t.E && d < t.D && !pure;
+        const int off = live ? (isB ? e : e * t.D + d) : 0;
+        const float *tb = pinned(t.b), *tW = pinned(t.W), *tEv = pinned(t.Ev);
+        const float *mb = pinned(o.mb), *mW = pinned(o.mW), *mEv = pinned(o.mEv);
+        const float *vb = pinned(o.vb), *vW = pinned(o.vW), *vEv = pinned(o.vEv);
+        pinned(o.nb); pinned(o.nW); pinned(o.nEv); pinned(o.gb); pinned(o.gW); pinned(o.gEv);
+        const float *pp = live ? (isB ? tb : (isW ? tW : tEv)) : slabs;
+        const float *mp = (live && fused) ? (isB ? mb : (isW ? mW : mEv)) : pp;
+        const float *vp = (live && fused) ? (isB ? vb : (isW ? vW : vEv)) : pp;
+        pre_p = pp[off]; pre_m = mp[off]; pre_v = vp[off];
     }
+    // this thread's column of the replicas sub, sub + kFinishSubs, ...: CH loads in flight together (clamped, not
+    // guarded), summed in replica order in fp64; the replicas are re-zeroed at the very end of the block, behind
+    // everything that is waited for (a store between the loads and their use is waited for with them)
+    constexpr int CH = 4;
+    const bool mine = idx < slab_len;
+    const float *col = slabs + (mine ? idx : 0);
     double acc = 0.0;
-    if (idx < slab_len)
-        for (int s = sub; s < nslabs; s += subs) {
-            float *q = slabs + (int64_t)s * slab_len + idx;
-            acc += (double)__builtin_nontemporal_load(q);
-            *q = 0.f;  // leave the replicas zeroed for the next step
+    double reg2 = 0.0, reg1 = 0.0;
+    for (int s0 = sub; s0 < nslabs; s0 += CH * kFinishSubs) {
+        float x[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+            x[j] = __builtin_nontemporal_load(col + (int64_t)min(s0 + j * kFinishSubs, nslabs - 1) * slab_len);
+        if (s0 == sub && last_block && dense && losses6 && sub == 0) {
+            // regulariser report of the classifier (models.py:211-217), while the replica loads are in flight
+            double w2 = 0, w1 = 0, b2 = 0, b1 = 0;
+            for (int i = threadIdx.x; i < t.E * t.D; i += 64) { const double xx = t.W[i]; w2 += xx * xx; w1 += fabs(xx); }
+            for (int i = threadIdx.x; i < t.E; i += 64) { const double xx = t.b[i]; b2 += xx * xx; b1 += fabs(xx); }
+            reg2 = w2 / ((double)t.D * t.E) + b2 / (double)t.E;
+            reg1 = w1 / ((double)t.D * t.E) + b1 / (double)t.E;
+            for (int m = 32; m >= 1; m >>= 1) { reg2 += __shfl_xor(reg2, m, 64); reg1 += __shfl_xor(reg1, m, 64); }
         }
-    part[sub * 64 + col] = acc;
-    if (threadIdx.x < 2) sreg[threadIdx.x] = 0.0;
+#pragma unroll
+        for (int j = 0; j < CH; j++) acc += (s0 + j * kFinishSubs < nslabs) ? (double)x[j] : 0.0;
+    }
+    part[sub * 64 + colx] = acc;
     __syncthreads();
-    const bool dense = (flags & INVPREF_DENSE_REG) && !(flags & INVPREF_REG_ONLY_EMBED) && !pure;
-    const bool last_block = block == hot.slab_blocks - 1;
-    if (sub == 0 && idx < slab_len) {
-        double v = 0.0;
-        for (int s = 0; s < subs; s++) v += part[s * 64 + col];
+    double v = 0.0;
+    if (sub == 0) {
+#pragma unroll
+        for (int q = 0; q < kFinishSubs; q++) v += part[q * 64 + colx];
+    }
+    FSTAMP(1);
+    if (mine && sub == 0) {
         if (idx < 2 * EDP) {
             const bool isW = idx >= EDP;
             const int r = isW ? idx - EDP : idx;
@@ -285,21 +388,12 @@ __device__ __forceinline__ void finish_block(const FinishArgs &f, const AdamScal
             sloss[idx - 2 * EDP - EMAX] = v;
         }
     }
-    __syncthreads();
+    FSTAMP(2);
     if (last_block && losses6) {
-        if (dense && threadIdx.x < 64) {
-            double w2 = 0, w1 = 0, b2 = 0, b1 = 0;
-            for (int i = threadIdx.x; i < t.E * t.D; i += 64) { const double x = t.W[i]; w2 += x * x; w1 += fabs(x); }
-            for (int i = threadIdx.x; i < t.E; i += 64) { const double x = t.b[i]; b2 += x * x; b1 += fabs(x); }
-            double r2v = w2 / ((double)t.D * t.E) + b2 / (double)t.E, r1v = w1 / ((double)t.D * t.E) + b1 / (double)t.E;
-            for (int m = 32; m >= 1; m >>= 1) { r2v += __shfl_xor(r2v, m, 64); r1v += __shfl_xor(r1v, m, 64); }
-            if (threadIdx.x == 0) { sreg[0] = r2v; sreg[1] = r1v; }
-        }
-        __syncthreads();
+        __syncthreads();   // (workgroup-uniform condition: the loss sums written above are visible to thread 0)
         if (threadIdx.x == 0) {
-            const double Bn = (double)Bnorm, BD2 = Bn * (double)t.D * 2.0;
-            const double Li = sloss[0] / Bn, Le = sloss[1] / Bn, Lc = sloss[2] / Bn;
-            const double L2 = sloss[3] / BD2 + sreg[0], L1 = sloss[4] / BD2 + sreg[1];
+            const double Li = sloss[0] * f.inv_B, Le = sloss[1] * f.inv_B, Lc = sloss[2] * f.inv_B;
+            const double L2 = sloss[3] * f.inv_BD2 + reg2, L1 = sloss[4] * f.inv_BD2 + reg1;
             // added with fire-and-forget atomics: a plain `+=` would hold the kernel's end back by one more
             // memory round trip (the same single fp32 addition either way)
             atomicAdd(losses6 + 0, (float)Li); atomicAdd(losses6 + 1, (float)Le); atomicAdd(losses6 + 2, (float)Lc);
@@ -307,6 +401,9 @@ __device__ __forceinline__ void finish_block(const FinishArgs &f, const AdamScal
             atomicAdd(losses6 + 5, (float)((double)k.ca * Li + (double)k.cb * Le + (double)k.cc * Lc + (double)l2 * L2 + (double)l1 * L1));
         }
     }
+    if (mine)
+        for (int s = sub; s < nslabs; s += kFinishSubs) slabs[(int64_t)s * slab_len + idx] = 0.f;  // zeroed for the next step
+    FSTAMP(3);
 }
 
 struct RowsArgs {
@@ -333,6 +430,7 @@ struct RowsArgs {
     int n, dense_per_task, n_dense_tasks;
     const int *item_hot_index;    // [item_num]: scratch row of an item whose gradient goes through atomics, or -1
     float *hot_scratch;           // [n_hot][2][DP] gradient accumulators of those rows (zero on entry, re-zeroed by finish)
+    int hot_direct;               // the accumulator row of a hot item is its item id (HotRows::item_cnt form)
     int *sched_state;             // optional device int32[32]: two slots {step, base, SchedRow}, see InvPrefAdamSchedule
     const SchedRow *sched_table;  // optional device table of per-step scalars (graph replay)
     int sched_n, sched_slot;
@@ -802,6 +900,7 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
         float *rec = rec0 + (DBUF ? (it & 1) : 0) * kGroups * 2 * DP;
         float *recs = recs0 + (DBUF ? (it & 1) : 0) * kGroups * (EMAX + 1);
         const int e = n_e, hidx = n_hidx;
+        const int hrow = a.hot_direct ? n_v : n_hidx;   // accumulator row of a hot item
         const float cur_y = n_y, cur_w = n_w;
         const bool valid = e >= 0;
         const bool more = base + kGroups < s1;
@@ -904,7 +1003,7 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
         // hot item rows: shaped atomics through a transpose buffer (NC = 4: the now free record slot)
         if (hidx >= 0) {
             float *tr = (DBUF ? trbuf : rec) + grp * 2 * DP;
-            float *dst = a.hot_scratch + (int64_t)hidx * 2 * DP;
+            float *dst = a.hot_scratch + (int64_t)hrow * 2 * DP;
 #pragma unroll
             for (int jj = 0; jj < NC; jj++) {
                 *reinterpret_cast<float4 *>(tr + (l16 + kRow * jj) * 4) = hq[jj];
@@ -1011,6 +1110,9 @@ template <int NC, bool VEC, int EMAX>
 __global__ __launch_bounds__(256, (NC * EMAX > 4) ? ROWS_MIN_WAVES_BIG : ROWS_MIN_WAVES)
 void mstep_rows_kernel(DevTables t, RowsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef ROWS_WARM_MAIN
+    warm_kernargs<sizeof(DevTables) + sizeof(RowsArgs)>();
+#endif
     // Workgroup b runs the tasks of class c = b % n_cls (XCD-affine order, InvPrefRowPlan), the j-th of them with
     // j = b / n_cls: the class's share of the dense tasks first (they walk several interactions in sequence), then its
     // item jobs, user jobs, streamed user rows, streamed item rows.  Every branch below is workgroup-uniform.
@@ -1061,25 +1163,32 @@ void mstep_rows_kernel(DevTables t, RowsArgs a) {
 }
 
 
-__global__ __launch_bounds__(1024) void rows_finish_kernel(const FinishArgs f, int *sched_state, const SchedRow *sched_table,
-                                                           int sched_n, int sched_slot) {
-    __shared__ double part[16 * 64];
+template <int NC, bool VEC>
+__global__ __launch_bounds__(kFinishThreads) void rows_finish_kernel(const FinishArgs f, int *sched_state,
+                                                                     const SchedRow *sched_table, int sched_n, int sched_slot) {
+    __shared__ double part[kFinishSubs * 64];
     __shared__ double sloss[kLossSlots];
-    __shared__ double sreg[2];
-    const AdamScalars ad = sched_state ? sched_slot_ptr(sched_state, sched_slot)->ad : f.ad;
-    // the device-side schedule moves on: one thread fills the OTHER slot with the next step's number and
+#ifndef ROWS_NO_WARM
+    warm_kernargs<sizeof(FinishArgs) + 32>();
+#endif
+    // the device-side schedule moves on: one thread of the LAST block (a block with nothing else to do, so that the two
+    // dependent loads of this look-up are on nobody's chain) fills the OTHER slot with the next step's number and
     // scalars.  Nobody reads that slot before the next launch, so no ordering between blocks is needed.
     // (in the gradient-pass form -- fused == 0 -- the stand-alone Adam kernel that follows is the step's last
     //  launch and moves the schedule on; here the slot is only read, for a scheduled alpha)
-    if (sched_state && f.fused && blockIdx.x == 0 && threadIdx.x == 0) {
-        const int *cur = sched_state + 16 * sched_slot;
-        int *nxt = sched_state + 16 * (sched_slot ^ 1);
-        const int next = cur[0] + 1, base = cur[1], idx = next - base;
-        nxt[0] = next;
-        nxt[1] = base;
-        if (idx >= 0 && idx < sched_n) *reinterpret_cast<SchedRow *>(nxt + 2) = sched_table[idx];
+    if (blockIdx.x == gridDim.x - 1) {
+        if (sched_state && f.fused && threadIdx.x == 0) {
+            const int *cur = sched_state + 16 * sched_slot;
+            int *nxt = sched_state + 16 * (sched_slot ^ 1);
+            const int next = cur[0] + 1, base = cur[1], idx = next - base;
+            nxt[0] = next;
+            nxt[1] = base;
+            if (idx >= 0 && idx < sched_n) *reinterpret_cast<SchedRow *>(nxt + 2) = sched_table[idx];
+        }
+        return;
     }
-    finish_block(f, ad, blockIdx.x, part, sloss, sreg);
+    const AdamScalars ad = sched_state ? sched_slot_ptr(sched_state, sched_slot)->ad : f.ad;
+    finish_block<NC, VEC>(f, ad, blockIdx.x, part, sloss);
 }
 
 
@@ -1121,12 +1230,14 @@ FinishArgs make_finish_args(const DevTables &t, const RowsArgs &a, const InvPref
     const int slab_len = 2 * t.E * DP + emax + kLossSlots;
     HotRows &h = f.hot;
     h.n = plan->n_hot; h.slab_blocks = (slab_len + 63) / 64; h.rows = plan->hot_rows; h.cnt = plan->hot_count;
+    if (a.hot_direct) { h.n = t.I; h.item_cnt = plan->item_hot_count; }
     h.scratch = hot_scratch;
     h.Qi = t.Qi; h.Qa = t.Qa;
     if (!fused) { h.gQi = a.g[1]; h.gQa = a.g[3]; }
     else { h.nQi = a.np[1]; h.nQa = a.np[3]; h.mQi = a.m[1]; h.mQa = a.m[3]; h.vQi = a.v[1]; h.vQa = a.v[3]; }
     f.slabs = slabs; f.nslabs = kReplicas; f.DP = DP; f.EMAX = emax; f.nc = nc; f.vec = vec; f.fused = fused;
     f.k = a.k; f.l2 = coefs->L2_coe; f.l1 = coefs->L1_coe; f.Bnorm = batch_norm; f.flags = flags; f.ad = ad;
+    f.inv_B = 1.0 / (double)batch_norm; f.inv_BD2 = 1.0 / ((double)batch_norm * (double)t.D * 2.0);
     f.losses6 = losses6;
     return f;
 }
@@ -1172,7 +1283,7 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     const int slab_len = 2 * EDP + emax + kLossSlots;
     if (plan->n_hot < 0 || (plan->n_hot > 0 && (!plan->hot_rows || !plan->hot_count || !plan->item_hot_index)))
         return INVPREF_EINVAL;
-    if (workspace_bytes < sizeof(float) * ((size_t)slab_len * kReplicas + (size_t)plan->n_hot * 2 * DP))
+    if (workspace_bytes < sizeof(float) * ((size_t)slab_len * kReplicas + hot_scratch_rows(tables, plan) * 2 * DP))
         return INVPREF_EWORKSPACE;
     StepScalars k;
     k.ca = coefs->invariant_coe; k.cb = coefs->env_aware_coe; k.cc = coefs->env_coe; k.alpha = coefs->alpha;
@@ -1222,6 +1333,7 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a.envs = envs; a.scores = scores; a.weights = weights;
     a.k = k; a.flags = flags; a.slabs = (float *)workspace; a.fused = fused; a.ad = ad;
     a.item_hot_index = plan->n_hot > 0 ? plan->item_hot_index : nullptr;
+    a.hot_direct = hot_direct(tables, plan) ? 1 : 0;
     a.hot_scratch = (float *)workspace + (size_t)slab_len * kReplicas;
     a.sched_state = sched ? sched->state : nullptr;
     a.sched_table = sched ? reinterpret_cast<const SchedRow *>(sched->table) : nullptr;
@@ -1257,9 +1369,14 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     }
     FinishArgs f = make_finish_args(t, a, plan, coefs, batch_norm, flags, fused, grads, new_tables, exp_avg, exp_avg_sq, ad,
                                     losses6, (float *)workspace, a.hot_scratch, DP, emax, nc, (int)vec);
-    const int hot_blocks = (plan->n_hot + 63) / 64;  // 1024 threads = 64 groups per block
-    hipLaunchKernelGGL(rows_finish_kernel, dim3(f.hot.slab_blocks + hot_blocks), dim3(1024), 0, st, f, a.sched_state,
-                       a.sched_table, a.sched_n, a.sched_slot);
+    f.stamps = a.stamps ? a.stamps + 12288 * 8 : nullptr;   // (the stamp buffer's last quarter belongs to the finish blocks)
+    f.hot.stamps = f.stamps;
+    const int hot_blocks = (f.hot.n + kFinishThreads / 16 - 1) / (kFinishThreads / 16);
+#define FIN(NCV, VECV)                                                                                              \
+    hipLaunchKernelGGL((rows_finish_kernel<NCV, VECV>), dim3(f.hot.slab_blocks + hot_blocks + 1), dim3(kFinishThreads), 0, st, \
+                       f, a.sched_state, a.sched_table, a.sched_n, a.sched_slot)
+    if (!vec) FIN(4, false); else if (nc == 1) FIN(1, true); else if (nc == 2) FIN(2, true); else FIN(4, true);
+#undef FIN
     return (int)hipGetLastError();
 }
 
@@ -1275,7 +1392,7 @@ int invpref_set_profile_event(void *event) {
 size_t invpref_rows_workspace_bytes(const InvPrefTables *tables, const InvPrefRowPlan *plan) {
     if (check_tables(tables, tables && !tables->embed_user_env_aware) || !plan || plan->n_hot < 0) return 0;
     const size_t slab_len = 2 * (size_t)tables->env_num * 256 + 16 + kLossSlots;
-    return sizeof(float) * (slab_len * kReplicas + (size_t)plan->n_hot * 2 * 256);
+    return sizeof(float) * (slab_len * kReplicas + hot_scratch_rows(tables, plan) * 2 * 256);
 }
 
 int invpref_mstep_rows_grad_hip(const InvPrefTables *tables, const InvPrefTables *grads, const InvPrefRowPlan *plan,

@@ -29,7 +29,7 @@ class RowPlanStruct(C.Structure):
                 ('n_stream_user', C.c_int32), ('n_stream_item', C.c_int32), ('rows_per_stream_task', C.c_int32),
                 ('dense_per_task', C.c_int32), ('stream_rows', C.c_void_p), ('batch_users', C.c_void_p),
                 ('batch_items', C.c_void_p), ('n_classes', C.c_int32), ('reserved2', C.c_int32),
-                ('cls', C.c_int32 * 64)]
+                ('cls', C.c_int32 * 64), ('item_hot_count', C.c_void_p)]
 
 N_CLASSES = 8          # XCDs of an MI355X: blocks b and b + 8 of a launch share one (round-robin placement)
 CLASS_SHIFT = 6        # rows are dealt to the classes in blocks of 64
@@ -135,7 +135,7 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     pu = np.argsort(users, kind='stable')
     pi = np.argsort(items, kind='stable')
     icnt = np.bincount(items, minlength=item_num)
-    hot = icnt > hot_threshold
+    hot = (icnt > hot_threshold) & (icnt > 0)     # (an untouched row is streamed, never hot)
     hot_rows = np.flatnonzero(hot).astype(np.int32)
     hot_index = np.full(item_num, -1, np.int32)
     hot_index[hot_rows] = np.arange(len(hot_rows), dtype=np.int32)
@@ -182,7 +182,8 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
                 n=n, n_item_rounds=len(di), rounds_per_task=rounds_per_task, desc=np.concatenate([di, du]),
                 other_user=items[pu].astype(np.int32), pos_user=pu.astype(np.int32),
                 other_item=users[pi].astype(np.int32), pos_item=pi.astype(np.int32),
-                hot_rows=hot_rows, hot_count=icnt[hot_rows].astype(np.int32), item_hot_index=hot_index)
+                hot_rows=hot_rows, hot_count=icnt[hot_rows].astype(np.int32), item_hot_index=hot_index,
+                item_hot_count=np.where(hot, icnt, 0).astype(np.int32))
 
 
 @dataclass
@@ -224,8 +225,12 @@ def struct_from_meta(buf: torch.Tensor, meta: torch.Tensor) -> RowPlanStruct:
 
 def upload(plan: dict, device) -> DevicePlan:
     keys = ('desc', 'other_user', 'pos_user', 'other_item', 'pos_item', 'hot_rows', 'hot_count', 'item_hot_index',
-            'stream_rows', 'batch_users', 'batch_items')
+            'stream_rows', 'batch_users', 'batch_items', 'item_hot_count')
     parts, ptrs, off = [], {}, 0
+    if 'item_hot_count' not in plan:   # (plans built by hand, tests)
+        cnt_of = np.zeros(len(plan['item_hot_index']), np.int32)
+        cnt_of[np.asarray(plan['hot_rows'], np.int64)] = plan['hot_count']
+        plan = dict(plan, item_hot_count=cnt_of)
     for k in keys:  # every array starts on a 16-byte boundary of the one device buffer
         a = np.ascontiguousarray(plan[k], np.int32).reshape(-1)
         pad = (-len(a)) % 4
@@ -246,7 +251,7 @@ def upload(plan: dict, device) -> DevicePlan:
                        ptrs['hot_rows'], ptrs['hot_count'], ptrs['item_hot_index'], plan['n_stream_user'],
                        plan['n_stream_item'], plan['rows_per_stream_task'], plan['dense_per_task'],
                        ptrs['stream_rows'], ptrs['batch_users'], ptrs['batch_items'], ncls, 0,
-                       (C.c_int32 * 64)(*cls.reshape(-1).tolist()))
+                       (C.c_int32 * 64)(*cls.reshape(-1).tolist()), ptrs['item_hot_count'])
     n_tasks = ncls * max(class_tasks(plan, cls, c) for c in range(ncls))
     meta = _meta_of(st, offs)
     return DevicePlan(st, [buf], n_tasks, nr, buf, torch.tensor(meta, dtype=torch.int64))

@@ -44,6 +44,8 @@ def check_plan(users, items, U, I, **kw):
     icnt = np.bincount(items, minlength=I)
     np.testing.assert_array_equal(p['hot_count'], icnt[p['hot_rows']])
     assert all(p['item_hot_index'][r] == i for i, r in enumerate(p['hot_rows'])) and (p['item_hot_index'] >= 0).sum() == len(hot)
+    np.testing.assert_array_equal(p['item_hot_count'], np.where(p['item_hot_index'] >= 0, icnt, 0))
+    assert (p['hot_count'] > 0).all()                                  # an untouched row is streamed, never hot
     for side, (own, oth, R, o_key, p_key, rounds) in enumerate((
             (users, items, U, 'other_user', 'pos_user', desc[nir:]),
             (items, users, I, 'other_item', 'pos_item', desc[:nir]))):

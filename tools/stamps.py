@@ -78,6 +78,20 @@ for per_slice, rpt, hot, dense in combos:
     d = st[(kind == 'dense') & live].astype(np.float64)
     print('  dense (us, median / max): start -> staged %.2f/%.2f | staged -> end of loop %.2f/%.2f | end of loop -> arrived %.2f/%.2f'
           % tuple(x for a_, b_ in ((0, 1), (1, 6), (6, 7)) for x in (np.median(d[:, b_] - d[:, a_]) / 100, (d[:, b_] - d[:, a_]).max() / 100)))
+    fs = stamps.cpu().numpy().reshape(-1, 8)[12288:12288 + 256].astype(np.int64)   # rows_finish_kernel's blocks
+    fl = fs[:, 0] > 0
+    if fl.any():
+        main_end = end[live].max()
+        slab = fl & (fs[:, 2] > 0)
+        hotb = fl & (fs[:, 2] == 0) & (fs[:, 3] > 0)
+        print(f'  finish kernel: {int(fl.sum())} stamped blocks; first block starts {(fs[fl, 0].min() - main_end) / 100:.2f} us after the last '
+              f'workgroup of the main kernel ended; last block ends {(fs[fl, 3].max() - main_end) / 100:.2f} us after it')
+        for nm, sel in (('slab', slab), ('hot ', hotb)):
+            if sel.any():
+                x = fs[sel].astype(np.float64)
+                print(f'    {nm} blocks n={int(sel.sum())}: start {np.median(x[:, 0] - main_end) / 100:.2f} | loads landed +{np.median(x[:, 1] - x[:, 0]) / 100:.2f}'
+                      + (f' | adam + stores issued and drained +{np.median(x[:, 2] - x[:, 1]) / 100:.2f} | end +{np.median(x[:, 3] - x[:, 2]) / 100:.2f} (max end {(x[:, 3].max() - main_end) / 100:.2f})'
+                         if nm == 'slab' else f' | end +{np.median(x[:, 3] - x[:, 1]) / 100:.2f} (max end {(x[:, 3].max() - main_end) / 100:.2f})'))
     f = st[(kind == 'finish') & live].astype(np.float64)
     if len(f):
         print('  finish blocks (us, median / max): waiting %.2f/%.2f | finish work %.2f/%.2f | counters %.2f/%.2f'

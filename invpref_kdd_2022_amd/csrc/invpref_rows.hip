@@ -277,7 +277,10 @@ struct FinishArgs {
 // (part: [kFinishSubs][64] doubles of LDS, sloss: [kLossSlots]); later blocks finish blockDim/16 hot rows.
 // 512 threads: the fold wants many threads with few loads each (one wave per block with 32 loads per thread measured
 // 0.5 us slower: a wave issues its loads one after the other), and 512 leave every instance its registers.
-constexpr int kFinishThreads = 512, kFinishSubs = kFinishThreads / 64;
+#ifndef ROWS_FIN_THREADS
+#define ROWS_FIN_THREADS 512
+#endif
+constexpr int kFinishThreads = ROWS_FIN_THREADS, kFinishSubs = kFinishThreads / 64;
 template <int NC, bool VEC>
 __device__ __forceinline__ void finish_block(const FinishArgs &f, const AdamScalars &ad, int block, double *part,
                                              double *sloss) {
@@ -322,7 +325,7 @@ __device__ __forceinline__ void finish_block(const FinishArgs &f, const AdamScal
     // this thread's column of the replicas sub, sub + kFinishSubs, ...: CH loads in flight together (clamped, not
     // guarded), summed in replica order in fp64; the replicas are re-zeroed at the very end of the block, behind
     // everything that is waited for (a store between the loads and their use is waited for with them)
-    constexpr int CH = 4;
+    constexpr int CH = kReplicas / kFinishSubs > 4 ? kReplicas / kFinishSubs : 4;   // one trip covers all replicas
     const bool mine = idx < slab_len;
     const float *col = slabs + (mine ? idx : 0);
     double acc = 0.0;

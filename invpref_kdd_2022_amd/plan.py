@@ -99,10 +99,39 @@ def _side_rounds(own, oth, pos, y, n_rows: int, per_slice: int, pad_to: int, ski
     return d
 
 
+RESIDENT_WORKGROUPS = 1024   # 256 CUs x 4 workgroups of mstep_rows_kernel (121 VGPRs): one residency wave
+
+
 def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, user_num: int, item_num: int,
                    per_slice: int | None = None, rounds_per_task: int | None = None,
                    hot_threshold: int | None = None, user_range=None, n_classes: int | None = None,
                    rows_per_stream_task: int | None = None) -> dict:
+    """See _build_row_plan.  With hot_threshold left to the builder (and no INVPREF_PLAN_HOT), a Yahoo-class plan
+    (slices of at most two interactions) whose launch would not fit one residency wave is rebuilt with a lower
+    threshold -- more rows through the atomics, fewer item jobs: the step time is flat below the default and jumps by
+    ~1.5 us the moment a second wave of workgroups is needed (measured, tools/ab2.sh: 19.4 us at > 6 ... > 10, 20.8 at > 12)."""
+    kw = dict(per_slice=per_slice, rounds_per_task=rounds_per_task, user_range=user_range, n_classes=n_classes,
+              rows_per_stream_task=rows_per_stream_task)
+    plan = _build_row_plan(users, items, scores, user_num, item_num, hot_threshold=hot_threshold, **kw)
+    if hot_threshold is not None or 'INVPREF_PLAN_HOT' in os.environ or plan['per_slice'] > 2:
+        return plan
+    for thr in (8, 6, 4, 2, 1):
+        if plan_workgroups(plan) <= RESIDENT_WORKGROUPS or plan_workgroups(plan) > 2 * RESIDENT_WORKGROUPS:
+            break   # fits -- or is a multi-wave launch anyway
+        plan = _build_row_plan(users, items, scores, user_num, item_num, hot_threshold=thr, **kw)
+    return plan
+
+
+def plan_workgroups(plan: dict) -> int:
+    """workgroups of the launch: the classes' task lists interleaved, padded to the longest"""
+    ncls = int(plan.get('n_classes', 1))
+    return ncls * max(class_tasks(plan, np.asarray(plan['cls']), c) for c in range(ncls))
+
+
+def _build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, user_num: int, item_num: int,
+                    per_slice: int | None = None, rounds_per_task: int | None = None,
+                    hot_threshold: int | None = None, user_range=None, n_classes: int | None = None,
+                    rows_per_stream_task: int | None = None) -> dict:
     """users/items/scores: ONE minibatch (or this rank's slice of it); scores as the fp32 labels.
     hot_threshold: item rows with MORE interactions than this get no job; their gradient is added with
     float atomics by the user-side jobs and completed by the finish kernel (-1: every item row).
@@ -178,7 +207,7 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
                 stream_rows=np.concatenate([stream_u, stream_i]).astype(np.int32), n_stream_user=len(stream_u),
                 n_stream_item=len(stream_i),
                 rows_per_stream_task=int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', str(rows_per_stream_task or 64))),
-                n_classes=n_classes, cls=cls,
+                n_classes=n_classes, cls=cls, per_slice=per_slice, hot_threshold=hot_threshold,
                 n=n, n_item_rounds=len(di), rounds_per_task=rounds_per_task, desc=np.concatenate([di, du]),
                 other_user=items[pu].astype(np.int32), pos_user=pu.astype(np.int32),
                 other_item=users[pi].astype(np.int32), pos_item=pi.astype(np.int32),

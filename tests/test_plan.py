@@ -92,6 +92,18 @@ def test_plan_yahoo_like_batch():
     assert len(p['desc']) < 4000
 
 
+def test_default_plan_fits_one_residency_wave():
+    """the builder lowers the hot-row threshold until the launch fits the 1 024 resident workgroups (a second wave of
+    workgroups costs ~1.5 us per step); an explicit threshold is taken as given"""
+    d = synth.yahoo_like()
+    for k in (0, 3, 8, 12):
+        b = d[k * 8192:(k + 1) * 8192]
+        p = planlib.build_row_plan(b[:, 0], b[:, 1], b[:, 2], 15400, 1000)
+        assert planlib.plan_workgroups(p) <= planlib.RESIDENT_WORKGROUPS and p['hot_threshold'] <= 10
+    b = d[8 * 8192:9 * 8192]
+    assert planlib.build_row_plan(b[:, 0], b[:, 1], b[:, 2], 15400, 1000, hot_threshold=16)['hot_threshold'] == 16
+
+
 @pytest.mark.parametrize('hot', [-1, 0, 8, 10 ** 9])
 @pytest.mark.parametrize('per_slice,rpt', [(1, 1), (2, 3), (4, 2), (64, 5)])
 def test_plan_parameters(per_slice, rpt, hot):

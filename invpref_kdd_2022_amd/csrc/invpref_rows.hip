@@ -1049,10 +1049,10 @@ __device__ __forceinline__ void dense_task(const DevTables &t, const RowsArgs &a
 
 // Untouched rows: gradient exactly zero, so m' = m + (1-b1)(0-m), v' = b2 v, p' = p - step*m'/(sqrt(v')/bc+eps)
 // (the same adam1f as everywhere, fed g = 0).  Each 16-lane group keeps R = 2 rows of both tables in flight (12 float4
-// loads; R = 3 was tried for 96-row tasks: 159 VGPRs, or 40 spilled at the 128 a one-wave step needs).
+// loads; R = 3 was tried for 96-row tasks: 159 VGPRs, or 40 spilled at the 128 a one-wave step needs); one row at 256 floats.
 template <int NC, bool VEC>
 __device__ __forceinline__ void stream_task(const DevTables &t, const RowsArgs &a, int side, const int *rows, int n) {
-    constexpr int R = 2;
+    constexpr int R = NC == 4 ? 1 : 2;   // (four row chunks: two rows in flight are 192 registers -- that alone spilled 250)
     const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
     const float *Tinv = side == 0 ? t.Pu : t.Qi, *Tenv = side == 0 ? t.Pa : t.Qa;

@@ -1171,6 +1171,9 @@ __global__ __launch_bounds__(kFinishThreads) void rows_finish_kernel(const Finis
                                                                      const SchedRow *sched_table, int sched_n, int sched_slot) {
     __shared__ double part[kFinishSubs * 64];
     __shared__ double sloss[kLossSlots];
+#ifdef ROWS_EMPTY_FINISH   // A/B builds: what a bare kernel boundary costs
+    if (f.fused >= 0) return;
+#endif
 #ifndef ROWS_NO_WARM
     warm_kernargs<sizeof(FinishArgs) + 32>();
 #endif

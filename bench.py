@@ -419,9 +419,13 @@ def main():
     import torch
     from invpref_kdd_2022_amd import parallel
 
-    rank, local, world = parallel.init_from_env('nccl')
+    # (INVPREF_BENCH_BACKEND=gloo INVPREF_BENCH_SAME_DEVICE=1: a rehearsal of the N-rank flow on a ONE-GPU box -- every
+    #  rank on cuda:0, collectives through gloo, so no captured collectives; never what a measurement uses)
+    rank, local, world = parallel.init_from_env(os.environ.get('INVPREF_BENCH_BACKEND', 'nccl'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if os.environ.get('INVPREF_BENCH_SAME_DEVICE'):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
@@ -454,7 +458,7 @@ def main():
         what = 'the whole optimiser step: gradient pass + all-reduce + stand-alone Adam'
     achieved = nbytes / (ms_step_dev * 1e-3) / 1e9
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(kname),
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(kname) if world == 1 else None,
                 'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/)', 'kernel': what,
                 'avg_launch_ms': ms_step_dev, 'algorithmic_bytes_per_launch': nbytes,
                 'timing': 'HIP events on the launch stream around replays of whole-epoch graphs, per step '
@@ -464,7 +468,7 @@ def main():
                 'cache_note': 'all five flat buffers (42 MB) sit in the 256 MiB Infinity Cache at this size: the 8 TB/s '
                               'HBM peak is the yardstick north_star names, not the level that serves the bytes; '
                               'roofline_large is the cache-exceeding launch',
-                'rocprofv3_avg_launch_ms': rocprof_avg_ms(knames),
+                'rocprofv3_avg_launch_ms': rocprof_avg_ms(knames) if world == 1 else None,   # (the committed profiles are 1-GPU runs)
                 'rocprofv3_note': 'sum of the average durations of the kernels of one step in the committed profile of this command',
                 'GBs_at_survey_unfused_pricing': bytes_survey / (ms_step_dev * 1e-3) / 1e9}
     out = {

@@ -1381,7 +1381,9 @@ int launch_rows(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
 #define FIN(NCV, VECV)                                                                                              \
     hipLaunchKernelGGL((rows_finish_kernel<NCV, VECV>), dim3(f.hot.slab_blocks + hot_blocks + 1), dim3(kFinishThreads), 0, st, \
                        f, a.sched_state, a.sched_table, a.sched_n, a.sched_slot)
+#ifndef ROWS_NO_FINISH_LAUNCH   // (A/B builds, timing only: the step without its second launch)
     if (!vec) FIN(4, false); else if (nc == 1) FIN(1, true); else if (nc == 2) FIN(2, true); else FIN(4, true);
+#endif
 #undef FIN
     return (int)hipGetLastError();
 }

@@ -131,21 +131,23 @@ def cpu_baseline():
         th //= 2
     cores = min(scan, key=scan.get) if scan else 1
     res = {}
-    for th, n_ep, n_es in ((cores, 5, 3), (1, 2, 1)):
+    # a bounded sample of ~10 s of CPU work: at least (5 epochs, 3 E-steps) and ~7 s on all cores, (3, 1) and ~2.5 s on one
+    for th, min_ep, min_es, budget_s in ((cores, 5, 3, 7.0), (1, 3, 1, 2.5)):
         tr = trainer(th)
         if th > 1:
             tr.train_a_epoch()          # thread pool / page warm-up, not timed
         tm, te = [], []
-        for _ in range(n_ep):
+        t_start = time.perf_counter()
+        while len(tm) < min_ep or (time.perf_counter() - t_start < 0.85 * budget_s and len(tm) < 400):
             t0 = time.perf_counter()
             tr.train_a_epoch()
             tm.append(time.perf_counter() - t0)
-        for _ in range(n_es):
+        while len(te) < min_es or (time.perf_counter() - t_start < budget_s and len(te) < 100):
             t0 = time.perf_counter()
             tr.cluster()
             te.append(time.perf_counter() - t0)
             tr.stat_envs()
-        res[th] = (min(tm), min(te), n_ep, n_es)
+        res[th] = (min(tm), min(te), len(tm), len(te))
     tm, te, n_ep, n_es = res[cores]
     blended = CLUSTER_INTERVAL * N_PER_GPU / (CLUSTER_INTERVAL * tm + te)
     tm1, te1 = res[1][0], res[1][1]

@@ -16,7 +16,12 @@ from invpref_kdd_2022_amd import ops, plan as planlib, synth
 
 U, I, E, D, B = 15400, 1000, 4, 64, 8192
 nsteps = int(os.environ.get('STAMPS_STEPS', '12'))
-data = synth.yahoo_like()[:nsteps * B]
+if os.environ.get('STAMPS_SHAPE'):   # "U,I,E,D,B": another shape (uniform synthetic interactions)
+    U, I, E, D, B = [int(x) for x in os.environ['STAMPS_SHAPE'].split(',')]
+    nsteps = min(nsteps, 3)
+    data = synth.interactions(1, U, I, nsteps * B, implicit=True)
+else:
+    data = synth.yahoo_like()[:nsteps * B]
 tabs = synth.tables(2, U, I, E, D)
 P = [torch.from_numpy(tabs[k]).to(dev) for k in ops.PARAM_NAMES]
 P2 = [torch.zeros_like(p) for p in P]

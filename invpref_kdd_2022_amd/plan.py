@@ -31,6 +31,8 @@ class RowPlanStruct(C.Structure):
                 ('batch_items', C.c_void_p), ('n_classes', C.c_int32), ('reserved2', C.c_int32),
                 ('cls', C.c_int32 * 64), ('item_hot_count', C.c_void_p)]
 
+OPTIONAL_ARRAYS = ('item_hot_count',)   # may be NULL (meta offset -1): plan['item_hot_count'] = None
+
 N_CLASSES = 8          # XCDs of an MI355X: blocks b and b + 8 of a launch share one (round-robin placement)
 CLASS_SHIFT = 6        # rows are dealt to the classes in blocks of 64
 
@@ -245,9 +247,12 @@ def struct_from_meta(buf: torch.Tensor, meta: torch.Tensor) -> RowPlanStruct:
         v = vals[i]
         i += 1
         if ty is C.c_void_p:
-            if not 0 <= v <= n:
+            if v == -1 and name in OPTIONAL_ARRAYS:
+                v = None
+            elif not 0 <= v <= n:
                 raise ValueError('row plan: array offset outside the buffer')
-            v = base + 4 * v
+            else:
+                v = base + 4 * v
         args.append(v)
     return RowPlanStruct(*args)
 
@@ -260,6 +265,7 @@ def upload(plan: dict, device) -> DevicePlan:
         cnt_of = np.zeros(len(plan['item_hot_index']), np.int32)
         cnt_of[np.asarray(plan['hot_rows'], np.int64)] = plan['hot_count']
         plan = dict(plan, item_hot_count=cnt_of)
+    keys = tuple(k for k in keys if not (k in OPTIONAL_ARRAYS and plan[k] is None))
     for k in keys:  # every array starts on a 16-byte boundary of the one device buffer
         a = np.ascontiguousarray(plan[k], np.int32).reshape(-1)
         pad = (-len(a)) % 4
@@ -269,6 +275,9 @@ def upload(plan: dict, device) -> DevicePlan:
     buf = torch.from_numpy(np.concatenate(parts)).to(device)
     offs = dict(ptrs)
     ptrs = {k: buf.data_ptr() + 4 * o for k, o in ptrs.items()}
+    for k in OPTIONAL_ARRAYS:
+        if k not in ptrs:
+            offs[k], ptrs[k] = -1, None
     nr, rpt = len(plan['desc']), plan['rounds_per_task']
     ncls = int(plan.get('n_classes', 1))
     cls = np.asarray(plan['cls'], np.int32) if 'cls' in plan else np.zeros((8, 8), np.int32)

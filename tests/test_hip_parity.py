@@ -307,3 +307,44 @@ def test_rows_path_movielens_shape_default_plan():
         O.adam(po, g.reshape(-1), np.zeros_like(po), np.zeros_like(po), 1, lr)
         dlt = np.abs(p2.cpu().numpy().reshape(-1) - po)
         assert dlt.max() < 0.05 * lr and np.quantile(dlt, 0.99) < 1e-5, k
+
+
+def test_hot_rows_direct_and_indexed_forms_agree():
+    """The finish kernel's two hot-row forms -- accumulators indexed by item id with one group per item (item tables of up
+    to 2 048 rows, InvPrefRowPlan.item_hot_count) and the indexed list -- on the same minibatch: rows without atomics
+    bitwise equal, hot rows to the atomics' reordering noise; both against the oracle."""
+    z, implicit, params, (roe, ree, cls_w, rec_w) = _load(G1[0])
+    U, I, E, D, B = [int(x) for x in z['meta'][:5]]
+    assert I <= 2048
+    P = dev_params(params)
+    ws = ops.Workspace(DEV)
+    flags = ops.flags_of(implicit, rec_w, cls_w, roe, ree)
+    pl = planlib.build_row_plan(z['u'], z['v'], z['y'], U, I, per_slice=PER_SLICE, hot_threshold=3)
+    assert len(pl['hot_rows']) > 0
+    outs = []
+    for form in (pl, dict(pl, item_hot_count=None)):
+        dp = planlib.upload(form, DEV)
+        assert (dp.struct.item_hot_count is None) == (form['item_hot_count'] is None)
+        lr = float(z['coefs'][6])
+        Q = [torch.zeros_like(p) for p in P]
+        M = [torch.zeros_like(p) for p in P]
+        V = [torch.zeros_like(p) for p in P]
+        Gd = [torch.full_like(p, 7.0) for p in P]
+        la, lb = torch.zeros(6, device=DEV), torch.zeros(6, device=DEV)
+        ops.mstep_rows_grad(P, Gd, dp, t64(z['e']), t32(z['y']), t32(z['w']), B, z['coefs'], flags, la, ws)
+        ops.mstep_rows_adam(P, Q, M, V, dp, t64(z['e']), t32(z['y']), t32(z['w']), B, z['coefs'], flags, lb, 1, lr, ws)
+        outs.append(([g.cpu().numpy() for g in Gd], [q.cpu().numpy() for q in Q], [m.cpu().numpy() for m in M], la.cpu().numpy()))
+    hot = pl['hot_rows']
+    cold = np.setdiff1d(np.arange(I), hot)
+    for i, k in enumerate(O.PARAM_NAMES):
+        for a, b in zip(outs[0][:3], outs[1][:3]):
+            if 'item' in k:
+                np.testing.assert_array_equal(a[i][cold], b[i][cold], err_msg=k)
+                assert _relerr(a[i][hot], b[i][hot]) < 1e-5, k
+            elif 'user' in k:
+                np.testing.assert_array_equal(a[i], b[i], err_msg=k)
+    og, ol = O.mstep(O.Tables(params), z['u'], z['v'], z['e'], z['y'], z['w'], z['coefs'], O.flags_of(implicit, rec_w, cls_w, roe, ree))
+    for form in outs:
+        np.testing.assert_allclose(form[3], ol, rtol=1e-5)
+        for k, g, o in zip(O.PARAM_NAMES, form[0], og):
+            assert _relerr(g, o) < 2e-5, k

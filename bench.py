@@ -301,24 +301,20 @@ def eager_kernel_times(mgr):
     if getattr(mgr, '_raw_ptrs', None) is None:
         mgr._raw_setup()
     nb = mgr.batch_num
-    ev = {'m0': [], 'mk': [], 'm1': [], 'a1': []}
+    ev = {'m0': [], 'm1': [], 'a1': []}
     fused = mgr.use_plan and mgr.world_size == 1 and not mgr._unfused
     torch.cuda._sleep(int(4e6))
     for k in range(nb):
-        e0, ek, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
-        if fused:  # the library records ek behind the main kernel of the step (before a separate finish kernel, if any)
-            ek.record()
-            _capi.lib().invpref_set_profile_event(ek.cuda_event)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
-        mgr._raw_step(k, mgr.alpha, mid_event=e1)
+        mgr._raw_step(k, mgr.alpha, mid_event=e1)   # fused: the library records e1 between the step's two launches
         e2.record()
-        ev['m0'].append(e0); ev['mk'].append(ek); ev['m1'].append(e1); ev['a1'].append(e2)
-    _capi.lib().invpref_set_profile_event(None)
+        ev['m0'].append(e0); ev['m1'].append(e1); ev['a1'].append(e2)
     torch.cuda.synchronize()
     med = lambda a, b: float(np.median([x.elapsed_time(y) for x, y in zip(ev[a], ev[b])]))  # noqa: E731
     out = {'step_ms_eager_events': med('m0', 'a1')}
     if fused:
-        out['main_kernel_ms_eager_events'] = med('m0', 'mk')
+        out['launch1_ms_eager_events'], out['launch2_ms_eager_events'] = med('m0', 'm1'), med('m1', 'a1')
     else:
         out['mstep_ms_eager_events'], out['adam_ms_eager_events'] = med('m0', 'm1'), med('m1', 'a1')
     return out
@@ -341,7 +337,7 @@ def roofline_large(dev):
     M = [torch.zeros_like(p) for p in P]
     V = [torch.zeros_like(p) for p in P]
     t0 = time.perf_counter()
-    dp = planlib.upload(planlib.build_row_plan(u, v, y, Ul, Il), dev)
+    dp = planlib.upload(planlib.build_row_plan(u, v, y, Ul, Il, factor_num=D), dev)
     plan_s = time.perf_counter() - t0
     e = torch.from_numpy(rs.randint(0, E, Bl).astype(np.int64)).to(dev)
     yt, w = torch.from_numpy(y).to(dev), torch.rand(Bl, device=dev)
@@ -451,11 +447,11 @@ def main():
     bytes_survey = B_PER_GPU * (32 + 32 * D) + 32 * P
     if fused:
         nbytes = B_PER_GPU * (32 + 16 * D) + 24 * P
-        kname, knames = 'mstep_rows_kernel', ['mstep_rows_kernel', 'rows_finish_kernel']
-        what = 'the whole optimiser step: mstep_rows_kernel (M-step + fused dense Adam) + rows_finish_kernel'
+        kname, knames = 'mstep_eval_kernel', ['mstep_eval_kernel', 'mstep_apply_kernel']
+        what = 'the whole optimiser step: mstep_eval_kernel (user jobs: evaluation, records, fused Adam) + mstep_apply_kernel (item jobs, fold, fused Adam)'
     else:
         nbytes = bytes_survey
-        kname = 'mstep_rows_kernel' if mgr.use_plan else 'mstep_atomic_kernel'
+        kname = 'mstep_eval_kernel' if mgr.use_plan else 'mstep_atomic_kernel'
         knames = [kname]
         what = 'the whole optimiser step: gradient pass + all-reduce + stand-alone Adam'
     achieved = nbytes / (ms_step_dev * 1e-3) / 1e9

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define INVPREF_ABI_VERSION 2
+#define INVPREF_ABI_VERSION 3
 
 /* error codes */
 #define INVPREF_OK 0
@@ -98,68 +98,62 @@ int invpref_mstep_grad_hip(const InvPrefTables *tables, const InvPrefTables *gra
                            const InvPrefCoefs *coefs, uint32_t flags, float *losses6, void *workspace,
                            size_t workspace_bytes, void *stream);
 
-/* ---- planned, atomic-free M-step ("row jobs").  utils.mini_batch (utils.py:12-19) yields the same
- * contiguous, unshuffled slices every epoch, so the scatter pattern of a minibatch is inverted once
- * into a plan (built on the host, invpref_kdd_2022_amd/plan.py).  All arrays are device memory and
- * are only read.
- *   job   = one row of the user tables (side 0) or of the item tables (side 1) + the minibatch's
- *           interactions that touch it, cut into 1, 2, 4, 8 or 16 equal slices;
- *   round = the 16 group slots (16 lanes each) of one workgroup; all jobs of a round have the same
- *           slice count; slices of a job sit in adjacent slots, the first one is the leader;
- *   workgroup b runs rounds [b*rounds_per_task, (b+1)*rounds_per_task); rounds [0, n_item_rounds)
- *           are item-side (n_item_rounds is a multiple of rounds_per_task), the rest user-side.
+/* ---- planned, atomic-free M-step ("row jobs"), two launches.  utils.mini_batch (utils.py:12-19) yields the same
+ * contiguous, unshuffled slices every epoch, so the scatter pattern of a minibatch is inverted once into a plan
+ * (built on the host, invpref_kdd_2022_amd/plan.py).  All arrays are device memory and are only read.
+ *   group = the lanes that hold one embedding row, one float4 per lane: lanes_per_group = 16 / 32 / 64 for
+ *           factor_num <= 64 / 128 / 256 (invpref_rows_lanes_per_group()); NG = 256 / lanes_per_group groups
+ *           per workgroup;
+ *   job   = one row of the user tables or of the item tables + the minibatch's interactions that touch it,
+ *           cut into 1, 2, 4, ... NG equal slices (a power of two), one slice per group;
+ *   round = the NG group slots of one workgroup; all jobs of a round have the same slice count; slices of a
+ *           job sit in adjacent slots, the first one is the leader;
+ *   task  = *_rounds_per_task consecutive rounds of one side, run by one workgroup.
+ * Launch 1 (mstep_eval_kernel) runs the USER jobs: every interaction is evaluated there, once, and leaves a
+ * record {g_p, g_q, env, gz[0..E)} in the workspace; launch 2 (mstep_apply_kernel) runs the ITEM jobs on those
+ * records and folds the per-workgroup partial sums of launch 1 into embed_env / classifier / the loss outputs.
  * desc[round][slot] is 8 int32:
  *   {row (-1: idle slot), meta, a, b, c, d, e, f}
- *   meta = leader | slices << 1 | mode << 6 | row_count << 8     (idle slots carry slices too)
- *   mode 0: no interaction; 1 / 2: one / two interactions inline as (partner_row, position, label
- *   bits) = (a, b, c) and (d, e, f); 3: interactions [a, b) of the side's sorted arrays below.
- * Every row of every table appears exactly once: in a job, in the hot-row list or in the stream list
- * (see the end of the struct).  other_*[j] / pos_*[j]: for the j-th interaction in that side's order (sorted by
- * own row), its row in the OTHER side's tables and its position inside the minibatch (index into the
- * envs / scores / sample_weights minibatch slices). */
+ *   meta = leader | slices << 1 | mode << 6 | row_count << 9       (idle slots carry slices too)
+ *   user side: mode 0 / 1 / 2 = that many interactions inline as (item row, position, label bits) = (a, b, c),
+ *              (d, e, f); mode 7: interactions [a, b) of user_list;
+ *   item side: mode 0 .. 3 = that many interactions inline as (user row, position) = (a, b), (c, d), (e, f);
+ *              mode 7: interactions [a, b) of item_list.
+ * `position` indexes the minibatch slices of envs / sample_weights and the record array.  Every row of every
+ * table appears exactly once: in a job or in the stream list (rows the minibatch does not touch: they get the
+ * dense-Adam step with a zero gradient, rows_per_stream_task rows per workgroup, in either launch). */
 typedef struct InvPrefRowPlan {
-    int32_t n_rounds, n_item_rounds, rounds_per_task, n;   /* n = interactions of the minibatch (shard) */
-    const int32_t *desc;                      /* [n_rounds][16][8] */
-    const int32_t *other_user, *pos_user;     /* [n] */
-    const int32_t *other_item, *pos_item;     /* [n] */
-    /* "hot" item rows: rows with more interactions in the minibatch than one workgroup should walk get
-     * NO job; the user-side jobs add their gradient with float atomics into a scratch row (shaped as
-     * 64 contiguous bytes per interaction and instruction) and the finish kernel completes them.
-     * n_hot may be 0 (then the three pointers are ignored) or item_num (no item-side jobs at all). */
-    int32_t n_hot, reserved;
-    const int32_t *hot_rows, *hot_count;      /* [n_hot] item row, its interaction count in this minibatch */
-    const int32_t *item_hot_index;            /* [item_num] index into hot_rows, or -1 */
-    /* rows the minibatch does not touch need no job either: they are listed here and streamed through
-     * the dense-Adam step (zero gradient) by workgroups of their own, rows_per_stream_task rows each. */
-    int32_t n_stream_user, n_stream_item, rows_per_stream_task, dense_per_task;
-    const int32_t *stream_rows;               /* [n_stream_user + n_stream_item], user rows first */
-    /* dense tasks: everything that is a reduction ACROSS rows (gradients of embed_env / classifier, loss
-     * sums, the hot rows' atomics) is computed by workgroups that walk the minibatch in its own order,
-     * dense_per_task interactions each: the ids of the minibatch as int32. */
-    const int32_t *batch_users, *batch_items; /* [n] */
+    int32_t n, lanes_per_group;               /* n = interactions of the minibatch (shard) */
+    int32_t n_user_rounds, n_item_rounds, user_rounds_per_task, item_rounds_per_task;
+    const int32_t *user_desc;                 /* [n_user_rounds][NG][8] */
+    const int32_t *item_desc;                 /* [n_item_rounds][NG][8] */
+    const int32_t *user_round_iters;          /* [n_user_rounds] interactions of the round's longest slice */
+    const int32_t *user_list;                 /* [n][4] {item row, position, label bits, 0}, sorted by user row */
+    const int32_t *item_list;                 /* [n][2] {user row, position}, sorted by item row */
+    int32_t n_stream, rows_per_stream_task;
+    const int32_t *stream_rows;               /* [n_stream] row id; bit 30 set: a row of the item tables */
     /* XCD-affine task order (speed only; any order gives the same results).  n_classes = 8 (the XCDs of an MI355X), or
      * 1 / 0 for the plain order.  Table rows are dealt to the classes in blocks of 64 rows, class(row) =
-     * (row >> 6) % n_classes; the rounds in `desc` and the rows in `stream_rows` are grouped by class, and workgroup b of
-     * the launch runs tasks of class b % n_classes only -- under the round-robin placement of workgroups over the XCDs
-     * that is the same XCD step after step, so a row's parameters and Adam moments are still in that XCD's L2 when the
-     * next step reads them.  cls[c] = { first item round, item rounds, first user round, user rounds, first streamed
-     * user row (index into stream_rows), streamed user rows, first streamed item row, streamed item rows } of class c. */
-    int32_t n_classes, reserved2;
+     * (row >> 6) % n_classes; rounds and streamed rows are grouped by class, and workgroup b of a launch runs tasks of
+     * class b % n_classes only -- under the round-robin placement of workgroups over the XCDs that is the same XCD step
+     * after step, so a row's parameters and Adam moments are still in that XCD's L2 when the next step reads them.
+     * cls[c] = { first user round, user rounds (both multiples of user_rounds_per_task), first streamed row of launch 1
+     * (index into stream_rows), streamed rows of launch 1, first item round, item rounds, first streamed row of
+     * launch 2, streamed rows of launch 2 } of class c. */
+    int32_t n_classes, reserved;
     int32_t cls[8][8];
-    /* optional (NULL: not used): [item_num] interactions of the item in this minibatch if the item is in the hot-row list,
-     * 0 otherwise.  With it, and an item table of at most 2 048 rows, the hot rows' accumulators are indexed by the item id
-     * and the finish kernel handles every item row with loads that depend on nothing but its thread index (one memory
-     * round trip instead of two on the step's critical path); the workspace holds item_num accumulator rows then. */
-    const int32_t *item_hot_count;
 } InvPrefRowPlan;
 
-/* The rows-path workspace must be ZERO-FILLED before its first use; every call leaves it zero-filled. */
+/* Scratch of one planned step: the records + the partial slabs.  It needs no initialisation (every word is stored
+ * before it is loaded) and carries nothing from one call to the next. */
 size_t invpref_rows_workspace_bytes(const InvPrefTables *tables, const InvPrefRowPlan *plan);
+/* lanes_per_group the kernels use for tables of this factor_num (16 / 32 / 64); a plan must be built for it. */
+int invpref_rows_lanes_per_group(const InvPrefTables *tables);
 
 /* same contract as invpref_mstep_grad_hip, except that EVERY row of every table of `grads` is
- * OVERWRITTEN (rows the minibatch does not touch get zeros): no zeroing pass is needed.  The four big
- * tables' gradients are bitwise reproducible run to run (register accumulation, fixed-order sums);
- * embed_env / classifier gradients and the loss sums go through a few float atomics. */
+ * OVERWRITTEN (rows the minibatch does not touch get zeros): no zeroing pass is needed.  There are no float
+ * atomics on this path: every gradient and loss term is bitwise reproducible run to run (register accumulation,
+ * fixed-order sums).  `scores` is ignored (the labels travel inside the plan) and may be NULL. */
 int invpref_mstep_rows_grad_hip(const InvPrefTables *tables, const InvPrefTables *grads, const InvPrefRowPlan *plan,
                                 const int64_t *envs, const float *scores, const float *sample_weights,
                                 int64_t batch_norm, const InvPrefCoefs *coefs, uint32_t flags, float *losses6,
@@ -176,10 +170,15 @@ int invpref_mstep_rows_adam_hip(const InvPrefTables *tables, const InvPrefTables
                                 uint32_t flags, float *losses6, int64_t step, double lr, double beta1, double beta2,
                                 double eps, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Profiling aid (bench.py's roofline figure): while a hipEvent_t is registered here, every planned M-step
- * call records it on its stream BETWEEN mstep_rows_kernel and rows_finish_kernel, so the dominant kernel
- * can be timed alone with events.  Process-global, not thread-safe; pass NULL to switch it off. */
-int invpref_set_profile_event(void *event);
+/* Profiling aid (bench.py's roofline figure): the same call, recording `mid_event` (a hipEvent_t) on the stream
+ * BETWEEN the two launches, so each launch can be timed alone with events.  No global state. */
+int invpref_mstep_rows_adam_profiled_hip(const InvPrefTables *tables, const InvPrefTables *new_tables,
+                                         const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
+                                         const InvPrefRowPlan *plan, const int64_t *envs, const float *scores,
+                                         const float *sample_weights, int64_t batch_norm, const InvPrefCoefs *coefs,
+                                         uint32_t flags, float *losses6, int64_t step, double lr, double beta1,
+                                         double beta2, double eps, void *workspace, size_t workspace_bytes, void *stream,
+                                         void *mid_event);
 
 /* ---- the same pass for HIP-graph replay.  A captured launch freezes its kernel arguments, so the
  * per-step scalars cannot be passed by value: they live in one of two device slots, picked by the

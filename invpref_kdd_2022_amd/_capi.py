@@ -22,9 +22,9 @@ EXPORTS = [
     'invpref_stat_envs_hip', 'invpref_sample_weights_hip', 'invpref_backward_hip', 'invpref_predict_hip',
     'invpref_rows_workspace_bytes', 'invpref_mstep_rows_grad_hip', 'invpref_mstep_rows_adam_hip',
     'invpref_adam_schedule_fill', 'invpref_mstep_rows_adam_sched_hip', 'invpref_eval_topk_hip',
-    'invpref_eval_error_sums_hip', 'invpref_set_profile_event', 'invpref_static_pop_workspace_bytes',
+    'invpref_eval_error_sums_hip', 'invpref_mstep_rows_adam_profiled_hip', 'invpref_static_pop_workspace_bytes',
     'invpref_static_pop_hip', 'invpref_adam_ranges_hip', 'invpref_mstep_rows_grad_sched_hip',
-    'invpref_adam_ranges_sched_hip',
+    'invpref_adam_ranges_sched_hip', 'invpref_rows_lanes_per_group',
 ]
 
 
@@ -96,12 +96,13 @@ def lib():
                                                         vp, C.POINTER(AdamSchedule), vp, C.c_size_t, vp]
         L.invpref_eval_topk_hip.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
         L.invpref_eval_error_sums_hip.argtypes = [vp, vp, i64, vp, vp]
-        L.invpref_set_profile_event.argtypes = [vp]
+        L.invpref_mstep_rows_adam_profiled_hip.argtypes = L.invpref_mstep_rows_adam_hip.argtypes + [vp]
+        L.invpref_rows_lanes_per_group.argtypes = [C.POINTER(Tables)]
         L.invpref_static_pop_workspace_bytes.argtypes = [i64, i64, i64]
         L.invpref_static_pop_workspace_bytes.restype = C.c_size_t
         L.invpref_static_pop_hip.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
         L.invpref_device_name.argtypes = [C.c_char_p, C.c_size_t]
-        if L.invpref_abi_version() != 2:
+        if L.invpref_abi_version() != 3:
             raise InvPrefError('libinvpref_hip.so ABI version mismatch')
         _lib = L
     return _lib

@@ -178,8 +178,8 @@ class _BasicTrainManager(_InvPrefTrainManager):
         u = batch_users_tensor.detach().cpu().numpy()
         v = batch_items_tensor.detach().cpu().numpy()
         y = batch_scores_tensor.detach().float().contiguous()
-        dp = planlib.upload(planlib.build_row_plan(u, v, y.cpu().numpy(), self.model.user_num, self.model.item_num),
-                            self.device)
+        dp = planlib.upload(planlib.build_row_plan(u, v, y.cpu().numpy(), self.model.user_num, self.model.item_num,
+                                                   factor_num=self.model.factor_num), self.device)
         st = self.state
         st.losses6.zero_()
         st.step += 1

@@ -12,7 +12,7 @@ LIB = os.path.join(PKG, 'libinvpref_hip.so')
 OBJDIR = os.path.join(PKG, 'build')
 INGEST_LIB = os.path.join(PKG, 'libinvpref_ingest.so')   # host-only data ingest (include/invpref_ingest.h)
 INGEST_SRC = os.path.join(CSRC, 'invpref_ingest.cpp')
-SOURCES = ['invpref_kernels.hip', 'invpref_rows.hip', 'invpref_eval.hip']
+SOURCES = ['invpref_kernels.hip', 'invpref_step.hip', 'invpref_eval.hip']
 HEADERS = ['canon_math.hpp', 'kernel_common.hpp', os.path.join('..', '..', 'include', 'invpref_hip.h')]
 # -ffp-contract=off: every fma of the canonical arithmetic is written explicitly
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-ffp-contract=off',

@@ -1,0 +1,1322 @@
+// invpref_step.hip -- the planned M-step as TWO balanced launches with no float atomics anywhere.
+//
+// The scatter pattern of a minibatch is static (utils.mini_batch, utils.py:12-19 yields the same contiguous,
+// unshuffled slices every epoch), so it is inverted once on the host (plan.py) into row jobs:
+//
+//   job   = one row of the user tables (or of the item tables) + the minibatch's interactions that touch
+//           it, cut into 1 .. NG equal slices, one slice per lane group;
+//   group = the 16 / 32 / 64 lanes that hold one embedding row, ONE float4 per lane (D <= 64 / 128 / 256):
+//           every instance of the kernels has the register profile of the D = 64 one;
+//   round = the NG = 256 / lanes group slots of one workgroup, filled with jobs of one slice count;
+//   task  = a few consecutive rounds of one side, run by one 256-thread workgroup.
+//
+// Launch 1, mstep_eval_kernel   = [user jobs | some of the untouched rows].  A user job keeps its two
+//   rows and their gradients in registers, gathers the partner item rows ONCE, evaluates every one of its
+//   interactions ONCE (forward + analytic backward of train.py:108-153, models.py:307-391) and stores a
+//   RECORD {g_p, g_q, env, gz[0..E)} per interaction for the item side; it finishes its own rows on the
+//   spot (Adam, or the gradient row for the multi-GPU path).  Everything that is a reduction ACROSS rows
+//   (gradients of embed_env / classifier, the five loss sums) is accumulated per workgroup and stored --
+//   plain stores -- as that workgroup's PARTIAL SLAB.
+// Launch 2, mstep_apply_kernel  = [item jobs | the other untouched rows | fold blocks].  An item job
+//   gathers the partner user rows + the records and only multiplies and adds (no exp / log / classifier,
+//   few registers, several gathers in flight: long item slices are cheap, so there are no "hot rows").
+//   The fold blocks sum the partial slabs in a fixed order, apply Adam to embed_env / classifier, write
+//   the six loss outputs and move the device-side schedule on.
+//
+// Rows are fetched 4 x per interaction in total (2 partner rows per side) -- the algorithmic minimum --
+// and every sum has a fixed order: the whole step is bitwise reproducible run to run.
+// Parameters are double-buffered (read old, write new): launch 2 still gathers the OLD user rows.
+#include <stdlib.h>
+#include <string.h>
+
+#include "kernel_common.hpp"
+
+using namespace invpref;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+
+// one row of the device-side schedule (include/invpref_hip.h: InvPrefAdamSchedule)
+struct SchedRow {
+    AdamScalars ad;
+    float alpha;   // gradient-reversal alpha of the step; NaN: use the one of the call's coefficient block
+    float pad;
+};
+__device__ __forceinline__ const SchedRow *sched_slot_ptr(const int *state, int slot) {
+    return reinterpret_cast<const SchedRow *>(state + 16 * slot + 2);
+}
+
+// ---- lane-group helpers: a group is LG consecutive lanes of one wave, lane lg holds floats [4 lg, 4 lg + 4)
+__device__ __forceinline__ float swz_xor16(float x) {   // lane l <-> l ^ 16 (inside each half of the wave)
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
+}
+template <int LG>
+__device__ __forceinline__ float group_sum(float x) {
+    x = row16_sum(x);
+    if (LG >= 32) x += swz_xor16(x);
+    if (LG >= 64) x += __shfl_xor(x, 32, 64);
+    return x;
+}
+template <int LG>
+__device__ __forceinline__ float group_max(float x) {
+    x = row16_max(x);
+    if (LG >= 32) x = __builtin_fmaxf(x, swz_xor16(x));
+    if (LG >= 64) x = __builtin_fmaxf(x, __shfl_xor(x, 32, 64));
+    return x;
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) {
+    float s = a.x * b.x;
+    s = __builtin_fmaf(a.y, b.y, s);
+    s = __builtin_fmaf(a.z, b.z, s);
+    return __builtin_fmaf(a.w, b.w, s);
+}
+__device__ __forceinline__ void f4fma(float4 &acc, float s, float4 a) {
+    acc.x = __builtin_fmaf(s, a.x, acc.x); acc.y = __builtin_fmaf(s, a.y, acc.y);
+    acc.z = __builtin_fmaf(s, a.z, acc.z); acc.w = __builtin_fmaf(s, a.w, acc.w);
+}
+__device__ __forceinline__ void f4add(float4 &acc, float4 a) { acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+__device__ __forceinline__ float4 f4scale(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+__device__ __forceinline__ float f4sq(float4 a) { return a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
+__device__ __forceinline__ float f4abs(float4 a) { return fabsf(a.x) + fabsf(a.y) + fabsf(a.z) + fabsf(a.w); }
+__device__ __forceinline__ float4 reg_term(float4 p, float r2, float r1) {   // r2 p + r1 sign(p)
+    return make_float4(r2 * p.x + r1 * c_sign(p.x), r2 * p.y + r1 * c_sign(p.y), r2 * p.z + r1 * c_sign(p.z),
+                       r2 * p.w + r1 * c_sign(p.w));
+}
+
+// the lane's float4 of row `row` (zero beyond D).  32-bit BYTE offsets (the launcher refuses tables of 2^32 bytes or
+// more): a load takes the table's base from scalar registers and ONE vector register of offset instead of a 64-bit
+// address pair.  Lanes beyond D read a clamped address and select zero: no branch around the load (a load under a
+// branch is waited for at the join).
+template <bool VEC>
+__device__ __forceinline__ float4 row4(const float *__restrict__ base, int row, int D, int lg) {
+    const unsigned i0 = (unsigned)lg * 4u;
+    if (VEC) {
+        const bool ok = i0 < (unsigned)D;
+        const unsigned boff = ((unsigned)row * (unsigned)D + (ok ? i0 : 0u)) * 4u;
+        const float4 r = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + boff);
+        return make_float4(ok ? r.x : 0.f, ok ? r.y : 0.f, ok ? r.z : 0.f, ok ? r.w : 0.f);
+    }
+    const float *p = base + (unsigned)row * (unsigned)D;
+    float4 r;
+    r.x = (i0 + 0 < (unsigned)D) ? p[i0 + 0] : 0.f;
+    r.y = (i0 + 1 < (unsigned)D) ? p[i0 + 1] : 0.f;
+    r.z = (i0 + 2 < (unsigned)D) ? p[i0 + 2] : 0.f;
+    r.w = (i0 + 3 < (unsigned)D) ? p[i0 + 3] : 0.f;
+    return r;
+}
+template <bool VEC>
+__device__ __forceinline__ void put4(float *__restrict__ base, int row, int D, int lg, float4 r) {
+    const int i0 = lg * 4;
+    if (VEC) {
+        const unsigned boff = ((unsigned)row * (unsigned)D + (unsigned)i0) * 4u;
+        if (i0 < D) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + boff) = r;
+    } else {
+        float *p = base + (unsigned)row * (unsigned)D;
+        if (i0 + 0 < D) p[i0 + 0] = r.x;
+        if (i0 + 1 < D) p[i0 + 1] = r.y;
+        if (i0 + 2 < D) p[i0 + 2] = r.z;
+        if (i0 + 3 < D) p[i0 + 3] = r.w;
+    }
+}
+__device__ __forceinline__ void adam4(float4 &p, float4 g, float4 &m, float4 &v, const AdamScalars &ad) {
+    adam1f(p.x, g.x, m.x, v.x, ad); adam1f(p.y, g.y, m.y, v.y, ad);
+    adam1f(p.z, g.z, m.z, v.z, ad); adam1f(p.w, g.w, m.w, v.w, ad);
+}
+
+// launch arguments shared by the two kernels (each launch gets its own copy: its rounds, its share of the streamed rows)
+struct StepArgs {
+    const int4 *desc;             // [rounds][NG][2]: see InvPrefRowPlan in include/invpref_hip.h
+    const int *round_iters;       // launch 1: [rounds] longest slice of the round (E > 4 instances: uniform loop count)
+    const int4 *ulist;            // launch 1: [n] {item row, position, label bits, 0} sorted by user row
+    const int2 *ilist;            // launch 2: [n] {user row, position} sorted by item row
+    const int64_t *envs;          // minibatch base pointers, indexed by position
+    const float *weights;
+    StepScalars k;
+    uint32_t flags;
+    int fused;                    // 0: store gradient rows to g; 1: Adam on the spot -> np / m / v
+    float *g[4];                  // Pu, Qi, Pa, Qa gradient tables   (fused == 0)
+    float *np[4];                 // new parameter tables              (fused == 1)
+    float *m[4], *v[4];           // Adam moments                      (fused == 1)
+    AdamScalars ad;
+    const int *stream_rows;       // untouched rows of this launch: row id, bit 30 set for item rows
+    int rows_per_stream_task, rounds_per_task;
+    int n_cls;                    // XCD-affine task order: workgroup b runs tasks of class b % n_cls (InvPrefRowPlan)
+    int cls[8][4];                // per class: first round, rounds, first streamed row, streamed rows
+    float *records;               // [n][4 + EMAX]
+    float *slabs;                 // [launch-1 job tasks][slab_len] partial sums
+    int *sched_state;             // optional device int32[32]: two slots {step, base, SchedRow}, see InvPrefAdamSchedule
+    int sched_slot;
+    int stamps_nodrain;
+    unsigned long long *stamps;   // diagnostic (INVPREF_STAMPS): [workgroup][8] s_memrealtime ticks
+};
+
+// diagnostic phase stamp: drains the wave's outstanding memory operations first, so the latency of a phase is charged
+// to that phase.  Never executed unless a stamp buffer is passed.
+#define STAMP(i)                                                                  \
+    do {                                                                          \
+        if (a.stamps) {                                                           \
+            if (!a.stamps_nodrain) __builtin_amdgcn_s_waitcnt(0);                 \
+            if (threadIdx.x == 0) a.stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                         \
+    } while (0)
+
+template <int LG, int EMAX>
+struct Geo {
+    static constexpr int NG = kThreads / LG;          // groups (rows in flight) per workgroup
+    static constexpr int DP = 4 * LG;                 // padded row length
+    static constexpr int RS = 4 + EMAX;               // floats per record: g_p, g_q, env bits, 0, gz[EMAX]
+    static constexpr bool REG = EMAX <= 4;            // E x D partial sums in registers (else: LDS records)
+    static constexpr int SLAB = 2 * EMAX * DP + EMAX + kLossSlots;   // dEv | dW | db | loss sums
+    // E > 4: thread -> column d_own, classes cg, cg + CG, ...
+    static constexpr int CG = (kThreads / DP) < EMAX ? (kThreads / DP) : EMAX;
+    static constexpr int CPT = (EMAX + CG - 1) / CG;
+};
+
+// LDS layout of launch 1 (floats)
+template <int LG, int EMAX>
+struct EvalLds {
+    using G = Geo<LG, EMAX>;
+    static constexpr int sEv = 0;                                   // [EMAX][DP]
+    static constexpr int sW = sEv + EMAX * G::DP;                   // [EMAX][DP]
+    static constexpr int sb = sW + EMAX * G::DP;                    // [EMAX]
+    static constexpr int slots = sb + EMAX;                         // [NG][2][DP] slice partials
+    static constexpr int mv = slots + G::NG * 2 * G::DP;            // [4 waves][4][64] float4 LDS-DMA landing area
+    static constexpr int red = mv + kWaves * 4 * 64 * 4;            // REG: [4 waves][SLAB]; else [4 waves][8] loss sums
+    static constexpr int rec = red + (G::REG ? kWaves * G::SLAB : kWaves * kLossSlots);   // E > 4: [2][NG][2][DP] x, o
+    static constexpr int recs = rec + (G::REG ? 0 : 2 * G::NG * 2 * G::DP);              // [2][NG][EMAX + 4] gz, env
+    static constexpr int total = recs + (G::REG ? 0 : 2 * G::NG * (EMAX + 4));
+};
+
+// ---- forward + analytic backward of ONE interaction on a lane group (M-step arithmetic: hardware exp/log/rcp).
+template <int EMAX>
+struct Eval {
+    float g_p, g_q, li, le, lcls;
+    float gz[EMAX <= 4 ? EMAX : 1];   // E <= 4: every lane holds all classes
+    float gz_lane;                    // E > 4: lane lg of the group holds class lg (0 beyond E)
+    float4 x, gx;                     // x = Pu*Qi ; gx = sum_c gz_c W_c
+};
+template <int LG, int EMAX>
+__device__ __forceinline__ void eval_interaction(Eval<EMAX> &o, float4 pu, float4 qi, float4 pa, float4 qa, float4 ev,
+                                                 const float *sW, const float *sb, float *gzs, int E, int e, float y,
+                                                 float cw_rec, float cw_cls, const StepScalars &k, bool implicit,
+                                                 bool pure, int lg) {
+    constexpr int DP = 4 * LG;
+    o.x = f4mul(pu, qi);
+    const float p = group_sum<LG>((o.x.x + o.x.y) + (o.x.z + o.x.w));
+    const float q = group_sum<LG>(dot4(f4mul(pa, qa), ev));
+    if (implicit) {
+        const float sp = f_sigmoid(p), sq = f_sigmoid(q), sv = sp * sq;
+        o.li = f_bce(sp, y);
+        o.le = f_bce(sv, y);
+        const float d_inv = k.ca * cw_rec * f_dbce(sp, y);
+        const float d_env = k.cb * cw_rec * f_dbce(sv, y);
+        o.g_p = (d_inv + d_env * sq) * (sp * (1.f - sp));
+        o.g_q = d_env * sp * (sq * (1.f - sq));
+    } else {
+        const float s2 = p + q;
+        o.li = (p - y) * (p - y);
+        o.le = (s2 - y) * (s2 - y);
+        const float d_env = k.cb * cw_rec * 2.f * (s2 - y);
+        o.g_p = k.ca * cw_rec * 2.f * (p - y) + d_env;
+        o.g_q = d_env;
+    }
+    o.gx = f4zero();
+    o.lcls = 0.f;
+    o.gz_lane = 0.f;
+    if (EMAX <= 4) {
+#pragma unroll
+        for (int c = 0; c < (EMAX <= 4 ? EMAX : 1); c++) o.gz[c] = 0.f;
+    }
+    if (pure) return;   // PureMF: no classifier
+    if (EMAX <= 4) {
+        // the W rows are read from LDS ONCE, unconditionally and back to back (rows c >= E are staged as zeros);
+        // everything after is selects and arithmetic
+        float4 wrow[EMAX <= 4 ? EMAX : 1];
+        float z[EMAX <= 4 ? EMAX : 1], mx = -__builtin_inff();
+#pragma unroll
+        for (int c = 0; c < (EMAX <= 4 ? EMAX : 1); c++) wrow[c] = *reinterpret_cast<const float4 *>(sW + c * DP + lg * 4);
+#pragma unroll
+        for (int c = 0; c < (EMAX <= 4 ? EMAX : 1); c++) {
+            const float zc = group_sum<LG>(dot4(o.x, wrow[c])) + sb[c];
+            z[c] = c < E ? zc : -__builtin_inff();
+            mx = z[c] > mx ? z[c] : mx;
+        }
+        float se = 0.f, ze = 0.f;
+#pragma unroll
+        for (int c = 0; c < (EMAX <= 4 ? EMAX : 1); c++) { z[c] = f_exp(z[c] - mx); se += z[c]; }   // exp(-inf) = 0
+#pragma unroll
+        for (int c = 0; c < (EMAX <= 4 ? EMAX : 1); c++) ze = (c == e) ? z[c] : ze;
+        const float rse = f_rcp(se);
+        o.lcls = -f_log(ze * rse);
+#pragma unroll
+        for (int c = 0; c < (EMAX <= 4 ? EMAX : 1); c++) {
+            o.gz[c] = c < E ? k.cc * cw_cls * (z[c] * rse - (c == e ? 1.f : 0.f)) : 0.f;
+            f4fma(o.gx, o.gz[c], wrow[c]);
+        }
+    } else {
+        // larger classifiers keep ONE class per lane: the logit of class c is a group-uniform value after the
+        // row reduction, lane c keeps it; max / sum of the softmax are group reductions, one exp per lane
+        float zmine = -__builtin_inff();
+#pragma unroll 4
+        for (int c = 0; c < E; c++) {
+            const float4 wr = *reinterpret_cast<const float4 *>(sW + c * DP + lg * 4);
+            const float zc = group_sum<LG>(dot4(o.x, wr)) + sb[c];
+            zmine = (lg == c) ? zc : zmine;
+        }
+        const float mxl = group_max<LG>(zmine);
+        const float ez = lg < E ? f_exp(zmine - mxl) : 0.f;
+        const float rsel = f_rcp(group_sum<LG>(ez));
+        const float gzl = lg < E ? k.cc * cw_cls * (ez * rsel - (lg == e ? 1.f : 0.f)) : 0.f;
+        o.gz_lane = gzl;
+        // every lane needs every gz_c for the backward: through the group's LDS record (in-order LDS operations
+        // of one wave: no barrier), which the E x D accumulation reads as well
+        if (lg < EMAX) gzs[lg] = gzl;
+        if (lg == e) gzs[EMAX + 1] = -f_log(ez * rsel);   // (lane e holds the picked class: its loss term)
+        WAVE_LDS_FENCE();
+        o.lcls = gzs[EMAX + 1];
+#pragma unroll
+        for (int c4 = 0; c4 < EMAX; c4 += 4) {
+            const float4 g4 = *reinterpret_cast<const float4 *>(gzs + c4);
+            f4fma(o.gx, g4.x, *reinterpret_cast<const float4 *>(sW + (c4 + 0) * DP + lg * 4));
+            f4fma(o.gx, g4.y, *reinterpret_cast<const float4 *>(sW + (c4 + 1) * DP + lg * 4));
+            f4fma(o.gx, g4.z, *reinterpret_cast<const float4 *>(sW + (c4 + 2) * DP + lg * 4));
+            f4fma(o.gx, g4.w, *reinterpret_cast<const float4 *>(sW + (c4 + 3) * DP + lg * 4));
+        }
+    }
+}
+
+// stage a small [E][D] table into LDS as [EMAX][DP], zero padded (an absent table, INVPREF_PURE_MF, stages zeros)
+__device__ __forceinline__ void stage_small(float *dst, const float *__restrict__ src, int E, int D, int EMAX, int DP) {
+    for (int i = threadIdx.x; i < EMAX * DP; i += kThreads) {
+        const int e = i / DP, d = i - e * DP;
+        dst[i] = (src && e < E && d < D) ? src[e * D + d] : 0.f;
+    }
+}
+
+struct USample {
+    int oth, ps;
+    float y;
+};
+
+// =====================================================================================
+// launch 1: rounds of USER jobs.  Per interaction: gather the item rows, evaluate, accumulate the user rows'
+// gradients in registers, store the record for the item side, accumulate the E x D / loss sums.
+// =====================================================================================
+template <int LG, bool VEC, int EMAX>
+__device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a, int r0, int nr, int slab_index, float *lds) {
+    using G = Geo<LG, EMAX>;
+    using L = EvalLds<LG, EMAX>;
+    constexpr int NG = G::NG, DP = G::DP, RS = G::RS;
+    float *sEv = lds + L::sEv, *sW = lds + L::sW, *sb = lds + L::sb, *slots = lds + L::slots;
+    float4 *mv = reinterpret_cast<float4 *>(lds + L::mv);
+    float *red = lds + L::red;
+    const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float4 *mv_wave = mv + wave * 4 * 64;
+    const bool implicit = a.flags & INVPREF_IMPLICIT;
+    const bool rw_rec = a.flags & INVPREF_REWEIGHT_REC, rw_cls = a.flags & INVPREF_REWEIGHT_CLS;
+    const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
+    const bool pure = a.flags & INVPREF_PURE_MF;   // env-aware tables, embed_env, classifier absent: never touched
+    const bool dma = VEC && a.fused;
+    StepScalars k = a.k;
+    if (a.sched_state) {  // scheduled alpha (train.py:214-217) under graph replay
+        const float al = sched_slot_ptr(a.sched_state, a.sched_slot)->alpha;
+        if (al == al) k.alpha = al;
+    }
+    const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
+
+    STAMP(0);
+    // the first round's descriptor goes out before anything else: every gather below hangs on it
+    int4 d = a.desc[(r0 * NG + grp) * 2], d1 = a.desc[(r0 * NG + grp) * 2 + 1];
+    stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
+    stage_small(sW, t.W, t.E, t.D, EMAX, DP);
+    if (threadIdx.x < EMAX) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
+    STAMP(1);
+
+    // E x D partial sums: registers (E <= 4: per group, all classes) or thread-owned outputs fed from LDS records
+    float4 dW[G::REG ? EMAX : 1], dE[G::REG ? EMAX : 1];
+    float dB[G::REG ? EMAX : 1];
+    float oW[G::REG ? 1 : G::CPT], oE[G::REG ? 1 : G::CPT], oB[G::REG ? 1 : G::CPT];
+#pragma unroll
+    for (int c = 0; c < (G::REG ? EMAX : 1); c++) { dW[c] = dE[c] = f4zero(); dB[c] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < (G::REG ? 1 : G::CPT); i++) oW[i] = oE[i] = oB[i] = 0.f;
+    const int d_own = threadIdx.x % DP, cg = threadIdx.x / DP;
+    float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
+    int it_total = 0;   // E > 4: record buffer parity
+
+    for (int r = r0; r < r0 + nr; r++) {
+        if (r != r0) { d = a.desc[(r * NG + grp) * 2]; d1 = a.desc[(r * NG + grp) * 2 + 1]; }
+        const int row = d.x, meta = d.y;
+        const bool active = row >= 0, leader = meta & 1;
+        const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
+        const int nsmp = active ? (mode == 7 ? d.w - d.z : mode) : 0;
+        const int iters = G::REG ? nsmp : a.round_iters[r];
+        if (r == r0) STAMP(2);
+        // sample sidx of the slice: inline in the descriptor (up to two) or one 16-byte load from the sorted list
+        auto sample_at = [&](int sidx) {
+            USample sm;
+            if (mode == 7) {
+                const int4 q = a.ulist[d.z + sidx];
+                sm.oth = q.x; sm.ps = q.y; sm.y = __builtin_bit_cast(float, q.z);
+            } else if (sidx == 0) { sm.oth = d.z; sm.ps = d.w; sm.y = __builtin_bit_cast(float, d1.x); }
+            else { sm.oth = d1.y; sm.ps = d1.z; sm.y = __builtin_bit_cast(float, d1.w); }
+            return sm;
+        };
+        // everything that depends only on the descriptor is requested together: own rows, the Adam moments of the
+        // row (needed last: LDS-DMA, no registers held across the loop) and the first interaction's rows / env / weight
+        float4 oi = f4zero(), oe = f4zero(), gi = f4zero(), ge = f4zero();
+        float4 nqi = f4zero(), nqa = f4zero();
+        USample nsm{0, 0, 0.f}, nsm2{0, 0, 0.f};
+        int ne = 0;
+        float nw = 1.f;
+        {   // (an idle slot reads row 0 rather than branching around the loads)
+            const int rowc = active ? row : 0;
+            oi = row4<VEC>(t.Pu, rowc, t.D, lg);
+            if (!pure) oe = row4<VEC>(t.Pa, rowc, t.D, lg);
+        }
+        auto gather = [&](const USample &sm) {
+            nqi = row4<VEC>(t.Qi, sm.oth, t.D, lg);
+            if (!pure) {
+                nqa = row4<VEC>(t.Qa, sm.oth, t.D, lg);
+                ne = (int)a.envs[sm.ps];
+            }
+            if (rw_rec || rw_cls) nw = a.weights[sm.ps];
+        };
+        if (nsmp > 0) { nsm = sample_at(0); gather(nsm); }
+        if (nsmp > 1) nsm2 = sample_at(1);   // (list form: the ids run one interaction ahead of the rows)
+        if (dma) {
+            // each lane sends its 16-byte piece of the row's four moment rows straight to LDS; the destination of a
+            // wave instruction is one contiguous 1 KiB block, lane-major
+            const bool mine = active && leader && lg * 4 < t.D;
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) {
+                const float *src_tab = (tn & 1) ? a.v[(tn >> 1) * 2] : a.m[(tn >> 1) * 2];
+                if (mine && !(pure && tn >= 2))
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(src_tab + ((unsigned)row * (unsigned)t.D + (unsigned)lg * 4u)),
+                        (__attribute__((address_space(3))) void *)(mv_wave + tn * 64), 16, 0, 0);
+            }
+        }
+        if (r == r0) { __syncthreads(); STAMP(3); }  // staged tables visible (the gathers above are in flight)
+        for (int sidx = 0; sidx < iters; sidx++) {
+            const bool has = sidx < nsmp;
+            const USample cur = nsm;
+            const float4 qi = nqi, qa = nqa;
+            const int e = ne;
+            const float w = nw;
+            if (sidx + 1 < nsmp) {   // next interaction's rows fly under this one's evaluation
+                nsm = nsm2;
+                gather(nsm);
+                if (sidx + 2 < nsmp) nsm2 = sample_at(sidx + 2);
+            }
+            float *gzs = nullptr;
+            if (!G::REG) gzs = lds + L::recs + ((it_total & 1) * NG + grp) * (EMAX + 4);
+            if (has) {
+                const float w_rec = rw_rec ? w : 1.f, w_cls = rw_cls ? w : 1.f;
+                const float4 ev = *reinterpret_cast<const float4 *>(sEv + e * DP + lg * 4);
+                Eval<EMAX> o;
+                eval_interaction<LG, EMAX>(o, oi, qi, oe, qa, ev, sW, sb, gzs, t.E, e, cur.y, w_rec * k.invB,
+                                           w_cls * k.invB, k, implicit, pure, lg);
+                float4 gip;
+                gip.x = o.g_p - k.alpha * o.gx.x; gip.y = o.g_p - k.alpha * o.gx.y;
+                gip.z = o.g_p - k.alpha * o.gx.z; gip.w = o.g_p - k.alpha * o.gx.w;
+                f4add(gi, f4mul(gip, qi));
+                f4fma(ge, o.g_q, f4mul(qa, ev));
+                // the record the item side consumes
+                float *rec_g = a.records + (unsigned)cur.ps * (unsigned)RS;
+                if (lg == 0)
+                    *reinterpret_cast<float4 *>(rec_g) = make_float4(o.g_p, o.g_q, __builtin_bit_cast(float, e), 0.f);
+                if (EMAX <= 4) {
+                    if (lg == 1) *reinterpret_cast<float4 *>(rec_g + 4) =
+                        make_float4(o.gz[0], EMAX > 1 ? o.gz[EMAX > 1 ? 1 : 0] : 0.f, EMAX > 2 ? o.gz[EMAX > 2 ? 2 : 0] : 0.f,
+                                    EMAX > 3 ? o.gz[EMAX > 3 ? 3 : 0] : 0.f);
+                } else if (lg < EMAX) {
+                    rec_g[4 + lg] = o.gz_lane;
+                }
+                // o = g_q Pa*Qa (+ env regulariser): the interaction's term of embed_env's gradient
+                float4 oo = f4scale(o.g_q, f4mul(oe, qa));
+                if (reg_env) f4add(oo, reg_term(ev, 2.f * k.r2, 2.f * k.r1));
+                if (G::REG) {
+#pragma unroll
+                    for (int c = 0; c < (G::REG ? EMAX : 1); c++) {
+                        f4fma(dW[c], o.gz[EMAX <= 4 ? c : 0], o.x);
+                        f4add(dE[c], c == e ? oo : f4zero());
+                        dB[c] += o.gz[EMAX <= 4 ? c : 0];
+                    }
+                } else {
+                    float *rx = lds + L::rec + (((it_total & 1) * NG + grp) * 2) * DP;
+                    *reinterpret_cast<float4 *>(rx + lg * 4) = o.x;
+                    *reinterpret_cast<float4 *>(rx + DP + lg * 4) = oo;
+                }
+                // regulariser REPORTS over the item rows of the interaction (env rows weigh double: 1/(BD) vs 1/(2BD))
+                float s2 = f4sq(qi) + f4sq(qa), s1 = f4abs(qi) + f4abs(qa);
+                if (reg_env) { s2 += 2.f * f4sq(ev); s1 += 2.f * f4abs(ev); }
+                accL2 += s2;
+                accL1 += s1;
+                if (lg == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; accLc += o.lcls * w_cls; }
+            }
+            if (!G::REG) {
+                // E > 4: every thread adds the NG records of this iteration into the outputs it OWNS (one column,
+                // a strided set of classes).  Branch-free: an empty record slot holds env id -1, its stale x / o /
+                // gz are masked by selects.  Double-buffered: one barrier per iteration.
+                if (lg == 0) gzs[EMAX] = __builtin_bit_cast(float, has ? e : -1);
+                __syncthreads();
+                const float *recx = lds + L::rec + ((it_total & 1) * NG * 2) * DP;
+                const float *recz = lds + L::recs + ((it_total & 1) * NG) * (EMAX + 4);
+                if (threadIdx.x < G::CG * DP) {
+                    constexpr int BATCH = NG < 4 ? NG : 4;   // records whose LDS reads are in flight together
+#pragma unroll 1
+                    for (int g0 = 0; g0 < NG; g0 += BATCH) {
+                        int er[BATCH];
+                        float xr[BATCH], orr[BATCH], gr[BATCH][G::CPT];
+#pragma unroll
+                        for (int b = 0; b < BATCH; b++) {
+                            const float *rs = recz + (g0 + b) * (EMAX + 4);
+                            er[b] = __builtin_bit_cast(int, rs[EMAX]);
+                            xr[b] = recx[((g0 + b) * 2) * DP + d_own];
+                            orr[b] = recx[((g0 + b) * 2 + 1) * DP + d_own];
+#pragma unroll
+                            for (int i = 0; i < G::CPT; i++) gr[b][i] = rs[(cg + G::CG * i) & (EMAX - 1)];
+                        }
+#pragma unroll
+                        for (int b = 0; b < BATCH; b++) {
+                            const bool ok = er[b] >= 0;
+                            const float xv = ok ? xr[b] : 0.f;
+#pragma unroll
+                            for (int i = 0; i < G::CPT; i++) {
+                                const float gzc = ok ? gr[b][i] : 0.f;
+                                oW[G::REG ? 0 : i] = __builtin_fmaf(gzc, xv, oW[G::REG ? 0 : i]);
+                                oE[G::REG ? 0 : i] += (ok && cg + G::CG * i == er[b]) ? orr[b] : 0.f;
+                                oB[G::REG ? 0 : i] += gzc;
+                            }
+                        }
+                    }
+                }
+                it_total++;
+            }
+        }
+        if (r == r0) STAMP(4);
+        // ---- slices of one row meet through LDS: plain stores, fixed-order sum by the leader
+        if (slices > 1) {  // same for every slot of a round, idle slots included
+            float *mine = slots + grp * 2 * DP;
+            *reinterpret_cast<float4 *>(mine + lg * 4) = gi;
+            *reinterpret_cast<float4 *>(mine + DP + lg * 4) = ge;
+            __syncthreads();
+            if (active && leader) {
+#pragma unroll 4
+                for (int s = 1; s < slices; s++) {
+                    const float *oth_slot = slots + (grp + s) * 2 * DP;
+                    f4add(gi, *reinterpret_cast<const float4 *>(oth_slot + lg * 4));
+                    f4add(ge, *reinterpret_cast<const float4 *>(oth_slot + DP + lg * 4));
+                }
+            }
+            if (r + 1 < r0 + nr) __syncthreads();  // the slots are rewritten by the next round
+        }
+        if (r == r0) STAMP(5);
+        // ---- the leader finishes the row
+        if (active && leader) {
+            const float cnt = (float)(meta >> 9);
+            if (cnt != 0.f) {
+                f4fma(gi, cnt, reg_term(oi, k.r2, k.r1));
+                f4fma(ge, cnt, reg_term(oe, k.r2, k.r1));
+                // regulariser reports: the user's rows count once per interaction
+                accL2 += cnt * (f4sq(oi) + f4sq(oe));
+                accL1 += cnt * (f4abs(oi) + f4abs(oe));
+            }
+            if (!a.fused) {
+                put4<VEC>(a.g[0], row, t.D, lg, gi);
+                if (!pure) put4<VEC>(a.g[2], row, t.D, lg, ge);
+            } else {
+                float4 mi = f4zero(), vi = f4zero(), me = f4zero(), ve = f4zero();
+                if (dma) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA pieces have landed
+                    mi = mv_wave[0 * 64 + lane]; vi = mv_wave[1 * 64 + lane];
+                    if (!pure) { me = mv_wave[2 * 64 + lane]; ve = mv_wave[3 * 64 + lane]; }
+                } else {
+                    mi = row4<VEC>(a.m[0], row, t.D, lg); vi = row4<VEC>(a.v[0], row, t.D, lg);
+                    if (!pure) { me = row4<VEC>(a.m[2], row, t.D, lg); ve = row4<VEC>(a.v[2], row, t.D, lg); }
+                }
+                adam4(oi, gi, mi, vi, ad);
+                put4<VEC>(a.np[0], row, t.D, lg, oi);
+                put4<VEC>(a.m[0], row, t.D, lg, mi);
+                put4<VEC>(a.v[0], row, t.D, lg, vi);
+                if (!pure) {
+                    adam4(oe, ge, me, ve, ad);
+                    put4<VEC>(a.np[2], row, t.D, lg, oe);
+                    put4<VEC>(a.m[2], row, t.D, lg, me);
+                    put4<VEC>(a.v[2], row, t.D, lg, ve);
+                }
+            }
+        }
+    }
+    STAMP(6);
+    // ---- this workgroup's partial slab: dEv | dW | db | loss sums, plain stores, fixed-order sums
+    float *slab = a.slabs + (int64_t)slab_index * G::SLAB;
+    accLi = wave_sum(accLi); accLe = wave_sum(accLe); accLc = wave_sum(accLc);
+    accL2 = wave_sum(accL2); accL1 = wave_sum(accL1);
+    if (G::REG) {
+        // groups of one wave first (lane exchanges), then the four waves through LDS
+        float *mine = red + wave * G::SLAB;
+#pragma unroll
+        for (int c = 0; c < (G::REG ? EMAX : 1); c++) {
+            float4 &w4 = dW[c], &e4 = dE[c];
+            if (LG == 16) {
+                w4.x += swz_xor16(w4.x); w4.y += swz_xor16(w4.y); w4.z += swz_xor16(w4.z); w4.w += swz_xor16(w4.w);
+                e4.x += swz_xor16(e4.x); e4.y += swz_xor16(e4.y); e4.z += swz_xor16(e4.z); e4.w += swz_xor16(e4.w);
+                dB[c] += swz_xor16(dB[c]);
+            }
+            if (LG <= 32) {
+                w4.x += __shfl_xor(w4.x, 32, 64); w4.y += __shfl_xor(w4.y, 32, 64);
+                w4.z += __shfl_xor(w4.z, 32, 64); w4.w += __shfl_xor(w4.w, 32, 64);
+                e4.x += __shfl_xor(e4.x, 32, 64); e4.y += __shfl_xor(e4.y, 32, 64);
+                e4.z += __shfl_xor(e4.z, 32, 64); e4.w += __shfl_xor(e4.w, 32, 64);
+                dB[c] += __shfl_xor(dB[c], 32, 64);
+            }
+            if (lane < LG) {
+                *reinterpret_cast<float4 *>(mine + c * DP + lane * 4) = e4;
+                *reinterpret_cast<float4 *>(mine + EMAX * DP + c * DP + lane * 4) = w4;
+            }
+            if (lane == 0) mine[2 * EMAX * DP + c] = dB[c];
+        }
+        if (lane == 0) {
+            float *ls = mine + 2 * EMAX * DP + EMAX;
+            ls[0] = accLi; ls[1] = accLe; ls[2] = accLc; ls[3] = accL2; ls[4] = accL1; ls[5] = ls[6] = ls[7] = 0.f;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < G::SLAB; i += kThreads)
+            slab[i] = ((red[i] + red[G::SLAB + i]) + red[2 * G::SLAB + i]) + red[3 * G::SLAB + i];
+    } else {
+        if (lane == 0) {
+            float *ls = red + wave * kLossSlots;
+            ls[0] = accLi; ls[1] = accLe; ls[2] = accLc; ls[3] = accL2; ls[4] = accL1; ls[5] = ls[6] = ls[7] = 0.f;
+        }
+        if (threadIdx.x < G::CG * DP) {
+#pragma unroll
+            for (int i = 0; i < (G::REG ? 1 : G::CPT); i++) {
+                const int c = cg + G::CG * i;
+                if (c < EMAX) {
+                    slab[c * DP + d_own] = oE[i];
+                    slab[EMAX * DP + c * DP + d_own] = oW[i];
+                    if (d_own == 0) slab[2 * EMAX * DP + c] = oB[i];
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < kLossSlots)
+            slab[2 * EMAX * DP + EMAX + threadIdx.x] = ((red[threadIdx.x] + red[kLossSlots + threadIdx.x]) +
+                                                         red[2 * kLossSlots + threadIdx.x]) + red[3 * kLossSlots + threadIdx.x];
+    }
+    STAMP(7);
+}
+
+// =====================================================================================
+// launch 2: rounds of ITEM jobs.  Per interaction: partner user rows + record, multiply-add only.
+// =====================================================================================
+struct IIn {
+    float4 pu, pa, r0;
+};
+template <int LG, bool VEC, int EMAX>
+__device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a, int r0, int nr, float *lds) {
+    using G = Geo<LG, EMAX>;
+    constexpr int DP = G::DP, RS = G::RS, NG = G::NG;
+    float *sEv = lds, *sW = sEv + EMAX * DP, *slots = sW + EMAX * DP;   // [EMAX][DP] x 2, [NG][2][DP]
+    float4 *mv = reinterpret_cast<float4 *>(slots + NG * 2 * DP);       // [4 waves][4][64] float4 LDS-DMA landing area
+    const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float4 *mv_wave = mv + wave * 4 * 64;
+    const bool pure = a.flags & INVPREF_PURE_MF;
+    const bool dma = VEC && a.fused;
+    StepScalars k = a.k;
+    if (a.sched_state) {
+        const float al = sched_slot_ptr(a.sched_state, a.sched_slot)->alpha;
+        if (al == al) k.alpha = al;
+    }
+    const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
+    STAMP(0);
+    int4 d = a.desc[(r0 * NG + grp) * 2], d1 = a.desc[(r0 * NG + grp) * 2 + 1];
+    stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
+    stage_small(sW, t.W, t.E, t.D, EMAX, DP);
+    STAMP(1);
+    for (int r = r0; r < r0 + nr; r++) {
+        if (r != r0) { d = a.desc[(r * NG + grp) * 2]; d1 = a.desc[(r * NG + grp) * 2 + 1]; }
+        const int row = d.x, meta = d.y;
+        const bool active = row >= 0, leader = meta & 1;
+        const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
+        const int nsmp = active ? (mode == 7 ? d.w - d.z : mode) : 0;
+        if (r == r0) STAMP(2);
+        float4 oi = f4zero(), oe = f4zero(), gi = f4zero(), ge = f4zero();
+        {   // (an idle slot reads row 0 rather than branching around the loads)
+            const int rowc = active ? row : 0;
+            oi = row4<VEC>(t.Qi, rowc, t.D, lg);
+            if (!pure) oe = row4<VEC>(t.Qa, rowc, t.D, lg);
+        }
+        // interaction sidx of the slice: (user row, position) inline (up to three) or from the sorted list
+        auto ids_at = [&](int sidx) {
+            if (mode == 7) return a.ilist[d.z + sidx];
+            if (sidx == 0) return make_int2(d.z, d.w);
+            if (sidx == 1) return make_int2(d1.x, d1.y);
+            return make_int2(d1.z, d1.w);
+        };
+        auto fetch = [&](IIn &in, float4 (&gzv)[EMAX / 4], int2 id) {
+            in.pu = row4<VEC>(t.Pu, id.x, t.D, lg);
+            const float *rec = a.records + (unsigned)id.y * (unsigned)RS;
+            in.r0 = *reinterpret_cast<const float4 *>(rec);
+            if (!pure) {
+                in.pa = row4<VEC>(t.Pa, id.x, t.D, lg);
+#pragma unroll
+                for (int c4 = 0; c4 < EMAX / 4; c4++) gzv[c4] = *reinterpret_cast<const float4 *>(rec + 4 + c4 * 4);
+            }
+        };
+        auto consume = [&](const IIn &in, const float4 (&gzv)[EMAX / 4]) {
+            const float g_p = in.r0.x, g_q = in.r0.y;
+            const int e = __builtin_bit_cast(int, in.r0.z);
+            float4 gx = f4zero();
+            if (!pure) {
+#pragma unroll
+                for (int c4 = 0; c4 < EMAX / 4; c4++) {
+                    f4fma(gx, gzv[c4].x, *reinterpret_cast<const float4 *>(sW + (c4 * 4 + 0) * DP + lg * 4));
+                    f4fma(gx, gzv[c4].y, *reinterpret_cast<const float4 *>(sW + (c4 * 4 + 1) * DP + lg * 4));
+                    f4fma(gx, gzv[c4].z, *reinterpret_cast<const float4 *>(sW + (c4 * 4 + 2) * DP + lg * 4));
+                    f4fma(gx, gzv[c4].w, *reinterpret_cast<const float4 *>(sW + (c4 * 4 + 3) * DP + lg * 4));
+                }
+                const float4 ev = *reinterpret_cast<const float4 *>(sEv + e * DP + lg * 4);
+                f4fma(ge, g_q, f4mul(in.pa, ev));
+            }
+            float4 gip;
+            gip.x = g_p - k.alpha * gx.x; gip.y = g_p - k.alpha * gx.y;
+            gip.z = g_p - k.alpha * gx.z; gip.w = g_p - k.alpha * gx.w;
+            f4add(gi, f4mul(gip, in.pu));
+        };
+        // two interactions in flight per group: the slot just consumed is refilled at once (no register copies)
+        IIn n0, n1;
+        float4 zn0[EMAX / 4], zn1[EMAX / 4];
+        n0.pu = n0.pa = n0.r0 = n1.pu = n1.pa = n1.r0 = f4zero();
+#pragma unroll
+        for (int c4 = 0; c4 < EMAX / 4; c4++) zn0[c4] = zn1[c4] = f4zero();
+        int2 i0 = make_int2(0, 0), i1 = make_int2(0, 0);
+        if (nsmp > 0) fetch(n0, zn0, ids_at(0));
+        if (nsmp > 1) fetch(n1, zn1, ids_at(1));
+        if (nsmp > 2) i0 = ids_at(2);
+        if (nsmp > 3) i1 = ids_at(3);
+        if (dma) {   // the row's Adam moments: needed last, sent straight to LDS (no registers held across the loop)
+            const bool mine = active && leader && lg * 4 < t.D;
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) {
+                const float *src_tab = (tn & 1) ? a.v[(tn >> 1) * 2 + 1] : a.m[(tn >> 1) * 2 + 1];
+                if (mine && !(pure && tn >= 2))
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(src_tab + ((unsigned)row * (unsigned)t.D + (unsigned)lg * 4u)),
+                        (__attribute__((address_space(3))) void *)(mv_wave + tn * 64), 16, 0, 0);
+            }
+        }
+        if (r == r0) { __syncthreads(); STAMP(3); }  // staged tables visible
+        for (int s = 0; s < nsmp; s += 2) {
+            consume(n0, zn0);
+            if (s + 2 < nsmp) fetch(n0, zn0, i0);
+            if (s + 4 < nsmp) i0 = ids_at(s + 4);
+            if (s + 1 < nsmp) consume(n1, zn1);
+            if (s + 3 < nsmp) fetch(n1, zn1, i1);
+            if (s + 5 < nsmp) i1 = ids_at(s + 5);
+        }
+        if (r == r0) STAMP(4);
+        if (slices > 1) {
+            float *mine = slots + grp * 2 * DP;
+            *reinterpret_cast<float4 *>(mine + lg * 4) = gi;
+            *reinterpret_cast<float4 *>(mine + DP + lg * 4) = ge;
+            __syncthreads();
+            if (active && leader) {
+#pragma unroll 4
+                for (int s = 1; s < slices; s++) {
+                    const float *oth_slot = slots + (grp + s) * 2 * DP;
+                    f4add(gi, *reinterpret_cast<const float4 *>(oth_slot + lg * 4));
+                    f4add(ge, *reinterpret_cast<const float4 *>(oth_slot + DP + lg * 4));
+                }
+            }
+            if (r + 1 < r0 + nr) __syncthreads();
+        }
+        if (r == r0) STAMP(5);
+        if (active && leader) {
+            const float cnt = (float)(meta >> 9);
+            if (cnt != 0.f) {
+                f4fma(gi, cnt, reg_term(oi, k.r2, k.r1));
+                f4fma(ge, cnt, reg_term(oe, k.r2, k.r1));
+            }
+            if (!a.fused) {
+                put4<VEC>(a.g[1], row, t.D, lg, gi);
+                if (!pure) put4<VEC>(a.g[3], row, t.D, lg, ge);
+            } else {
+                float4 mi = f4zero(), vi = f4zero(), me = f4zero(), ve = f4zero();
+                if (dma) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA pieces have landed
+                    mi = mv_wave[0 * 64 + lane]; vi = mv_wave[1 * 64 + lane];
+                    if (!pure) { me = mv_wave[2 * 64 + lane]; ve = mv_wave[3 * 64 + lane]; }
+                } else {
+                    mi = row4<VEC>(a.m[1], row, t.D, lg); vi = row4<VEC>(a.v[1], row, t.D, lg);
+                    if (!pure) { me = row4<VEC>(a.m[3], row, t.D, lg); ve = row4<VEC>(a.v[3], row, t.D, lg); }
+                }
+                adam4(oi, gi, mi, vi, ad);
+                put4<VEC>(a.np[1], row, t.D, lg, oi);
+                put4<VEC>(a.m[1], row, t.D, lg, mi);
+                put4<VEC>(a.v[1], row, t.D, lg, vi);
+                if (!pure) {
+                    adam4(oe, ge, me, ve, ad);
+                    put4<VEC>(a.np[3], row, t.D, lg, oe);
+                    put4<VEC>(a.m[3], row, t.D, lg, me);
+                    put4<VEC>(a.v[3], row, t.D, lg, ve);
+                }
+            }
+        }
+    }
+    STAMP(6);
+}
+
+// Untouched rows: gradient exactly zero, so m' = m + (1-b1)(0-m), v' = b2 v, p' = p - step*m'/(sqrt(v')/bc+eps)
+// (the same adam1f as everywhere, fed g = 0).  Each group keeps R = 2 rows of both tables in flight (12 float4 loads).
+template <int LG, bool VEC>
+__device__ __forceinline__ void stream_task(const DevTables &t, const StepArgs &a, const int *rows, int n) {
+    constexpr int R = 2, NG = kThreads / LG;
+    const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG;
+    const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
+    const bool pure = a.flags & INVPREF_PURE_MF;
+    for (int i = grp; i < n; i += R * NG) {
+        int row[R], side[R];
+        bool on[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            on[q] = i + q * NG < n;
+            const int rid = rows[on[q] ? i + q * NG : i];
+            side[q] = (rid >> 30) & 1;
+            row[q] = rid & 0x3fffffff;
+        }
+        if (!a.fused) {
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                if (!on[q]) continue;
+                put4<VEC>(side[q] ? a.g[1] : a.g[0], row[q], t.D, lg, f4zero());
+                if (!pure) put4<VEC>(side[q] ? a.g[3] : a.g[2], row[q], t.D, lg, f4zero());
+            }
+            continue;
+        }
+        float4 p[2 * R], m[2 * R], v[2 * R];  // {row 0 inv, row 0 env, row 1 inv, ...}
+#pragma unroll
+        for (int q = 0; q < 2 * R; q++) {
+            p[q] = m[q] = v[q] = f4zero();
+            const int s = side[q >> 1];
+            if (!(pure && (q & 1))) {
+                const float *T = (q & 1) ? (s ? t.Qa : t.Pa) : (s ? t.Qi : t.Pu);
+                const float *M = (q & 1) ? (s ? a.m[3] : a.m[2]) : (s ? a.m[1] : a.m[0]);
+                const float *V = (q & 1) ? (s ? a.v[3] : a.v[2]) : (s ? a.v[1] : a.v[0]);
+                p[q] = row4<VEC>(T, row[q >> 1], t.D, lg);
+                m[q] = row4<VEC>(M, row[q >> 1], t.D, lg);
+                v[q] = row4<VEC>(V, row[q >> 1], t.D, lg);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2 * R; q++) {
+            const int s = side[q >> 1];
+            if (on[q >> 1] && !(pure && (q & 1))) {
+                adam4(p[q], f4zero(), m[q], v[q], ad);
+                float *NP = (q & 1) ? (s ? a.np[3] : a.np[2]) : (s ? a.np[1] : a.np[0]);
+                float *M = (q & 1) ? (s ? a.m[3] : a.m[2]) : (s ? a.m[1] : a.m[0]);
+                float *V = (q & 1) ? (s ? a.v[3] : a.v[2]) : (s ? a.v[1] : a.v[0]);
+                put4<VEC>(NP, row[q >> 1], t.D, lg, p[q]);
+                put4<VEC>(M, row[q >> 1], t.D, lg, m[q]);
+                put4<VEC>(V, row[q >> 1], t.D, lg, v[q]);
+            }
+        }
+    }
+}
+
+// ---- the fold: partial slabs -> gradients of embed_env / classifier (+ classifier regulariser, models.py:211-217)
+// -> Adam (fused) or gradient store; the six loss outputs; the device-side schedule moves on.
+struct FoldArgs {
+    float *gEv, *gW, *gb;        // fused == 0
+    float *nEv, *nW, *nb;        // fused == 1: new parameters
+    float *mEv, *mW, *mb, *vEv, *vW, *vb;
+    int n_partials, n_task_wgs, fold_blocks;
+    float l2, l1;
+    double inv_B, inv_BD2;       // 1 / Bnorm, 1 / (2 Bnorm D)
+    float *losses6;
+    const SchedRow *sched_table;
+    int sched_n;
+};
+constexpr int kFoldCols = 16, kFoldSubs = kThreads / kFoldCols;   // a fold block: 16 columns x 16 sub-rows of partials
+
+template <int LG, int EMAX>
+__device__ __forceinline__ void fold_block(const DevTables &t, const StepArgs &a, const FoldArgs &f, int fb, float *lds) {
+    using G = Geo<LG, EMAX>;
+    constexpr int DP = G::DP, SLAB = G::SLAB, EDP = EMAX * DP;
+    double *part = reinterpret_cast<double *>(lds);   // [kFoldSubs][kFoldCols]
+    const int colx = threadIdx.x % kFoldCols, sub = threadIdx.x / kFoldCols;
+    const int idx = fb * kFoldCols + colx;
+    const bool pure = a.flags & INVPREF_PURE_MF;
+    const bool dense = (a.flags & INVPREF_DENSE_REG) && !(a.flags & INVPREF_REG_ONLY_EMBED) && !pure;
+    const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
+    const bool mine = idx < SLAB;
+    // which output this column is
+    const bool isLoss = idx >= 2 * EDP + EMAX, isB = !isLoss && idx >= 2 * EDP, isW = !isLoss && !isB && idx >= EDP;
+    const int rr = isW ? idx - EDP : idx;
+    const int e = isB ? idx - 2 * EDP : rr / DP, dd = isB ? 0 : rr - e * DP;
+    const bool live = mine && !isLoss && e < t.E && dd < t.D && !pure;
+    const int off = live ? (isB ? e : e * t.D + dd) : 0;
+    // parameter / moments of the output this thread finishes (sub == 0 threads), requested up front
+    float pre_p = 0.f, pre_m = 0.f, pre_v = 0.f;
+    if (sub == 0 && live) {
+        pre_p = (isB ? t.b : (isW ? t.W : t.Ev))[off];
+        if (a.fused) {
+            pre_m = (isB ? f.mb : (isW ? f.mW : f.mEv))[off];
+            pre_v = (isB ? f.vb : (isW ? f.vW : f.vEv))[off];
+        }
+    }
+    // this thread's column of the partials sub, sub + kFoldSubs, ...: 8 loads in flight together (clamped, not
+    // guarded), summed in partial order in fp64
+    const float *col = a.slabs + (mine ? idx : 0);
+    const int np = f.n_partials;
+    double acc = 0.0;
+    constexpr int CH = 8;
+    for (int s0 = sub; s0 < np; s0 += CH * kFoldSubs) {
+        float x[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) x[j] = col[(int64_t)min(s0 + j * kFoldSubs, np - 1) * SLAB];
+#pragma unroll
+        for (int j = 0; j < CH; j++) acc += (s0 + j * kFoldSubs < np) ? (double)x[j] : 0.0;
+    }
+    part[sub * kFoldCols + colx] = acc;
+    __syncthreads();
+    if (sub != 0 || !mine) return;
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < kFoldSubs; q++) v += part[q * kFoldCols + colx];
+    if (!isLoss) {
+        if (!live) return;
+        float gv = (float)v, pv = pre_p;
+        if (isB) {
+            if (dense) gv += 2.f * f.l2 / (float)t.E * pv + f.l1 / (float)t.E * c_sign(pv);
+        } else if (isW && dense) {
+            gv += 2.f * f.l2 / ((float)t.D * (float)t.E) * pv + f.l1 / ((float)t.D * (float)t.E) * c_sign(pv);
+        }
+        if (!a.fused) {
+            (isB ? f.gb : (isW ? f.gW : f.gEv))[off] = gv;
+        } else {
+            float mm = pre_m, vv = pre_v;
+            adam1(pv, gv, mm, vv, ad);
+            (isB ? f.nb : (isW ? f.nW : f.nEv))[off] = pv;
+            (isB ? f.mb : (isW ? f.mW : f.mEv))[off] = mm;
+            (isB ? f.vb : (isW ? f.vW : f.vEv))[off] = vv;
+        }
+        return;
+    }
+    // the loss columns (they are contiguous and, SLAB being a multiple of 4, inside ONE fold block when
+    // kFoldCols >= 8 divides their offset -- asserted on the host): lanes share them through LDS
+    double *sl = part + kFoldSubs * kFoldCols;
+    sl[idx - 2 * EDP - EMAX] = v;
+}
+
+template <int LG, int EMAX>
+__device__ __forceinline__ void fold_losses(const DevTables &t, const StepArgs &a, const FoldArgs &f, float *lds) {
+    // called by the block that holds the loss columns, after fold_block and a barrier
+    const double *sl = reinterpret_cast<const double *>(lds) + kFoldSubs * kFoldCols;
+    const bool pure = a.flags & INVPREF_PURE_MF;
+    const bool dense = (a.flags & INVPREF_DENSE_REG) && !(a.flags & INVPREF_REG_ONLY_EMBED) && !pure;
+    double reg2 = 0.0, reg1 = 0.0;
+    if (threadIdx.x < 64) {
+        if (dense) {   // regulariser report of the classifier (models.py:211-217)
+            double w2 = 0, w1 = 0, b2 = 0, b1 = 0;
+            for (int i = threadIdx.x; i < t.E * t.D; i += 64) { const double xx = t.W[i]; w2 += xx * xx; w1 += fabs(xx); }
+            for (int i = threadIdx.x; i < t.E; i += 64) { const double xx = t.b[i]; b2 += xx * xx; b1 += fabs(xx); }
+            reg2 = w2 / ((double)t.D * t.E) + b2 / (double)t.E;
+            reg1 = w1 / ((double)t.D * t.E) + b1 / (double)t.E;
+            for (int m = 32; m >= 1; m >>= 1) { reg2 += __shfl_xor(reg2, m, 64); reg1 += __shfl_xor(reg1, m, 64); }
+        }
+        if (threadIdx.x == 0 && f.losses6) {
+            const StepScalars &k = a.k;
+            const double Li = sl[0] * f.inv_B, Le = sl[1] * f.inv_B, Lc = sl[2] * f.inv_B;
+            const double L2 = sl[3] * f.inv_BD2 + reg2, L1 = sl[4] * f.inv_BD2 + reg1;
+            // ADDED (the caller zeroes; a row-sharded run sums its ranks' partial terms): fire-and-forget atomics from
+            // this single thread -- one adder per call, so the result does not depend on any ordering
+            atomicAdd(f.losses6 + 0, (float)Li); atomicAdd(f.losses6 + 1, (float)Le); atomicAdd(f.losses6 + 2, (float)Lc);
+            atomicAdd(f.losses6 + 3, (float)L2); atomicAdd(f.losses6 + 4, (float)L1);
+            atomicAdd(f.losses6 + 5, (float)((double)k.ca * Li + (double)k.cb * Le + (double)k.cc * Lc + (double)f.l2 * L2 + (double)f.l1 * L1));
+        }
+    }
+}
+
+// class c's task counts from the by-value table (a masked sum instead of a dynamic index: indexing a by-value kernel
+// argument with a run-time value can make the compiler copy the whole argument block to scratch memory)
+__device__ __forceinline__ void class_row(const StepArgs &a, int c, int (&q)[4]) {
+    q[0] = q[1] = q[2] = q[3] = 0;
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+        const int on = (c == kk) ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) q[i] += a.cls[kk][i] * on;
+    }
+}
+
+// registers: the instances are held to 4 (E <= 4) / 3 workgroups per CU for launch 1 and 6 / 4 / 3 for launch 2
+#ifndef STEP_EVAL_WAVES
+#define STEP_EVAL_WAVES 4
+#endif
+#ifndef STEP_APPLY_WAVES
+#define STEP_APPLY_WAVES 6
+#endif
+template <int LG, bool VEC, int EMAX>
+__global__ __launch_bounds__(kThreads, EMAX <= 4 ? STEP_EVAL_WAVES : 3) void mstep_eval_kernel(DevTables t, StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // Workgroup b runs the tasks of class c = b % n_cls (XCD-affine order, InvPrefRowPlan), the j-th of them with
+    // j = b / n_cls: its user jobs first, then its share of the untouched rows.  Every branch is workgroup-uniform.
+    const int ncls = a.n_cls;
+    const int c = (int)blockIdx.x % ncls;
+    int j = (int)blockIdx.x / ncls;
+    int q[4];
+    class_row(a, c, q);
+    const int rpt = a.rounds_per_task, spt = a.rows_per_stream_task;
+    const int tj = (q[1] + rpt - 1) / rpt;
+    if (j < tj) {
+#ifndef DBG_NO_JOBS
+        user_task<LG, VEC, EMAX>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), q[0] / rpt + j, lds);
+#endif
+        return;
+    }
+    j -= tj;
+    if (j * spt < q[3]) {
+        STAMP(0);
+#ifndef DBG_NO_STREAM
+        stream_task<LG, VEC>(t, a, a.stream_rows + q[2] + j * spt, min(spt, q[3] - j * spt));
+#endif
+        STAMP(7);
+    }
+}
+
+template <int LG, bool VEC, int EMAX>
+__global__ __launch_bounds__(kThreads, EMAX <= 4 ? STEP_APPLY_WAVES : (EMAX <= 8 ? 4 : 3)) void mstep_apply_kernel(DevTables t, StepArgs a, FoldArgs f) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x >= f.n_task_wgs) {
+        const int fb = (int)blockIdx.x - f.n_task_wgs;
+        if (fb == f.fold_blocks) {
+            // the device-side schedule moves on: one thread of the LAST block fills the OTHER slot with the next step's
+            // number and scalars.  Nobody reads that slot before the next launch, so no ordering is needed.
+            // (gradient-pass form, fused == 0: the stand-alone Adam kernel that follows is the step's last launch and
+            //  moves the schedule on; here the slot is only read, for a scheduled alpha)
+            if (a.sched_state && a.fused && threadIdx.x == 0) {
+                const int *cur = a.sched_state + 16 * a.sched_slot;
+                int *nxt = a.sched_state + 16 * (a.sched_slot ^ 1);
+                const int next = cur[0] + 1, base = cur[1], idx = next - base;
+                nxt[0] = next;
+                nxt[1] = base;
+                if (idx >= 0 && idx < f.sched_n) *reinterpret_cast<SchedRow *>(nxt + 2) = f.sched_table[idx];
+            }
+            return;
+        }
+        STAMP(0);
+#ifndef DBG_NO_FOLD
+        fold_block<LG, EMAX>(t, a, f, fb, lds);
+        constexpr int loss0 = 2 * EMAX * 4 * LG + EMAX;
+        if (fb == loss0 / kFoldCols) {   // (workgroup-uniform)
+            __syncthreads();
+            fold_losses<LG, EMAX>(t, a, f, lds);
+        }
+#endif
+        STAMP(7);
+        return;
+    }
+    const int ncls = a.n_cls;
+    const int c = (int)blockIdx.x % ncls;
+    int j = (int)blockIdx.x / ncls;
+    int q[4];
+    class_row(a, c, q);
+    const int rpt = a.rounds_per_task, spt = a.rows_per_stream_task;
+    const int tj = (q[1] + rpt - 1) / rpt;
+    if (j < tj) {
+#ifndef DBG_NO_JOBS
+        item_task<LG, VEC, EMAX>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), lds);
+#endif
+        return;
+    }
+    j -= tj;
+    if (j * spt < q[3]) {
+        STAMP(0);
+#ifndef DBG_NO_STREAM
+        stream_task<LG, VEC>(t, a, a.stream_rows + q[2] + j * spt, min(spt, q[3] - j * spt));
+#endif
+        STAMP(7);
+    }
+}
+
+inline int lanes_of(int D, bool vec) { return D <= 64 ? 16 : (D <= 128 ? 32 : 64); }
+inline int emax4_of(int E) { return E <= 4 ? 4 : (E <= 8 ? 8 : 16); }
+inline size_t slab_floats(int lg, int emax) { return (size_t)2 * emax * 4 * lg + emax + kLossSlots; }
+inline size_t eval_lds_bytes(int lg, int emax) {
+    const size_t DP = 4 * (size_t)lg, NG = kThreads / lg;
+    const bool reg = emax <= 4;
+    size_t fl = 2 * emax * DP + emax + NG * 2 * DP + kWaves * 4 * 64 * 4;
+    fl += reg ? kWaves * slab_floats(lg, emax) : kWaves * kLossSlots;
+    if (!reg) fl += 2 * NG * 2 * DP + 2 * NG * (emax + 4);
+    return fl * sizeof(float);
+}
+inline size_t apply_lds_bytes(int lg, int emax) {
+    const size_t DP = 4 * (size_t)lg, NG = kThreads / lg;
+    const size_t job = (2 * emax * DP + NG * 2 * DP + kWaves * 4 * 64 * 4) * sizeof(float);
+    const size_t fold = (kFoldSubs * kFoldCols + kLossSlots) * sizeof(double);
+    return job > fold ? job : fold;
+}
+
+template <typename K>
+int ensure_lds(K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+inline int plan_tasks(const InvPrefRowPlan *plan, int launch, int *task_wgs) {
+    // workgroups of one launch: the classes' task lists interleaved, padded to the longest
+    const int ncls = plan->n_classes > 0 ? plan->n_classes : 1;
+    const int rpt = launch == 0 ? plan->user_rounds_per_task : plan->item_rounds_per_task;
+    const int spt = plan->rows_per_stream_task;
+    int per_class = 0;
+    for (int c = 0; c < ncls; c++) {
+        const int32_t *q = plan->cls[c] + 4 * launch;
+        const int tot = (q[1] + rpt - 1) / rpt + (q[3] + spt - 1) / spt;
+        per_class = tot > per_class ? tot : per_class;
+    }
+    *task_wgs = per_class * ncls;
+    return 0;
+}
+
+int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const int64_t *envs, const float *scores,
+                const float *weights, int64_t batch_norm, const InvPrefCoefs *coefs, uint32_t flags, float *losses6,
+                void *workspace, size_t workspace_bytes, hipStream_t st, int fused, const InvPrefTables *grads,
+                const InvPrefTables *new_tables, const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
+                const AdamScalars &ad, const InvPrefAdamSchedule *sched, void *profile_event) {
+    const bool pure = flags & INVPREF_PURE_MF;
+    int rc = check_tables(tables, pure);
+    if (sched && (!sched->state || !sched->table || sched->n <= 0)) return INVPREF_EINVAL;
+    if (rc) return rc;
+    if (!plan || !coefs || !losses6 || !workspace || (!envs && !pure) || batch_norm <= 0) return INVPREF_EINVAL;
+    (void)scores;   // (the labels travel inside the plan)
+    if (pure && (flags & (INVPREF_REWEIGHT_CLS | INVPREF_REG_ENV_EMBED))) return INVPREF_EINVAL;
+    if ((flags & (INVPREF_REWEIGHT_REC | INVPREF_REWEIGHT_CLS)) && !weights) return INVPREF_EINVAL;
+    const DevTables t = dev_tables(tables);
+    bool vec = vec_ok(tables);
+    StepArgs a{};
+    if (!fused) {
+        if ((rc = check_tables(grads, pure))) return rc;
+        vec = vec && vec_ok(grads);
+        a.g[0] = grads->embed_user_invariant; a.g[1] = grads->embed_item_invariant;
+        a.g[2] = grads->embed_user_env_aware; a.g[3] = grads->embed_item_env_aware;
+    } else {
+        if ((rc = check_tables(new_tables, pure)) || (rc = check_tables(exp_avg, pure)) ||
+            (rc = check_tables(exp_avg_sq, pure)))
+            return rc;
+        vec = vec && vec_ok(new_tables) && vec_ok(exp_avg) && vec_ok(exp_avg_sq);
+        const InvPrefTables *src[3] = {new_tables, exp_avg, exp_avg_sq};
+        float **dst[3] = {a.np, a.m, a.v};
+        for (int i = 0; i < 3; i++) {
+            dst[i][0] = src[i]->embed_user_invariant; dst[i][1] = src[i]->embed_item_invariant;
+            dst[i][2] = src[i]->embed_user_env_aware; dst[i][3] = src[i]->embed_item_env_aware;
+        }
+    }
+    const int lg = lanes_of(t.D, vec), emax = emax4_of(t.E);
+    const int NG = kThreads / lg;
+    // ---- the plan
+    if (plan->lanes_per_group != lg) return INVPREF_EINVAL;   // built for another row layout
+    if (plan->n < 0 || plan->n_user_rounds < 0 || plan->n_item_rounds < 0 || plan->user_rounds_per_task <= 0 ||
+        plan->item_rounds_per_task <= 0 || plan->n_user_rounds % plan->user_rounds_per_task != 0 ||
+        plan->n_item_rounds % plan->item_rounds_per_task != 0 || plan->rows_per_stream_task <= 0 || plan->n_stream < 0 ||
+        (plan->n_user_rounds > 0 && (!plan->user_desc || !plan->user_round_iters)) ||
+        (plan->n_item_rounds > 0 && !plan->item_desc) || (plan->n > 0 && (!plan->user_list || !plan->item_list)) ||
+        (plan->n_stream > 0 && !plan->stream_rows))
+        return INVPREF_EINVAL;
+    const int ncls = plan->n_classes > 0 ? plan->n_classes : 1;
+    if (ncls > 8) return INVPREF_EINVAL;
+    for (int c = 0; c < ncls; c++) {
+        const int32_t *q = plan->cls[c];
+        for (int i = 0; i < 8; i++) if (q[i] < 0) return INVPREF_EINVAL;
+        if (q[0] + q[1] > plan->n_user_rounds || q[4] + q[5] > plan->n_item_rounds || q[2] + q[3] > plan->n_stream ||
+            q[6] + q[7] > plan->n_stream || q[0] % plan->user_rounds_per_task || q[4] % plan->item_rounds_per_task)
+            return INVPREF_EINVAL;
+    }
+    const int n_partials = plan->n_user_rounds / plan->user_rounds_per_task;
+    const size_t slab = slab_floats(lg, emax), RS = 4 + (size_t)emax;
+    const size_t rec_floats = ((size_t)plan->n * RS + 63) & ~(size_t)63;
+    if (workspace_bytes < sizeof(float) * (rec_floats + slab * (size_t)(n_partials > 0 ? n_partials : 1)))
+        return INVPREF_EWORKSPACE;
+    StepScalars k;
+    k.ca = coefs->invariant_coe; k.cb = coefs->env_aware_coe; k.cc = coefs->env_coe; k.alpha = coefs->alpha;
+    k.invB = 1.0f / (float)batch_norm;
+    k.r2 = coefs->L2_coe / ((float)batch_norm * (float)t.D);
+    k.r1 = coefs->L1_coe / (2.0f * (float)batch_norm * (float)t.D);
+    a.envs = envs; a.weights = weights; a.k = k; a.flags = flags; a.fused = fused; a.ad = ad;
+    a.rows_per_stream_task = plan->rows_per_stream_task; a.n_cls = ncls;
+    a.records = (float *)workspace; a.slabs = (float *)workspace + rec_floats;
+    a.sched_state = sched ? sched->state : nullptr;
+    a.sched_slot = sched ? (sched->slot & 1) : 0;
+    static const char *stamp_env = getenv("INVPREF_STAMPS");   // diagnostics: device pointer (hex) of a stamp buffer
+    unsigned long long *stamps = stamp_env ? reinterpret_cast<unsigned long long *>(strtoull(stamp_env, nullptr, 16)) : nullptr;
+    static const bool nodrain = getenv("INVPREF_STAMPS_NODRAIN") != nullptr;
+    a.stamps_nodrain = nodrain;
+    int wg1 = 0, wg2 = 0;
+    plan_tasks(plan, 0, &wg1);
+    plan_tasks(plan, 1, &wg2);
+    const size_t lds1 = eval_lds_bytes(lg, emax), lds2 = apply_lds_bytes(lg, emax);
+    if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return INVPREF_EUNSUPPORTED;
+    // launch 1
+    StepArgs a1 = a;
+    a1.desc = reinterpret_cast<const int4 *>(plan->user_desc);
+    a1.round_iters = plan->user_round_iters;
+    a1.ulist = reinterpret_cast<const int4 *>(plan->user_list);
+    a1.rounds_per_task = plan->user_rounds_per_task;
+    a1.stream_rows = plan->stream_rows;
+    a1.stamps = stamps;
+    for (int c = 0; c < 8; c++) for (int i = 0; i < 4; i++) a1.cls[c][i] = c < ncls ? plan->cls[c][i] : 0;
+    // launch 2
+    StepArgs a2 = a;
+    a2.desc = reinterpret_cast<const int4 *>(plan->item_desc);
+    a2.ilist = reinterpret_cast<const int2 *>(plan->item_list);
+    a2.rounds_per_task = plan->item_rounds_per_task;
+    a2.stream_rows = plan->stream_rows;
+    a2.stamps = stamps ? stamps + 8192 * 8 : nullptr;   // (the stamp buffer's second half belongs to launch 2)
+    for (int c = 0; c < 8; c++) for (int i = 0; i < 4; i++) a2.cls[c][i] = c < ncls ? plan->cls[c][4 + i] : 0;
+    FoldArgs f{};
+    if (!fused) {
+        f.gEv = grads->embed_env; f.gW = grads->classifier_weight; f.gb = grads->classifier_bias;
+    } else {
+        f.nEv = new_tables->embed_env; f.nW = new_tables->classifier_weight; f.nb = new_tables->classifier_bias;
+        f.mEv = exp_avg->embed_env; f.mW = exp_avg->classifier_weight; f.mb = exp_avg->classifier_bias;
+        f.vEv = exp_avg_sq->embed_env; f.vW = exp_avg_sq->classifier_weight; f.vb = exp_avg_sq->classifier_bias;
+    }
+    f.n_partials = n_partials; f.n_task_wgs = wg2; f.fold_blocks = (int)((slab + kFoldCols - 1) / kFoldCols);
+    f.l2 = coefs->L2_coe; f.l1 = coefs->L1_coe;
+    f.inv_B = 1.0 / (double)batch_norm; f.inv_BD2 = 1.0 / ((double)batch_norm * (double)t.D * 2.0);
+    f.losses6 = losses6;
+    f.sched_table = sched ? reinterpret_cast<const SchedRow *>(sched->table) : nullptr;
+    f.sched_n = sched ? sched->n : 0;
+    const int grid2 = wg2 + f.fold_blocks + 1;
+#define CALL(LGV, VECV, EMAXV)                                                                                  \
+    do {                                                                                                        \
+        if ((rc = ensure_lds(mstep_eval_kernel<LGV, VECV, EMAXV>, lds1))) return rc;                            \
+        if ((rc = ensure_lds(mstep_apply_kernel<LGV, VECV, EMAXV>, lds2))) return rc;                           \
+        if (wg1 > 0)                                                                                            \
+            hipLaunchKernelGGL((mstep_eval_kernel<LGV, VECV, EMAXV>), dim3(wg1), dim3(kThreads), lds1, st, t, a1); \
+        if (profile_event && hipEventRecord((hipEvent_t)profile_event, st) != hipSuccess) return INVPREF_EINVAL; \
+        hipLaunchKernelGGL((mstep_apply_kernel<LGV, VECV, EMAXV>), dim3(grid2), dim3(kThreads), lds2, st, t, a2, f); \
+    } while (0)
+#define CALL_E(LGV, VECV)                                                                         \
+    do {                                                                                          \
+        if (emax == 4) CALL(LGV, VECV, 4); else if (emax == 8) CALL(LGV, VECV, 8); else CALL(LGV, VECV, 16); \
+    } while (0)
+    if (!vec) {
+        if (lg == 16) CALL_E(16, false); else if (lg == 32) CALL_E(32, false); else CALL_E(64, false);
+    } else {
+        if (lg == 16) CALL_E(16, true); else if (lg == 32) CALL_E(32, true); else CALL_E(64, true);
+    }
+#undef CALL_E
+#undef CALL
+    return (int)hipGetLastError();
+}
+
+AdamScalars adam_scalars(int64_t step, double lr, double beta1, double beta2, double eps) {
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    AdamScalars ad;
+    ad.step_size = (float)(lr / bc1);
+    ad.bc2_sqrt = (float)sqrt(bc2);
+    ad.w1 = (float)(1.0 - beta1);
+    ad.b2 = (float)beta2;
+    ad.w2 = (float)(1.0 - beta2);
+    ad.eps = (float)eps;
+    return ad;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t invpref_rows_workspace_bytes(const InvPrefTables *tables, const InvPrefRowPlan *plan) {
+    if (check_tables(tables, tables && !tables->embed_user_env_aware) || !plan || plan->n < 0 || plan->n_user_rounds < 0 ||
+        plan->user_rounds_per_task <= 0)
+        return 0;
+    const int lg = plan->lanes_per_group, emax = emax4_of((int)tables->env_num);
+    if (lg != 16 && lg != 32 && lg != 64) return 0;
+    const size_t rec_floats = ((size_t)plan->n * (4 + (size_t)emax) + 63) & ~(size_t)63;
+    const size_t np = (size_t)(plan->n_user_rounds / plan->user_rounds_per_task);
+    return sizeof(float) * (rec_floats + slab_floats(lg, emax) * (np > 0 ? np : 1));
+}
+
+int invpref_rows_lanes_per_group(const InvPrefTables *tables) {
+    if (!tables || tables->factor_num <= 0 || tables->factor_num > INVPREF_MAX_FACTORS) return INVPREF_EUNSUPPORTED;
+    return lanes_of((int)tables->factor_num, true);
+}
+
+int invpref_mstep_rows_grad_hip(const InvPrefTables *tables, const InvPrefTables *grads, const InvPrefRowPlan *plan,
+                                const int64_t *envs, const float *scores, const float *sample_weights,
+                                int64_t batch_norm, const InvPrefCoefs *coefs, uint32_t flags, float *losses6,
+                                void *workspace, size_t workspace_bytes, void *stream) {
+    return launch_step(tables, plan, envs, scores, sample_weights, batch_norm, coefs, flags, losses6, workspace,
+                       workspace_bytes, (hipStream_t)stream, 0, grads, nullptr, nullptr, nullptr, AdamScalars{}, nullptr,
+                       nullptr);
+}
+
+int invpref_mstep_rows_grad_sched_hip(const InvPrefTables *tables, const InvPrefTables *grads, const InvPrefRowPlan *plan,
+                                      const int64_t *envs, const float *scores, const float *sample_weights,
+                                      int64_t batch_norm, const InvPrefCoefs *coefs, uint32_t flags, float *losses6,
+                                      const InvPrefAdamSchedule *sched, void *workspace, size_t workspace_bytes,
+                                      void *stream) {
+    if (!sched) return INVPREF_EINVAL;
+    return launch_step(tables, plan, envs, scores, sample_weights, batch_norm, coefs, flags, losses6, workspace,
+                       workspace_bytes, (hipStream_t)stream, 0, grads, nullptr, nullptr, nullptr, AdamScalars{}, sched,
+                       nullptr);
+}
+
+int invpref_mstep_rows_adam_hip(const InvPrefTables *tables, const InvPrefTables *new_tables,
+                                const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
+                                const InvPrefRowPlan *plan, const int64_t *envs, const float *scores,
+                                const float *sample_weights, int64_t batch_norm, const InvPrefCoefs *coefs,
+                                uint32_t flags, float *losses6, int64_t step, double lr, double beta1, double beta2,
+                                double eps, void *workspace, size_t workspace_bytes, void *stream) {
+    if (step < 1) return INVPREF_EINVAL;
+    return launch_step(tables, plan, envs, scores, sample_weights, batch_norm, coefs, flags, losses6, workspace,
+                       workspace_bytes, (hipStream_t)stream, 1, nullptr, new_tables, exp_avg, exp_avg_sq,
+                       adam_scalars(step, lr, beta1, beta2, eps), nullptr, nullptr);
+}
+
+int invpref_mstep_rows_adam_profiled_hip(const InvPrefTables *tables, const InvPrefTables *new_tables,
+                                         const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
+                                         const InvPrefRowPlan *plan, const int64_t *envs, const float *scores,
+                                         const float *sample_weights, int64_t batch_norm, const InvPrefCoefs *coefs,
+                                         uint32_t flags, float *losses6, int64_t step, double lr, double beta1,
+                                         double beta2, double eps, void *workspace, size_t workspace_bytes, void *stream,
+                                         void *mid_event) {
+    if (step < 1) return INVPREF_EINVAL;
+    return launch_step(tables, plan, envs, scores, sample_weights, batch_norm, coefs, flags, losses6, workspace,
+                       workspace_bytes, (hipStream_t)stream, 1, nullptr, new_tables, exp_avg, exp_avg_sq,
+                       adam_scalars(step, lr, beta1, beta2, eps), nullptr, mid_event);
+}
+
+/* host helper: the per-step Adam scalars exactly as invpref_adam_hip / invpref_mstep_rows_adam_hip form
+ * them from (step, lr, betas, eps); table[i] belongs to step first_step + i. */
+int invpref_adam_schedule_fill(float *host_table, int64_t first_step, int64_t n, double lr, double beta1, double beta2,
+                               double eps) {
+    if (!host_table || first_step < 1 || n < 0) return INVPREF_EINVAL;
+    for (int64_t i = 0; i < n; i++) {
+        const AdamScalars ad = adam_scalars(first_step + i, lr, beta1, beta2, eps);
+        float *r = host_table + 8 * i;
+        r[0] = ad.step_size; r[1] = ad.bc2_sqrt; r[2] = ad.w1; r[3] = ad.b2; r[4] = ad.w2; r[5] = ad.eps;
+        r[6] = __builtin_nanf("");   // alpha: the call's coefficient block, unless the caller writes one here
+        r[7] = 0.f;
+    }
+    return 0;
+}
+
+int invpref_mstep_rows_adam_sched_hip(const InvPrefTables *tables, const InvPrefTables *new_tables,
+                                      const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
+                                      const InvPrefRowPlan *plan, const int64_t *envs, const float *scores,
+                                      const float *sample_weights, int64_t batch_norm, const InvPrefCoefs *coefs,
+                                      uint32_t flags, float *losses6, const InvPrefAdamSchedule *sched,
+                                      void *workspace, size_t workspace_bytes, void *stream) {
+    if (!sched) return INVPREF_EINVAL;
+    return launch_step(tables, plan, envs, scores, sample_weights, batch_norm, coefs, flags, losses6, workspace,
+                       workspace_bytes, (hipStream_t)stream, 1, nullptr, new_tables, exp_avg, exp_avg_sq, AdamScalars{},
+                       sched, nullptr);
+}
+
+}  // extern "C"

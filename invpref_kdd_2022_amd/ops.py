@@ -42,16 +42,24 @@ class Workspace:
     def __init__(self, device):
         self.device = device
         self.buf = torch.empty(0, dtype=torch.uint8, device=device)
+        # A buffer that is outgrown is RETIRED, not freed: a captured HIP graph bakes the address of the scratch it was
+        # recorded with, and replays must keep finding live memory there (scratch carries nothing between calls, and
+        # every user is ordered on the stream, so a replay working in a retired buffer is as good as in the new one).
+        self._retired = []
 
     def get(self, nbytes: int) -> torch.Tensor:
         if self.buf.numel() < nbytes:
+            if self.buf.numel():
+                self._retired.append(self.buf)
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         return self.buf
 
     def get_zeroed(self, nbytes: int) -> torch.Tensor:
-        """the owner path's replica slabs: zero-filled before first use, left zeroed by every call"""
+        """the scratch of the planned M-step (records + partial slabs), a buffer of its own"""
         z = getattr(self, 'zbuf', None)
         if z is None or z.numel() < nbytes:
+            if z is not None:
+                self._retired.append(z)
             self.zbuf = z = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         return z
 
@@ -155,7 +163,7 @@ def predict(user_table: torch.Tensor, item_table: torch.Tensor, users: torch.Ten
 
 
 def rows_workspace(params, dplan, workspace: Workspace, pure: bool = False) -> torch.Tensor:
-    """the zero-initialised scratch of the planned M-step (replica slabs + hot-row accumulators)"""
+    """the scratch of the planned M-step (per-interaction records + per-workgroup partial slabs)"""
     t = (_capi.make_pure_tables if (pure or len(params) == 2) else make_tables)(params)
     return workspace.get_zeroed(lib().invpref_rows_workspace_bytes(C.byref(t), C.byref(dplan.struct)))
 
@@ -174,14 +182,27 @@ def mstep_rows_grad(params, grads, dplan, envs, scores, sample_weights, batch_no
 def mstep_rows_adam(params, new_params, exp_avg, exp_avg_sq, dplan, envs, scores, sample_weights, batch_norm: int,
                     coefs, flags: int, losses6: torch.Tensor, step: int, lr: float, workspace: Workspace,
                     beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, pure: bool = False,
-                    sched=None) -> None:
+                    sched=None, mid_event=None) -> None:
     """M-step + Adam in one pass: reads params, writes new_params, updates the moments in place.
     pure=True: PureMF step (INVPREF_PURE_MF): the table lists hold [user table, item table] only, envs /
     sample_weights may be None.  sched = (state int32[32], table fp32[n, 8], slot): per-step scalars from the
-    device-side schedule (graph replay) instead of (step, lr, betas, eps)."""
+    device-side schedule (graph replay) instead of (step, lr, betas, eps).
+    mid_event (profiling, bench.py): a torch.cuda.Event recorded on the stream BETWEEN the step's two launches; the call
+    goes straight to the C ABI then (invpref_mstep_rows_adam_profiled_hip)."""
     if pure:
         flags |= _capi.PURE_MF
     ws = rows_workspace(params, dplan, workspace, pure)
+    if mid_event is not None:
+        mk = _capi.make_pure_tables if pure else make_tables
+        t, tn, tm, tv = mk(params), mk(new_params), mk(exp_avg), mk(exp_avg_sq)
+        cf = _capi.Coefs(*[float(c) for c in coefs[:6]])
+        mid_event.record()   # (creates the underlying hipEvent_t; re-recorded by the library between the launches)
+        check(lib().invpref_mstep_rows_adam_profiled_hip(
+            C.byref(t), C.byref(tn), C.byref(tm), C.byref(tv), C.byref(dplan.struct), ptr(envs), ptr(scores),
+            ptr(sample_weights), int(batch_norm), C.byref(cf), int(flags), ptr(losses6), int(step), float(lr),
+            float(beta1), float(beta2), float(eps), ptr(ws), ws.numel(), stream_ptr(), C.c_void_p(mid_event.cuda_event)),
+            'invpref_mstep_rows_adam_profiled_hip')
+        return
     s_state, s_table, s_slot = sched if sched is not None else (None, None, 0)
     _o().train_step_planned_adam_(list(params), list(new_params), list(exp_avg), list(exp_avg_sq), dplan.buf, dplan.meta,
                                   envs, scores, sample_weights, int(batch_norm), [float(c) for c in coefs[:6]],

@@ -307,13 +307,13 @@ class _InvPrefTrainManager:
             self._plans = []
             for lo, n, *_ in self._raw_batches:
                 pl = planlib.build_row_plan(u[lo:lo + n], v[lo:lo + n], y[lo:lo + n], self.model.user_num,
-                                            self.model.item_num,
-                                            user_range=self.shard.user_range(self.model.user_num),
-                                            rows_per_stream_task=planlib.stream_rows_default(self.model.factor_num))
+                                            self.model.item_num, factor_num=self.model.factor_num,
+                                            user_range=self.shard.user_range(self.model.user_num))
                 self._plans.append(planlib.upload(pl, self.device))
             self.plan_build_s = time.perf_counter() - t0     # host-side, once per run (reported by bench.py)
         if self.use_plan and self.users_tensor.is_cuda:
-            # every plan shares ONE zero-initialised scratch (each step leaves it zeroed): size it for the largest
+            # every plan shares ONE scratch (records + partial slabs; nothing carries over between steps): size it for
+            # the largest BEFORE any graph capture bakes its address in
             t = self._make_tables(st.p_views)
             self.workspace.get_zeroed(max(L.invpref_rows_workspace_bytes(C.byref(t), C.byref(dp.struct))
                                           for dp in self._plans))
@@ -333,10 +333,9 @@ class _InvPrefTrainManager:
             st.step += 1
             sc = (self._sched['state'], self._sched['table'], st.step & 1) if sched else None
             ops.mstep_rows_adam(st.p_views, st.p_views_alt, st.m_views, st.v_views, self._plans[k], be, by, bw, bn,
-                                coefs, self._flags, lp, st.step, self.lr, self.workspace, pure=self._pure, sched=sc)
+                                coefs, self._flags, lp, st.step, self.lr, self.workspace, pure=self._pure, sched=sc,
+                                mid_event=mid_event)   # (profiling: recorded between the step's two launches)
             st.swap()
-            if mid_event is not None:
-                mid_event.record()
             return
         st.step += 1
         # graph capture: per-step scalars (Adam bias corrections, a scheduled alpha) come from the device-side

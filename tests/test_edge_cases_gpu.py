@@ -57,7 +57,7 @@ def test_ragged_and_extreme_shapes(U, I, E, D, B, implicit):
     G1 = [torch.zeros_like(p) for p in P]
     l1 = torch.zeros(6, device=DEV)
     ops.mstep_grad(P, G1, t64(u), t64(v), t64(e), t32(y), t32(w), B, COEFS, flags, l1, ws)
-    dp = planlib.upload(planlib.build_row_plan(u, v, y, U, I), DEV)
+    dp = planlib.upload(planlib.build_row_plan(u, v, y, U, I, factor_num=D), DEV)
     G2 = [torch.full_like(p, 9.0) for p in P]
     l2 = torch.zeros(6, device=DEV)
     ops.mstep_rows_grad(P, G2, dp, t64(e), t32(y), t32(w), B, COEFS, flags, l2, ws)
@@ -145,8 +145,9 @@ def test_train_loop_end_to_end_with_device_evaluator():
 @pytest.mark.parametrize('seed', range(int(os.environ.get('INVPREF_FUZZ', '12'))))
 def test_random_plan_parameters_and_shapes(seed):
     """Randomised sweep: shapes (D aligned and not, E up to 16), duplicate-heavy and sparse minibatches, every plan
-    parameter (interactions per slice, rounds per workgroup, hot threshold, dense / stream task sizes, a user range),
-    flag combinations, InvPref and PureMF -- planned gradient pass and fused pass against the oracle."""
+    parameter (interactions per slice on either side, rounds per workgroup, stream task size, the share of the streamed
+    rows per launch, the class order, a user range), flag combinations, InvPref and PureMF -- planned gradient pass and
+    fused pass against the oracle."""
     rs = np.random.RandomState(1000 + seed)
     U, I = int(rs.choice([3, 17, 60, 300])), int(rs.choice([2, 9, 40, 150]))
     E, D = int(rs.choice([1, 2, 4, 5, 8, 16])), int(rs.choice([4, 8, 20, 30, 64, 100, 128, 256]))
@@ -165,15 +166,18 @@ def test_random_plan_parameters_and_shapes(seed):
     rw_rec, rw_cls = (False, False) if pure else (bool(rs.randint(2)), bool(rs.randint(2)))
     roe, ree = (True, False) if pure else (bool(rs.randint(2)), bool(rs.randint(2)))
     coefs = O.pure_mf_coefs(0.3, 0.05) if pure else np.array(COEFS[:6], np.float64)
-    os_env = dict(INVPREF_PLAN_STREAM_ROWS=str(int(rs.choice([1, 16, 64, 200]))), INVPREF_PLAN_DENSE=str(int(rs.choice([16, 32, 48, 128]))))
+    os_env = dict(INVPREF_PLAN_STREAM_ROWS=str(int(rs.choice([1, 16, 64, 200]))))
     old = {k: os.environ.get(k) for k in os_env}
     os.environ.update(os_env)
     try:
         lo = int(rs.randint(0, U)) if rs.randint(2) else 0
         user_range = (lo, int(rs.randint(lo, U)) + 1) if rs.randint(2) else None
-        pl = planlib.build_row_plan(u, v, y, U, I, per_slice=int(rs.choice([1, 2, 3, 8, 16])),
+        pl = planlib.build_row_plan(u, v, y, U, I, factor_num=D, per_slice=int(rs.choice([1, 2, 3, 8, 16])),
+                                    item_per_slice=int(rs.choice([1, 2, 3, 5, 40])),
                                     rounds_per_task=int(rs.choice([1, 1, 2, 3])),
-                                    hot_threshold=int(rs.choice([-1, 0, 2, 16, 10 ** 9])), user_range=user_range)
+                                    item_rounds_per_task=int(rs.choice([1, 1, 2, 3])),
+                                    n_classes=int(rs.choice([1, 3, 8])), stream_split=float(rs.choice([0.0, 0.4, 1.0])),
+                                    user_range=user_range)
     finally:
         for k, val in old.items():
             os.environ.pop(k, None) if val is None else os.environ.__setitem__(k, val)

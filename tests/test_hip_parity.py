@@ -169,7 +169,6 @@ def test_mstep_g5_mind_shape():
 
 # ------------------------------------------------------------------ planned, atomic-free rows path
 PER_SLICE = 2
-HOT = 6   # item rows with more than 6 interactions in the minibatch go through the atomics path
 from invpref_kdd_2022_amd import plan as planlib  # noqa: E402
 
 
@@ -180,7 +179,7 @@ def test_rows_grad_matches_oracle_and_is_reproducible(path):
     P = dev_params(params)
     ws = ops.Workspace(DEV)
     flags = ops.flags_of(implicit, rec_w, cls_w, roe, ree)
-    dp = planlib.upload(planlib.build_row_plan(z['u'], z['v'], z['y'], U, I, per_slice=PER_SLICE, hot_threshold=HOT), DEV)
+    dp = planlib.upload(planlib.build_row_plan(z['u'], z['v'], z['y'], U, I, factor_num=D, per_slice=PER_SLICE), DEV)
     outs = []
     for _ in range(2):
         Gd = [torch.full_like(p, 7.0) for p in P]  # garbage: the kernel must overwrite every row
@@ -194,11 +193,11 @@ def test_rows_grad_matches_oracle_and_is_reproducible(path):
     for k, g, o in zip(O.PARAM_NAMES, outs[0][0], og):
         assert _relerr(g, o) < 2e-5, k
         assert _relerr(g, z['g_f32_' + k]) < 2e-5, k
-    for i, (a, b) in enumerate(zip(outs[0][0][:4], outs[1][0][:4])):
-        if i in (0, 2):  # user tables: registers + fixed-order sums -> bitwise stable
-            np.testing.assert_array_equal(a, b)
-        else:            # item tables: rows above the hot threshold take float atomics
-            assert _relerr(a, b) < 1e-6
+    # no float atomics anywhere on this path (registers, plain stores, fixed-order sums): every gradient and every
+    # loss term is bitwise reproducible run to run
+    for a, b in zip(outs[0][0], outs[1][0]):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
 @pytest.mark.parametrize('path', G1[::2], ids=[os.path.basename(p)[3:-4] for p in G1[::2]])
@@ -210,7 +209,7 @@ def test_rows_fused_adam_equals_grad_then_adam(path):
     lr = float(z['coefs'][6])
     ws = ops.Workspace(DEV)
     flags = ops.flags_of(implicit, rec_w, cls_w, roe, ree)
-    dp = planlib.upload(planlib.build_row_plan(z['u'], z['v'], z['y'], U, I, per_slice=PER_SLICE, hot_threshold=HOT), DEV)
+    dp = planlib.upload(planlib.build_row_plan(z['u'], z['v'], z['y'], U, I, factor_num=D, per_slice=PER_SLICE), DEV)
     e, y, w = t64(z['e']), t32(z['y']), t32(z['w'])
     # path A: fused, ping-pong buffers
     A = [dev_params(params), [torch.zeros_like(p) for p in dev_params(params)]]
@@ -247,8 +246,8 @@ def test_rows_fused_adam_equals_grad_then_adam(path):
 
 
 def test_rows_path_mind_shape_g5():
-    """Planned path at the MIND-shaped fixture (E=16, D=256, B=262 144: NC=4 row chunks, LDS-atomic dense
-    path, thousands of hot item rows) against the reference's recorded step."""
+    """Planned path at the MIND-shaped fixture (E=16, D=256, B=262 144: 64-lane groups, the E x D sums through LDS
+    records, item rows with thousands of interactions) against the reference's recorded step."""
     z = np.load(os.path.join(G, 'g5_mind_like_step.npz'))
     U, I, E, D, B, seed = [int(x) for x in z['meta']]
     data = synth.interactions(seed, U, I, B, implicit=True, zipf=True)
@@ -257,7 +256,7 @@ def test_rows_path_mind_shape_g5():
     env0 = z['env0'].astype(np.int64)
     ws = ops.Workspace(DEV)
     _, _, sw = ops.stat_envs(t64(env0), E, ws)
-    dp = planlib.upload(planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I), DEV)
+    dp = planlib.upload(planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, factor_num=D), DEV)
     Gd = [torch.full_like(p, 3.0) for p in P]
     losses = torch.zeros(6, device=DEV)
     ops.mstep_rows_grad(P, Gd, dp, t64(env0), t32(data[:, 2]), sw, B, z['coefs'],
@@ -280,14 +279,14 @@ def test_rows_path_mind_shape_g5():
 
 def test_rows_path_movielens_shape_default_plan():
     """MovieLens-class step (U=6 040, I=3 706, E=8, D=128, B=65 536) through the planned fused
-    pass with the DEFAULT plan parameters for that minibatch size (16 interactions per slice, hot rows above 256,
-    256 interactions per dense task) against oracle gradient + oracle Adam."""
+    pass with the DEFAULT plan parameters for that minibatch size (32-lane groups, 16 interactions per slice,
+    8 rounds per task) against oracle gradient + oracle Adam."""
     U, I, E, D, B = 6040, 3706, 8, 128, 65536
     data = synth.interactions(31, U, I, B, implicit=True, zipf=False)
     tabs = synth.tables(32, U, I, E, D, std=0.1)
     envs = np.random.RandomState(33).randint(0, E, B).astype(np.int64)
-    pl = planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I)
-    assert pl['dense_per_task'] == 256 and pl['n_item_rounds'] > 0
+    pl = planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, factor_num=D)
+    assert pl['lanes_per_group'] == 32 and pl['user_rounds_per_task'] == 8 and len(pl['item_desc']) > 0
     dp = planlib.upload(pl, DEV)
     P = dev_params(tabs)
     P2, M, V = ([torch.zeros_like(p) for p in P] for _ in range(3))
@@ -309,42 +308,42 @@ def test_rows_path_movielens_shape_default_plan():
         assert dlt.max() < 0.05 * lr and np.quantile(dlt, 0.99) < 1e-5, k
 
 
-def test_hot_rows_direct_and_indexed_forms_agree():
-    """The finish kernel's two hot-row forms -- accumulators indexed by item id with one group per item (item tables of up
-    to 2 048 rows, InvPrefRowPlan.item_hot_count) and the indexed list -- on the same minibatch: rows without atomics
-    bitwise equal, hot rows to the atomics' reordering noise; both against the oracle."""
+def test_plan_parameters_change_nothing_but_the_order_of_sums():
+    """The same minibatch under different plans (slice lengths, rounds per task, class order, share of the streamed rows
+    per launch): every result agrees to the reordering of float sums, each plan is bitwise reproducible, all match the
+    oracle."""
     z, implicit, params, (roe, ree, cls_w, rec_w) = _load(G1[0])
     U, I, E, D, B = [int(x) for x in z['meta'][:5]]
-    assert I <= 2048
     P = dev_params(params)
     ws = ops.Workspace(DEV)
     flags = ops.flags_of(implicit, rec_w, cls_w, roe, ree)
-    pl = planlib.build_row_plan(z['u'], z['v'], z['y'], U, I, per_slice=PER_SLICE, hot_threshold=3)
-    assert len(pl['hot_rows']) > 0
+    lr = float(z['coefs'][6])
     outs = []
-    for form in (pl, dict(pl, item_hot_count=None)):
-        dp = planlib.upload(form, DEV)
-        assert (dp.struct.item_hot_count is None) == (form['item_hot_count'] is None)
-        lr = float(z['coefs'][6])
-        Q = [torch.zeros_like(p) for p in P]
-        M = [torch.zeros_like(p) for p in P]
-        V = [torch.zeros_like(p) for p in P]
-        Gd = [torch.full_like(p, 7.0) for p in P]
-        la, lb = torch.zeros(6, device=DEV), torch.zeros(6, device=DEV)
-        ops.mstep_rows_grad(P, Gd, dp, t64(z['e']), t32(z['y']), t32(z['w']), B, z['coefs'], flags, la, ws)
-        ops.mstep_rows_adam(P, Q, M, V, dp, t64(z['e']), t32(z['y']), t32(z['w']), B, z['coefs'], flags, lb, 1, lr, ws)
-        outs.append(([g.cpu().numpy() for g in Gd], [q.cpu().numpy() for q in Q], [m.cpu().numpy() for m in M], la.cpu().numpy()))
-    hot = pl['hot_rows']
-    cold = np.setdiff1d(np.arange(I), hot)
-    for i, k in enumerate(O.PARAM_NAMES):
-        for a, b in zip(outs[0][:3], outs[1][:3]):
-            if 'item' in k:
-                np.testing.assert_array_equal(a[i][cold], b[i][cold], err_msg=k)
-                assert _relerr(a[i][hot], b[i][hot]) < 1e-5, k
-            elif 'user' in k:
-                np.testing.assert_array_equal(a[i], b[i], err_msg=k)
+    for kw in (dict(per_slice=1, item_per_slice=1, n_classes=1, stream_split=0.0),
+               dict(per_slice=2, item_per_slice=3, rounds_per_task=3, item_rounds_per_task=2, stream_split=1.0),
+               dict(per_slice=64, item_per_slice=64, n_classes=3)):
+        dp = planlib.upload(planlib.build_row_plan(z['u'], z['v'], z['y'], U, I, factor_num=D, **kw), DEV)
+        rep = []
+        for _ in range(2):
+            Q = [torch.zeros_like(p) for p in P]
+            M = [torch.zeros_like(p) for p in P]
+            V = [torch.zeros_like(p) for p in P]
+            Gd = [torch.full_like(p, 7.0) for p in P]
+            la, lb = torch.zeros(6, device=DEV), torch.zeros(6, device=DEV)
+            ops.mstep_rows_grad(P, Gd, dp, t64(z['e']), t32(z['y']), t32(z['w']), B, z['coefs'], flags, la, ws)
+            ops.mstep_rows_adam(P, Q, M, V, dp, t64(z['e']), t32(z['y']), t32(z['w']), B, z['coefs'], flags, lb, 1, lr, ws)
+            rep.append(([g.cpu().numpy() for g in Gd], [q.cpu().numpy() for q in Q], [m.cpu().numpy() for m in M],
+                        la.cpu().numpy(), lb.cpu().numpy()))
+        for x, y in zip(rep[0][:3], rep[1][:3]):
+            for a, b in zip(x, y):
+                np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(rep[0][3], rep[1][3])
+        np.testing.assert_array_equal(rep[0][4], rep[1][4])
+        outs.append(rep[0])
     og, ol = O.mstep(O.Tables(params), z['u'], z['v'], z['e'], z['y'], z['w'], z['coefs'], O.flags_of(implicit, rec_w, cls_w, roe, ree))
     for form in outs:
         np.testing.assert_allclose(form[3], ol, rtol=1e-5)
-        for k, g, o in zip(O.PARAM_NAMES, form[0], og):
+        np.testing.assert_allclose(form[4], ol, rtol=1e-5)
+        for k, g, o, g0 in zip(O.PARAM_NAMES, form[0], og, outs[0][0]):
             assert _relerr(g, o) < 2e-5, k
+            assert _relerr(g, g0) < 1e-5, k

@@ -38,7 +38,7 @@ def test_fused_step_vs_reference_and_oracle(kind):
     (U, I, D, n, bs, epochs), data, init, cfg = pure_mf_inputs(kind)
     P = [torch.from_numpy(init[k]).to(DEV) for k in ('user_emb.weight', 'item_emb.weight')]
     P2, M, V = ([torch.zeros_like(p) for p in P] for _ in range(3))
-    dp = planlib.upload(planlib.build_row_plan(data[:bs, 0], data[:bs, 1], data[:bs, 2], U, I), DEV)
+    dp = planlib.upload(planlib.build_row_plan(data[:bs, 0], data[:bs, 1], data[:bs, 2], U, I, factor_num=D), DEV)
     y = torch.from_numpy(data[:bs, 2].astype(np.float32)).to(DEV)
     losses = torch.zeros(6, device=DEV)
     flags = ops.flags_of(kind == 'implicit', False, False, True, False, dense_reg=False)

@@ -1,125 +1,144 @@
-"""CPU: invariants of the host-side row plan (plan.py) that the planned M-step kernel relies on."""
+"""CPU: invariants of the host-side row plan (plan.py) that the planned M-step kernels rely on."""
 import numpy as np
 import pytest
 
 from invpref_kdd_2022_amd import plan as planlib, synth
 
 
-def check_plan(users, items, U, I, **kw):
+def check_plan(users, items, U, I, D=64, **kw):
     y = (np.arange(len(users)) % 5).astype(np.float32)
-    p = planlib.build_row_plan(users, items, y, U, I, **kw)
-    desc, rpt, nir = p['desc'], p['rounds_per_task'], p['n_item_rounds']
+    p = planlib.build_row_plan(users, items, y, U, I, factor_num=D, **kw)
     n = len(users)
-    assert desc.shape[1:] == (16, 8) and nir % rpt == 0 and 0 <= nir <= len(desc)
-    np.testing.assert_array_equal(p['batch_users'], users)
-    np.testing.assert_array_equal(p['batch_items'], items)
-    assert p['dense_per_task'] > 0
-    su, si = p['stream_rows'][:p['n_stream_user']], p['stream_rows'][p['n_stream_user']:]
-    assert len(si) == p['n_stream_item']
-    np.testing.assert_array_equal(np.sort(su), np.flatnonzero(np.bincount(users, minlength=U) == 0))
-    np.testing.assert_array_equal(np.sort(si), np.flatnonzero(np.bincount(items, minlength=I) == 0))
-    # XCD-affine order: rounds and streamed rows are grouped by class = (row >> 6) % n_classes, cls[c] delimits them
+    lanes = p['lanes_per_group']
+    ng = 256 // lanes
+    assert lanes == planlib.lanes_of(D) and p['n'] == n
+    ud, idd = p['user_desc'], p['item_desc']
+    assert ud.shape[1:] == (ng, 8) and idd.shape[1:] == (ng, 8)
+    assert len(ud) % p['user_rounds_per_task'] == 0 and len(idd) % p['item_rounds_per_task'] == 0
+    assert len(p['user_round_iters']) == len(ud)
+    ulist, ilist = p['user_list'].reshape(-1, 4), p['item_list'].reshape(-1, 2)
+    assert len(ulist) == n and len(ilist) == n
+    assert sorted(ulist[:, 1].tolist()) == list(range(n)) and sorted(ilist[:, 1].tolist()) == list(range(n))
+    assert (np.diff(users[ulist[:, 1]]) >= 0).all() and (np.diff(items[ilist[:, 1]]) >= 0).all()   # sorted by own row
+    np.testing.assert_array_equal(ulist[:, 0], items[ulist[:, 1]])
+    np.testing.assert_array_equal(ulist[:, 2].view(np.float32), y[ulist[:, 1]])
+    np.testing.assert_array_equal(ilist[:, 0], users[ilist[:, 1]])
+    # streamed rows: every untouched row exactly once, in launch 1 or launch 2, grouped by class
+    sr = p['stream_rows']
+    assert len(sr) == p['n_stream']
+    su = np.sort(sr[(sr & planlib.ITEM_BIT) == 0])
+    si = np.sort(sr[(sr & planlib.ITEM_BIT) != 0] & (planlib.ITEM_BIT - 1))
+    np.testing.assert_array_equal(su, np.flatnonzero(np.bincount(users, minlength=U) == 0))
+    np.testing.assert_array_equal(si, np.flatnonzero(np.bincount(items, minlength=I) == 0))
     ncls, cls = p['n_classes'], p['cls']
     assert 1 <= ncls <= 8
-    ib, ub, sb = 0, nir, 0
+    ub = ib = sb = 0
     for c in range(ncls):
-        assert cls[c, 0] == ib and cls[c, 2] == ub and cls[c, 1] % rpt == 0
-        for lo, cnt_ in ((cls[c, 0], cls[c, 1]), (cls[c, 2], cls[c, 3])):
+        assert cls[c, 0] == ub and cls[c, 4] == ib
+        assert cls[c, 0] % p['user_rounds_per_task'] == 0 and cls[c, 4] % p['item_rounds_per_task'] == 0
+        for desc, lo, cnt_ in ((ud, cls[c, 0], cls[c, 1]), (idd, cls[c, 4], cls[c, 5])):
             rows = desc[lo:lo + cnt_, :, 0].reshape(-1)
             rows = rows[rows >= 0]
             assert (planlib.row_class(rows, ncls) == c).all()
-        ib += cls[c, 1]
-        ub += cls[c, 3]
-    assert ib == nir and ub == len(desc)
-    for c in range(ncls):
-        assert cls[c, 4] == sb
-        seg = p['stream_rows'][sb:sb + cls[c, 5]]
-        assert (planlib.row_class(seg, ncls) == c).all() and (np.diff(seg) > 0).all()
-        sb += cls[c, 5]
-    assert sb == p['n_stream_user'] and cls[0, 6] == sb and cls[:ncls, 7].sum() == p['n_stream_item']
-    for c in range(ncls):   # untouched item rows: by class when there are many, all in class 0 otherwise
-        seg = p['stream_rows'][cls[c, 6]:cls[c, 6] + cls[c, 7]]
-        assert (np.diff(seg) > 0).all() and (len(si) <= 512 or (planlib.row_class(seg, ncls) == c).all())
-    hot = set(p['hot_rows'].tolist())
-    icnt = np.bincount(items, minlength=I)
-    np.testing.assert_array_equal(p['hot_count'], icnt[p['hot_rows']])
-    assert all(p['item_hot_index'][r] == i for i, r in enumerate(p['hot_rows'])) and (p['item_hot_index'] >= 0).sum() == len(hot)
-    np.testing.assert_array_equal(p['item_hot_count'], np.where(p['item_hot_index'] >= 0, icnt, 0))
-    assert (p['hot_count'] > 0).all()                                  # an untouched row is streamed, never hot
-    for side, (own, oth, R, o_key, p_key, rounds) in enumerate((
-            (users, items, U, 'other_user', 'pos_user', desc[nir:]),
-            (items, users, I, 'other_item', 'pos_item', desc[:nir]))):
-        pos = p[p_key]
-        assert sorted(pos.tolist()) == list(range(n))                 # a permutation of the minibatch
-        assert (np.diff(own[pos]) >= 0).all()                         # sorted by own row
-        np.testing.assert_array_equal(p[o_key], oth[pos])
-        d = rounds.reshape(-1, 8)
+        ub += cls[c, 1]
+        ib += cls[c, 5]
+    assert ub == len(ud) and ib == len(idd)
+    for launch in (0, 1):
+        for c in range(ncls):
+            lo, cnt_ = cls[c, 2 + 4 * launch], cls[c, 3 + 4 * launch]
+            assert lo == sb
+            seg = sr[lo:lo + cnt_]
+            useg = seg[(seg & planlib.ITEM_BIT) == 0]
+            assert (planlib.row_class(useg, ncls) == c).all()
+            iseg = seg[(seg & planlib.ITEM_BIT) != 0] & (planlib.ITEM_BIT - 1)
+            assert len(si) <= 512 or (planlib.row_class(iseg, ncls) == c).all()
+            sb += cnt_
+    assert sb == p['n_stream']
+    for side, (own, oth, R, lst, desc, inline, w) in enumerate((
+            (users, items, U, ulist, ud, 2, 3), (items, users, I, ilist, idd, 3, 2))):
+        d = desc.reshape(-1, 8)
         act = d[d[:, 0] >= 0]
         leaders = act[(act[:, 1] & 1) == 1]
-        jobless = (hot | set(si.tolist())) if side == 1 else set(su.tolist())
-        assert sorted(leaders[:, 0].tolist()) == [r for r in range(R) if r not in jobless]   # one job per row
+        touched = np.flatnonzero(np.bincount(own, minlength=R) > 0)
+        assert sorted(leaders[:, 0].tolist()) == touched.tolist()     # one job per touched row
         cnt = np.bincount(own, minlength=R)
-        np.testing.assert_array_equal(leaders[:, 1] >> 8, cnt[leaders[:, 0]])
+        np.testing.assert_array_equal(leaders[:, 1] >> 9, cnt[leaders[:, 0]])
         seen = np.zeros(n, np.int32)
-        for row, meta, a, b, c, dd, e, f in act:
-            mode = (meta >> 6) & 3
-            if mode == 3:
-                assert a < b
-                js = pos[a:b]
-                assert (own[js] == row).all() and b - a > 2
+        for slot in act:
+            row, meta = slot[0], slot[1]
+            mode = (meta >> 6) & 7
+            if mode == planlib.MODE_LIST:
+                a, b = slot[2], slot[3]
+                assert b - a > inline
+                js = lst[a:b, 1]
+                assert (own[js] == row).all()
                 seen[js] += 1
             else:
-                for (o_, p_, y_) in ((a, b, c), (dd, e, f))[:mode]:
-                    assert own[p_] == row and oth[p_] == o_           # inline copy of the interaction
-                    assert np.int32(y_).view(np.float32) == y[p_]
-                    seen[p_] += 1
-        in_job = np.array([own[i] not in jobless for i in range(n)], bool) if n else np.zeros(0, bool)
-        assert (seen == in_job.astype(np.int32)).all()                # each interaction of a job row in exactly one slice
-        for rd in rounds:                                             # slot layout inside a round
+                assert mode <= inline
+                for q in range(mode):
+                    f = slot[2 + q * w: 2 + (q + 1) * w]
+                    assert own[f[1]] == row and oth[f[1]] == f[0]     # inline copy of the interaction
+                    if side == 0:
+                        assert np.int32(f[2]).view(np.float32) == y[f[1]]
+                    seen[f[1]] += 1
+        assert (seen == 1).all()                                      # each interaction in exactly one slice per side
+        for ri, rd in enumerate(desc):                                # slot layout inside a round
             g = (rd[0, 1] >> 1) & 31
-            assert g in (1, 2, 4, 8, 16) and (((rd[:, 1] >> 1) & 31) == g).all()
-            for s0 in range(0, 16, g):
+            assert g in (1, 2, 4, 8, 16, 32, 64) and g <= ng and (((rd[:, 1] >> 1) & 31) == g).all()
+            longest = 0
+            for s0 in range(0, ng, g):
                 if rd[s0, 0] < 0:
                     assert (rd[s0:s0 + g, 0] < 0).all()
                     continue
                 assert rd[s0, 1] & 1 and (rd[s0:s0 + g, 0] == rd[s0, 0]).all() and ((rd[s0 + 1:s0 + g, 1] & 1) == 0).all()
+                for sl in rd[s0:s0 + g]:
+                    mode = (sl[1] >> 6) & 7
+                    longest = max(longest, sl[3] - sl[2] if mode == planlib.MODE_LIST else mode)
+            if side == 0:
+                assert p['user_round_iters'][ri] == longest
     return p
 
 
 def test_plan_yahoo_like_batch():
     d = synth.yahoo_like()[:8192]
     p = check_plan(d[:, 0], d[:, 1], 15400, 1000)
-    assert len(p['desc']) < 4000
+    assert len(p['user_desc']) < 500 and len(p['item_desc']) < 400
 
 
 def test_default_plan_fits_one_residency_wave():
-    """the builder lowers the hot-row threshold until the launch fits the 1 024 resident workgroups (a second wave of
-    workgroups costs ~1.5 us per step); an explicit threshold is taken as given"""
+    """both launches of a Yahoo-shaped step stay well inside one residency wave of workgroups (256 CUs x 3)"""
     d = synth.yahoo_like()
     for k in (0, 3, 8, 12):
         b = d[k * 8192:(k + 1) * 8192]
         p = planlib.build_row_plan(b[:, 0], b[:, 1], b[:, 2], 15400, 1000)
-        assert planlib.plan_workgroups(p) <= planlib.RESIDENT_WORKGROUPS and p['hot_threshold'] <= 10
-    b = d[8 * 8192:9 * 8192]
-    assert planlib.build_row_plan(b[:, 0], b[:, 1], b[:, 2], 15400, 1000, hot_threshold=16)['hot_threshold'] == 16
+        assert planlib.launch_workgroups(p, 0) <= 640 and planlib.launch_workgroups(p, 1) <= 640
+        assert 0.0 <= p['stream_split'] <= 1.0
 
 
-@pytest.mark.parametrize('hot', [-1, 0, 8, 10 ** 9])
+@pytest.mark.parametrize('D', [30, 64, 128, 256])
 @pytest.mark.parametrize('per_slice,rpt', [(1, 1), (2, 3), (4, 2), (64, 5)])
-def test_plan_parameters(per_slice, rpt, hot):
+def test_plan_parameters(per_slice, rpt, D):
     rs = np.random.RandomState(per_slice)
     u, v = rs.randint(0, 37, 500), rs.randint(0, 5, 500)  # item rows with ~100 interactions each
-    check_plan(u, v, 40, 7, per_slice=per_slice, rounds_per_task=rpt, hot_threshold=hot)
+    check_plan(u, v, 40, 7, D=D, per_slice=per_slice, item_per_slice=per_slice, rounds_per_task=rpt,
+               item_rounds_per_task=rpt, stream_split=[0.0, 0.3, 1.0][rpt % 3])
 
 
 def test_plan_single_class_is_the_plain_order():
     d = synth.yahoo_like()[:8192]
-    p = check_plan(d[:, 0], d[:, 1], 15400, 1000, n_classes=1)
-    np.testing.assert_array_equal(p['stream_rows'][:p['n_stream_user']], np.flatnonzero(np.bincount(d[:, 0], minlength=15400) == 0))
+    p = check_plan(d[:, 0], d[:, 1], 15400, 1000, n_classes=1, stream_split=1.0)
+    sr = p['stream_rows']
+    np.testing.assert_array_equal(sr[(sr & planlib.ITEM_BIT) == 0], np.flatnonzero(np.bincount(d[:, 0], minlength=15400) == 0))
 
 
 def test_plan_empty_and_single():
     check_plan(np.zeros(0, np.int64), np.zeros(0, np.int64), 5, 3)
     check_plan(np.array([2]), np.array([0]), 5, 3)
-    check_plan(np.full(300, 1), np.full(300, 2), 4, 4, hot_threshold=10 ** 9)   # one hot row on both sides: 16 slices of 19
-    check_plan(np.full(300, 1), np.full(300, 2), 4, 4, hot_threshold=16)
+    check_plan(np.full(300, 1), np.full(300, 2), 4, 4)          # one hot row on both sides: 16 slices of 19
+    check_plan(np.full(300, 1), np.full(300, 2), 4, 4, D=256)   # 4 slices of 75
+
+
+def test_plan_large_shapes():
+    d = synth.interactions(5, 6040, 3706, 65536, implicit=True, zipf=False)
+    p = check_plan(d[:, 0], d[:, 1], 6040, 3706, D=128)
+    assert p['lanes_per_group'] == 32 and p['user_rounds_per_task'] == 8

@@ -126,7 +126,7 @@ def test_estep_assign_functional_and_inplace(implicit):
 def test_planned_ops_vs_oracle():
     """train_step_planned_grad_ / train_step_planned_adam_ (the path bench.py times) through torch.ops"""
     data, tabs, envs, w, P, t = _setup(True, seed=9)
-    dp = planlib.upload(planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I), DEV)
+    dp = planlib.upload(planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, factor_num=D), DEV)
     flags = ops.flags_of(True, False, True, True, False)
     og, ol = O.mstep(O.Tables(tabs), data[:, 0], data[:, 1], envs, data[:, 2], w, COEFS,
                      O.flags_of(True, False, True, True, False))
@@ -175,7 +175,7 @@ def test_opcheck():
     oc(torch.ops.invpref.forward.default, (P, t['u'], t['v'], t['e'], True))
     oc(torch.ops.invpref.stat_envs.default, (t['e'], E, True, _ws()))
     oc(torch.ops.invpref.predict.default, (P[0], P[1], t['u'][:16], True))
-    dp = planlib.upload(planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I), DEV)
+    dp = planlib.upload(planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, factor_num=D), DEV)
     oc(torch.ops.invpref.train_step_planned_grad_.default,
        (P, G, dp.buf, dp.meta, t['e'], t['y'], t['w'], B, COEFS, flags, torch.zeros(6, device=DEV), None, None, 0,
         _ws(zero=True)))

@@ -48,24 +48,38 @@ __device__ __forceinline__ const SchedRow *sched_slot_ptr(const int *state, int 
     return reinterpret_cast<const SchedRow *>(state + 16 * slot + 2);
 }
 
-// ---- lane-group helpers: a group is LG consecutive lanes of one wave, lane lg holds floats [4 lg, 4 lg + 4)
-__device__ __forceinline__ float swz_xor16(float x) {   // lane l <-> l ^ 16 (inside each half of the wave)
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), 0x401F));
+// ---- lane-group helpers: a group is LG consecutive lanes of one wave, lane lg holds floats [4 lg, 4 lg + 4).
+// Exchanges across the 16-lane rows of a wave use gfx950's v_permlane16_swap / v_permlane32_swap: vector-ALU
+// instructions (no LDS pipe, no lgkmcnt wait).  With both operands holding x, the two results are
+// {x.row0, x.row0, x.row2, x.row2} / {x.row1, x.row1, x.row3, x.row3} (16) and {x.rows01, x.rows01} / {x.rows23, x.rows23}
+// (32): their sum (max) is the xor-16 / xor-32 butterfly step.  Inline assembly on purpose: through
+// __builtin_amdgcn_permlane16_swap hipcc (ROCm 7.2) adds the FIRST result to itself (checked on the hardware,
+// tools/scratch); the s_nop covers the vector-write -> permlane-read hazard the compiler would otherwise pad.
+__device__ __forceinline__ void permlane16_swap(float &a, float &b) {
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
+__device__ __forceinline__ void permlane32_swap(float &a, float &b) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float xor16_sum(float x) { float a = x, b = x; permlane16_swap(a, b); return a + b; }
+__device__ __forceinline__ float xor32_sum(float x) { float a = x, b = x; permlane32_swap(a, b); return a + b; }
+__device__ __forceinline__ float xor16_max(float x) { float a = x, b = x; permlane16_swap(a, b); return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float xor32_max(float x) { float a = x, b = x; permlane32_swap(a, b); return __builtin_fmaxf(a, b); }
 template <int LG>
 __device__ __forceinline__ float group_sum(float x) {
     x = row16_sum(x);
-    if (LG >= 32) x += swz_xor16(x);
-    if (LG >= 64) x += __shfl_xor(x, 32, 64);
+    if (LG >= 32) x = xor16_sum(x);
+    if (LG >= 64) x = xor32_sum(x);
     return x;
 }
 template <int LG>
 __device__ __forceinline__ float group_max(float x) {
     x = row16_max(x);
-    if (LG >= 32) x = __builtin_fmaxf(x, swz_xor16(x));
-    if (LG >= 64) x = __builtin_fmaxf(x, __shfl_xor(x, 32, 64));
+    if (LG >= 32) x = xor16_max(x);
+    if (LG >= 64) x = xor32_max(x);
     return x;
 }
+__device__ __forceinline__ float wave_sum_valu(float x) { return xor32_sum(xor16_sum(row16_sum(x))); }
 __device__ __forceinline__ float dot4(float4 a, float4 b) {
     float s = a.x * b.x;
     s = __builtin_fmaf(a.y, b.y, s);
@@ -106,12 +120,23 @@ __device__ __forceinline__ float4 row4(const float *__restrict__ base, int row, 
     r.w = (i0 + 3 < (unsigned)D) ? p[i0 + 3] : 0.f;
     return r;
 }
-template <bool VEC>
+typedef float v4f __attribute__((ext_vector_type(4)));
+// MODE 0: plain store; 1: write-through (sc1: the line leaves the XCD's L2 at once instead of at the end of the kernel)
+template <bool VEC, int MODE = 0>
 __device__ __forceinline__ void put4(float *__restrict__ base, int row, int D, int lg, float4 r) {
     const int i0 = lg * 4;
     if (VEC) {
         const unsigned boff = ((unsigned)row * (unsigned)D + (unsigned)i0) * 4u;
-        if (i0 < D) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + boff) = r;
+        if (i0 < D) {
+            float4 *dst = reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + boff);
+            if (MODE == 0) *dst = r;
+            else {
+                v4f val = {r.x, r.y, r.z, r.w};
+                // (the trailing s_nop: a store of more than 8 bytes followed by a vector write of its data registers is
+                //  a hazard the compiler pads for its own stores, not for inline assembly)
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(val) : "memory");
+            }
+        }
     } else {
         float *p = base + (unsigned)row * (unsigned)D;
         if (i0 + 0 < D) p[i0 + 0] = r.x;
@@ -345,23 +370,26 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
     const int d_own = threadIdx.x % DP, cg = threadIdx.x / DP;
     float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
     int it_total = 0;   // E > 4: record buffer parity
+    float *slab = a.slabs + (int64_t)slab_index * G::SLAB;   // this workgroup's partial slab
 
     for (int r = r0; r < r0 + nr; r++) {
-        if (r != r0) { d = a.desc[(r * NG + grp) * 2]; d1 = a.desc[(r * NG + grp) * 2 + 1]; }
-        const int row = d.x, meta = d.y;
+        // (the next round's descriptor flies under this round: a further round does not start with a dependent load)
+        const int4 dd = d, dd1 = d1;   // (this round's copy: what the lambdas below read)
+        if (r + 1 < r0 + nr) { d = a.desc[((r + 1) * NG + grp) * 2]; d1 = a.desc[((r + 1) * NG + grp) * 2 + 1]; }
+        const int row = dd.x, meta = dd.y;
         const bool active = row >= 0, leader = meta & 1;
         const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
-        const int nsmp = active ? (mode == 7 ? d.w - d.z : mode) : 0;
+        const int nsmp = active ? (mode == 7 ? dd.w - dd.z : mode) : 0;
         const int iters = G::REG ? nsmp : a.round_iters[r];
         if (r == r0) STAMP(2);
         // sample sidx of the slice: inline in the descriptor (up to two) or one 16-byte load from the sorted list
         auto sample_at = [&](int sidx) {
             USample sm;
             if (mode == 7) {
-                const int4 q = a.ulist[d.z + sidx];
+                const int4 q = a.ulist[dd.z + sidx];
                 sm.oth = q.x; sm.ps = q.y; sm.y = __builtin_bit_cast(float, q.z);
-            } else if (sidx == 0) { sm.oth = d.z; sm.ps = d.w; sm.y = __builtin_bit_cast(float, d1.x); }
-            else { sm.oth = d1.y; sm.ps = d1.z; sm.y = __builtin_bit_cast(float, d1.w); }
+            } else if (sidx == 0) { sm.oth = dd.z; sm.ps = dd.w; sm.y = __builtin_bit_cast(float, dd1.x); }
+            else { sm.oth = dd1.y; sm.ps = dd1.z; sm.y = __builtin_bit_cast(float, dd1.w); }
             return sm;
         };
         // everything that depends only on the descriptor is requested together: own rows, the Adam moments of the
@@ -498,12 +526,79 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             }
         }
         if (r == r0) STAMP(4);
+        const float cnt = (float)(meta >> 9);
+        if (active && leader) {   // regulariser reports: the user's rows count once per interaction
+            accL2 += cnt * (f4sq(oi) + f4sq(oe));
+            accL1 += cnt * (f4abs(oi) + f4abs(oe));
+        }
+        // The task's LAST round also hands over the workgroup's partial sums (dEv | dW | db | loss sums): they go to LDS
+        // in front of the barrier the slices meet at and leave -- plain stores, fixed-order sums -- right behind it, so
+        // that the slab's stores fly under the leaders' Adam instead of forming a phase of their own.
+        const bool last = r == r0 + nr - 1;
+        if (last) {
+            accLi = wave_sum_valu(accLi); accLe = wave_sum_valu(accLe); accLc = wave_sum_valu(accLc);
+            accL2 = wave_sum_valu(accL2); accL1 = wave_sum_valu(accL1);
+            if (G::REG) {
+                // groups of one wave first (lane exchanges), then the four waves through LDS
+                float *mine = red + wave * G::SLAB;
+#pragma unroll
+                for (int c = 0; c < (G::REG ? EMAX : 1); c++) {
+                    float4 &w4 = dW[c], &e4 = dE[c];
+                    if (LG == 16) {
+                        w4.x = xor16_sum(w4.x); w4.y = xor16_sum(w4.y); w4.z = xor16_sum(w4.z); w4.w = xor16_sum(w4.w);
+                        e4.x = xor16_sum(e4.x); e4.y = xor16_sum(e4.y); e4.z = xor16_sum(e4.z); e4.w = xor16_sum(e4.w);
+                        dB[c] = xor16_sum(dB[c]);
+                    }
+                    if (LG <= 32) {
+                        w4.x = xor32_sum(w4.x); w4.y = xor32_sum(w4.y); w4.z = xor32_sum(w4.z); w4.w = xor32_sum(w4.w);
+                        e4.x = xor32_sum(e4.x); e4.y = xor32_sum(e4.y); e4.z = xor32_sum(e4.z); e4.w = xor32_sum(e4.w);
+                        dB[c] = xor32_sum(dB[c]);
+                    }
+                    if (lane < LG) {
+                        *reinterpret_cast<float4 *>(mine + c * DP + lane * 4) = e4;
+                        *reinterpret_cast<float4 *>(mine + EMAX * DP + c * DP + lane * 4) = w4;
+                    }
+                    if (lane == 0) mine[2 * EMAX * DP + c] = dB[c];
+                }
+                if (lane == 0) {
+                    float *ls = mine + 2 * EMAX * DP + EMAX;
+                    ls[0] = accLi; ls[1] = accLe; ls[2] = accLc; ls[3] = accL2; ls[4] = accL1; ls[5] = ls[6] = ls[7] = 0.f;
+                }
+            } else {
+                if (lane == 0) {
+                    float *ls = red + wave * kLossSlots;
+                    ls[0] = accLi; ls[1] = accLe; ls[2] = accLc; ls[3] = accL2; ls[4] = accL1; ls[5] = ls[6] = ls[7] = 0.f;
+                }
+                if (threadIdx.x < G::CG * DP) {   // thread-owned outputs: straight to the slab
+#pragma unroll
+                    for (int i = 0; i < (G::REG ? 1 : G::CPT); i++) {
+                        const int c = cg + G::CG * i;
+                        if (c < EMAX) {
+                            slab[c * DP + d_own] = oE[i];
+                            slab[EMAX * DP + c * DP + d_own] = oW[i];
+                            if (d_own == 0) slab[2 * EMAX * DP + c] = oB[i];
+                        }
+                    }
+                }
+            }
+        }
         // ---- slices of one row meet through LDS: plain stores, fixed-order sum by the leader
         if (slices > 1) {  // same for every slot of a round, idle slots included
             float *mine = slots + grp * 2 * DP;
             *reinterpret_cast<float4 *>(mine + lg * 4) = gi;
             *reinterpret_cast<float4 *>(mine + DP + lg * 4) = ge;
-            __syncthreads();
+        }
+        if (slices > 1 || last) __syncthreads();
+        if (last) {
+            if (G::REG) {
+                for (int i = threadIdx.x; i < G::SLAB; i += kThreads)
+                    slab[i] = ((red[i] + red[G::SLAB + i]) + red[2 * G::SLAB + i]) + red[3 * G::SLAB + i];
+            } else if (threadIdx.x < kLossSlots) {
+                slab[2 * EMAX * DP + EMAX + threadIdx.x] = ((red[threadIdx.x] + red[kLossSlots + threadIdx.x]) +
+                                                             red[2 * kLossSlots + threadIdx.x]) + red[3 * kLossSlots + threadIdx.x];
+            }
+        }
+        if (slices > 1) {
             if (active && leader) {
 #pragma unroll 4
                 for (int s = 1; s < slices; s++) {
@@ -512,18 +607,14 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                     f4add(ge, *reinterpret_cast<const float4 *>(oth_slot + DP + lg * 4));
                 }
             }
-            if (r + 1 < r0 + nr) __syncthreads();  // the slots are rewritten by the next round
+            if (!last) __syncthreads();  // the slots are rewritten by the next round
         }
         if (r == r0) STAMP(5);
         // ---- the leader finishes the row
         if (active && leader) {
-            const float cnt = (float)(meta >> 9);
             if (cnt != 0.f) {
                 f4fma(gi, cnt, reg_term(oi, k.r2, k.r1));
                 f4fma(ge, cnt, reg_term(oe, k.r2, k.r1));
-                // regulariser reports: the user's rows count once per interaction
-                accL2 += cnt * (f4sq(oi) + f4sq(oe));
-                accL1 += cnt * (f4abs(oi) + f4abs(oe));
             }
             if (!a.fused) {
                 put4<VEC>(a.g[0], row, t.D, lg, gi);
@@ -552,62 +643,6 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
         }
     }
     STAMP(6);
-    // ---- this workgroup's partial slab: dEv | dW | db | loss sums, plain stores, fixed-order sums
-    float *slab = a.slabs + (int64_t)slab_index * G::SLAB;
-    accLi = wave_sum(accLi); accLe = wave_sum(accLe); accLc = wave_sum(accLc);
-    accL2 = wave_sum(accL2); accL1 = wave_sum(accL1);
-    if (G::REG) {
-        // groups of one wave first (lane exchanges), then the four waves through LDS
-        float *mine = red + wave * G::SLAB;
-#pragma unroll
-        for (int c = 0; c < (G::REG ? EMAX : 1); c++) {
-            float4 &w4 = dW[c], &e4 = dE[c];
-            if (LG == 16) {
-                w4.x += swz_xor16(w4.x); w4.y += swz_xor16(w4.y); w4.z += swz_xor16(w4.z); w4.w += swz_xor16(w4.w);
-                e4.x += swz_xor16(e4.x); e4.y += swz_xor16(e4.y); e4.z += swz_xor16(e4.z); e4.w += swz_xor16(e4.w);
-                dB[c] += swz_xor16(dB[c]);
-            }
-            if (LG <= 32) {
-                w4.x += __shfl_xor(w4.x, 32, 64); w4.y += __shfl_xor(w4.y, 32, 64);
-                w4.z += __shfl_xor(w4.z, 32, 64); w4.w += __shfl_xor(w4.w, 32, 64);
-                e4.x += __shfl_xor(e4.x, 32, 64); e4.y += __shfl_xor(e4.y, 32, 64);
-                e4.z += __shfl_xor(e4.z, 32, 64); e4.w += __shfl_xor(e4.w, 32, 64);
-                dB[c] += __shfl_xor(dB[c], 32, 64);
-            }
-            if (lane < LG) {
-                *reinterpret_cast<float4 *>(mine + c * DP + lane * 4) = e4;
-                *reinterpret_cast<float4 *>(mine + EMAX * DP + c * DP + lane * 4) = w4;
-            }
-            if (lane == 0) mine[2 * EMAX * DP + c] = dB[c];
-        }
-        if (lane == 0) {
-            float *ls = mine + 2 * EMAX * DP + EMAX;
-            ls[0] = accLi; ls[1] = accLe; ls[2] = accLc; ls[3] = accL2; ls[4] = accL1; ls[5] = ls[6] = ls[7] = 0.f;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < G::SLAB; i += kThreads)
-            slab[i] = ((red[i] + red[G::SLAB + i]) + red[2 * G::SLAB + i]) + red[3 * G::SLAB + i];
-    } else {
-        if (lane == 0) {
-            float *ls = red + wave * kLossSlots;
-            ls[0] = accLi; ls[1] = accLe; ls[2] = accLc; ls[3] = accL2; ls[4] = accL1; ls[5] = ls[6] = ls[7] = 0.f;
-        }
-        if (threadIdx.x < G::CG * DP) {
-#pragma unroll
-            for (int i = 0; i < (G::REG ? 1 : G::CPT); i++) {
-                const int c = cg + G::CG * i;
-                if (c < EMAX) {
-                    slab[c * DP + d_own] = oE[i];
-                    slab[EMAX * DP + c * DP + d_own] = oW[i];
-                    if (d_own == 0) slab[2 * EMAX * DP + c] = oB[i];
-                }
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < kLossSlots)
-            slab[2 * EMAX * DP + EMAX + threadIdx.x] = ((red[threadIdx.x] + red[kLossSlots + threadIdx.x]) +
-                                                         red[2 * kLossSlots + threadIdx.x]) + red[3 * kLossSlots + threadIdx.x];
-    }
     STAMP(7);
 }
 
@@ -617,9 +652,13 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
 struct IIn {
     float4 pu, pa, r0;
 };
+#ifndef STEP_ITEM_DEPTH
+#define STEP_ITEM_DEPTH 2
+#endif
 template <int LG, bool VEC, int EMAX>
 __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a, int r0, int nr, float *lds) {
     using G = Geo<LG, EMAX>;
+    constexpr int U = EMAX <= 4 ? STEP_ITEM_DEPTH : 2;   // interactions in flight per group
     constexpr int DP = G::DP, RS = G::RS, NG = G::NG;
     float *sEv = lds, *sW = sEv + EMAX * DP, *slots = sW + EMAX * DP;   // [EMAX][DP] x 2, [NG][2][DP]
     float4 *mv = reinterpret_cast<float4 *>(slots + NG * 2 * DP);       // [4 waves][4][64] float4 LDS-DMA landing area
@@ -639,11 +678,13 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
     stage_small(sW, t.W, t.E, t.D, EMAX, DP);
     STAMP(1);
     for (int r = r0; r < r0 + nr; r++) {
-        if (r != r0) { d = a.desc[(r * NG + grp) * 2]; d1 = a.desc[(r * NG + grp) * 2 + 1]; }
-        const int row = d.x, meta = d.y;
+        // (the next round's descriptor flies under this round: a further round does not start with a dependent load)
+        const int4 dd = d, dd1 = d1;   // (this round's copy: what the lambdas below read)
+        if (r + 1 < r0 + nr) { d = a.desc[((r + 1) * NG + grp) * 2]; d1 = a.desc[((r + 1) * NG + grp) * 2 + 1]; }
+        const int row = dd.x, meta = dd.y;
         const bool active = row >= 0, leader = meta & 1;
         const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
-        const int nsmp = active ? (mode == 7 ? d.w - d.z : mode) : 0;
+        const int nsmp = active ? (mode == 7 ? dd.w - dd.z : mode) : 0;
         if (r == r0) STAMP(2);
         float4 oi = f4zero(), oe = f4zero(), gi = f4zero(), ge = f4zero();
         {   // (an idle slot reads row 0 rather than branching around the loads)
@@ -653,10 +694,10 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
         }
         // interaction sidx of the slice: (user row, position) inline (up to three) or from the sorted list
         auto ids_at = [&](int sidx) {
-            if (mode == 7) return a.ilist[d.z + sidx];
-            if (sidx == 0) return make_int2(d.z, d.w);
-            if (sidx == 1) return make_int2(d1.x, d1.y);
-            return make_int2(d1.z, d1.w);
+            if (mode == 7) return a.ilist[dd.z + sidx];
+            if (sidx == 0) return make_int2(dd.z, dd.w);
+            if (sidx == 1) return make_int2(dd1.x, dd1.y);
+            return make_int2(dd1.z, dd1.w);
         };
         auto fetch = [&](IIn &in, float4 (&gzv)[EMAX / 4], int2 id) {
             in.pu = row4<VEC>(t.Pu, id.x, t.D, lg);
@@ -688,17 +729,21 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
             gip.z = g_p - k.alpha * gx.z; gip.w = g_p - k.alpha * gx.w;
             f4add(gi, f4mul(gip, in.pu));
         };
-        // two interactions in flight per group: the slot just consumed is refilled at once (no register copies)
-        IIn n0, n1;
-        float4 zn0[EMAX / 4], zn1[EMAX / 4];
-        n0.pu = n0.pa = n0.r0 = n1.pu = n1.pa = n1.r0 = f4zero();
+        // U interactions in flight per group: the slot just consumed is refilled at once (no register copies)
+        IIn nx[U];
+        float4 zn[U][EMAX / 4];
+        int2 idn[U];
 #pragma unroll
-        for (int c4 = 0; c4 < EMAX / 4; c4++) zn0[c4] = zn1[c4] = f4zero();
-        int2 i0 = make_int2(0, 0), i1 = make_int2(0, 0);
-        if (nsmp > 0) fetch(n0, zn0, ids_at(0));
-        if (nsmp > 1) fetch(n1, zn1, ids_at(1));
-        if (nsmp > 2) i0 = ids_at(2);
-        if (nsmp > 3) i1 = ids_at(3);
+        for (int j = 0; j < U; j++) {
+            nx[j].pu = nx[j].pa = nx[j].r0 = f4zero();
+#pragma unroll
+            for (int c4 = 0; c4 < EMAX / 4; c4++) zn[j][c4] = f4zero();
+            idn[j] = make_int2(0, 0);
+            if (j < nsmp) fetch(nx[j], zn[j], ids_at(j));
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++)
+            if (U + j < nsmp) idn[j] = ids_at(U + j);
         if (dma) {   // the row's Adam moments: needed last, sent straight to LDS (no registers held across the loop)
             const bool mine = active && leader && lg * 4 < t.D;
 #pragma unroll
@@ -711,13 +756,13 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
             }
         }
         if (r == r0) { __syncthreads(); STAMP(3); }  // staged tables visible
-        for (int s = 0; s < nsmp; s += 2) {
-            consume(n0, zn0);
-            if (s + 2 < nsmp) fetch(n0, zn0, i0);
-            if (s + 4 < nsmp) i0 = ids_at(s + 4);
-            if (s + 1 < nsmp) consume(n1, zn1);
-            if (s + 3 < nsmp) fetch(n1, zn1, i1);
-            if (s + 5 < nsmp) i1 = ids_at(s + 5);
+        for (int s = 0; s < nsmp; s += U) {
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                if (s + j < nsmp) consume(nx[j], zn[j]);
+                if (s + U + j < nsmp) fetch(nx[j], zn[j], idn[j]);
+                if (s + 2 * U + j < nsmp) idn[j] = ids_at(s + 2 * U + j);
+            }
         }
         if (r == r0) STAMP(4);
         if (slices > 1) {
@@ -773,6 +818,9 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
 
 // Untouched rows: gradient exactly zero, so m' = m + (1-b1)(0-m), v' = b2 v, p' = p - step*m'/(sqrt(v')/bc+eps)
 // (the same adam1f as everywhere, fed g = 0).  Each group keeps R = 2 rows of both tables in flight (12 float4 loads).
+#ifndef STEP_STREAM_ST
+#define STEP_STREAM_ST 1   // (A/B knob: 1 = write-through stores for the streamed rows)
+#endif
 template <int LG, bool VEC>
 __device__ __forceinline__ void stream_task(const DevTables &t, const StepArgs &a, const int *rows, int n) {
     constexpr int R = 2, NG = kThreads / LG;
@@ -820,9 +868,9 @@ __device__ __forceinline__ void stream_task(const DevTables &t, const StepArgs &
                 float *NP = (q & 1) ? (s ? a.np[3] : a.np[2]) : (s ? a.np[1] : a.np[0]);
                 float *M = (q & 1) ? (s ? a.m[3] : a.m[2]) : (s ? a.m[1] : a.m[0]);
                 float *V = (q & 1) ? (s ? a.v[3] : a.v[2]) : (s ? a.v[1] : a.v[0]);
-                put4<VEC>(NP, row[q >> 1], t.D, lg, p[q]);
-                put4<VEC>(M, row[q >> 1], t.D, lg, m[q]);
-                put4<VEC>(V, row[q >> 1], t.D, lg, v[q]);
+                put4<VEC, STEP_STREAM_ST>(NP, row[q >> 1], t.D, lg, p[q]);
+                put4<VEC, STEP_STREAM_ST>(M, row[q >> 1], t.D, lg, m[q]);
+                put4<VEC, STEP_STREAM_ST>(V, row[q >> 1], t.D, lg, v[q]);
             }
         }
     }
@@ -874,7 +922,10 @@ __device__ __forceinline__ void fold_block(const DevTables &t, const StepArgs &a
     const float *col = a.slabs + (mine ? idx : 0);
     const int np = f.n_partials;
     double acc = 0.0;
-    constexpr int CH = 8;
+#ifndef STEP_FOLD_CH
+#define STEP_FOLD_CH 32
+#endif
+    constexpr int CH = STEP_FOLD_CH;   // 32 x 16 sub-rows: up to 512 partials in ONE round trip
     for (int s0 = sub; s0 < np; s0 += CH * kFoldSubs) {
         float x[CH];
 #pragma unroll
@@ -956,13 +1007,13 @@ __device__ __forceinline__ void class_row(const StepArgs &a, int c, int (&q)[4])
 
 // registers: the instances are held to 4 (E <= 4) / 3 workgroups per CU for launch 1 and 6 / 4 / 3 for launch 2
 #ifndef STEP_EVAL_WAVES
-#define STEP_EVAL_WAVES 4
+#define STEP_EVAL_WAVES 2
 #endif
 #ifndef STEP_APPLY_WAVES
-#define STEP_APPLY_WAVES 6
+#define STEP_APPLY_WAVES 4
 #endif
 template <int LG, bool VEC, int EMAX>
-__global__ __launch_bounds__(kThreads, EMAX <= 4 ? STEP_EVAL_WAVES : 3) void mstep_eval_kernel(DevTables t, StepArgs a) {
+__global__ __launch_bounds__(kThreads, STEP_EVAL_WAVES) void mstep_eval_kernel(DevTables t, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // Workgroup b runs the tasks of class c = b % n_cls (XCD-affine order, InvPrefRowPlan), the j-th of them with
     // j = b / n_cls: its user jobs first, then its share of the untouched rows.  Every branch is workgroup-uniform.

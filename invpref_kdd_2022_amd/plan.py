@@ -27,6 +27,7 @@ THREADS = 256
 ITEM_BIT = 1 << 30     # stream_rows: a row of the item tables
 MODE_LIST = 7
 MAX_ROW_COUNT = 1 << 22
+TARGET_WORKGROUPS = 1536
 
 
 class RowPlanStruct(C.Structure):
@@ -51,8 +52,9 @@ def lanes_of(factor_num: int) -> int:
 
 
 def stream_rows_default(factor_num: int) -> int:
-    """untouched rows per stream task: two iterations of a workgroup (2 rows per group in flight)"""
-    return 4 * (THREADS // lanes_of(factor_num))
+    """untouched rows per stream task: ONE iteration of a workgroup (2 rows per group in flight); a second iteration would be a
+    second serial round trip -- the loads of an iteration cannot be hoisted above the stores of the one before"""
+    return 2 * (THREADS // lanes_of(factor_num))
 
 
 def row_class(rows: np.ndarray, n_classes: int) -> np.ndarray:
@@ -144,19 +146,29 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     lanes = lanes_of(factor_num)
     ng = THREADS // lanes
     n = len(users)
-    # Defaults follow the minibatch size: a Yahoo step (8 192 interactions) is one latency chain and wants many short
-    # tasks; a MovieLens-sized one (65 536) is throughput-bound and wants fewer, longer ones.
-    scale = max(1, n // 8192)
+    # Defaults: a launch wants about TARGET_WORKGROUPS job workgroups -- enough to fill 256 CUs a few times over, few
+    # enough that the per-workgroup partial slabs of launch 1 stay a small share of the step's bytes.  A Yahoo step
+    # (8 192 interactions) is one latency chain and gets the shortest slices (2 interactions); larger minibatches get
+    # longer slices first (a slice walks its interactions with the next gathers in flight; a further ROUND of a task
+    # starts with a dependent descriptor load), then more rounds per task.
+    target = int(os.environ.get('INVPREF_PLAN_TARGET_WGS', str(TARGET_WORKGROUPS)))
     if per_slice is None:
-        per_slice = int(os.environ.get('INVPREF_PLAN_PER_SLICE', str(min(16, 2 * scale))))
+        per_slice = int(os.environ.get('INVPREF_PLAN_PER_SLICE', str(min(8, max(2, -(-n // (ng * target)))))))
     if item_per_slice is None:
-        item_per_slice = int(os.environ.get('INVPREF_PLAN_ITEM_PER_SLICE', str(min(32, 2 * scale))))
+        item_per_slice = int(os.environ.get('INVPREF_PLAN_ITEM_PER_SLICE', str(min(32, max(2, -(-n // (ng * 2 * target)))))))
+
+    def rounds_for(cnt, ps):   # group slots / ng: the rounds a side needs at `ps` interactions per slice
+        c = cnt[cnt > 0]
+        need = np.maximum(1, -(-c // ps))
+        return int(np.minimum(ng, 1 << np.ceil(np.log2(need)).astype(np.int64)).sum()) // ng + 1
     if rounds_per_task is None:
-        rounds_per_task = int(os.environ.get('INVPREF_PLAN_ROUNDS', str(min(16, scale))))
+        rounds_per_task = int(os.environ.get('INVPREF_PLAN_ROUNDS', '0')) or \
+            min(16, max(1, round(rounds_for(np.bincount(users, minlength=1), per_slice) / target)))
     if item_rounds_per_task is None:
-        item_rounds_per_task = int(os.environ.get('INVPREF_PLAN_ITEM_ROUNDS', '1'))
+        item_rounds_per_task = int(os.environ.get('INVPREF_PLAN_ITEM_ROUNDS', '0')) or \
+            min(16, max(1, round(rounds_for(np.bincount(items, minlength=1), item_per_slice) / (4 * target))))
     if rows_per_stream_task is None:
-        rows_per_stream_task = int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', str(stream_rows_default(factor_num))))
+        rows_per_stream_task = int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', str(stream_rows_default(factor_num))))  # one iteration of a workgroup
     ucnt = np.bincount(users, minlength=user_num)
     icnt = np.bincount(items, minlength=item_num)
     if n and max(ucnt.max(), icnt.max()) >= MAX_ROW_COUNT:

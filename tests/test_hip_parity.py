@@ -286,7 +286,7 @@ def test_rows_path_movielens_shape_default_plan():
     tabs = synth.tables(32, U, I, E, D, std=0.1)
     envs = np.random.RandomState(33).randint(0, E, B).astype(np.int64)
     pl = planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, factor_num=D)
-    assert pl['lanes_per_group'] == 32 and pl['user_rounds_per_task'] == 8 and len(pl['item_desc']) > 0
+    assert pl['lanes_per_group'] == 32 and len(pl['item_desc']) > 0
     dp = planlib.upload(pl, DEV)
     P = dev_params(tabs)
     P2, M, V = ([torch.zeros_like(p) for p in P] for _ in range(3))

@@ -192,7 +192,7 @@ struct Geo {
     static constexpr int NG = kThreads / LG;          // groups (rows in flight) per workgroup
     static constexpr int DP = 4 * LG;                 // padded row length
     static constexpr int RS = 4 + EMAX;               // floats per record: g_p, g_q, env bits, 0, gz[EMAX]
-    static constexpr bool REG = EMAX <= 4;            // E x D partial sums in registers (else: LDS records)
+    static constexpr bool REG = EMAX <= 8;            // E x D partial sums in registers (else: LDS records)
     static constexpr int SLAB = 2 * EMAX * DP + EMAX + kLossSlots;   // dEv | dW | db | loss sums
     // E > 4: thread -> column d_own, classes cg, cg + CG, ...
     static constexpr int CG = (kThreads / DP) < EMAX ? (kThreads / DP) : EMAX;
@@ -209,9 +209,9 @@ struct EvalLds {
     static constexpr int slots = sb + EMAX;                         // [NG][2][DP] slice partials
     static constexpr int mv = slots + G::NG * 2 * G::DP;            // [4 waves][4][64] float4 LDS-DMA landing area
     static constexpr int red = mv + kWaves * 4 * 64 * 4;            // REG: [4 waves][SLAB]; else [4 waves][8] loss sums
-    static constexpr int rec = red + (G::REG ? kWaves * G::SLAB : kWaves * kLossSlots);   // E > 4: [2][NG][2][DP] x, o
-    static constexpr int recs = rec + (G::REG ? 0 : 2 * G::NG * 2 * G::DP);              // [2][NG][EMAX + 4] gz, env
-    static constexpr int total = recs + (G::REG ? 0 : 2 * G::NG * (EMAX + 4));
+    static constexpr int rec = red + (G::REG ? kWaves * G::SLAB : kWaves * kLossSlots);   // E > 8: [2][NG][2][DP] x, o
+    static constexpr int recs = rec + (G::REG ? 0 : 2 * G::NG * 2 * G::DP);              // E > 4: [2][NG][EMAX + 4] gz, env
+    static constexpr int total = recs + (EMAX <= 4 ? 0 : 2 * G::NG * (EMAX + 4));
 };
 
 // ---- forward + analytic backward of ONE interaction on a lane group (M-step arithmetic: hardware exp/log/rcp).
@@ -329,9 +329,18 @@ struct USample {
 // launch 1: rounds of USER jobs.  Per interaction: gather the item rows, evaluate, accumulate the user rows'
 // gradients in registers, store the record for the item side, accumulate the E x D / loss sums.
 // =====================================================================================
+#ifndef STEP_EVAL_DEPTH
+#define STEP_EVAL_DEPTH 3
+#endif
+#ifndef STEP_ROW_ST
+#define STEP_ROW_ST 0   // (A/B knob: 1 = write-through stores for the rows the jobs finish)
+#endif
 template <int LG, bool VEC, int EMAX>
 __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a, int r0, int nr, int slab_index, float *lds) {
     using G = Geo<LG, EMAX>;
+    // interactions in flight per group (measured: 2 for the D <= 64, E <= 4 instances -- a third slot only costs registers
+    // there -- and 3 for the larger rows)
+    constexpr int UE = (LG == 16 && EMAX <= 4 && STEP_EVAL_DEPTH > 2) ? 2 : STEP_EVAL_DEPTH;
     using L = EvalLds<LG, EMAX>;
     constexpr int NG = G::NG, DP = G::DP, RS = G::RS;
     float *sEv = lds + L::sEv, *sW = lds + L::sW, *sb = lds + L::sb, *slots = lds + L::slots;
@@ -369,7 +378,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
     for (int i = 0; i < (G::REG ? 1 : G::CPT); i++) oW[i] = oE[i] = oB[i] = 0.f;
     const int d_own = threadIdx.x % DP, cg = threadIdx.x / DP;
     float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
-    int it_total = 0;   // E > 4: record buffer parity
+    int it_total = 0;   // E > 4: parity of the gz scratch / record buffers
     float *slab = a.slabs + (int64_t)slab_index * G::SLAB;   // this workgroup's partial slab
 
     for (int r = r0; r < r0 + nr; r++) {
@@ -393,27 +402,44 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             return sm;
         };
         // everything that depends only on the descriptor is requested together: own rows, the Adam moments of the
-        // row (needed last: LDS-DMA, no registers held across the loop) and the first interaction's rows / env / weight
+        // row (needed last: LDS-DMA, no registers held across the loop) and the first interactions' rows / env / weight
         float4 oi = f4zero(), oe = f4zero(), gi = f4zero(), ge = f4zero();
-        float4 nqi = f4zero(), nqa = f4zero();
-        USample nsm{0, 0, 0.f}, nsm2{0, 0, 0.f};
-        int ne = 0;
-        float nw = 1.f;
         {   // (an idle slot reads row 0 rather than branching around the loads)
             const int rowc = active ? row : 0;
             oi = row4<VEC>(t.Pu, rowc, t.D, lg);
             if (!pure) oe = row4<VEC>(t.Pa, rowc, t.D, lg);
         }
-        auto gather = [&](const USample &sm) {
-            nqi = row4<VEC>(t.Qi, sm.oth, t.D, lg);
-            if (!pure) {
-                nqa = row4<VEC>(t.Qa, sm.oth, t.D, lg);
-                ne = (int)a.envs[sm.ps];
-            }
-            if (rw_rec || rw_cls) nw = a.weights[sm.ps];
+        // UE interactions in flight per group, each in a register slot of its own: the slot just consumed is refilled
+        // at once (no register copies: a copy of a register that is still being loaded would wait for the load)
+        struct Slot {
+            float4 qi, qa;
+            USample sm;
+            int e;
+            float w;
         };
-        if (nsmp > 0) { nsm = sample_at(0); gather(nsm); }
-        if (nsmp > 1) nsm2 = sample_at(1);   // (list form: the ids run one interaction ahead of the rows)
+        Slot sl[UE];
+        USample idn[UE];   // (list form: the ids run UE interactions ahead of the rows)
+        auto gather = [&](Slot &q, const USample &sm) {
+            q.sm = sm;
+            q.qi = row4<VEC>(t.Qi, sm.oth, t.D, lg);
+            if (!pure) {
+                q.qa = row4<VEC>(t.Qa, sm.oth, t.D, lg);
+                q.e = (int)a.envs[sm.ps];
+            }
+            if (rw_rec || rw_cls) q.w = a.weights[sm.ps];
+        };
+#pragma unroll
+        for (int j = 0; j < UE; j++) {
+            sl[j].qi = sl[j].qa = f4zero();
+            sl[j].sm = USample{0, 0, 0.f};
+            sl[j].e = 0;
+            sl[j].w = 1.f;
+            idn[j] = USample{0, 0, 0.f};
+            if (j < nsmp) gather(sl[j], sample_at(j));
+        }
+#pragma unroll
+        for (int j = 0; j < UE; j++)
+            if (UE + j < nsmp) idn[j] = sample_at(UE + j);
         if (dma) {
             // each lane sends its 16-byte piece of the row's four moment rows straight to LDS; the destination of a
             // wave instruction is one contiguous 1 KiB block, lane-major
@@ -428,32 +454,24 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             }
         }
         if (r == r0) { __syncthreads(); STAMP(3); }  // staged tables visible (the gathers above are in flight)
-        for (int sidx = 0; sidx < iters; sidx++) {
-            const bool has = sidx < nsmp;
-            const USample cur = nsm;
-            const float4 qi = nqi, qa = nqa;
-            const int e = ne;
-            const float w = nw;
-            if (sidx + 1 < nsmp) {   // next interaction's rows fly under this one's evaluation
-                nsm = nsm2;
-                gather(nsm);
-                if (sidx + 2 < nsmp) nsm2 = sample_at(sidx + 2);
-            }
+        // one interaction: evaluate, accumulate the user rows' gradients, store the record, feed the E x D / loss sums
+        auto step = [&](const Slot &q, bool has) {
             float *gzs = nullptr;
-            if (!G::REG) gzs = lds + L::recs + ((it_total & 1) * NG + grp) * (EMAX + 4);
+            if (EMAX > 4) gzs = lds + L::recs + ((it_total & 1) * NG + grp) * (EMAX + 4);
+            const int e = q.e;
             if (has) {
-                const float w_rec = rw_rec ? w : 1.f, w_cls = rw_cls ? w : 1.f;
+                const float w_rec = rw_rec ? q.w : 1.f, w_cls = rw_cls ? q.w : 1.f;
                 const float4 ev = *reinterpret_cast<const float4 *>(sEv + e * DP + lg * 4);
                 Eval<EMAX> o;
-                eval_interaction<LG, EMAX>(o, oi, qi, oe, qa, ev, sW, sb, gzs, t.E, e, cur.y, w_rec * k.invB,
+                eval_interaction<LG, EMAX>(o, oi, q.qi, oe, q.qa, ev, sW, sb, gzs, t.E, e, q.sm.y, w_rec * k.invB,
                                            w_cls * k.invB, k, implicit, pure, lg);
                 float4 gip;
                 gip.x = o.g_p - k.alpha * o.gx.x; gip.y = o.g_p - k.alpha * o.gx.y;
                 gip.z = o.g_p - k.alpha * o.gx.z; gip.w = o.g_p - k.alpha * o.gx.w;
-                f4add(gi, f4mul(gip, qi));
-                f4fma(ge, o.g_q, f4mul(qa, ev));
+                f4add(gi, f4mul(gip, q.qi));
+                f4fma(ge, o.g_q, f4mul(q.qa, ev));
                 // the record the item side consumes
-                float *rec_g = a.records + (unsigned)cur.ps * (unsigned)RS;
+                float *rec_g = a.records + (unsigned)q.sm.ps * (unsigned)RS;
                 if (lg == 0)
                     *reinterpret_cast<float4 *>(rec_g) = make_float4(o.g_p, o.g_q, __builtin_bit_cast(float, e), 0.f);
                 if (EMAX <= 4) {
@@ -464,14 +482,26 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                     rec_g[4 + lg] = o.gz_lane;
                 }
                 // o = g_q Pa*Qa (+ env regulariser): the interaction's term of embed_env's gradient
-                float4 oo = f4scale(o.g_q, f4mul(oe, qa));
+                float4 oo = f4scale(o.g_q, f4mul(oe, q.qa));
                 if (reg_env) f4add(oo, reg_term(ev, 2.f * k.r2, 2.f * k.r1));
                 if (G::REG) {
+                    float gzv[G::REG ? EMAX : 1];   // every class in every lane
+                    if (EMAX <= 4) {
+#pragma unroll
+                        for (int c = 0; c < (G::REG ? EMAX : 1); c++) gzv[c] = o.gz[EMAX <= 4 ? c : 0];
+                    } else {
+#pragma unroll
+                        for (int c4 = 0; c4 < (G::REG ? EMAX : 4); c4 += 4) {
+                            const float4 g4 = *reinterpret_cast<const float4 *>(gzs + c4);   // (written by the evaluation)
+                            gzv[G::REG ? c4 : 0] = g4.x; gzv[G::REG ? c4 + 1 : 0] = g4.y;
+                            gzv[G::REG ? c4 + 2 : 0] = g4.z; gzv[G::REG ? c4 + 3 : 0] = g4.w;
+                        }
+                    }
 #pragma unroll
                     for (int c = 0; c < (G::REG ? EMAX : 1); c++) {
-                        f4fma(dW[c], o.gz[EMAX <= 4 ? c : 0], o.x);
+                        f4fma(dW[c], gzv[c], o.x);
                         f4add(dE[c], c == e ? oo : f4zero());
-                        dB[c] += o.gz[EMAX <= 4 ? c : 0];
+                        dB[c] += gzv[c];
                     }
                 } else {
                     float *rx = lds + L::rec + (((it_total & 1) * NG + grp) * 2) * DP;
@@ -479,14 +509,14 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                     *reinterpret_cast<float4 *>(rx + DP + lg * 4) = oo;
                 }
                 // regulariser REPORTS over the item rows of the interaction (env rows weigh double: 1/(BD) vs 1/(2BD))
-                float s2 = f4sq(qi) + f4sq(qa), s1 = f4abs(qi) + f4abs(qa);
+                float s2 = f4sq(q.qi) + f4sq(q.qa), s1 = f4abs(q.qi) + f4abs(q.qa);
                 if (reg_env) { s2 += 2.f * f4sq(ev); s1 += 2.f * f4abs(ev); }
                 accL2 += s2;
                 accL1 += s1;
                 if (lg == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; accLc += o.lcls * w_cls; }
             }
             if (!G::REG) {
-                // E > 4: every thread adds the NG records of this iteration into the outputs it OWNS (one column,
+                // E > 8: every thread adds the NG records of this iteration into the outputs it OWNS (one column,
                 // a strided set of classes).  Branch-free: an empty record slot holds env id -1, its stale x / o /
                 // gz are masked by selects.  Double-buffered: one barrier per iteration.
                 if (lg == 0) gzs[EMAX] = __builtin_bit_cast(float, has ? e : -1);
@@ -522,7 +552,15 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                         }
                     }
                 }
-                it_total++;
+            }
+            if (EMAX > 4) it_total++;
+        };
+        for (int s = 0; s < iters; s += UE) {
+#pragma unroll
+            for (int j = 0; j < UE; j++) {
+                if (s + j < iters) step(sl[j], s + j < nsmp);   // (E > 8: `iters` is uniform, the barrier inside is too)
+                if (s + UE + j < nsmp) gather(sl[j], idn[j]);
+                if (s + 2 * UE + j < nsmp) idn[j] = sample_at(s + 2 * UE + j);
             }
         }
         if (r == r0) STAMP(4);
@@ -630,14 +668,14 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                     if (!pure) { me = row4<VEC>(a.m[2], row, t.D, lg); ve = row4<VEC>(a.v[2], row, t.D, lg); }
                 }
                 adam4(oi, gi, mi, vi, ad);
-                put4<VEC>(a.np[0], row, t.D, lg, oi);
-                put4<VEC>(a.m[0], row, t.D, lg, mi);
-                put4<VEC>(a.v[0], row, t.D, lg, vi);
+                put4<VEC, STEP_ROW_ST>(a.np[0], row, t.D, lg, oi);
+                put4<VEC, STEP_ROW_ST>(a.m[0], row, t.D, lg, mi);
+                put4<VEC, STEP_ROW_ST>(a.v[0], row, t.D, lg, vi);
                 if (!pure) {
                     adam4(oe, ge, me, ve, ad);
-                    put4<VEC>(a.np[2], row, t.D, lg, oe);
-                    put4<VEC>(a.m[2], row, t.D, lg, me);
-                    put4<VEC>(a.v[2], row, t.D, lg, ve);
+                    put4<VEC, STEP_ROW_ST>(a.np[2], row, t.D, lg, oe);
+                    put4<VEC, STEP_ROW_ST>(a.m[2], row, t.D, lg, me);
+                    put4<VEC, STEP_ROW_ST>(a.v[2], row, t.D, lg, ve);
                 }
             }
         }
@@ -801,14 +839,14 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
                     if (!pure) { me = row4<VEC>(a.m[3], row, t.D, lg); ve = row4<VEC>(a.v[3], row, t.D, lg); }
                 }
                 adam4(oi, gi, mi, vi, ad);
-                put4<VEC>(a.np[1], row, t.D, lg, oi);
-                put4<VEC>(a.m[1], row, t.D, lg, mi);
-                put4<VEC>(a.v[1], row, t.D, lg, vi);
+                put4<VEC, STEP_ROW_ST>(a.np[1], row, t.D, lg, oi);
+                put4<VEC, STEP_ROW_ST>(a.m[1], row, t.D, lg, mi);
+                put4<VEC, STEP_ROW_ST>(a.v[1], row, t.D, lg, vi);
                 if (!pure) {
                     adam4(oe, ge, me, ve, ad);
-                    put4<VEC>(a.np[3], row, t.D, lg, oe);
-                    put4<VEC>(a.m[3], row, t.D, lg, me);
-                    put4<VEC>(a.v[3], row, t.D, lg, ve);
+                    put4<VEC, STEP_ROW_ST>(a.np[3], row, t.D, lg, oe);
+                    put4<VEC, STEP_ROW_ST>(a.m[3], row, t.D, lg, me);
+                    put4<VEC, STEP_ROW_ST>(a.v[3], row, t.D, lg, ve);
                 }
             }
         }
@@ -1100,10 +1138,11 @@ inline int emax4_of(int E) { return E <= 4 ? 4 : (E <= 8 ? 8 : 16); }
 inline size_t slab_floats(int lg, int emax) { return (size_t)2 * emax * 4 * lg + emax + kLossSlots; }
 inline size_t eval_lds_bytes(int lg, int emax) {
     const size_t DP = 4 * (size_t)lg, NG = kThreads / lg;
-    const bool reg = emax <= 4;
+    const bool reg = emax <= 8;
     size_t fl = 2 * emax * DP + emax + NG * 2 * DP + kWaves * 4 * 64 * 4;
     fl += reg ? kWaves * slab_floats(lg, emax) : kWaves * kLossSlots;
-    if (!reg) fl += 2 * NG * 2 * DP + 2 * NG * (emax + 4);
+    if (!reg) fl += 2 * NG * 2 * DP;
+    if (emax > 4) fl += 2 * NG * (emax + 4);
     return fl * sizeof(float);
 }
 inline size_t apply_lds_bytes(int lg, int emax) {

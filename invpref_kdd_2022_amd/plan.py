@@ -148,12 +148,13 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     n = len(users)
     # Defaults: a launch wants about TARGET_WORKGROUPS job workgroups -- enough to fill 256 CUs a few times over, few
     # enough that the per-workgroup partial slabs of launch 1 stay a small share of the step's bytes.  A Yahoo step
-    # (8 192 interactions) is one latency chain and gets the shortest slices (2 interactions); larger minibatches get
-    # longer slices first (a slice walks its interactions with the next gathers in flight; a further ROUND of a task
-    # starts with a dependent descriptor load), then more rounds per task.
+    # (8 192 interactions) is one latency chain and gets the shortest slices (2 interactions); larger minibatches are
+    # throughput-bound and get long slices (measured at 65 536 .. 1 048 576 interactions: 16 per slice beats 2 .. 8 -- a
+    # slice walks its interactions with the next gathers in flight, while every further slot, round and workgroup pays
+    # its own start-up round trips), then more rounds per task.
     target = int(os.environ.get('INVPREF_PLAN_TARGET_WGS', str(TARGET_WORKGROUPS)))
     if per_slice is None:
-        per_slice = int(os.environ.get('INVPREF_PLAN_PER_SLICE', str(min(8, max(2, -(-n // (ng * target)))))))
+        per_slice = int(os.environ.get('INVPREF_PLAN_PER_SLICE', str(2 if n <= 4 * ng * target // 3 else 16)))
     if item_per_slice is None:
         item_per_slice = int(os.environ.get('INVPREF_PLAN_ITEM_PER_SLICE', str(min(32, max(2, -(-n // (ng * 2 * target)))))))
 

@@ -320,50 +320,111 @@ def eager_kernel_times(mgr):
     return out
 
 
-def roofline_large(dev):
-    """The same fused kernel on ONE cache-exceeding launch (SURVEY.md §8(d) "Roofline launch"): 2^20 uniformly random
-    interactions over tables of 400 000 users x 100 000 items, D=64, E=4 -- 256 MB per flat buffer, five buffers, far
-    beyond the 256 MiB Infinity Cache, so this is the HBM figure; the Yahoo-sized step above is cache-resident."""
+def step_bench(dev, Us, Is, Es, Ds, Bs, n_steps, zipf=False, seed=5, note=''):
+    """The planned fused step (M-step + dense Adam, the headline's kernels) at another shape: `n_steps` DIFFERENT
+    minibatches of Bs synthetic interactions, ping-pong parameter buffers, all steps captured in one HIP graph and timed
+    with HIP events on the launch stream -- the training loop's conditions without the manager around it.  Returns the
+    whole-step figures (both launches, kernel boundaries included) against the 8 TB/s yardstick."""
     import numpy as np
     import torch
     from invpref_kdd_2022_amd import ops, plan as planlib, synth
-    Ul, Il, Bl = 400000, 100000, 1 << 20
-    rs = np.random.RandomState(5)
-    u, v = rs.randint(0, Ul, Bl), rs.randint(0, Il, Bl)
-    y = (rs.random_sample(Bl) < 0.5).astype(np.float32)
-    tabs = synth.tables(6, Ul, Il, E, D)
+    data = synth.interactions(seed, Us, Is, n_steps * Bs, implicit=True, zipf=zipf)
+    rs = np.random.RandomState(seed + 1)
+    tabs = synth.tables(seed + 2, Us, Is, Es, Ds)
     P = [torch.from_numpy(tabs[k]).to(dev) for k in ops.PARAM_NAMES]
     P2 = [torch.zeros_like(p) for p in P]
     M = [torch.zeros_like(p) for p in P]
     V = [torch.zeros_like(p) for p in P]
     t0 = time.perf_counter()
-    dp = planlib.upload(planlib.build_row_plan(u, v, y, Ul, Il, factor_num=D), dev)
+    plans = [planlib.upload(planlib.build_row_plan(data[k * Bs:(k + 1) * Bs, 0], data[k * Bs:(k + 1) * Bs, 1],
+                                                   data[k * Bs:(k + 1) * Bs, 2], Us, Is, factor_num=Ds), dev)
+             for k in range(n_steps)]
     plan_s = time.perf_counter() - t0
-    e = torch.from_numpy(rs.randint(0, E, Bl).astype(np.int64)).to(dev)
-    yt, w = torch.from_numpy(y).to(dev), torch.rand(Bl, device=dev)
+    e = torch.from_numpy(rs.randint(0, Es, n_steps * Bs).astype(np.int64)).to(dev)
+    yt = torch.from_numpy(data[:, 2].astype(np.float32)).to(dev)
+    w = torch.rand(n_steps * Bs, device=dev)
     ws = ops.Workspace(dev)
     losses = torch.zeros(6, device=dev)
     cf = [YAHOO[k] for k in ('invariant_coe', 'env_aware_coe', 'env_coe', 'L2_coe', 'L1_coe', 'alpha')]
     flags = ops.flags_of(True, False, True, True, False)
-    times = []
-    a, b = P, P2
-    for it in range(4):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        ops.mstep_rows_adam(a, b, M, V, dp, e, yt, w, Bl, cf, flags, losses, it + 1, 0.005, ws)
-        e1.record()
+
+    def run():
+        a, b = P, P2
+        for k in range(n_steps):
+            sl = slice(k * Bs, (k + 1) * Bs)
+            ops.mstep_rows_adam(a, b, M, V, plans[k], e[sl], yt[sl], w[sl], Bs, cf, flags, losses, k + 1, 0.005, ws)
+            a, b = b, a
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        run()
         torch.cuda.synchronize()
-        times.append(e0.elapsed_time(e1))
-        a, b = b, a
-    ms = min(times[1:])
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            run()
+        g.replay()
+        torch.cuda.synchronize()
+        best, reps = 1e30, max(1, int(2000 // max(1, n_steps)) if Bs <= 70000 else 2)
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / (reps * n_steps))
+    assert bool(torch.isfinite(losses).all())
     Pn = sum(p.numel() for p in P)
-    nbytes = Bl * (32 + 16 * D) + 24 * Pn
-    return {'bound': 'hbm', 'achieved': nbytes / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': None, 'cache_resident': False,
-            'kernel': 'the fused M-step + Adam step (same kernels as the headline), one launch',
-            'launch_ms': ms, 'algorithmic_bytes_per_launch': nbytes,
-            'workload': f'{Bl} uniform interactions, {Ul} x {Il} tables, D={D}, E={E}: {4 * Pn / 1e6:.0f} MB per flat '
-                        f'buffer (p, p\', m, v: {16 * Pn / 1e6:.0f} MB)', 'plan_build_s': plan_s}
+    nbytes = Bs * (32 + 16 * Ds) + 24 * Pn
+    res = {'ms_per_step': best, 'interactions_per_s': Bs / (best * 1e-3), 'bound': 'hbm',
+           'achieved': nbytes / (best * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+           'frac': nbytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_step': nbytes,
+           'cache_resident': 16 * Pn < 200e6,
+           'shape': {'users': Us, 'items': Is, 'envs': Es, 'factor_num': Ds, 'minibatch': Bs, 'minibatches': n_steps,
+                     'ids': 'zipf' if zipf else 'uniform'},
+           'flat_buffer_MB': 4 * Pn / 1e6, 'plan_build_s': plan_s,
+           'timing': f'HIP events around {reps} replays of a graph of {n_steps} fused steps (different minibatch plans, '
+                     'ping-pong parameter buffers); whole step = both launches'}
+    if note:
+        res['note'] = note
+    del plans, P, P2, M, V
+    torch.cuda.empty_cache()
+    return res
+
+
+def other_configs(dev):
+    """BASELINE.json configs 3 and 5 (and config 4's large-batch variant) on ONE GPU, driver-run: the planned fused step
+    at the MovieLens shape (MovieLens_InvPref.py:17-26), at the MIND shape (MIND_InvPref.py:17-25: the full minibatch
+    and the 1/8 row share one of config 5's eight ranks walks), and the Yahoo shape with one minibatch per epoch."""
+    out = {}
+    out['movielens_config3'] = step_bench(dev, 6040, 3706, 8, 128, 65536, 16, seed=31,
+                                          note='BASELINE.json configs[2]: 2^20 uniform synthetic interactions, 16 minibatches')
+    out['mind_config5_full_minibatch'] = step_bench(dev, 50000, 51283, 16, 256, 262144, 4, seed=41,
+                                                    note='BASELINE.json configs[4] on one GPU: the whole 262 144-row minibatch')
+    out['mind_config5_rank_share'] = step_bench(dev, 50000, 51283, 16, 256, 32768, 8, seed=43,
+                                                note='the 1/8 row share of a MIND minibatch one of eight ranks walks, '
+                                                     'fused form (a sharded rank runs gradient pass + all-reduce + Adam)')
+    out['yahoo_config4_large_batch'] = step_bench(dev, U, I, E, D, N_PER_GPU, 2, zipf=True, seed=SEED,
+                                                  note='SURVEY 8(d)-4: B = N = 250 154, one optimiser step per epoch')
+    return out
+
+
+def roofline_large(dev):
+    """SURVEY.md 8(d) "Roofline launch": the same fused step on cache-exceeding launches -- uniformly random interactions
+    over tables of 400 000 users x 100 000 items (256 MB .. 1 GB per flat buffer, four to five buffers: far beyond the
+    256 MiB Infinity Cache), D in {64, 128, 256} with E = 4 / 8 / 16.  INVPREF_BENCH_LARGE_LOG2N (default 22 / 21 / 20 for
+    the three row lengths; 24 = SURVEY's size where the host-side plan build is affordable)."""
+    res = {}
+    forced = os.environ.get('INVPREF_BENCH_LARGE_LOG2N')
+    for Dl, El, lg in ((64, 4, 22), (128, 8, 21), (256, 16, 20)):
+        lg = int(forced) if forced else lg
+        r = step_bench(dev, 400000, 100000, El, Dl, 1 << lg, 2, seed=5 + Dl)
+        r['kernel'] = 'the fused M-step + Adam step (same kernels as the headline)'
+        res[f'D{Dl}_E{El}'] = r
+    head = dict(res['D64_E4'])
+    head['sweep'] = {k: {kk: v[kk] for kk in ('frac', 'achieved', 'ms_per_step', 'algorithmic_bytes_per_step', 'shape')}
+                     for k, v in res.items()}
+    head['traffic'] = None
+    return head
 
 
 def eval_timing(dev):
@@ -491,7 +552,10 @@ def main():
         out['detail']['user_sharded'] = {'value': steps_u * B_PER_GPU * world / dt_u, 'ms_per_step': dt_u / steps_u * 1e3,
                                          'steps': steps_u, 'all_reduce_bytes': 4 * (mgr_u.state.n + 8 - mgr_u._ar_lo)}
     if rank == 0 and world == 1 and not args.no_extras:
+        del mgr
+        torch.cuda.empty_cache()
         out['roofline_large'] = roofline_large(dev)
+        out['detail']['configs'] = other_configs(dev)
         out['detail']['evaluation'] = eval_timing(dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()

@@ -258,13 +258,11 @@ __device__ __forceinline__ void eval_interaction(Eval<EMAX> &o, float4 pu, float
     if (EMAX <= 4) {
         // the W rows are read from LDS ONCE, unconditionally and back to back (rows c >= E are staged as zeros);
         // everything after is selects and arithmetic
-        float4 wrow[EMAX <= 4 ? EMAX : 1];
         float z[EMAX <= 4 ? EMAX : 1], mx = -__builtin_inff();
 #pragma unroll
-        for (int c = 0; c < (EMAX <= 4 ? EMAX : 1); c++) wrow[c] = *reinterpret_cast<const float4 *>(sW + c * DP + lg * 4);
-#pragma unroll
         for (int c = 0; c < (EMAX <= 4 ? EMAX : 1); c++) {
-            const float zc = group_sum<LG>(dot4(o.x, wrow[c])) + sb[c];
+            const float4 wrow = *reinterpret_cast<const float4 *>(sW + c * DP + lg * 4);
+            const float zc = group_sum<LG>(dot4(o.x, wrow)) + sb[c];
             z[c] = c < E ? zc : -__builtin_inff();
             mx = z[c] > mx ? z[c] : mx;
         }
@@ -278,7 +276,8 @@ __device__ __forceinline__ void eval_interaction(Eval<EMAX> &o, float4 pu, float
 #pragma unroll
         for (int c = 0; c < (EMAX <= 4 ? EMAX : 1); c++) {
             o.gz[c] = c < E ? k.cc * cw_cls * (z[c] * rse - (c == e ? 1.f : 0.f)) : 0.f;
-            f4fma(o.gx, o.gz[c], wrow[c]);
+            // (read again rather than held across the softmax: 16 registers at the kernel's pressure peak)
+            f4fma(o.gx, o.gz[c], *reinterpret_cast<const float4 *>(sW + c * DP + lg * 4));
         }
     } else {
         // larger classifiers keep ONE class per lane: the logit of class c is a group-uniform value after the
@@ -382,9 +381,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
     float *slab = a.slabs + (int64_t)slab_index * G::SLAB;   // this workgroup's partial slab
 
     for (int r = r0; r < r0 + nr; r++) {
-        // (the next round's descriptor flies under this round: a further round does not start with a dependent load)
         const int4 dd = d, dd1 = d1;   // (this round's copy: what the lambdas below read)
-        if (r + 1 < r0 + nr) { d = a.desc[((r + 1) * NG + grp) * 2]; d1 = a.desc[((r + 1) * NG + grp) * 2 + 1]; }
         const int row = dd.x, meta = dd.y;
         const bool active = row >= 0, leader = meta & 1;
         const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
@@ -497,12 +494,14 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                             gzv[G::REG ? c4 + 2 : 0] = g4.z; gzv[G::REG ? c4 + 3 : 0] = g4.w;
                         }
                     }
+#ifndef DBG_NO_EXD
 #pragma unroll
                     for (int c = 0; c < (G::REG ? EMAX : 1); c++) {
                         f4fma(dW[c], gzv[c], o.x);
                         f4add(dE[c], c == e ? oo : f4zero());
                         dB[c] += gzv[c];
                     }
+#endif
                 } else {
                     float *rx = lds + L::rec + (((it_total & 1) * NG + grp) * 2) * DP;
                     *reinterpret_cast<float4 *>(rx + lg * 4) = o.x;
@@ -564,6 +563,8 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             }
         }
         if (r == r0) STAMP(4);
+        // (requested here, behind the interaction loop's register peak: it flies under the slice meet and the row finish)
+        if (r + 1 < r0 + nr) { d = a.desc[((r + 1) * NG + grp) * 2]; d1 = a.desc[((r + 1) * NG + grp) * 2 + 1]; }
         const float cnt = (float)(meta >> 9);
         if (active && leader) {   // regulariser reports: the user's rows count once per interaction
             accL2 += cnt * (f4sq(oi) + f4sq(oe));

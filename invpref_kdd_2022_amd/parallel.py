@@ -128,6 +128,13 @@ def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     return t
 
 
+def all_reduce_min_(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place minimum over ranks (collective decisions: every rank must take the same branch)."""
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return t
+
+
 def init_from_env(backend: str | None = None):
     """torchrun-style init (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*): one process per GPU."""
     import os

@@ -32,7 +32,7 @@ import ctypes as C
 
 from . import _capi, ops
 from . import plan as planlib
-from .parallel import RowShard, UserShard, all_reduce_sum_
+from .parallel import RowShard, UserShard, all_reduce_min_, all_reduce_sum_
 
 LOSS_KEYS = ('invariant_loss', 'env_aware_loss', 'envs_loss', 'L2_reg', 'L1_reg', 'loss')
 _ALIGN = 64  # floats; every table starts on a 256-byte boundary of the flat buffer
@@ -179,11 +179,11 @@ class _InvPrefTrainManager:
         # (measured, tools/kbench.py, planned fused step vs plan-free gradient + Adam: Yahoo class 19 vs 78 us,
         #  MovieLens class -- E = 8, D = 128, 65 536 interactions -- 110 vs 181 us, MIND class -- E = 16, D = 256,
         #  262 144 interactions -- 1.1 vs 1.66 ms: the plan wins everywhere, so it is the default for every shape)
-        # rows of more than 128 floats (four 16-lane chunks): the gradient pass + the flat Adam kernel is faster than
-        # the fused pass there (no LDS-DMA moment prefetch at that row size; MIND class 0.88 vs 0.94 ms per step)
-        self._unfused = self.use_plan and model.factor_num % 4 == 0 and model.factor_num > 128 \
-            and os.environ.get('INVPREF_FUSED', '') != '1'
+        # INVPREF_UNFUSED=1: gradient pass + flat Adam kernel instead of the fused pass on one GPU (the sequence a sharded
+        # rank runs, without the exchange); every row length takes the fused pass by default
+        self._unfused = self.use_plan and os.environ.get('INVPREF_UNFUSED', '') == '1'
         self._plans = None
+        self._batch_plans, self.planned_batch_steps = {}, 0   # train_a_batch on caller tensors: see _cached_batch_plan
         # runs of whole epochs as one HIP graph launch (single GPU, planned path); INVPREF_NO_GRAPH=1 disables
         self.use_graph = os.environ.get('INVPREF_NO_GRAPH', '0') != '1'
         # testing aid: run the multi-GPU step sequence (gradient pass -> all-reduce -> stand-alone Adam) on one rank
@@ -269,11 +269,50 @@ class _InvPrefTrainManager:
             t = torch.tensor([bn], dtype=torch.int64, device=self.device)
             all_reduce_sum_(t, self.process_group)
             bn = int(t.item())
-        self._step(batch_users_tensor.contiguous(), batch_items_tensor.contiguous(),
-                   batch_scores_tensor.float().contiguous(), batch_envs_tensor.contiguous(),
-                   batch_sample_weights.contiguous(), alpha, bn)
+        dp = self._cached_batch_plan(batch_users_tensor, batch_items_tensor, batch_scores_tensor)
+        if dp is not None:
+            # the reference's own loop (`for batch in mini_batch(...)`, train.py:204-233) hands over the same slices of
+            # the same resident tensors every epoch: from their second sighting they run the planned fused step
+            st = self.state
+            st.losses6.zero_()
+            st.step += 1
+            self._sched_synced = False
+            ops.mstep_rows_adam(st.p_views, st.p_views_alt, st.m_views, st.v_views, dp, batch_envs_tensor.contiguous(),
+                                batch_scores_tensor.float().contiguous(), batch_sample_weights.contiguous(), bn,
+                                self._coefs(alpha), self._flags, st.losses6, st.step, self.lr, self.workspace,
+                                pure=self._pure)
+            st.swap()
+            self.planned_batch_steps += 1
+        else:
+            self._step(batch_users_tensor.contiguous(), batch_items_tensor.contiguous(),
+                       batch_scores_tensor.float().contiguous(), batch_envs_tensor.contiguous(),
+                       batch_sample_weights.contiguous(), alpha, bn)
         vals = self.state.losses6.tolist()
         return dict(zip(LOSS_KEYS, vals))
+
+    # row plans of caller-supplied minibatches, keyed by the identity of the tensors they were built from: (data_ptr,
+    # length, _version) of users / items / scores -- a slice of a resident tensor that nobody has written to keeps all three
+    _BATCH_PLAN_CACHE_MAX = 4096
+
+    def _cached_batch_plan(self, users, items, scores):
+        if not (self.use_plan and self.world_size == 1 and not self._unfused and not self._force_sharded_path
+                and users.is_cuda and users.numel() > 0 and users.is_contiguous() and items.is_contiguous()
+                and os.environ.get('INVPREF_NO_BATCH_PLAN_CACHE', '0') != '1'):
+            return None
+        key = tuple(x for t in (users, items, scores) for x in (t.data_ptr(), t.numel(), t._version, t.dtype))
+        hit = self._batch_plans.get(key)
+        if hit is None:
+            if len(self._batch_plans) >= self._BATCH_PLAN_CACHE_MAX:
+                self._batch_plans.clear()
+            self._batch_plans[key] = 1          # first sighting: remember it, run plan-free
+            return None
+        if hit == 1:                            # second sighting: invert the scatter pattern once (host side)
+            hit = planlib.upload(planlib.build_row_plan(users.cpu().numpy(), items.cpu().numpy(),
+                                                        scores.float().cpu().numpy(), self.model.user_num,
+                                                        self.model.item_num, factor_num=self.model.factor_num),
+                                 self.device)
+            self._batch_plans[key] = hit
+        return hit
 
     # ---- the epoch loop: every per-minibatch argument (views of the resident interaction arrays, the row plan,
     #      the zero-initialised scratch) is prepared once; a step is one or two torch.ops.invpref.* calls
@@ -456,12 +495,24 @@ class _InvPrefTrainManager:
             n = min(want, self._graph_epochs)
             steps = n * self.batch_num
             self._sched_prepare(steps)
+            fresh = self._graph_key(n) not in self._graphs
             try:
                 g = self._graph_for(n)
             except Exception as exc:   # e.g. a collective library that cannot record into a graph: stay eager
                 import warnings
                 warnings.warn(f'HIP-graph capture of the epoch failed ({exc!r}); continuing with eager launches')
+                g = None
+            if fresh and self.world_size > 1:
+                # graph or eager changes the order and the sizes of the collectives that follow (one loss all-reduce per
+                # replayed run against one per epoch): a capture that failed on ANY rank puts EVERY rank on eager launches
+                ok = torch.tensor([0 if g is None else 1], dtype=torch.int32, device=self.device)
+                all_reduce_min_(ok, self.process_group)
+                if int(ok.item()) == 0:
+                    g = None
+                    self._graphs.pop(self._graph_key(n), None)
+            if g is None:
                 self.use_graph = False
+                self._graphs_agreed = None
                 self._loss_slot = 0
         if g is not None:
             g.replay()
@@ -490,9 +541,19 @@ class _InvPrefTrainManager:
         """Are whole epochs replayed as HIP graphs?  (after the first, eagerly issued, epoch)"""
         if getattr(self, '_raw_ptrs', None) is None:
             self._raw_setup()
-        return bool(self.use_graph and self.use_plan and self.users_tensor.is_cuda
+        mine = bool(self.use_graph and self.use_plan and self.users_tensor.is_cuda
                     and self.batch_num <= self._SCHED_N // 2
                     and (self._fused_seq() or (self._adam_ranges_ok and self._graph_collectives())))
+        if self.world_size == 1:
+            return mine
+        # The decision must be the SAME on every rank (it fixes the sequence of collectives), but its inputs are not:
+        # _adam_ranges_ok depends on this rank's row range (user-sharded runs with factor_num % 4 != 0).  Agreed once
+        # per manager state with an all-reduce(MIN); a failed capture resets it (see _enqueue_epochs).
+        if getattr(self, '_graphs_agreed', None) is None or self._graphs_agreed[0] != mine:
+            ok = torch.tensor([1 if mine else 0], dtype=torch.int32, device=self.device)
+            all_reduce_min_(ok, self.process_group)
+            self._graphs_agreed = (mine, bool(int(ok.item())))
+        return self._graphs_agreed[1]
 
     def _graph_collectives(self) -> bool:
         """May the step's all-reduce be captured?  Yes on the RCCL backend (or when there is none to capture);
@@ -504,10 +565,13 @@ class _InvPrefTrainManager:
         import torch.distributed as dist
         return dist.get_backend(self.process_group) == 'nccl'
 
+    def _graph_key(self, n: int):
+        return (self.state.p_views[0].data_ptr(), n, self.state.step & 1)
+
     def _graph_for(self, n: int):
         """The HIP graph of n epochs starting from the current parameter buffer (captured on first use)."""
         st = self.state
-        key = (id(st.p_views), n, st.step & 1)
+        key = self._graph_key(n)
         g = self._graphs.get(key)
         if g is None:
             step0, views0 = st.step, st.p_views
@@ -598,7 +662,7 @@ class _InvPrefTrainManager:
     def _cluster_replay(self, eps):
         """The E-step + the count / weight half of stat_envs as a captured graph, one per parameter buffer (the
         fused M-step ping-pongs between two) and per interaction-array set; outputs live in the graph's pool."""
-        key = (id(self.state.p_views), self.envs.data_ptr(), self.users_tensor.data_ptr(), eps is not None)
+        key = (self.state.p_views[0].data_ptr(), self.envs.data_ptr(), self.users_tensor.data_ptr(), eps is not None)
         ent = self._estep_graphs.get(key)
         if ent is None:
             eps_buf = None if eps is None else torch.empty_like(eps)

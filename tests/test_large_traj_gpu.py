@@ -35,7 +35,7 @@ def test_manager_vs_reference_large_trajectory(case):
                                use_recommend_re_weight=True, cluster_use_random_sort=False)
     env0 = z['env0'].astype(np.int64)
     np.testing.assert_array_equal(mgr.envs.cpu().numpy(), env0)
-    assert mgr.use_plan and mgr._unfused == (D > 128)
+    assert mgr.use_plan and not mgr._unfused
     mgr.stat_envs()
     steps, ep = [], []
     for _ in range(epochs):

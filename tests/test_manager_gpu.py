@@ -95,6 +95,40 @@ def test_g4_yahoo_like_trajectory_through_manager():
     assert sum(cnts[0].values()) == len(data)
 
 
+def test_reference_loop_through_train_a_batch_is_planned_from_its_second_epoch():
+    """The reference's own epoch loop (train.py:204-233: `for batch in mini_batch(...)`: train_a_batch on slices of the
+    resident tensors) driven from outside the manager: the first epoch runs plan-free (float-atomic scatter-add), every
+    later one the planned fused step -- the row plans are cached by the identity of the slices -- and the losses follow the
+    reference's recorded trajectory (golden g4) at 1e-5."""
+    z = np.load(os.path.join(G, 'g4_yahoo_like_traj.npz'))
+    U, I, E, D, bs, epochs, seed = [int(x) for x in z['meta']]
+    data = synth.yahoo_like(seed)
+    tabs = synth.tables(seed + 7, U, I, E, D, std=0.01)
+    model = InvPrefImplicit(U, I, E, D, reg_only_embed=True, reg_env_embed=False)
+    model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+    np.random.seed(seed)
+    mgr = _mgr(ImplicitTrainManager, model, data, z, use_class_re_weight=True, use_recommend_re_weight=False)
+    mgr.stat_envs()
+    n = mgr.users_tensor.shape[0]
+    trace = []
+    for ep in range(3):
+        rows = []
+        for lo in range(0, n, bs):     # utils.mini_batch (utils.py:12-19): contiguous, unshuffled slices
+            sl = slice(lo, min(lo + bs, n))
+            d = mgr.train_a_batch(mgr.users_tensor[sl], mgr.items_tensor[sl], mgr.scores_tensor[sl], mgr.envs[sl],
+                                  mgr.sample_weights[sl], mgr.alpha)
+            rows.append([d[k] for k in LOSS_KEYS])
+        trace.append(np.mean(np.array(rows, np.float64), axis=0))
+        assert mgr.planned_batch_steps == ep * len(rows)      # epoch 0 plan-free, then every step planned
+    np.testing.assert_allclose(np.array(trace)[:, [0, 1, 2, 5]], z['loss_trace'][:3, [0, 1, 2, 5]], rtol=1e-5)
+    # a tensor written in place is a different minibatch: its plan is not reused
+    mgr.scores_tensor[:bs] = 1 - mgr.scores_tensor[:bs]
+    before = mgr.planned_batch_steps
+    mgr.train_a_batch(mgr.users_tensor[:bs], mgr.items_tensor[:bs], mgr.scores_tensor[:bs], mgr.envs[:bs],
+                      mgr.sample_weights[:bs], mgr.alpha)
+    assert mgr.planned_batch_steps == before
+
+
 def test_g12_train_control_flow_matches_reference():
     """train()'s outer loop (train.py:282-342): which epochs evaluate (evaluate_interval, test_begin_epoch), which cluster
     (cluster_interval inside [begin_cluster_epoch, stop_cluster_epoch), diff_num 0 recorded outside) -- the lists the
@@ -444,31 +478,24 @@ def test_sharded_epochs_graph_vs_eager(monkeypatch, mode):
                         {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}))
     finally:
         dist.destroy_process_group()
-    # Two runs of the same sequence differ through the order of the float atomics (hot rows, E x D slabs).  Up to the
-    # E-step that stays at rounding level: 5e-5 on the five epochs before it (the bound the other multi-epoch manager tests
-    # use).  The E-step then turns last-bit differences into a few different assignments, and the two epochs after it
-    # train on slightly different environments: those are held to 1e-3 -- this test is about the mechanics (capture /
-    # replay with the collective inside, the device-side schedule), whose failures are gross (a wrong Adam scalar or a
-    # stale alpha moves the losses by percents).  (Seen once in ~10 runs with the tight bound everywhere.)
-    np.testing.assert_allclose(res[0][0][:5], res[1][0][:5], rtol=5e-5)
-    np.testing.assert_allclose(res[0][0][5:], res[1][0][5:], rtol=1e-3)
-    assert abs(res[0][1] - res[1][1]) <= max(5, len(data) // 2000)
-    lr = float(z['coefs'][6])
+    # The planned step has no float atomics and every sum has a fixed order; the scalars of a step are the same floats
+    # whether they come from the call (eager) or from the device-side schedule (graph replay): the two runs must agree
+    # BITWISE -- losses of every epoch, the E-step's assignments, every parameter.
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    assert res[0][1] == res[1][1]
     for k in O.PARAM_NAMES:
-        dlt = np.abs(res[0][2][k] - res[1][2][k])
-        assert np.quantile(dlt, 0.99) < (2e-5 if dlt.size > 4096 else 2e-4) and np.quantile(dlt, 0.9999) < 2e-3 \
-            and dlt.max() < 4 * lr, k
+        np.testing.assert_array_equal(res[0][2][k], res[1][2][k], err_msg=k)
 
 
 def test_wide_rows_take_the_unfused_sequence(monkeypatch):
-    """factor_num > 128 (four 16-lane chunks per row): the manager runs gradient pass + flat Adam instead of the fused
-    pass (faster at that row size); INVPREF_FUSED=1 forces the fused pass.  Same trajectory either way."""
+    """factor_num > 128 (64-lane groups): the fused pass is the default at every row length; INVPREF_UNFUSED=1 runs the
+    gradient pass + flat Adam sequence (what a sharded rank runs) on one GPU.  Same trajectory either way."""
     U, I, E, D, n, bs = 300, 200, 5, 256, 6000, 1024
     data = synth.interactions(77, U, I, n, implicit=True)
     tabs = synth.tables(78, U, I, E, D, std=0.05)
     res = []
     for fused in ('', '1'):
-        monkeypatch.setenv('INVPREF_FUSED', fused)
+        monkeypatch.setenv('INVPREF_UNFUSED', '' if fused else '1')
         model = InvPrefImplicit(U, I, E, D, reg_only_embed=False, reg_env_embed=True)
         model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
         np.random.seed(5)

@@ -544,9 +544,21 @@ def main():
         'roofline': roofline, 'detail': detail,
     }
     if world > 1:
-        # the xGMI-first layout beside the configuration BASELINE.json names
+        # beside the headline (rows, reduce-scatter -> slice Adam -> all-gather): the literal all-reduce form of
+        # BASELINE.json configs[3], and the xGMI-first user-sharded layout
+        out['config']['parallelism'] = (f'rows-sharded x{world}, exchange {mgr.exchange}: '
+                                        + ('reduce-scatter(grad) + all-gather(param), ' if mgr.exchange == 'scatter' else '1 all-reduce, ')
+                                        + f'{4 * mgr.state.cap} B of flat buffer per step')
         del mgr
         torch.cuda.empty_cache()
+        os.environ['INVPREF_EXCHANGE'] = 'allreduce'
+        mgr_a = build_manager(dev, rank, world, 'rows')
+        dt_a, steps_a, _, _ = timed_run(mgr_a, world, args.steps, args.warmup)
+        out['detail']['rows_allreduce'] = {'value': steps_a * B_PER_GPU * world / dt_a, 'ms_per_step': dt_a / steps_a * 1e3,
+                                           'steps': steps_a, 'all_reduce_bytes': 4 * (mgr_a.state.n + 8 - mgr_a._ar_lo)}
+        del mgr_a
+        torch.cuda.empty_cache()
+        os.environ.pop('INVPREF_EXCHANGE', None)
         mgr_u = build_manager(dev, rank, world, 'users')
         dt_u, steps_u, _, _ = timed_run(mgr_u, world, args.steps, args.warmup)
         out['detail']['user_sharded'] = {'value': steps_u * B_PER_GPU * world / dt_u, 'ms_per_step': dt_u / steps_u * 1e3,

@@ -148,11 +148,15 @@ class _BasicTrainManager(_InvPrefTrainManager):
         self.alpha, self.update_alpha = 0., False
         self.cluster_interval = 1 << 62
         self.model.to(self.device)
-        self.state = FlatState(model.tables(), self.device)     # [user table | item table]: the shared part is last
+        # (row-sharded: reduce-scatter / slice Adam / all-gather exchange like the InvPref managers, train.py)
+        self.exchange = os.environ.get('INVPREF_EXCHANGE', 'scatter') if self.shard_mode == 'rows' else 'allreduce'
+        self.state = FlatState(model.tables(), self.device,     # [user table | item table]: the shared part is last
+                               chunks=self.world_size if self.exchange == 'scatter' else 1)
         self._setup_ranges(model)
         self.workspace = ops.Workspace(self.device)
         self._flags = ops.flags_of(self.implicit, False, False, True, False, dense_reg=False) | _capi.PURE_MF
         self.use_plan, self._plans = True, None
+        self._batch_plans, self.planned_batch_steps = {}, 0
         self.use_graph = os.environ.get('INVPREF_NO_GRAPH', '0') != '1'
         import torch.distributed as _dist
         self._force_sharded_path, self._unfused = forced, False

@@ -128,6 +128,35 @@ def all_reduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     return t
 
 
+def reduce_scatter_sum_(full: torch.Tensor, rank: int, world: int, group=None) -> torch.Tensor:
+    """In-place reduce-scatter of a flat buffer of world * chunk floats: on return this rank's chunk
+    full[rank*chunk : (rank+1)*chunk] holds the sum over ranks (the other chunks are left unspecified).  RCCL's in-place
+    form (output = the rank's own chunk of the input); gloo has no reduce-scatter: there it is an all-reduce of the whole
+    buffer, which leaves the same values in the rank's chunk."""
+    import torch.distributed as dist
+    chunk = full.numel() // world
+    assert chunk * world == full.numel()
+    if dist.get_backend(group) == 'nccl':
+        dist.reduce_scatter_tensor(full[rank * chunk:(rank + 1) * chunk], full, op=dist.ReduceOp.SUM, group=group)
+    else:
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+    return full[rank * chunk:(rank + 1) * chunk]
+
+
+def all_gather_chunks_(full: torch.Tensor, rank: int, world: int, group=None) -> torch.Tensor:
+    """In-place all-gather: every rank contributes its chunk full[rank*chunk : (rank+1)*chunk] and receives all of
+    them in place (RCCL's in-place form; gloo: through a list of chunk views)."""
+    import torch.distributed as dist
+    chunk = full.numel() // world
+    assert chunk * world == full.numel()
+    if dist.get_backend(group) == 'nccl':
+        dist.all_gather_into_tensor(full, full[rank * chunk:(rank + 1) * chunk], group=group)
+    else:
+        mine = full[rank * chunk:(rank + 1) * chunk].clone()
+        dist.all_gather([full[r * chunk:(r + 1) * chunk] for r in range(world)], mine, group=group)
+    return full
+
+
 def all_reduce_min_(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place minimum over ranks (collective decisions: every rank must take the same branch)."""
     import torch.distributed as dist

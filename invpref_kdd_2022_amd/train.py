@@ -32,7 +32,8 @@ import ctypes as C
 
 from . import _capi, ops
 from . import plan as planlib
-from .parallel import RowShard, UserShard, all_reduce_min_, all_reduce_sum_
+from .parallel import (RowShard, UserShard, all_gather_chunks_, all_reduce_min_, all_reduce_sum_,
+                       reduce_scatter_sum_)
 
 LOSS_KEYS = ('invariant_loss', 'env_aware_loss', 'envs_loss', 'L2_reg', 'L1_reg', 'loss')
 _ALIGN = 64  # floats; every table starts on a 256-byte boundary of the flat buffer
@@ -45,10 +46,12 @@ def transfer_loss_dict_to_line_str(d: dict) -> str:
 class FlatState:
     """params / grads / exp_avg / exp_avg_sq as four flat buffers + per-table views."""
 
-    def __init__(self, tabs, device, order=None):
+    def __init__(self, tabs, device, order=None, chunks: int = 1):
         """tabs: the model's parameter tensors (InvPref: the seven of state_dict order; PureMF: two).
         order: physical placement of the tables inside the flat buffers (default: as listed).  A user-sharded
-        run puts the two user tables first, so that everything the ranks share is ONE contiguous range."""
+        run puts the two user tables first, so that everything the ranks share is ONE contiguous range.
+        chunks: the buffers' capacity `cap` is padded so that it splits into that many equal pieces of whole
+        256-byte lines (the reduce-scatter / all-gather exchange of a row-sharded run); `n` stays the used length."""
         tabs = list(tabs)
         self.shapes = [tuple(p.shape) for p in tabs]
         self.offsets = [0] * len(tabs)
@@ -57,12 +60,16 @@ class FlatState:
             self.offsets[i] = off
             off += (tabs[i].numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.n = off
-        self.param = torch.zeros(self.n, dtype=torch.float32, device=device)
+        piece = max(1, chunks) * _ALIGN
+        self.cap = cap = (off + piece - 1) // piece * piece
+        self.param_full = torch.zeros(cap, dtype=torch.float32, device=device)
+        self.param = self.param_full[:self.n]
         # +8: the six loss partials ride at the tail of the gradient buffer so that ONE all-reduce
-        # carries everything
-        self.grad_ext = torch.zeros(self.n + 8, dtype=torch.float32, device=device)
-        self.grad = self.grad_ext[:self.n]
-        self.losses6 = self.grad_ext[self.n:self.n + 6]
+        # carries everything; they sit behind the padding: [0, n) gradient, [cap, cap + 6) losses
+        self.grad_full = torch.zeros(cap + 8, dtype=torch.float32, device=device)
+        self.grad_ext = self.grad_full          # gradient | padding (zeros) | loss tail: one contiguous range
+        self.grad = self.grad_full[:self.n]
+        self.losses6 = self.grad_full[cap:cap + 6]
         self.exp_avg = torch.zeros(self.n, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(self.n, dtype=torch.float32, device=device)
         # double buffer for the fused M-step+Adam pass (reads old rows, writes new rows)
@@ -168,8 +175,15 @@ class _InvPrefTrainManager:
         self.model.to(self.device)
         # user-sharded: [Pu | Pa | Qi | Qa | Ev | W | b]: the replicated part (items + small tables) and the loss
         # tail form one contiguous range for the all-reduce, the owned user rows two ranges for Adam
+        # row-sharded exchange (INVPREF_EXCHANGE): "scatter" = reduce-scatter of the flat gradient, Adam on this rank's 1/G
+        # slice of the flat buffers, all-gather of the new parameters (same bytes on the wire as the all-reduce, the dense
+        # Adam stream cut G-fold); "allreduce" = SURVEY 8(e) as written: every rank reduces and updates everything
+        self.exchange = os.environ.get('INVPREF_EXCHANGE', 'scatter') if self.shard_mode == 'rows' else 'allreduce'
+        if self.exchange not in ('scatter', 'allreduce'):
+            raise ValueError('INVPREF_EXCHANGE must be "scatter" or "allreduce"')
         self.state = FlatState(model.tables(), self.device,
-                               order=[0, 2, 1, 3, 4, 5, 6] if self.shard_mode == 'users' else None)
+                               order=[0, 2, 1, 3, 4, 5, 6] if self.shard_mode == 'users' else None,
+                               chunks=self.world_size if self.exchange == 'scatter' else 1)
         self._setup_ranges(model)
         self.workspace = ops.Workspace(self.device)
         self._flags = ops.flags_of(self.implicit, use_recommend_re_weight, use_class_re_weight,
@@ -213,6 +227,24 @@ class _InvPrefTrainManager:
         else:
             self._ar_lo = 0
             self._adam_ranges = [(0, st.n)]
+            if self.exchange == 'scatter' and self.world_size > 1:
+                chunk = st.cap // self.world_size          # whole 256-byte lines (FlatState.cap)
+                lo = min(self.rank * chunk, st.n)
+                self._adam_ranges = [(lo, min(chunk, st.n - lo))] if st.n > lo else []
+
+    def _exchange_gradient(self):
+        """the step's exchange in front of Adam (also on the 1-rank group of the forced sharded path: the same
+        collectives, captured and replayed like on N ranks)"""
+        st = self.state
+        if self.exchange == 'scatter':
+            reduce_scatter_sum_(st.grad_full[:st.cap], self.rank, self.world_size, self.process_group)
+        else:
+            all_reduce_sum_(st.grad[self._ar_lo:], self.process_group)
+
+    def _exchange_parameters(self):
+        """the step's exchange behind Adam (scatter mode: every rank updated its own slice of the flat buffer)"""
+        if self.exchange == 'scatter':
+            all_gather_chunks_(self.state.param_full, self.rank, self.world_size, self.process_group)
 
     def sync_parameters(self) -> None:
         """User-sharded runs: bring every rank's copy of the user tables up to date (each rank contributes its
@@ -257,6 +289,10 @@ class _InvPrefTrainManager:
         for o, n in self._adam_ranges:
             ops.adam_(st.param[o:o + n], st.grad[o:o + n], st.exp_avg[o:o + n], st.exp_avg_sq[o:o + n], st.step, self.lr,
                       zero_grad=True)
+        if self.world_size > 1:
+            if self.exchange == 'scatter':
+                st.grad.zero_()             # (only this rank's slice was cleared by its Adam)
+            self._exchange_parameters()     # scatter mode: every rank updated its own slice of the flat buffer
 
     def train_a_batch(self, batch_users_tensor, batch_items_tensor, batch_scores_tensor, batch_envs_tensor,
                       batch_sample_weights, alpha) -> dict:
@@ -387,7 +423,7 @@ class _InvPrefTrainManager:
             ops.mstep_grad(st.p_views, st.g_views, bu, bi, be, by, bw, bn, coefs, self._flags, lp, self.workspace)
         if multi:
             if self.world_size > 1 or self._collective_ok:
-                all_reduce_sum_(st.grad[self._ar_lo:], self.process_group)   # the step's one exchange
+                self._exchange_gradient()   # all-reduce, or reduce-scatter (this rank keeps its slice of the sum)
         if mid_event is not None:
             mid_event.record()
         # the planned gradient pass overwrites every row it is responsible for, so the gradient buffer needs no zeroing
@@ -401,6 +437,10 @@ class _InvPrefTrainManager:
             for o, ln in self._adam_ranges:
                 ops.adam_(st.param[o:o + ln], st.grad[o:o + ln], st.exp_avg[o:o + ln], st.exp_avg_sq[o:o + ln], st.step,
                           self.lr, zero_grad=zero)
+        if multi and (self.world_size > 1 or self._collective_ok):
+            if zero and self.exchange == 'scatter' and self.world_size > 1:
+                st.grad.zero_()   # plan-free gradients ADD: the slices this rank's Adam did not clear must start from zero too
+            self._exchange_parameters()
 
     def _alpha_for(self, k: int) -> float:
         if self.update_alpha:  # train.py:214-217

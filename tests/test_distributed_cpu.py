@@ -222,8 +222,9 @@ YU, YI, YE, YD, YN, YB = 15400, 1000, 4, 16, 250154, 8192
 
 
 def _yahoo_worker(rank, world, port, out_dir, mode):
+    mode, _, exchange = mode.partition('-')
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), INVPREF_SHARD=mode, INVPREF_NO_PLAN='1',
-                      OMP_NUM_THREADS='1')
+                      OMP_NUM_THREADS='1', INVPREF_EXCHANGE=exchange or 'scatter')
     torch.set_num_threads(1)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -246,7 +247,16 @@ def _yahoo_worker(rank, world, port, out_dir, mode):
                                    world_size=world, invariant_coe=3.35, env_aware_coe=9.99, env_coe=9.06, L2_coe=3.13,
                                    L1_coe=0.49, alpha=1.9)
         assert mgr.batch_num == 31 and mgr.shard.global_batch_len(30) == YN - 30 * YB
-        if mode == 'rows':   # the ragged last minibatch: slices differ by at most one row and tile it exactly
+        if mode == 'rows':
+            # scatter exchange: this rank applies Adam to ONE slice of whole 256-byte lines, the slices tile the buffer
+            st = mgr.state
+            assert mgr.exchange == (exchange or 'scatter')
+            if mgr.exchange == 'scatter':
+                chunk = st.cap // world
+                assert st.cap % (world * 64) == 0 and st.cap >= st.n and st.cap - st.n < world * 64
+                assert mgr._adam_ranges == [(rank * chunk, min(chunk, st.n - rank * chunk))]
+            else:
+                assert mgr._adam_ranges == [(0, st.n)]   # the ragged last minibatch: slices differ by at most one row and tile it exactly
             lens = [RowShard(YN, YB, r, world).slice_in_batch(30) for r in range(world)]
             assert lens[0][0] == 0 and lens[-1][1] == YN - 30 * YB and max(b - a for a, b in lens) - min(b - a for a, b in lens) <= 1
         mgr.stat_envs()
@@ -264,7 +274,7 @@ def _yahoo_worker(rank, world, port, out_dir, mode):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('world,mode', [(4, 'rows'), (8, 'rows'), (8, 'users')])
+@pytest.mark.parametrize('world,mode', [(4, 'rows'), (8, 'rows'), (8, 'rows-allreduce'), (8, 'users')])
 def test_yahoo_shaped_epochs_world_4_and_8(tmp_path, world, mode):
     mp.spawn(_yahoo_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
     r = [np.load(tmp_path / f'rank{i}.npz') for i in range(world)]
@@ -273,7 +283,7 @@ def test_yahoo_shaped_epochs_world_4_and_8(tmp_path, world, mode):
         np.testing.assert_array_equal(r[0]['losses'], x['losses'])
         assert int(r[0]['diff']) == int(x['diff'])
     P = 2 * (YU + YI) * YD + 2 * YE * YD + YE
-    if mode == 'rows':
+    if mode.startswith('rows'):
         assert int(r[0]['ar_floats']) >= P + 8            # the whole flat gradient + the loss tail, one all-reduce
     else:
         assert int(r[0]['ar_floats']) < 2 * YI * YD + 2 * YE * YD + YE + 8 + 5 * 64   # item side + small tables only

@@ -136,7 +136,8 @@ def reduce_scatter_sum_(full: torch.Tensor, rank: int, world: int, group=None) -
     import torch.distributed as dist
     chunk = full.numel() // world
     assert chunk * world == full.numel()
-    if dist.get_backend(group) == 'nccl':
+    # (a group smaller than the declared world -- the rank-0-of-N rehearsal on one GPU -- takes the all-reduce form too)
+    if dist.get_backend(group) == 'nccl' and dist.get_world_size(group) == world:
         dist.reduce_scatter_tensor(full[rank * chunk:(rank + 1) * chunk], full, op=dist.ReduceOp.SUM, group=group)
     else:
         dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
@@ -149,6 +150,8 @@ def all_gather_chunks_(full: torch.Tensor, rank: int, world: int, group=None) ->
     import torch.distributed as dist
     chunk = full.numel() // world
     assert chunk * world == full.numel()
+    if dist.get_world_size(group) != world:
+        return full          # (rehearsal on a smaller group: the other ranks' slices simply stay as they are)
     if dist.get_backend(group) == 'nccl':
         dist.all_gather_into_tensor(full, full[rank * chunk:(rank + 1) * chunk], group=group)
     else:

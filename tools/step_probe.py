@@ -132,3 +132,16 @@ for launch, name in ((0, 'launch 1 (eval)'), (1, 'launch 2 (apply)')):
         tail = (j[:, 7] - j[:, 6]) / 100 if launch == 0 else np.zeros(len(j))
         print('  job phases (us, median): stage issue %.2f | descriptor %.2f | gathers+sync %.2f | interactions %.2f | slice meet %.2f | '
               'adam+store %.2f | partial slab %.2f' % (tuple(np.median(ph, axis=0)) + (np.median(tail),)))
+        if os.environ.get('PROBE_TOP'):
+            desc = pl['user_desc'] if launch == 0 else pl['item_desc']
+            idx = np.flatnonzero((kind == 'job') & live)
+            order = idx[np.argsort(-(end[idx] - st[idx, 0]))][:int(os.environ['PROBE_TOP'])]
+            for bk in order:
+                c, jj = bk % ncls, bk // ncls
+                rnd = int(cls[c, 4 * launch]) + jj * rpt
+                meta = desc[rnd, :, 1]
+                cnts = (meta >> 9)[desc[rnd, :, 0] >= 0]
+                print('    wg %4d start %.2f life %.2f phases %s | round %d: slices %d, rows %s' % (
+                    bk, (st[bk, 0] - t0) / 100, (end[bk] - st[bk, 0]) / 100,
+                    ' '.join('%.2f' % x for x in np.diff(st[bk, :7].astype(np.float64)) / 100), rnd, (meta[0] >> 1) & 31,
+                    sorted(set(cnts.tolist()), reverse=True)[:4]))

@@ -437,6 +437,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
 #pragma unroll
         for (int j = 0; j < UE; j++)
             if (UE + j < nsmp) idn[j] = sample_at(UE + j);
+#ifndef STEP_DMA_LATE
         if (dma) {
             // each lane sends its 16-byte piece of the row's four moment rows straight to LDS; the destination of a
             // wave instruction is one contiguous 1 KiB block, lane-major
@@ -450,6 +451,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                         (__attribute__((address_space(3))) void *)(mv_wave + tn * 64), 16, 0, 0);
             }
         }
+#endif
         if (r == r0) { __syncthreads(); STAMP(3); }  // staged tables visible (the gathers above are in flight)
         // one interaction: evaluate, accumulate the user rows' gradients, store the record, feed the E x D / loss sums
         auto step = [&](const Slot &q, bool has) {
@@ -554,6 +556,23 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             }
             if (EMAX > 4) it_total++;
         };
+#ifdef STEP_DMA_LATE
+        // (A/B knob: the moments are requested behind the first gathers' burst instead of inside it)
+        __builtin_amdgcn_sched_barrier(0);
+        if (dma) {
+            // each lane sends its 16-byte piece of the row's four moment rows straight to LDS; the destination of a
+            // wave instruction is one contiguous 1 KiB block, lane-major
+            const bool mine = active && leader && lg * 4 < t.D;
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) {
+                const float *src_tab = (tn & 1) ? a.v[(tn >> 1) * 2] : a.m[(tn >> 1) * 2];
+                if (mine && !(pure && tn >= 2))
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(src_tab + ((unsigned)row * (unsigned)t.D + (unsigned)lg * 4u)),
+                        (__attribute__((address_space(3))) void *)(mv_wave + tn * 64), 16, 0, 0);
+            }
+        }
+#endif
         for (int s = 0; s < iters; s += UE) {
 #pragma unroll
             for (int j = 0; j < UE; j++) {
@@ -857,6 +876,21 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
 
 // Untouched rows: gradient exactly zero, so m' = m + (1-b1)(0-m), v' = b2 v, p' = p - step*m'/(sqrt(v')/bc+eps)
 // (the same adam1f as everywhere, fed g = 0).  Each group keeps R = 2 rows of both tables in flight (12 float4 loads).
+// The untouched rows are independent of everything else in a launch and their workgroups are short: started a little
+// late, their load burst does not queue in front of the row jobs' first gathers (the launch's critical chain).
+// Units: s_sleep counts of 64 clocks (0: no delay).  Measured at the Yahoo shape (tools/ab.sh): 75 / 40 = about 2 / 1 us in
+// launch 1 / launch 2: 21.9 -> 21.3 us per step; longer delays give the gain back.
+#ifndef STEP_STREAM_DELAY1
+#define STEP_STREAM_DELAY1 75
+#endif
+#ifndef STEP_STREAM_DELAY2
+#define STEP_STREAM_DELAY2 40
+#endif
+template <int N>
+__device__ __forceinline__ void stream_delay() {
+    if (N > 0) __builtin_amdgcn_s_sleep(N > 127 ? 127 : N);
+    if (N > 127) __builtin_amdgcn_s_sleep(N - 127 > 127 ? 127 : N - 127);
+}
 #ifndef STEP_STREAM_ST
 #define STEP_STREAM_ST 1   // (A/B knob: 1 = write-through stores for the streamed rows)
 #endif
@@ -1073,6 +1107,7 @@ __global__ __launch_bounds__(kThreads, STEP_EVAL_WAVES) void mstep_eval_kernel(D
     if (j * spt < q[3]) {
         STAMP(0);
 #ifndef DBG_NO_STREAM
+        stream_delay<STEP_STREAM_DELAY1>();
         stream_task<LG, VEC>(t, a, a.stream_rows + q[2] + j * spt, min(spt, q[3] - j * spt));
 #endif
         STAMP(7);
@@ -1128,6 +1163,7 @@ __global__ __launch_bounds__(kThreads, EMAX <= 4 ? STEP_APPLY_WAVES : (EMAX <= 8
     if (j * spt < q[3]) {
         STAMP(0);
 #ifndef DBG_NO_STREAM
+        stream_delay<STEP_STREAM_DELAY2>();
         stream_task<LG, VEC>(t, a, a.stream_rows + q[2] + j * spt, min(spt, q[3] - j * spt));
 #endif
         STAMP(7);

@@ -140,8 +140,14 @@ typedef struct InvPrefRowPlan {
      * cls[c] = { first user round, user rounds (both multiples of user_rounds_per_task), first streamed row of launch 1
      * (index into stream_rows), streamed rows of launch 1, first item round, item rounds, first streamed row of
      * launch 2, streamed rows of launch 2 } of class c. */
-    int32_t n_classes, reserved;
+    int32_t n_classes, rows_per_stream_task2;  /* streamed rows per workgroup in launch 2 (0: rows_per_stream_task) */
     int32_t cls[8][8];
+    /* optional (NULL: "pull" form, launch 2 gathers partner rows + records): the "push" form.  push_slot[position] = the
+     * interaction's index in item_list order.  Launch 1 then stores, per interaction, its two contribution rows to its
+     * item's gradient at that slot of the workspace, and launch 2's item jobs sum contiguous rows: every item descriptor
+     * must be of mode 7 (or 0) with [a, b) = the slice's slots.  One extra row write + read per interaction and table: for
+     * minibatches whose rows are a small share of the step's bytes (plan.py decides). */
+    const int32_t *push_slot;                 /* [n] */
 } InvPrefRowPlan;
 
 /* Scratch of one planned step: the records + the partial slabs.  It needs no initialisation (every word is stored

@@ -161,15 +161,16 @@ struct StepArgs {
     StepScalars k;
     uint32_t flags;
     int fused;                    // 0: store gradient rows to g; 1: Adam on the spot -> np / m / v
-    float *g[4];                  // Pu, Qi, Pa, Qa gradient tables   (fused == 0)
-    float *np[4];                 // new parameter tables              (fused == 1)
+    float *np[4];                 // fused == 1: the new parameter tables (Pu, Qi, Pa, Qa); fused == 0: the GRADIENT tables
+                                  // (one set of pointers for both forms: scalar registers are the scarce resource here)
     float *m[4], *v[4];           // Adam moments                      (fused == 1)
     AdamScalars ad;
     const int *stream_rows;       // untouched rows of this launch: row id, bit 30 set for item rows
     int rows_per_stream_task, rounds_per_task;
     int n_cls;                    // XCD-affine task order: workgroup b runs tasks of class b % n_cls (InvPrefRowPlan)
     int cls[8][4];                // per class: first round, rounds, first streamed row, streamed rows
-    float *records;               // [n][4 + EMAX]
+    const int *push_slot;         // push form (InvPrefRowPlan::push_slot): [n] contribution slot of a minibatch position
+    float *records;               // pull form: [n][4 + EMAX] records; push form: [n][2][DP] contribution rows
     float *slabs;                 // [launch-1 job tasks][slab_len] partial sums
     int *sched_state;             // optional device int32[32]: two slots {step, base, SchedRow}, see InvPrefAdamSchedule
     int sched_slot;
@@ -352,6 +353,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
     const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
     const bool pure = a.flags & INVPREF_PURE_MF;   // env-aware tables, embed_env, classifier absent: never touched
     const bool dma = VEC && a.fused;
+    const bool push = a.push_slot != nullptr;
     StepScalars k = a.k;
     if (a.sched_state) {  // scheduled alpha (train.py:214-217) under graph replay
         const float al = sched_slot_ptr(a.sched_state, a.sched_slot)->alpha;
@@ -411,7 +413,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
         struct Slot {
             float4 qi, qa;
             USample sm;
-            int e;
+            int e, cs;
             float w;
         };
         Slot sl[UE];
@@ -424,12 +426,13 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 q.e = (int)a.envs[sm.ps];
             }
             if (rw_rec || rw_cls) q.w = a.weights[sm.ps];
+            if (push) q.cs = a.push_slot[sm.ps];
         };
 #pragma unroll
         for (int j = 0; j < UE; j++) {
             sl[j].qi = sl[j].qa = f4zero();
             sl[j].sm = USample{0, 0, 0.f};
-            sl[j].e = 0;
+            sl[j].e = sl[j].cs = 0;
             sl[j].w = 1.f;
             idn[j] = USample{0, 0, 0.f};
             if (j < nsmp) gather(sl[j], sample_at(j));
@@ -469,16 +472,24 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 gip.z = o.g_p - k.alpha * o.gx.z; gip.w = o.g_p - k.alpha * o.gx.w;
                 f4add(gi, f4mul(gip, q.qi));
                 f4fma(ge, o.g_q, f4mul(q.qa, ev));
-                // the record the item side consumes
-                float *rec_g = a.records + (unsigned)q.sm.ps * (unsigned)RS;
-                if (lg == 0)
-                    *reinterpret_cast<float4 *>(rec_g) = make_float4(o.g_p, o.g_q, __builtin_bit_cast(float, e), 0.f);
-                if (EMAX <= 4) {
-                    if (lg == 1) *reinterpret_cast<float4 *>(rec_g + 4) =
-                        make_float4(o.gz[0], EMAX > 1 ? o.gz[EMAX > 1 ? 1 : 0] : 0.f, EMAX > 2 ? o.gz[EMAX > 2 ? 2 : 0] : 0.f,
-                                    EMAX > 3 ? o.gz[EMAX > 3 ? 3 : 0] : 0.f);
-                } else if (lg < EMAX) {
-                    rec_g[4 + lg] = o.gz_lane;
+                if (push) {
+                    // push form: the interaction's two contribution rows to its ITEM's gradient, stored at the item-sorted
+                    // slot -- launch 2 then sums contiguous rows, no gathers, no classifier
+                    float *cr = a.records + (unsigned)q.cs * (unsigned)(2 * DP) + lg * 4;
+                    *reinterpret_cast<float4 *>(cr) = f4mul(gip, oi);
+                    *reinterpret_cast<float4 *>(cr + DP) = f4scale(o.g_q, f4mul(oe, ev));
+                } else {
+                    // pull form: the record the item side consumes
+                    float *rec_g = a.records + (unsigned)q.sm.ps * (unsigned)RS;
+                    if (lg == 0)
+                        *reinterpret_cast<float4 *>(rec_g) = make_float4(o.g_p, o.g_q, __builtin_bit_cast(float, e), 0.f);
+                    if (EMAX <= 4) {
+                        if (lg == 1) *reinterpret_cast<float4 *>(rec_g + 4) =
+                            make_float4(o.gz[0], EMAX > 1 ? o.gz[EMAX > 1 ? 1 : 0] : 0.f, EMAX > 2 ? o.gz[EMAX > 2 ? 2 : 0] : 0.f,
+                                        EMAX > 3 ? o.gz[EMAX > 3 ? 3 : 0] : 0.f);
+                    } else if (lg < EMAX) {
+                        rec_g[4 + lg] = o.gz_lane;
+                    }
                 }
                 // o = g_q Pa*Qa (+ env regulariser): the interaction's term of embed_env's gradient
                 float4 oo = f4scale(o.g_q, f4mul(oe, q.qa));
@@ -675,8 +686,8 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 f4fma(ge, cnt, reg_term(oe, k.r2, k.r1));
             }
             if (!a.fused) {
-                put4<VEC>(a.g[0], row, t.D, lg, gi);
-                if (!pure) put4<VEC>(a.g[2], row, t.D, lg, ge);
+                put4<VEC>(a.np[0], row, t.D, lg, gi);
+                if (!pure) put4<VEC>(a.np[2], row, t.D, lg, ge);
             } else {
                 float4 mi = f4zero(), vi = f4zero(), me = f4zero(), ve = f4zero();
                 if (dma) {
@@ -710,6 +721,9 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
 struct IIn {
     float4 pu, pa, r0;
 };
+#ifndef STEP_PUSH_DEPTH
+#define STEP_PUSH_DEPTH 4
+#endif
 #ifndef STEP_ITEM_DEPTH
 #define STEP_ITEM_DEPTH 2
 #endif
@@ -846,8 +860,127 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
                 f4fma(ge, cnt, reg_term(oe, k.r2, k.r1));
             }
             if (!a.fused) {
-                put4<VEC>(a.g[1], row, t.D, lg, gi);
-                if (!pure) put4<VEC>(a.g[3], row, t.D, lg, ge);
+                put4<VEC>(a.np[1], row, t.D, lg, gi);
+                if (!pure) put4<VEC>(a.np[3], row, t.D, lg, ge);
+            } else {
+                float4 mi = f4zero(), vi = f4zero(), me = f4zero(), ve = f4zero();
+                if (dma) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA pieces have landed
+                    mi = mv_wave[0 * 64 + lane]; vi = mv_wave[1 * 64 + lane];
+                    if (!pure) { me = mv_wave[2 * 64 + lane]; ve = mv_wave[3 * 64 + lane]; }
+                } else {
+                    mi = row4<VEC>(a.m[1], row, t.D, lg); vi = row4<VEC>(a.v[1], row, t.D, lg);
+                    if (!pure) { me = row4<VEC>(a.m[3], row, t.D, lg); ve = row4<VEC>(a.v[3], row, t.D, lg); }
+                }
+                adam4(oi, gi, mi, vi, ad);
+                put4<VEC, STEP_ROW_ST>(a.np[1], row, t.D, lg, oi);
+                put4<VEC, STEP_ROW_ST>(a.m[1], row, t.D, lg, mi);
+                put4<VEC, STEP_ROW_ST>(a.v[1], row, t.D, lg, vi);
+                if (!pure) {
+                    adam4(oe, ge, me, ve, ad);
+                    put4<VEC, STEP_ROW_ST>(a.np[3], row, t.D, lg, oe);
+                    put4<VEC, STEP_ROW_ST>(a.m[3], row, t.D, lg, me);
+                    put4<VEC, STEP_ROW_ST>(a.v[3], row, t.D, lg, ve);
+                }
+            }
+        }
+    }
+    STAMP(6);
+}
+
+// launch 2, push form: an item job sums the CONTIGUOUS contribution rows launch 1 stored for its row (item-sorted slots
+// [a, b) of the slice, read from the descriptor alone): no partner gathers, no records, no classifier rows -- every load of
+// a slice of up to PCH interactions leaves in one burst.  Chosen by the plan for minibatches whose contribution rows are a
+// small share of the step's bytes (they cost one extra row write + read per interaction and table).
+template <int LG, bool VEC, int EMAX>
+__device__ __forceinline__ void item_task_push(const DevTables &t, const StepArgs &a, int r0, int nr, float *lds) {
+    using G = Geo<LG, EMAX>;
+    constexpr int DP = G::DP, NG = G::NG;
+    constexpr int PCH = LG == 16 ? STEP_PUSH_DEPTH : 3;   // contribution-row pairs in flight per group
+    float *slots = lds;                                                  // [NG][2][DP] slice partials
+    float4 *mv = reinterpret_cast<float4 *>(slots + NG * 2 * DP);       // [4 waves][4][64] float4 LDS-DMA landing area
+    const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float4 *mv_wave = mv + wave * 4 * 64;
+    const bool pure = a.flags & INVPREF_PURE_MF;
+    const bool dma = VEC && a.fused;
+    const StepScalars k = a.k;
+    const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
+    STAMP(0);
+    int4 d = a.desc[(r0 * NG + grp) * 2];
+    STAMP(1);
+    for (int r = r0; r < r0 + nr; r++) {
+        const int4 dd = d;
+        if (r + 1 < r0 + nr) d = a.desc[((r + 1) * NG + grp) * 2];
+        const int row = dd.x, meta = dd.y;
+        const bool active = row >= 0, leader = meta & 1;
+        const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
+        const int nsmp = (active && mode == 7) ? dd.w - dd.z : 0;
+        if (r == r0) STAMP(2);
+        float4 oi, oe = f4zero(), gi = f4zero(), ge = f4zero();
+        {
+            const int rowc = active ? row : 0;
+            oi = row4<VEC>(t.Qi, rowc, t.D, lg);
+            if (!pure) oe = row4<VEC>(t.Qa, rowc, t.D, lg);
+        }
+        const float *base = a.records + (unsigned)dd.z * (unsigned)(2 * DP) + lg * 4;
+        float4 ci[PCH], ce[PCH];
+        auto fetch = [&](int s0) {   // contribution rows s0 .. s0 + PCH of the slice (clamped: no branch around a load)
+#pragma unroll
+            for (int j = 0; j < PCH; j++) {
+                const int sj = s0 + j < nsmp ? s0 + j : (nsmp > 0 ? nsmp - 1 : 0);
+                const float *p = base + (unsigned)sj * (unsigned)(2 * DP);
+                ci[j] = *reinterpret_cast<const float4 *>(nsmp > 0 ? p : a.records + lg * 4);
+                if (!pure) ce[j] = *reinterpret_cast<const float4 *>(nsmp > 0 ? p + DP : a.records + DP + lg * 4);
+            }
+        };
+        fetch(0);
+        if (dma) {   // the row's Adam moments: needed last, sent straight to LDS
+            const bool mine = active && leader && lg * 4 < t.D;
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) {
+                const float *src_tab = (tn & 1) ? a.v[(tn >> 1) * 2 + 1] : a.m[(tn >> 1) * 2 + 1];
+                if (mine && !(pure && tn >= 2))
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void *)(src_tab + ((unsigned)row * (unsigned)t.D + (unsigned)lg * 4u)),
+                        (__attribute__((address_space(3))) void *)(mv_wave + tn * 64), 16, 0, 0);
+            }
+        }
+        if (r == r0) STAMP(3);
+        for (int s0 = 0; s0 < nsmp; s0 += PCH) {
+#pragma unroll
+            for (int j = 0; j < PCH; j++) {
+                const bool has = s0 + j < nsmp;
+                f4add(gi, has ? ci[j] : f4zero());
+                if (!pure) f4add(ge, has ? ce[j] : f4zero());
+            }
+            if (s0 + PCH < nsmp) fetch(s0 + PCH);
+        }
+        if (r == r0) STAMP(4);
+        if (slices > 1) {
+            float *mine = slots + grp * 2 * DP;
+            *reinterpret_cast<float4 *>(mine + lg * 4) = gi;
+            *reinterpret_cast<float4 *>(mine + DP + lg * 4) = ge;
+            __syncthreads();
+            if (active && leader) {
+#pragma unroll 4
+                for (int s = 1; s < slices; s++) {
+                    const float *oth_slot = slots + (grp + s) * 2 * DP;
+                    f4add(gi, *reinterpret_cast<const float4 *>(oth_slot + lg * 4));
+                    f4add(ge, *reinterpret_cast<const float4 *>(oth_slot + DP + lg * 4));
+                }
+            }
+            if (r + 1 < r0 + nr) __syncthreads();
+        }
+        if (r == r0) STAMP(5);
+        if (active && leader) {
+            const float cnt = (float)(meta >> 9);
+            if (cnt != 0.f) {
+                f4fma(gi, cnt, reg_term(oi, k.r2, k.r1));
+                f4fma(ge, cnt, reg_term(oe, k.r2, k.r1));
+            }
+            if (!a.fused) {
+                put4<VEC>(a.np[1], row, t.D, lg, gi);
+                if (!pure) put4<VEC>(a.np[3], row, t.D, lg, ge);
             } else {
                 float4 mi = f4zero(), vi = f4zero(), me = f4zero(), ve = f4zero();
                 if (dma) {
@@ -878,13 +1011,14 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
 // (the same adam1f as everywhere, fed g = 0).  Each group keeps R = 2 rows of both tables in flight (12 float4 loads).
 // The untouched rows are independent of everything else in a launch and their workgroups are short: started a little
 // late, their load burst does not queue in front of the row jobs' first gathers (the launch's critical chain).
-// Units: s_sleep counts of 64 clocks (0: no delay).  Measured at the Yahoo shape (tools/ab.sh): 75 / 40 = about 2 / 1 us in
-// launch 1 / launch 2: 21.9 -> 21.3 us per step; longer delays give the gain back.
+// Units: s_sleep counts of 64 clocks (0: no delay).  Measured at the Yahoo shape (tools/ab.sh): 75 = about 2 us in
+// launch 1: 21.9 -> 21.3 us per step; longer delays give the gain back.  (Launch 2 in the push form: its item jobs are
+// shorter than its stream workgroups, so no delay there.)
 #ifndef STEP_STREAM_DELAY1
 #define STEP_STREAM_DELAY1 75
 #endif
 #ifndef STEP_STREAM_DELAY2
-#define STEP_STREAM_DELAY2 40
+#define STEP_STREAM_DELAY2 0
 #endif
 template <int N>
 __device__ __forceinline__ void stream_delay() {
@@ -914,8 +1048,8 @@ __device__ __forceinline__ void stream_task(const DevTables &t, const StepArgs &
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 if (!on[q]) continue;
-                put4<VEC>(side[q] ? a.g[1] : a.g[0], row[q], t.D, lg, f4zero());
-                if (!pure) put4<VEC>(side[q] ? a.g[3] : a.g[2], row[q], t.D, lg, f4zero());
+                put4<VEC>(side[q] ? a.np[1] : a.np[0], row[q], t.D, lg, f4zero());
+                if (!pure) put4<VEC>(side[q] ? a.np[3] : a.np[2], row[q], t.D, lg, f4zero());
             }
             continue;
         }
@@ -1155,7 +1289,8 @@ __global__ __launch_bounds__(kThreads, EMAX <= 4 ? STEP_APPLY_WAVES : (EMAX <= 8
     const int tj = (q[1] + rpt - 1) / rpt;
     if (j < tj) {
 #ifndef DBG_NO_JOBS
-        item_task<LG, VEC, EMAX>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), lds);
+        if (a.push_slot) item_task_push<LG, VEC, EMAX>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), lds);
+        else item_task<LG, VEC, EMAX>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), lds);
 #endif
         return;
     }
@@ -1195,11 +1330,17 @@ int ensure_lds(K kernel, size_t bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+inline size_t record_floats(const InvPrefRowPlan *plan, int lg, int emax) {
+    // pull form: a record of 4 + EMAX floats per interaction; push form: two padded contribution rows
+    const size_t per = plan->push_slot ? (size_t)8 * lg : (size_t)4 + emax;
+    return ((size_t)(plan->n > 0 ? plan->n : 1) * per + 63) & ~(size_t)63;
+}
+
 inline int plan_tasks(const InvPrefRowPlan *plan, int launch, int *task_wgs) {
     // workgroups of one launch: the classes' task lists interleaved, padded to the longest
     const int ncls = plan->n_classes > 0 ? plan->n_classes : 1;
     const int rpt = launch == 0 ? plan->user_rounds_per_task : plan->item_rounds_per_task;
-    const int spt = plan->rows_per_stream_task;
+    const int spt = (launch == 1 && plan->rows_per_stream_task2 > 0) ? plan->rows_per_stream_task2 : plan->rows_per_stream_task;
     int per_class = 0;
     for (int c = 0; c < ncls; c++) {
         const int32_t *q = plan->cls[c] + 4 * launch;
@@ -1229,8 +1370,8 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     if (!fused) {
         if ((rc = check_tables(grads, pure))) return rc;
         vec = vec && vec_ok(grads);
-        a.g[0] = grads->embed_user_invariant; a.g[1] = grads->embed_item_invariant;
-        a.g[2] = grads->embed_user_env_aware; a.g[3] = grads->embed_item_env_aware;
+        a.np[0] = grads->embed_user_invariant; a.np[1] = grads->embed_item_invariant;
+        a.np[2] = grads->embed_user_env_aware; a.np[3] = grads->embed_item_env_aware;
     } else {
         if ((rc = check_tables(new_tables, pure)) || (rc = check_tables(exp_avg, pure)) ||
             (rc = check_tables(exp_avg_sq, pure)))
@@ -1264,8 +1405,8 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
             return INVPREF_EINVAL;
     }
     const int n_partials = plan->n_user_rounds / plan->user_rounds_per_task;
-    const size_t slab = slab_floats(lg, emax), RS = 4 + (size_t)emax;
-    const size_t rec_floats = ((size_t)plan->n * RS + 63) & ~(size_t)63;
+    const size_t slab = slab_floats(lg, emax);
+    const size_t rec_floats = record_floats(plan, lg, emax);
     if (workspace_bytes < sizeof(float) * (rec_floats + slab * (size_t)(n_partials > 0 ? n_partials : 1)))
         return INVPREF_EWORKSPACE;
     StepScalars k;
@@ -1276,6 +1417,7 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a.envs = envs; a.weights = weights; a.k = k; a.flags = flags; a.fused = fused; a.ad = ad;
     a.rows_per_stream_task = plan->rows_per_stream_task; a.n_cls = ncls;
     a.records = (float *)workspace; a.slabs = (float *)workspace + rec_floats;
+    a.push_slot = plan->push_slot;
     a.sched_state = sched ? sched->state : nullptr;
     a.sched_slot = sched ? (sched->slot & 1) : 0;
     static const char *stamp_env = getenv("INVPREF_STAMPS");   // diagnostics: device pointer (hex) of a stamp buffer
@@ -1301,6 +1443,7 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a2.desc = reinterpret_cast<const int4 *>(plan->item_desc);
     a2.ilist = reinterpret_cast<const int2 *>(plan->item_list);
     a2.rounds_per_task = plan->item_rounds_per_task;
+    if (plan->rows_per_stream_task2 > 0) a2.rows_per_stream_task = plan->rows_per_stream_task2;
     a2.stream_rows = plan->stream_rows;
     a2.stamps = stamps ? stamps + 8192 * 8 : nullptr;   // (the stamp buffer's second half belongs to launch 2)
     for (int c = 0; c < 8; c++) for (int i = 0; i < 4; i++) a2.cls[c][i] = c < ncls ? plan->cls[c][4 + i] : 0;
@@ -1364,7 +1507,7 @@ size_t invpref_rows_workspace_bytes(const InvPrefTables *tables, const InvPrefRo
         return 0;
     const int lg = plan->lanes_per_group, emax = emax4_of((int)tables->env_num);
     if (lg != 16 && lg != 32 && lg != 64) return 0;
-    const size_t rec_floats = ((size_t)plan->n * (4 + (size_t)emax) + 63) & ~(size_t)63;
+    const size_t rec_floats = record_floats(plan, lg, emax);
     const size_t np = (size_t)(plan->n_user_rounds / plan->user_rounds_per_task);
     return sizeof(float) * (rec_floats + slab_floats(lg, emax) * (np > 0 ? np : 1));
 }

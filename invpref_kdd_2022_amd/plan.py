@@ -37,10 +37,11 @@ class RowPlanStruct(C.Structure):
                 ('user_desc', C.c_void_p), ('item_desc', C.c_void_p), ('user_round_iters', C.c_void_p),
                 ('user_list', C.c_void_p), ('item_list', C.c_void_p), ('n_stream', C.c_int32),
                 ('rows_per_stream_task', C.c_int32), ('stream_rows', C.c_void_p), ('n_classes', C.c_int32),
-                ('reserved', C.c_int32), ('cls', C.c_int32 * 64)]
+                ('rows_per_stream_task2', C.c_int32), ('cls', C.c_int32 * 64), ('push_slot', C.c_void_p)]
 
 
-ARRAYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list', 'stream_rows')
+ARRAYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list', 'stream_rows', 'push_slot')
+OPTIONAL_ARRAYS = ('push_slot',)   # may be absent (plan[k] is None; meta offset -1; NULL in the struct)
 
 N_CLASSES = 8          # XCDs of an MI355X: blocks b and b + 8 of a launch share one (round-robin placement)
 CLASS_SHIFT = 6        # rows are dealt to the classes in blocks of 64
@@ -126,7 +127,7 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
                    factor_num: int = 64, per_slice: int | None = None, item_per_slice: int | None = None,
                    rounds_per_task: int | None = None, item_rounds_per_task: int | None = None, user_range=None,
                    n_classes: int | None = None, rows_per_stream_task: int | None = None,
-                   stream_split: float | None = None) -> dict:
+                   stream_split: float | None = None, push: bool | None = None) -> dict:
     """users/items/scores: ONE minibatch (or this rank's slice of it); scores as the fp32 labels.
     factor_num: decides the row layout the plan is built for (lanes_of).
     per_slice / item_per_slice: interactions one group walks for a user / an item row (more interactions: more slices).
@@ -139,7 +140,12 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     tools/xcd_probe.py: a pure streaming step takes 8.4 us with a stable assignment and 11.5 us when the assignment
     moves to another XCD every step).  Speed only: any order gives the same results.
     stream_split: share of the untouched rows that launch 1 streams (the rest goes to launch 2); default: what
-    balances the two launches' row traffic."""
+    balances the two launches' row traffic.
+    push: the "push" form of the item side (InvPrefRowPlan.push_slot): launch 1 stores every interaction's two
+    contribution rows to its item's gradient at the interaction's item-sorted slot and launch 2 sums contiguous rows
+    instead of gathering partner rows + records.  One extra row write + read per interaction and table; default
+    (INVPREF_PLAN_PUSH): on while that traffic stays below a quarter of the dense-Adam stream (Yahoo-class steps: the item
+    jobs become one burst of contiguous loads -- no hot-row tail)."""
     users = np.asarray(users, dtype=np.int64)
     items = np.asarray(items, dtype=np.int64)
     scores = np.asarray(scores, dtype=np.float32)
@@ -155,8 +161,14 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     target = int(os.environ.get('INVPREF_PLAN_TARGET_WGS', str(TARGET_WORKGROUPS)))
     if per_slice is None:
         per_slice = int(os.environ.get('INVPREF_PLAN_PER_SLICE', str(2 if n <= 4 * ng * target // 3 else 16)))
+    if push is None:
+        env = os.environ.get('INVPREF_PLAN_PUSH')
+        p_floats = 2 * (user_num + item_num) * factor_num
+        push = (env == '1') if env is not None else (0 < n * 4 * lanes * 16 <= 0.25 * 24 * 4 * p_floats)
     if item_per_slice is None:
-        item_per_slice = int(os.environ.get('INVPREF_PLAN_ITEM_PER_SLICE', str(min(32, max(2, -(-n // (ng * 2 * target)))))))
+        # (push form: a slice's contribution rows are contiguous and leave in one burst of up to four: measured 4 > 2, 3)
+        item_per_slice = int(os.environ.get('INVPREF_PLAN_ITEM_PER_SLICE',
+                                            str(min(32, max(4 if push else 2, -(-n // (ng * 2 * target)))))))
 
     def rounds_for(cnt, ps):   # group slots / ng: the rounds a side needs at `ps` interactions per slice
         c = cnt[cnt > 0]
@@ -169,7 +181,8 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         item_rounds_per_task = int(os.environ.get('INVPREF_PLAN_ITEM_ROUNDS', '0')) or \
             min(16, max(1, round(rounds_for(np.bincount(items, minlength=1), item_per_slice) / (4 * target))))
     if rows_per_stream_task is None:
-        rows_per_stream_task = int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', str(stream_rows_default(factor_num))))  # one iteration of a workgroup
+        rows_per_stream_task = int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', str(stream_rows_default(factor_num))))
+    rows_per_stream_task2 = int(os.environ.get('INVPREF_PLAN_STREAM_ROWS2', str(rows_per_stream_task)))  # one iteration of a workgroup
     ucnt = np.bincount(users, minlength=user_num)
     icnt = np.bincount(items, minlength=item_num)
     if n and max(ucnt.max(), icnt.max()) >= MAX_ROW_COUNT:
@@ -208,7 +221,7 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
                              skip=(ucnt == 0) | (ucls != c))
         du_parts.append(d)
         it_parts.append(it)
-        d, _ = _side_rounds(items[pi], icols, item_num, ng, item_per_slice, item_rounds_per_task, 3,
+        d, _ = _side_rounds(items[pi], icols, item_num, ng, item_per_slice, item_rounds_per_task, 0 if push else 3,
                             skip=(icnt == 0) | (icls != c))
         di_parts.append(d)
         # (a few untouched item rows are not worth one tiny task per class: class 0 streams them all then)
@@ -231,15 +244,17 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
                 user_round_iters=np.concatenate(it_parts),
                 user_list=np.stack([ucols[0], ucols[1], ucols[2], np.zeros(n, np.int32)], axis=1).reshape(-1),
                 item_list=np.stack([icols[0], icols[1]], axis=1).reshape(-1),
+                push_slot=(np.argsort(pi, kind='stable').astype(np.int32) if push else None), push=bool(push),
                 stream_rows=np.concatenate(s1_parts + s2_parts).astype(np.int32), n_stream=sb,
-                rows_per_stream_task=rows_per_stream_task, stream_split=stream_split, n_classes=n_classes, cls=cls)
+                rows_per_stream_task=rows_per_stream_task, rows_per_stream_task2=rows_per_stream_task2,
+                stream_split=stream_split, n_classes=n_classes, cls=cls)
 
 
 def launch_workgroups(plan: dict, launch: int) -> int:
     """task workgroups of launch 0 / 1: the classes' task lists interleaved, padded to the longest"""
     ncls, cls = int(plan['n_classes']), np.asarray(plan['cls'])
     rpt = plan['user_rounds_per_task'] if launch == 0 else plan['item_rounds_per_task']
-    spt = plan['rows_per_stream_task']
+    spt = plan['rows_per_stream_task'] if launch == 0 else plan.get('rows_per_stream_task2', plan['rows_per_stream_task'])
     return ncls * max(-(-int(cls[c, 4 * launch + 1]) // rpt) + -(-int(cls[c, 4 * launch + 3]) // spt) for c in range(ncls))
 
 
@@ -278,9 +293,12 @@ def struct_from_meta(buf: torch.Tensor, meta: torch.Tensor) -> RowPlanStruct:
         v = vals[i]
         i += 1
         if ty is C.c_void_p:
-            if not 0 <= v <= n:
+            if v == -1 and name in OPTIONAL_ARRAYS:
+                v = None
+            elif not 0 <= v <= n:
                 raise ValueError('row plan: array offset outside the buffer')
-            v = base + 4 * v
+            else:
+                v = base + 4 * v
         args.append(v)
     return RowPlanStruct(*args)
 
@@ -288,6 +306,9 @@ def struct_from_meta(buf: torch.Tensor, meta: torch.Tensor) -> RowPlanStruct:
 def upload(plan: dict, device) -> DevicePlan:
     parts, offs, off = [], {}, 0
     for k in ARRAYS:  # every array starts on a 16-byte boundary of the one device buffer
+        if k in OPTIONAL_ARRAYS and plan.get(k) is None:
+            offs[k] = -1
+            continue
         a = np.ascontiguousarray(plan[k], np.int32).reshape(-1)
         pad = (-len(a)) % 4
         parts.append(np.concatenate([a, np.zeros(pad, np.int32)]))
@@ -295,13 +316,14 @@ def upload(plan: dict, device) -> DevicePlan:
         off += len(a) + pad
     parts.append(np.zeros(4, np.int32))   # (never an empty buffer)
     buf = torch.from_numpy(np.concatenate(parts)).to(device)
-    ptrs = {k: buf.data_ptr() + 4 * o for k, o in offs.items()}
+    ptrs = {k: (buf.data_ptr() + 4 * o if o >= 0 else None) for k, o in offs.items()}
     cls = np.asarray(plan['cls'], np.int32)
     st = RowPlanStruct(plan['n'], plan['lanes_per_group'], len(plan['user_desc']), len(plan['item_desc']),
                        plan['user_rounds_per_task'], plan['item_rounds_per_task'], ptrs['user_desc'], ptrs['item_desc'],
                        ptrs['user_round_iters'], ptrs['user_list'], ptrs['item_list'], plan['n_stream'],
-                       plan['rows_per_stream_task'], ptrs['stream_rows'], int(plan['n_classes']), 0,
-                       (C.c_int32 * 64)(*cls.reshape(-1).tolist()))
+                       plan['rows_per_stream_task'], ptrs['stream_rows'], int(plan['n_classes']),
+                       int(plan.get('rows_per_stream_task2', 0)),
+                       (C.c_int32 * 64)(*cls.reshape(-1).tolist()), ptrs['push_slot'])
     meta = _meta_of(st, offs)
     return DevicePlan(st, [buf], plan_workgroups(plan), len(plan['user_desc']) + len(plan['item_desc']), buf,
                       torch.tensor(meta, dtype=torch.int64))

@@ -177,6 +177,7 @@ def test_random_plan_parameters_and_shapes(seed):
                                     rounds_per_task=int(rs.choice([1, 1, 2, 3])),
                                     item_rounds_per_task=int(rs.choice([1, 1, 2, 3])),
                                     n_classes=int(rs.choice([1, 3, 8])), stream_split=float(rs.choice([0.0, 0.4, 1.0])),
+                                    push=bool(rs.randint(2)),
                                     user_range=user_range)
     finally:
         for k, val in old.items():

@@ -54,8 +54,12 @@ def check_plan(users, items, U, I, D=64, **kw):
             assert len(si) <= 512 or (planlib.row_class(iseg, ncls) == c).all()
             sb += cnt_
     assert sb == p['n_stream']
+    if p['push']:   # push form: a position's contribution slot is its index in the item-sorted list; item slices are ranges
+        np.testing.assert_array_equal(ilist[p['push_slot'], 1], np.arange(n))
+    else:
+        assert p['push_slot'] is None
     for side, (own, oth, R, lst, desc, inline, w) in enumerate((
-            (users, items, U, ulist, ud, 2, 3), (items, users, I, ilist, idd, 3, 2))):
+            (users, items, U, ulist, ud, 2, 3), (items, users, I, ilist, idd, 0 if p['push'] else 3, 2))):
         d = desc.reshape(-1, 8)
         act = d[d[:, 0] >= 0]
         leaders = act[(act[:, 1] & 1) == 1]
@@ -129,6 +133,16 @@ def test_plan_single_class_is_the_plain_order():
     p = check_plan(d[:, 0], d[:, 1], 15400, 1000, n_classes=1, stream_split=1.0)
     sr = p['stream_rows']
     np.testing.assert_array_equal(sr[(sr & planlib.ITEM_BIT) == 0], np.flatnonzero(np.bincount(d[:, 0], minlength=15400) == 0))
+
+
+@pytest.mark.parametrize('push', [False, True])
+def test_plan_push_and_pull_forms(push):
+    d = synth.yahoo_like()[:8192]
+    p = check_plan(d[:, 0], d[:, 1], 15400, 1000, push=push)
+    assert p['push'] == push
+    assert planlib.build_row_plan(d[:, 0], d[:, 1], d[:, 2], 15400, 1000)['push']          # Yahoo-class default: push
+    m = synth.interactions(5, 6040, 3706, 65536, implicit=True, zipf=False)
+    assert not planlib.build_row_plan(m[:, 0], m[:, 1], m[:, 2], 6040, 3706, factor_num=128)['push']   # MovieLens-class: pull
 
 
 def test_plan_empty_and_single():

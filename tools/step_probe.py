@@ -97,11 +97,12 @@ for rep in range(3):
     ops.mstep_rows_adam(a, b, M, V, plans[ks], e[sl], y[sl], w[sl], B, coefs, flags, losses, 5 + ks, 0.005, ws)
 torch.cuda.synchronize()
 pl = pls[ks]
-ncls, cls, spt = pl['n_classes'], np.asarray(pl['cls']), pl['rows_per_stream_task']
+ncls, cls = pl['n_classes'], np.asarray(pl['cls'])
 raw = stamps.cpu().numpy().reshape(-1, 8).astype(np.int64)
 t0 = None
 for launch, name in ((0, 'launch 1 (eval)'), (1, 'launch 2 (apply)')):
     rpt = pl['user_rounds_per_task'] if launch == 0 else pl['item_rounds_per_task']
+    spt = pl['rows_per_stream_task'] if launch == 0 else pl['rows_per_stream_task2']
     wg = planlib.launch_workgroups(pl, launch)
     extra = 0 if launch == 0 else 64
     st = raw[launch * 8192: launch * 8192 + wg + extra]

@@ -195,6 +195,11 @@ struct Geo {
     static constexpr int RS = 4 + EMAX;               // floats per record: g_p, g_q, env bits, 0, gz[EMAX]
     static constexpr bool REG = EMAX <= 8;            // E x D partial sums in registers (else: LDS records)
     static constexpr int SLAB = 2 * EMAX * DP + EMAX + kLossSlots;   // dEv | dW | db | loss sums
+    // the workgroup's partial sums meet in LDS as RED rows of SLAB floats: one per GROUP for the smallest instance (plain
+    // stores, no lane exchanges: the 72 permlane + add pairs of a per-wave pre-reduction sat on the step's critical
+    // chain), one per WAVE for the larger ones (their slabs would not fit one per group)
+    static constexpr bool DIRECT = LG == 16 && EMAX <= 4;
+    static constexpr int RED = DIRECT ? NG : kWaves;
     // E > 4: thread -> column d_own, classes cg, cg + CG, ...
     static constexpr int CG = (kThreads / DP) < EMAX ? (kThreads / DP) : EMAX;
     static constexpr int CPT = (EMAX + CG - 1) / CG;
@@ -210,7 +215,7 @@ struct EvalLds {
     static constexpr int slots = sb + EMAX;                         // [NG][2][DP] slice partials
     static constexpr int mv = slots + G::NG * 2 * G::DP;            // [4 waves][4][64] float4 LDS-DMA landing area
     static constexpr int red = mv + kWaves * 4 * 64 * 4;            // REG: [4 waves][SLAB]; else [4 waves][8] loss sums
-    static constexpr int rec = red + (G::REG ? kWaves * G::SLAB : kWaves * kLossSlots);   // E > 8: [2][NG][2][DP] x, o
+    static constexpr int rec = red + (G::REG ? G::RED * G::SLAB : kWaves * kLossSlots);   // E > 8: [2][NG][2][DP] x, o
     static constexpr int recs = rec + (G::REG ? 0 : 2 * G::NG * 2 * G::DP);              // E > 4: [2][NG][EMAX + 4] gz, env
     static constexpr int total = recs + (EMAX <= 4 ? 0 : 2 * G::NG * (EMAX + 4));
 };
@@ -605,9 +610,25 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
         // that the slab's stores fly under the leaders' Adam instead of forming a phase of their own.
         const bool last = r == r0 + nr - 1;
         if (last) {
-            accLi = wave_sum_valu(accLi); accLe = wave_sum_valu(accLe); accLc = wave_sum_valu(accLc);
-            accL2 = wave_sum_valu(accL2); accL1 = wave_sum_valu(accL1);
-            if (G::REG) {
+            if (G::REG && G::DIRECT) {
+                // one row per group: every lane stores its own pieces, nothing is exchanged
+                accLi = row16_sum(accLi); accLe = row16_sum(accLe); accLc = row16_sum(accLc);
+                accL2 = row16_sum(accL2); accL1 = row16_sum(accL1);
+                float *mine = red + grp * G::SLAB;
+#pragma unroll
+                for (int c = 0; c < (G::REG ? EMAX : 1); c++) {
+                    *reinterpret_cast<float4 *>(mine + c * DP + lg * 4) = dE[c];
+                    *reinterpret_cast<float4 *>(mine + EMAX * DP + c * DP + lg * 4) = dW[c];
+                    if (lg == 0) mine[2 * EMAX * DP + c] = dB[c];
+                }
+                if (lg == 0) {
+                    float *ls = mine + 2 * EMAX * DP + EMAX;
+                    ls[0] = accLi; ls[1] = accLe; ls[2] = accLc; ls[3] = accL2; ls[4] = accL1; ls[5] = ls[6] = ls[7] = 0.f;
+                }
+            } else if (G::REG) {
+                accLi = wave_sum_valu(accLi); accLe = wave_sum_valu(accLe); accLc = wave_sum_valu(accLc);
+                accL2 = wave_sum_valu(accL2); accL1 = wave_sum_valu(accL1);
+
                 // groups of one wave first (lane exchanges), then the four waves through LDS
                 float *mine = red + wave * G::SLAB;
 #pragma unroll
@@ -634,6 +655,8 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                     ls[0] = accLi; ls[1] = accLe; ls[2] = accLc; ls[3] = accL2; ls[4] = accL1; ls[5] = ls[6] = ls[7] = 0.f;
                 }
             } else {
+                accLi = wave_sum_valu(accLi); accLe = wave_sum_valu(accLe); accLc = wave_sum_valu(accLc);
+                accL2 = wave_sum_valu(accL2); accL1 = wave_sum_valu(accL1);
                 if (lane == 0) {
                     float *ls = red + wave * kLossSlots;
                     ls[0] = accLi; ls[1] = accLe; ls[2] = accLc; ls[3] = accL2; ls[4] = accL1; ls[5] = ls[6] = ls[7] = 0.f;
@@ -660,8 +683,15 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
         if (slices > 1 || last) __syncthreads();
         if (last) {
             if (G::REG) {
-                for (int i = threadIdx.x; i < G::SLAB; i += kThreads)
-                    slab[i] = ((red[i] + red[G::SLAB + i]) + red[2 * G::SLAB + i]) + red[3 * G::SLAB + i];
+                for (int i = threadIdx.x; i < G::SLAB; i += kThreads) {
+                    float x[G::RED];
+#pragma unroll
+                    for (int q = 0; q < G::RED; q++) x[q] = red[q * G::SLAB + i];   // (all reads first, then a fixed-order sum)
+                    float sum = x[0];
+#pragma unroll
+                    for (int q = 1; q < G::RED; q++) sum += x[q];
+                    slab[i] = sum;
+                }
             } else if (threadIdx.x < kLossSlots) {
                 slab[2 * EMAX * DP + EMAX + threadIdx.x] = ((red[threadIdx.x] + red[kLossSlots + threadIdx.x]) +
                                                              red[2 * kLossSlots + threadIdx.x]) + red[3 * kLossSlots + threadIdx.x];
@@ -1312,7 +1342,7 @@ inline size_t eval_lds_bytes(int lg, int emax) {
     const size_t DP = 4 * (size_t)lg, NG = kThreads / lg;
     const bool reg = emax <= 8;
     size_t fl = 2 * emax * DP + emax + NG * 2 * DP + kWaves * 4 * 64 * 4;
-    fl += reg ? kWaves * slab_floats(lg, emax) : kWaves * kLossSlots;
+    fl += reg ? ((lg == 16 && emax <= 4) ? NG : (size_t)kWaves) * slab_floats(lg, emax) : kWaves * kLossSlots;
     if (!reg) fl += 2 * NG * 2 * DP;
     if (emax > 4) fl += 2 * NG * (emax + 4);
     return fl * sizeof(float);

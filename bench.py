@@ -59,21 +59,35 @@ def spawn_ranks(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def pmc_traffic_bytes(kernel_name: str):
-    """L2<->fabric bytes per launch of `kernel_name` from the committed rocprofv3 PMC summaries (separate
-    --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, tools/profile.sh).  Counters are in KiB;
-    FETCH_SIZE is doubled (gfx950 counts 128-byte read requests as 64 bytes, MI355X_MICROARCH.md §HBM)."""
+def pmc_traffic_bytes(kernel_names):
+    """L2<->fabric bytes per step -- summed over the step's kernels -- from the committed rocprofv3 PMC summaries
+    (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, tools/profile_r03.sh).  Counters are in KiB;
+    FETCH_SIZE is doubled (gfx950 counts 128-byte read requests as 64 bytes, MI355X_MICROARCH.md §HBM).  Returns
+    (bytes, stamp): the stamp names the profile directory and the commit the profile was taken at."""
     import csv
     import glob
-    tot = {}
+    if isinstance(kernel_names, str):
+        kernel_names = [kernel_names]
+    tot, src = 0.0, None
     for cname, scale in (('FETCH_SIZE', 2048.0), ('WRITE_SIZE', 1024.0)):
         files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', f'pmc_{cname.split("_")[0].lower()}_summary.csv')))
         if not files:
-            return None
+            return None, None
+        src = os.path.dirname(files[-1])
+        found = set()
         for row in csv.DictReader(open(files[-1])):
-            if kernel_name in row['kernel'] and row['counter'] == cname:
-                tot[cname] = float(row['mean_value']) * scale
-    return tot['FETCH_SIZE'] + tot['WRITE_SIZE'] if len(tot) == 2 else None
+            for k in kernel_names:
+                if k in row['kernel'] and row['counter'] == cname and k not in found:
+                    tot += float(row['mean_value']) * scale
+                    found.add(k)
+        if len(found) != len(kernel_names):
+            return None, None
+    stamp = {'profile': os.path.relpath(src, ROOT)}
+    try:
+        stamp.update(json.load(open(os.path.join(src, 'STAMP.json'))))
+    except (OSError, ValueError):
+        pass
+    return tot, stamp
 
 
 def rocprof_avg_ms(kernel_names):
@@ -516,9 +530,10 @@ def main():
         knames = [kname]
         what = 'the whole optimiser step: gradient pass + all-reduce + stand-alone Adam'
     achieved = nbytes / (ms_step_dev * 1e-3) / 1e9
+    traffic, traffic_stamp = pmc_traffic_bytes(knames) if world == 1 else (None, None)
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic_bytes(kname) if world == 1 else None,
-                'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/)', 'kernel': what,
+                'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_profile': traffic_stamp,
+                'traffic_unit': 'bytes/step, both launches (rocprofv3 PMC, FETCH_SIZE x 2 + WRITE_SIZE)', 'kernel': what,
                 'avg_launch_ms': ms_step_dev, 'algorithmic_bytes_per_launch': nbytes,
                 'timing': 'HIP events on the launch stream around replays of whole-epoch graphs, per step '
                           '(kernel boundaries included)' if graphs else 'HIP events on the launch stream around '

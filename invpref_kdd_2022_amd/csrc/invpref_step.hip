@@ -1395,6 +1395,8 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     if (pure && (flags & (INVPREF_REWEIGHT_CLS | INVPREF_REG_ENV_EMBED))) return INVPREF_EINVAL;
     if ((flags & (INVPREF_REWEIGHT_REC | INVPREF_REWEIGHT_CLS)) && !weights) return INVPREF_EINVAL;
     const DevTables t = dev_tables(tables);
+    // rows are addressed with 32-bit byte offsets (row4 / put4): every table must stay below 4 GiB
+    if ((uint64_t)(t.U > t.I ? t.U : t.I) * (uint64_t)t.D * 4ull >= (1ull << 32)) return INVPREF_EUNSUPPORTED;
     bool vec = vec_ok(tables);
     StepArgs a{};
     if (!fused) {

@@ -144,8 +144,8 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     push: the "push" form of the item side (InvPrefRowPlan.push_slot): launch 1 stores every interaction's two
     contribution rows to its item's gradient at the interaction's item-sorted slot and launch 2 sums contiguous rows
     instead of gathering partner rows + records.  One extra row write + read per interaction and table; default
-    (INVPREF_PLAN_PUSH): on while that traffic stays below a quarter of the dense-Adam stream (Yahoo-class steps: the item
-    jobs become one burst of contiguous loads -- no hot-row tail)."""
+    (INVPREF_PLAN_PUSH): on while the step's working set is cache-resident or that traffic is a small share of the
+    step's bytes (the item jobs become one burst of contiguous loads -- no hot-row tail)."""
     users = np.asarray(users, dtype=np.int64)
     items = np.asarray(items, dtype=np.int64)
     scores = np.asarray(scores, dtype=np.float32)
@@ -163,8 +163,18 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         per_slice = int(os.environ.get('INVPREF_PLAN_PER_SLICE', str(2 if n <= 4 * ng * target // 3 else 16)))
     if push is None:
         env = os.environ.get('INVPREF_PLAN_PUSH')
-        p_floats = 2 * (user_num + item_num) * factor_num
-        push = (env == '1') if env is not None else (0 < n * 4 * lanes * 16 <= 0.25 * 24 * 4 * p_floats)
+        if env is not None:
+            push = env == '1'
+        else:
+            # measured (tools/ab.sh, push vs pull): push wins wherever the step's working set sits in the 256 MiB Infinity
+            # Cache (Yahoo 19.4 vs 20.4 us, Yahoo with B = N 134 vs 178, MovieLens 100 vs 111) and wherever the contribution
+            # rows are a small share of the bytes (a 1/8 MIND minibatch 457 vs 534); it loses on cache-exceeding launches
+            # whose rows dominate (2^20 interactions over 500 000 rows: 768 vs 732)
+            p_floats = 2 * (user_num + item_num) * factor_num
+            contrib = n * 4 * lanes * 16                            # two padded rows written and read per interaction
+            total = n * (32 + 16 * factor_num) + 24 * p_floats       # algorithmic bytes of the step
+            resident = 20 * p_floats + contrib // 2 <= 200e6       # p, p', m, v, g-free: five flat buffers + the rows
+            push = n > 0 and (resident or contrib <= 0.2 * total)
     if item_per_slice is None:
         # (push form: a slice's contribution rows are contiguous and leave in one burst of up to four: measured 4 > 2, 3)
         item_per_slice = int(os.environ.get('INVPREF_PLAN_ITEM_PER_SLICE',

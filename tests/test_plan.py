@@ -142,7 +142,9 @@ def test_plan_push_and_pull_forms(push):
     assert p['push'] == push
     assert planlib.build_row_plan(d[:, 0], d[:, 1], d[:, 2], 15400, 1000)['push']          # Yahoo-class default: push
     m = synth.interactions(5, 6040, 3706, 65536, implicit=True, zipf=False)
-    assert not planlib.build_row_plan(m[:, 0], m[:, 1], m[:, 2], 6040, 3706, factor_num=128)['push']   # MovieLens-class: pull
+    assert planlib.build_row_plan(m[:, 0], m[:, 1], m[:, 2], 6040, 3706, factor_num=128)['push']       # MovieLens-class: cache-resident, push
+    g = synth.interactions(6, 400000, 100000, 1 << 20, implicit=True, zipf=False)
+    assert not planlib.build_row_plan(g[:, 0], g[:, 1], g[:, 2], 400000, 100000)['push']            # cache-exceeding, rows dominate: pull
 
 
 def test_plan_empty_and_single():

@@ -82,6 +82,12 @@ p0 = pls[0]
 print(f'shape U={U} I={I} E={E} D={D} B={B}: lanes {p0["lanes_per_group"]}, per_slice {p0["per_slice"]}/{p0["item_per_slice"]}, '
       f'rounds/task {p0["user_rounds_per_task"]}/{p0["item_rounds_per_task"]}, stream rows/task {p0["rows_per_stream_task"]}, '
       f'split {p0["stream_split"]:.2f}; workgroups launch 1 {planlib.launch_workgroups(p0, 0)}, launch 2 {planlib.launch_workgroups(p0, 1)}')
+if os.environ.get('PROBE_EAGER') == '1':   # (profiling passes: every launch issued eagerly, a few times)
+    for _ in range(3):
+        run_steps()
+    torch.cuda.synchronize()
+    print(f'algorithmic bytes per step {nbytes}')
+    sys.exit(0)
 if not want_stamps:
     us = graph_time()
     print(f'{os.environ.get("INVPREF_LIB", "default")}: {us:.2f} us per step = {nbytes / us / 1e3:.0f} GB/s of algorithmic bytes = '

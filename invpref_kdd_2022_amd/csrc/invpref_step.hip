@@ -80,6 +80,41 @@ __device__ __forceinline__ float group_max(float x) {
     return x;
 }
 __device__ __forceinline__ float wave_sum_valu(float x) { return xor32_sum(xor16_sum(row16_sum(x))); }
+// Reduce-scatter butterfly over the low log2(N) lane bits: every lane holds N partial sums v[0..N) (one per class); on
+// return lane l holds, as the function's value, the sum over its 2^log2(N) butterfly partners of class (l & (N - 1)).
+// Step k keeps the classes whose bit k equals the lane's bit k and trades the others with lane l ^ (1 << k): N - 1
+// exchanged values in all, against N * log2(N) for N separate butterflies.  (xor 1, 2: quad_perm; xor 4: row_shl:4 /
+// row_shr:4 picked by the lane's bit 2; xor 8: row_ror:8.)
+template <int M>
+__device__ __forceinline__ float dpp_xor(float x, int lane) {
+    if (M == 1) return dpp_move<0xB1>(x);
+    if (M == 2) return dpp_move<0x4E>(x);
+    if (M == 4) { const float up = dpp_move<0x104>(x), dn = dpp_move<0x114>(x); return (lane & 4) ? dn : up; }
+    return dpp_move<0x128>(x);   // M == 8: rotate the row of 16 by 8
+}
+template <int N, int M = 1>
+__device__ __forceinline__ float class_butterfly(const float (&v)[N], int lane) {
+    if constexpr (N == 1) {
+        return v[0];
+    } else {
+        float w[N / 2];
+        const bool bit = lane & M;
+#pragma unroll
+        for (int i = 0; i < N / 2; i++) {
+            const float keep = bit ? v[2 * i + 1] : v[2 * i], send = bit ? v[2 * i] : v[2 * i + 1];
+            w[i] = keep + dpp_xor<M>(send, lane);
+        }
+        return class_butterfly<N / 2, M * 2>(w, lane);
+    }
+}
+// the remaining lane bits of the group (classes are spread over the low log2(EMAX) bits only)
+template <int LG, int EMAX>
+__device__ __forceinline__ float group_sum_above(float x, int lane) {
+    if (EMAX <= 8) x += dpp_xor<8>(x, lane);
+    if (LG >= 32) x = xor16_sum(x);
+    if (LG >= 64) x = xor32_sum(x);
+    return x;
+}
 __device__ __forceinline__ float dot4(float4 a, float4 b) {
     float s = a.x * b.x;
     s = __builtin_fmaf(a.y, b.y, s);
@@ -288,13 +323,14 @@ __device__ __forceinline__ void eval_interaction(Eval<EMAX> &o, float4 pu, float
     } else {
         // larger classifiers keep ONE class per lane: the logit of class c is a group-uniform value after the
         // row reduction, lane c keeps it; max / sum of the softmax are group reductions, one exp per lane
-        float zmine = -__builtin_inff();
-#pragma unroll 4
-        for (int c = 0; c < E; c++) {
-            const float4 wr = *reinterpret_cast<const float4 *>(sW + c * DP + lg * 4);
-            const float zc = group_sum<LG>(dot4(o.x, wr)) + sb[c];
-            zmine = (lg == c) ? zc : zmine;
-        }
+        // all EMAX class dot products per lane (rows c >= E are staged as zeros), then ONE reduce-scatter butterfly:
+        // lane l ends up with the logit of class l & (EMAX - 1)
+        float part[EMAX > 4 ? EMAX : 1];
+#pragma unroll
+        for (int c = 0; c < (EMAX > 4 ? EMAX : 1); c++)
+            part[c] = dot4(o.x, *reinterpret_cast<const float4 *>(sW + c * DP + lg * 4));
+        const float zred = group_sum_above<LG, EMAX>(class_butterfly<(EMAX > 4 ? EMAX : 1)>(part, lg), lg);
+        const float zmine = lg < E ? zred + sb[lg & (EMAX - 1)] : -__builtin_inff();
         const float mxl = group_max<LG>(zmine);
         const float ez = lg < E ? f_exp(zmine - mxl) : 0.f;
         const float rsel = f_rcp(group_sum<LG>(ez));
@@ -1058,58 +1094,71 @@ __device__ __forceinline__ void stream_delay() {
 #ifndef STEP_STREAM_ST
 #define STEP_STREAM_ST 1   // (A/B knob: 1 = write-through stores for the streamed rows)
 #endif
+// (Tried in round 3: two register sets with the next rows' loads issued before the current rows' stores, so that a task
+//  of several iterations would be one round trip + work -- 128-row tasks in launch 1 ran 23-28 us per step against
+//  19.4: the rows per CU, not the iterations' round trips, pace these workgroups.  One iteration per task it is.)
 template <int LG, bool VEC>
 __device__ __forceinline__ void stream_task(const DevTables &t, const StepArgs &a, const int *rows, int n) {
     constexpr int R = 2, NG = kThreads / LG;
     const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG;
     const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
     const bool pure = a.flags & INVPREF_PURE_MF;
-    for (int i = grp; i < n; i += R * NG) {
+    if (!a.fused) {   // gradient form: the untouched rows' gradient is a row of zeros
+        for (int i = grp; i < n; i += NG) {
+            const int rid = rows[i], side = (rid >> 30) & 1, row = rid & 0x3fffffff;
+            put4<VEC>(side ? a.np[1] : a.np[0], row, t.D, lg, f4zero());
+            if (!pure) put4<VEC>(side ? a.np[3] : a.np[2], row, t.D, lg, f4zero());
+        }
+        return;
+    }
+    struct Set {
         int row[R], side[R];
         bool on[R];
+        float4 p[2 * R], m[2 * R], v[2 * R];  // {row 0 inv, row 0 env, row 1 inv, ...}
+    };
+    auto load = [&](Set &S, int i0) {
 #pragma unroll
         for (int q = 0; q < R; q++) {
-            on[q] = i + q * NG < n;
-            const int rid = rows[on[q] ? i + q * NG : i];
-            side[q] = (rid >> 30) & 1;
-            row[q] = rid & 0x3fffffff;
+            const int idx = i0 + q * NG;
+            S.on[q] = idx < n;
+            const int rid = rows[S.on[q] ? idx : 0];      // (clamped: a slot beyond the task re-reads row 0 of it)
+            S.side[q] = (rid >> 30) & 1;
+            S.row[q] = rid & 0x3fffffff;
         }
-        if (!a.fused) {
-#pragma unroll
-            for (int q = 0; q < R; q++) {
-                if (!on[q]) continue;
-                put4<VEC>(side[q] ? a.np[1] : a.np[0], row[q], t.D, lg, f4zero());
-                if (!pure) put4<VEC>(side[q] ? a.np[3] : a.np[2], row[q], t.D, lg, f4zero());
-            }
-            continue;
-        }
-        float4 p[2 * R], m[2 * R], v[2 * R];  // {row 0 inv, row 0 env, row 1 inv, ...}
 #pragma unroll
         for (int q = 0; q < 2 * R; q++) {
-            p[q] = m[q] = v[q] = f4zero();
-            const int s = side[q >> 1];
+            S.p[q] = S.m[q] = S.v[q] = f4zero();
+            const int s = S.side[q >> 1];
             if (!(pure && (q & 1))) {
                 const float *T = (q & 1) ? (s ? t.Qa : t.Pa) : (s ? t.Qi : t.Pu);
                 const float *M = (q & 1) ? (s ? a.m[3] : a.m[2]) : (s ? a.m[1] : a.m[0]);
                 const float *V = (q & 1) ? (s ? a.v[3] : a.v[2]) : (s ? a.v[1] : a.v[0]);
-                p[q] = row4<VEC>(T, row[q >> 1], t.D, lg);
-                m[q] = row4<VEC>(M, row[q >> 1], t.D, lg);
-                v[q] = row4<VEC>(V, row[q >> 1], t.D, lg);
+                S.p[q] = row4<VEC>(T, S.row[q >> 1], t.D, lg);
+                S.m[q] = row4<VEC>(M, S.row[q >> 1], t.D, lg);
+                S.v[q] = row4<VEC>(V, S.row[q >> 1], t.D, lg);
             }
         }
+    };
+    auto finish = [&](Set &S) {
 #pragma unroll
         for (int q = 0; q < 2 * R; q++) {
-            const int s = side[q >> 1];
-            if (on[q >> 1] && !(pure && (q & 1))) {
-                adam4(p[q], f4zero(), m[q], v[q], ad);
+            const int s = S.side[q >> 1];
+            if (S.on[q >> 1] && !(pure && (q & 1))) {
+                adam4(S.p[q], f4zero(), S.m[q], S.v[q], ad);
                 float *NP = (q & 1) ? (s ? a.np[3] : a.np[2]) : (s ? a.np[1] : a.np[0]);
                 float *M = (q & 1) ? (s ? a.m[3] : a.m[2]) : (s ? a.m[1] : a.m[0]);
                 float *V = (q & 1) ? (s ? a.v[3] : a.v[2]) : (s ? a.v[1] : a.v[0]);
-                put4<VEC, STEP_STREAM_ST>(NP, row[q >> 1], t.D, lg, p[q]);
-                put4<VEC, STEP_STREAM_ST>(M, row[q >> 1], t.D, lg, m[q]);
-                put4<VEC, STEP_STREAM_ST>(V, row[q >> 1], t.D, lg, v[q]);
+                put4<VEC, STEP_STREAM_ST>(NP, S.row[q >> 1], t.D, lg, S.p[q]);
+                put4<VEC, STEP_STREAM_ST>(M, S.row[q >> 1], t.D, lg, S.m[q]);
+                put4<VEC, STEP_STREAM_ST>(V, S.row[q >> 1], t.D, lg, S.v[q]);
             }
         }
+    };
+    const int iters = (n + R * NG - 1) / (R * NG);   // (workgroup-uniform)
+    Set A;
+    for (int it = 0; it < iters; it++) {
+        load(A, grp + it * R * NG);
+        finish(A);
     }
 }
 

@@ -380,8 +380,8 @@ template <int LG, bool VEC, int EMAX>
 __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a, int r0, int nr, int slab_index, float *lds) {
     using G = Geo<LG, EMAX>;
     // interactions in flight per group (measured: 2 for the D <= 64, E <= 4 instances -- a third slot only costs registers
-    // there -- and 3 for the larger rows)
-    constexpr int UE = (LG == 16 && EMAX <= 4 && STEP_EVAL_DEPTH > 2) ? 2 : STEP_EVAL_DEPTH;
+    // there -- and for E > 8, whose per-interaction barrier paces the groups anyway; 3 for the other larger rows)
+    constexpr int UE = EMAX > 8 ? 1 : ((LG == 16 && EMAX <= 4 && STEP_EVAL_DEPTH > 2) ? 2 : STEP_EVAL_DEPTH);
     using L = EvalLds<LG, EMAX>;
     constexpr int NG = G::NG, DP = G::DP, RS = G::RS;
     float *sEv = lds + L::sEv, *sW = lds + L::sW, *sb = lds + L::sb, *slots = lds + L::slots;
@@ -393,8 +393,10 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
     const bool rw_rec = a.flags & INVPREF_REWEIGHT_REC, rw_cls = a.flags & INVPREF_REWEIGHT_CLS;
     const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
     const bool pure = a.flags & INVPREF_PURE_MF;   // env-aware tables, embed_env, classifier absent: never touched
-    const bool dma = VEC && a.fused;
+    // (E > 8: the LDS-DMA landing area holds the embed_env partial sums instead; the moments are loaded late)
+    const bool dma = VEC && a.fused && EMAX <= 8;
     const bool push = a.push_slot != nullptr;
+    float *sdE = lds + L::mv;   // E > 8: [EMAX][DP] embed_env partial sums of the workgroup, rows indexed by the environment
     StepScalars k = a.k;
     if (a.sched_state) {  // scheduled alpha (train.py:214-217) under graph replay
         const float al = sched_slot_ptr(a.sched_state, a.sched_slot)->alpha;
@@ -408,16 +410,18 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
     stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
     stage_small(sW, t.W, t.E, t.D, EMAX, DP);
     if (threadIdx.x < EMAX) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
+    if (!G::REG)
+        for (int i = threadIdx.x; i < EMAX * DP; i += kThreads) sdE[i] = 0.f;
     STAMP(1);
 
     // E x D partial sums: registers (E <= 4: per group, all classes) or thread-owned outputs fed from LDS records
     float4 dW[G::REG ? EMAX : 1], dE[G::REG ? EMAX : 1];
     float dB[G::REG ? EMAX : 1];
-    float oW[G::REG ? 1 : G::CPT], oE[G::REG ? 1 : G::CPT], oB[G::REG ? 1 : G::CPT];
+    float oW[G::REG ? 1 : G::CPT], oB1 = 0.f;
 #pragma unroll
     for (int c = 0; c < (G::REG ? EMAX : 1); c++) { dW[c] = dE[c] = f4zero(); dB[c] = 0.f; }
 #pragma unroll
-    for (int i = 0; i < (G::REG ? 1 : G::CPT); i++) oW[i] = oE[i] = oB[i] = 0.f;
+    for (int i = 0; i < (G::REG ? 1 : G::CPT); i++) oW[i] = 0.f;
     const int d_own = threadIdx.x % DP, cg = threadIdx.x / DP;
     float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
     int it_total = 0;   // E > 4: parity of the gz scratch / record buffers
@@ -577,7 +581,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 const float *recx = lds + L::rec + ((it_total & 1) * NG * 2) * DP;
                 const float *recz = lds + L::recs + ((it_total & 1) * NG) * (EMAX + 4);
                 if (threadIdx.x < G::CG * DP) {
-                    constexpr int BATCH = NG < 4 ? NG : 4;   // records whose LDS reads are in flight together
+                    constexpr int BATCH = G::CPT > 8 ? 2 : (NG < 4 ? NG : 4);   // records whose LDS reads are in flight together
 #pragma unroll 1
                     for (int g0 = 0; g0 < NG; g0 += BATCH) {
                         int er[BATCH];
@@ -599,9 +603,11 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                             for (int i = 0; i < G::CPT; i++) {
                                 const float gzc = ok ? gr[b][i] : 0.f;
                                 oW[G::REG ? 0 : i] = __builtin_fmaf(gzc, xv, oW[G::REG ? 0 : i]);
-                                oE[G::REG ? 0 : i] += (ok && cg + G::CG * i == er[b]) ? orr[b] : 0.f;
-                                oB[G::REG ? 0 : i] += gzc;
                             }
+                            // embed_env: ONE read-modify-write of the row the record's environment names (this thread's
+                            // column; one thread per column) instead of a select + add per class
+                            if (ok && cg == 0) sdE[er[b] * DP + d_own] += orr[b];
+                            if (threadIdx.x < EMAX) oB1 += ok ? recz[(g0 + b) * (EMAX + 4) + threadIdx.x] : 0.f;
                         }
                     }
                 }
@@ -697,15 +703,16 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                     float *ls = red + wave * kLossSlots;
                     ls[0] = accLi; ls[1] = accLe; ls[2] = accLc; ls[3] = accL2; ls[4] = accL1; ls[5] = ls[6] = ls[7] = 0.f;
                 }
+                if (threadIdx.x < EMAX) slab[2 * EMAX * DP + threadIdx.x] = oB1;
+                if (cg == 0 && d_own < DP) {        // (this thread's own column of the LDS rows: its own program order)
+#pragma unroll 4
+                    for (int c = 0; c < EMAX; c++) slab[c * DP + d_own] = sdE[c * DP + d_own];
+                }
                 if (threadIdx.x < G::CG * DP) {   // thread-owned outputs: straight to the slab
 #pragma unroll
                     for (int i = 0; i < (G::REG ? 1 : G::CPT); i++) {
                         const int c = cg + G::CG * i;
-                        if (c < EMAX) {
-                            slab[c * DP + d_own] = oE[i];
-                            slab[EMAX * DP + c * DP + d_own] = oW[i];
-                            if (d_own == 0) slab[2 * EMAX * DP + c] = oB[i];
-                        }
+                        if (c < EMAX) slab[EMAX * DP + c * DP + d_own] = oW[i];
                     }
                 }
             }

@@ -162,6 +162,7 @@ class _BasicTrainManager(_InvPrefTrainManager):
         self._force_sharded_path, self._unfused = forced, False
         self._collective_ok = _dist.is_available() and _dist.is_initialized()
         self._graphs, self._graph_warm = {}, False
+        self._estep_graphs = {}
         self._grad_stale = False
         self._sched, self._sched_synced = None, False
 

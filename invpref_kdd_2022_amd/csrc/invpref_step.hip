@@ -361,6 +361,39 @@ __device__ __forceinline__ void stage_small(float *dst, const float *__restrict_
     }
 }
 
+// A task's FIRST descriptors through the scalar cache (A/B knob STEP_SCALAR_DESC): the wave's group slots are adjacent,
+// so their descriptors are one or two scalar loads; each lane then picks its group's words.  The scalar path is not
+// queued behind the launch's vector load burst.  (Plans are written once, before any launch reads them: the scalar
+// cache's lack of coherence with vector stores does not matter here.)
+#ifndef STEP_SCALAR_DESC
+#define STEP_SCALAR_DESC 0
+#endif
+template <int LG>
+__device__ __forceinline__ void first_desc(const int4 *desc, int r0, int grp, int4 &d, int4 &d1) {
+    constexpr int NG = kThreads / LG, GW = 64 / LG;   // groups per wave
+    if (!STEP_SCALAR_DESC) {
+        d = desc[(r0 * NG + grp) * 2];
+        d1 = desc[(r0 * NG + grp) * 2 + 1];
+        return;
+    }
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) v4i *cptr;
+    const int wave = threadIdx.x >> 6, gw = (threadIdx.x & 63) / LG;
+    const int base = __builtin_amdgcn_readfirstlane((r0 * NG + wave * GW) * 2);
+    cptr sd = (cptr)(uintptr_t)desc;
+    v4i s[2 * GW];
+#pragma unroll
+    for (int i = 0; i < 2 * GW; i++) s[i] = sd[base + i];
+    d = make_int4(s[0].x, s[0].y, s[0].z, s[0].w); d1 = make_int4(s[1].x, s[1].y, s[1].z, s[1].w);
+#pragma unroll
+    for (int g = 1; g < GW; g++) {
+        const bool me = gw == g;
+        d.x = me ? s[2 * g].x : d.x; d.y = me ? s[2 * g].y : d.y; d.z = me ? s[2 * g].z : d.z; d.w = me ? s[2 * g].w : d.w;
+        d1.x = me ? s[2 * g + 1].x : d1.x; d1.y = me ? s[2 * g + 1].y : d1.y;
+        d1.z = me ? s[2 * g + 1].z : d1.z; d1.w = me ? s[2 * g + 1].w : d1.w;
+    }
+}
+
 struct USample {
     int oth, ps;
     float y;
@@ -406,7 +439,8 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
 
     STAMP(0);
     // the first round's descriptor goes out before anything else: every gather below hangs on it
-    int4 d = a.desc[(r0 * NG + grp) * 2], d1 = a.desc[(r0 * NG + grp) * 2 + 1];
+    int4 d, d1;
+    first_desc<LG>(a.desc, r0, grp, d, d1);
     stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
     stage_small(sW, t.W, t.E, t.D, EMAX, DP);
     if (threadIdx.x < EMAX) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
@@ -818,7 +852,8 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
     }
     const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
     STAMP(0);
-    int4 d = a.desc[(r0 * NG + grp) * 2], d1 = a.desc[(r0 * NG + grp) * 2 + 1];
+    int4 d, d1;
+    first_desc<LG>(a.desc, r0, grp, d, d1);
     stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
     stage_small(sW, t.W, t.E, t.D, EMAX, DP);
     STAMP(1);
@@ -979,7 +1014,8 @@ __device__ __forceinline__ void item_task_push(const DevTables &t, const StepArg
     const StepScalars k = a.k;
     const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
     STAMP(0);
-    int4 d = a.desc[(r0 * NG + grp) * 2];
+    int4 d, d1_unused;
+    first_desc<LG>(a.desc, r0, grp, d, d1_unused);
     STAMP(1);
     for (int r = r0; r < r0 + nr; r++) {
         const int4 dd = d;

@@ -525,6 +525,7 @@ class _InvPrefTrainManager:
                 or self._raw_ptrs[4] != self.sample_weights.data_ptr():
             self._raw_setup()
             self._graphs.clear()
+            self._estep_graphs.clear()
         st = self.state
         # the fused single-GPU step, and the gradient-pass -> [all-reduce] -> ranged-Adam sequence of sharded runs and
         # wide rows (RCCL collectives record into a HIP graph like kernels do), are replayed as whole-epoch graphs
@@ -643,6 +644,12 @@ class _InvPrefTrainManager:
                     self.state.swap()
                 self.state.step += 1
             self.state.step = step0
+        # the E-step graphs of both parameter buffers too (their capture warms up and synchronises the host)
+        if self.users_tensor.is_cuda and self.world_size == 1 and not self._pure:
+            for _ in range(2):
+                self._estep_graph(self.cluster_use_random_sort)
+                if self._fused_seq():
+                    self.state.swap()
 
     def _epochs_to_next_event(self) -> int:
         """How many epochs train() may enqueue before the next evaluate / cluster / end of training."""
@@ -699,13 +706,16 @@ class _InvPrefTrainManager:
         self._pending_stat = (counts, cw, sw)
         return int(diff.item()) if sync else diff.clone()
 
-    def _cluster_replay(self, eps):
-        """The E-step + the count / weight half of stat_envs as a captured graph, one per parameter buffer (the
-        fused M-step ping-pongs between two) and per interaction-array set; outputs live in the graph's pool."""
-        key = (self.state.p_views[0].data_ptr(), self.envs.data_ptr(), self.users_tensor.data_ptr(), eps is not None)
+    def _estep_graph(self, with_eps: bool):
+        """The captured E-step (+ the count / weight half of stat_envs) for the CURRENT parameter buffer and interaction
+        arrays, captured on first use: (graph, eps staging buffer or None, output tensors in the graph's pool).
+        The capture needs a warm-up E-step and a host sync; prepare_graphs() does it ahead of time for both
+        parameter buffers, so that cluster(sync=False) inside a timed loop only replays."""
+        key = (self.state.p_views[0].data_ptr(), self.envs.data_ptr(), self.users_tensor.data_ptr(), with_eps)
         ent = self._estep_graphs.get(key)
         if ent is None:
-            eps_buf = None if eps is None else torch.empty_like(eps)
+            eps_buf = torch.zeros(self.users_tensor.shape[0], self.envs_num, dtype=torch.float32, device=self.device) \
+                if with_eps else None
 
             def run():
                 _, counts, diff, cw, sw = ops.estep(self.state.p_views, self.users_tensor, self.items_tensor,
@@ -714,8 +724,6 @@ class _InvPrefTrainManager:
                 return counts, diff, cw, sw
             # sizes the workspace outside the capture (envs is restored: the warm-up is not an E-step)
             keep = self.envs.clone()
-            if eps_buf is not None:
-                eps_buf.copy_(eps)
             run()
             self.envs.copy_(keep)
             torch.cuda.synchronize()
@@ -723,7 +731,11 @@ class _InvPrefTrainManager:
             with torch.cuda.graph(g):
                 outs = run()
             ent = self._estep_graphs[key] = (g, eps_buf, outs)
-        g, eps_buf, outs = ent
+        return ent
+
+    def _cluster_replay(self, eps):
+        """One graph per parameter buffer (the fused M-step ping-pongs between two) and per interaction-array set."""
+        g, eps_buf, outs = self._estep_graph(eps is not None)
         if eps_buf is not None:
             eps_buf.copy_(eps)
         g.replay()

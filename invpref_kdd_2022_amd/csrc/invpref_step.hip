@@ -223,12 +223,18 @@ struct StepArgs {
         }                                                                         \
     } while (0)
 
+#ifndef STEP_NO_DMA
+#define STEP_NO_DMA 0   // (A/B knob: the smallest instance without the LDS-DMA landing area: 44 KB, three workgroups per CU)
+#endif
+#ifndef STEP_REG_EMAX
+#define STEP_REG_EMAX 8   // (A/B knob: the largest class count whose E x D partial sums live in registers)
+#endif
 template <int LG, int EMAX>
 struct Geo {
     static constexpr int NG = kThreads / LG;          // groups (rows in flight) per workgroup
     static constexpr int DP = 4 * LG;                 // padded row length
     static constexpr int RS = 4 + EMAX;               // floats per record: g_p, g_q, env bits, 0, gz[EMAX]
-    static constexpr bool REG = EMAX <= 8;            // E x D partial sums in registers (else: LDS records)
+    static constexpr bool REG = EMAX <= STEP_REG_EMAX;   // E x D partial sums in registers (else: LDS records)
     static constexpr int SLAB = 2 * EMAX * DP + EMAX + kLossSlots;   // dEv | dW | db | loss sums
     // the workgroup's partial sums meet in LDS as RED rows of SLAB floats: one per GROUP for the smallest instance (plain
     // stores, no lane exchanges: the 72 permlane + add pairs of a per-wave pre-reduction sat on the step's critical
@@ -249,7 +255,7 @@ struct EvalLds {
     static constexpr int sb = sW + EMAX * G::DP;                    // [EMAX]
     static constexpr int slots = sb + EMAX;                         // [NG][2][DP] slice partials
     static constexpr int mv = slots + G::NG * 2 * G::DP;            // [4 waves][4][64] float4 LDS-DMA landing area
-    static constexpr int red = mv + kWaves * 4 * 64 * 4;            // REG: [4 waves][SLAB]; else [4 waves][8] loss sums
+    static constexpr int red = mv + (STEP_NO_DMA && G::DIRECT ? 0 : kWaves * 4 * 64 * 4);            // REG: [4 waves][SLAB]; else [4 waves][8] loss sums
     static constexpr int rec = red + (G::REG ? G::RED * G::SLAB : kWaves * kLossSlots);   // E > 8: [2][NG][2][DP] x, o
     static constexpr int recs = rec + (G::REG ? 0 : 2 * G::NG * 2 * G::DP);              // E > 4: [2][NG][EMAX + 4] gz, env
     static constexpr int total = recs + (EMAX <= 4 ? 0 : 2 * G::NG * (EMAX + 4));
@@ -414,7 +420,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
     using G = Geo<LG, EMAX>;
     // interactions in flight per group (measured: 2 for the D <= 64, E <= 4 instances -- a third slot only costs registers
     // there -- and for E > 8, whose per-interaction barrier paces the groups anyway; 3 for the other larger rows)
-    constexpr int UE = EMAX > 8 ? 1 : ((LG == 16 && EMAX <= 4 && STEP_EVAL_DEPTH > 2) ? 2 : STEP_EVAL_DEPTH);
+    constexpr int UE = !G::REG ? 1 : ((LG == 16 && EMAX <= 4 && STEP_EVAL_DEPTH > 2) ? 2 : STEP_EVAL_DEPTH);
     using L = EvalLds<LG, EMAX>;
     constexpr int NG = G::NG, DP = G::DP, RS = G::RS;
     float *sEv = lds + L::sEv, *sW = lds + L::sW, *sb = lds + L::sb, *slots = lds + L::slots;
@@ -427,7 +433,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
     const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
     const bool pure = a.flags & INVPREF_PURE_MF;   // env-aware tables, embed_env, classifier absent: never touched
     // (E > 8: the LDS-DMA landing area holds the embed_env partial sums instead; the moments are loaded late)
-    const bool dma = VEC && a.fused && EMAX <= 8;
+    const bool dma = VEC && a.fused && G::REG && !(STEP_NO_DMA && G::DIRECT);
     const bool push = a.push_slot != nullptr;
     float *sdE = lds + L::mv;   // E > 8: [EMAX][DP] embed_env partial sums of the workgroup, rows indexed by the environment
     StepScalars k = a.k;
@@ -446,14 +452,16 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
     if (threadIdx.x < EMAX) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
     if (!G::REG)
         for (int i = threadIdx.x; i < EMAX * DP; i += kThreads) sdE[i] = 0.f;
+    else   // embed_env's partial sums are accumulated IN the rows the workgroup's partial sums meet in (below)
+        for (int i = threadIdx.x; i < G::RED * EMAX * DP; i += kThreads) red[(i / (EMAX * DP)) * G::SLAB + i % (EMAX * DP)] = 0.f;
     STAMP(1);
 
     // E x D partial sums: registers (E <= 4: per group, all classes) or thread-owned outputs fed from LDS records
-    float4 dW[G::REG ? EMAX : 1], dE[G::REG ? EMAX : 1];
+    float4 dW[G::REG ? EMAX : 1];
     float dB[G::REG ? EMAX : 1];
     float oW[G::REG ? 1 : G::CPT], oB1 = 0.f;
 #pragma unroll
-    for (int c = 0; c < (G::REG ? EMAX : 1); c++) { dW[c] = dE[c] = f4zero(); dB[c] = 0.f; }
+    for (int c = 0; c < (G::REG ? EMAX : 1); c++) { dW[c] = f4zero(); dB[c] = 0.f; }
 #pragma unroll
     for (int i = 0; i < (G::REG ? 1 : G::CPT); i++) oW[i] = 0.f;
     const int d_own = threadIdx.x % DP, cg = threadIdx.x / DP;
@@ -590,8 +598,24 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
 #pragma unroll
                     for (int c = 0; c < (G::REG ? EMAX : 1); c++) {
                         f4fma(dW[c], gzv[c], o.x);
-                        f4add(dE[c], c == e ? oo : f4zero());
                         dB[c] += gzv[c];
+                    }
+                    // embed_env: ONE read-modify-write of the LDS row the interaction's environment names -- a row set per
+                    // group (smallest instance) or per wave, whose groups then take turns (in-order LDS operations of one
+                    // wave: fixed order, no barrier) -- instead of a select + add per class on registers
+                    float4 *erow = reinterpret_cast<float4 *>(red + (G::DIRECT ? grp : wave) * G::SLAB + e * DP + lg * 4);
+                    if (G::DIRECT || LG == 64) {
+                        float4 cur = *erow;
+                        f4add(cur, oo);
+                        *erow = cur;
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 64 / LG; g++)
+                            if (lane / LG == g) {
+                                float4 cur = *erow;
+                                f4add(cur, oo);
+                                *erow = cur;
+                            }
                     }
 #endif
                 } else {
@@ -692,8 +716,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 accL2 = row16_sum(accL2); accL1 = row16_sum(accL1);
                 float *mine = red + grp * G::SLAB;
 #pragma unroll
-                for (int c = 0; c < (G::REG ? EMAX : 1); c++) {
-                    *reinterpret_cast<float4 *>(mine + c * DP + lg * 4) = dE[c];
+                for (int c = 0; c < (G::REG ? EMAX : 1); c++) {   // (the embed_env rows are there already)
                     *reinterpret_cast<float4 *>(mine + EMAX * DP + c * DP + lg * 4) = dW[c];
                     if (lg == 0) mine[2 * EMAX * DP + c] = dB[c];
                 }
@@ -709,21 +732,16 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 float *mine = red + wave * G::SLAB;
 #pragma unroll
                 for (int c = 0; c < (G::REG ? EMAX : 1); c++) {
-                    float4 &w4 = dW[c], &e4 = dE[c];
+                    float4 &w4 = dW[c];
                     if (LG == 16) {
                         w4.x = xor16_sum(w4.x); w4.y = xor16_sum(w4.y); w4.z = xor16_sum(w4.z); w4.w = xor16_sum(w4.w);
-                        e4.x = xor16_sum(e4.x); e4.y = xor16_sum(e4.y); e4.z = xor16_sum(e4.z); e4.w = xor16_sum(e4.w);
                         dB[c] = xor16_sum(dB[c]);
                     }
                     if (LG <= 32) {
                         w4.x = xor32_sum(w4.x); w4.y = xor32_sum(w4.y); w4.z = xor32_sum(w4.z); w4.w = xor32_sum(w4.w);
-                        e4.x = xor32_sum(e4.x); e4.y = xor32_sum(e4.y); e4.z = xor32_sum(e4.z); e4.w = xor32_sum(e4.w);
                         dB[c] = xor32_sum(dB[c]);
                     }
-                    if (lane < LG) {
-                        *reinterpret_cast<float4 *>(mine + c * DP + lane * 4) = e4;
-                        *reinterpret_cast<float4 *>(mine + EMAX * DP + c * DP + lane * 4) = w4;
-                    }
+                    if (lane < LG) *reinterpret_cast<float4 *>(mine + EMAX * DP + c * DP + lane * 4) = w4;
                     if (lane == 0) mine[2 * EMAX * DP + c] = dB[c];
                 }
                 if (lane == 0) {
@@ -1342,7 +1360,7 @@ __device__ __forceinline__ void class_row(const StepArgs &a, int c, int (&q)[4])
 #define STEP_APPLY_WAVES 4
 #endif
 template <int LG, bool VEC, int EMAX>
-__global__ __launch_bounds__(kThreads, STEP_EVAL_WAVES) void mstep_eval_kernel(DevTables t, StepArgs a) {
+__global__ __launch_bounds__(kThreads, (STEP_NO_DMA && LG == 16 && EMAX <= 4) ? 3 : STEP_EVAL_WAVES) void mstep_eval_kernel(DevTables t, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // Workgroup b runs the tasks of class c = b % n_cls (XCD-affine order, InvPrefRowPlan), the j-th of them with
     // j = b / n_cls: its user jobs first, then its share of the untouched rows.  Every branch is workgroup-uniform.

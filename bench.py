@@ -351,7 +351,7 @@ def step_bench(dev, Us, Is, Es, Ds, Bs, n_steps, zipf=False, seed=5, note=''):
     V = [torch.zeros_like(p) for p in P]
     t0 = time.perf_counter()
     plans = [planlib.upload(planlib.build_row_plan(data[k * Bs:(k + 1) * Bs, 0], data[k * Bs:(k + 1) * Bs, 1],
-                                                   data[k * Bs:(k + 1) * Bs, 2], Us, Is, factor_num=Ds), dev)
+                                                   data[k * Bs:(k + 1) * Bs, 2], Us, Is, factor_num=Ds, env_num=Es), dev)
              for k in range(n_steps)]
     plan_s = time.perf_counter() - t0
     e = torch.from_numpy(rs.randint(0, Es, n_steps * Bs).astype(np.int64)).to(dev)

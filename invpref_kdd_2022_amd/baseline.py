@@ -184,7 +184,7 @@ class _BasicTrainManager(_InvPrefTrainManager):
         v = batch_items_tensor.detach().cpu().numpy()
         y = batch_scores_tensor.detach().float().contiguous()
         dp = planlib.upload(planlib.build_row_plan(u, v, y.cpu().numpy(), self.model.user_num, self.model.item_num,
-                                                   factor_num=self.model.factor_num), self.device)
+                                                   factor_num=self.model.factor_num, env_num=0), self.device)
         st = self.state
         st.losses6.zero_()
         st.step += 1

@@ -223,6 +223,12 @@ struct StepArgs {
         }                                                                         \
     } while (0)
 
+#ifndef STEP_SLOT_ALIAS
+#define STEP_SLOT_ALIAS 1
+#endif
+#ifndef STEP_LDS_DW
+#define STEP_LDS_DW 1   // (A/B knob: smallest instance, classifier partial sums accumulated in LDS rows too)
+#endif
 #ifndef STEP_NO_DMA
 #define STEP_NO_DMA 0   // (A/B knob: the smallest instance without the LDS-DMA landing area: 44 KB, three workgroups per CU)
 #endif
@@ -253,8 +259,12 @@ struct EvalLds {
     static constexpr int sEv = 0;                                   // [EMAX][DP]
     static constexpr int sW = sEv + EMAX * G::DP;                   // [EMAX][DP]
     static constexpr int sb = sW + EMAX * G::DP;                    // [EMAX]
-    static constexpr int slots = sb + EMAX;                         // [NG][2][DP] slice partials
-    static constexpr int mv = slots + G::NG * 2 * G::DP;            // [4 waves][4][64] float4 LDS-DMA landing area
+    // slice partials [NG][2][DP]: an area of their own, or (ALIAS) inside the LDS-DMA landing area of the group's OWN wave
+    // -- the leader takes the row's moments out of it first, same wave, program order -- which is what lets three
+    // workgroups of the smallest instance share a CU's 160 KB
+    static constexpr bool ALIAS = G::REG && STEP_SLOT_ALIAS;
+    static constexpr int slots = sb + EMAX;
+    static constexpr int mv = slots + (ALIAS ? 0 : G::NG * 2 * G::DP);   // [4 waves][4][64] float4 LDS-DMA landing area
     static constexpr int red = mv + (STEP_NO_DMA && G::DIRECT ? 0 : kWaves * 4 * 64 * 4);            // REG: [4 waves][SLAB]; else [4 waves][8] loss sums
     static constexpr int rec = red + (G::REG ? G::RED * G::SLAB : kWaves * kLossSlots);   // E > 8: [2][NG][2][DP] x, o
     static constexpr int recs = rec + (G::REG ? 0 : 2 * G::NG * 2 * G::DP);              // E > 4: [2][NG][EMAX + 4] gz, env
@@ -452,8 +462,12 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
     if (threadIdx.x < EMAX) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
     if (!G::REG)
         for (int i = threadIdx.x; i < EMAX * DP; i += kThreads) sdE[i] = 0.f;
-    else   // embed_env's partial sums are accumulated IN the rows the workgroup's partial sums meet in (below)
-        for (int i = threadIdx.x; i < G::RED * EMAX * DP; i += kThreads) red[(i / (EMAX * DP)) * G::SLAB + i % (EMAX * DP)] = 0.f;
+    else {
+        // embed_env's partial sums -- in the smallest instance the classifier's too (STEP_LDS_DW) -- are accumulated IN
+        // the rows the workgroup's partial sums meet in (below)
+        constexpr int ZR = (G::DIRECT && STEP_LDS_DW) ? 2 * EMAX * DP + EMAX : EMAX * DP;
+        for (int i = threadIdx.x; i < G::RED * ZR; i += kThreads) red[(i / ZR) * G::SLAB + i % ZR] = 0.f;
+    }
     STAMP(1);
 
     // E x D partial sums: registers (E <= 4: per group, all classes) or thread-owned outputs fed from LDS records
@@ -595,10 +609,28 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                         }
                     }
 #ifndef DBG_NO_EXD
+                    if (G::DIRECT && STEP_LDS_DW) {
+                        // the classifier's partial sums as well: a read-modify-write of the group's own rows
+                        float *mine = red + grp * G::SLAB;
 #pragma unroll
-                    for (int c = 0; c < (G::REG ? EMAX : 1); c++) {
-                        f4fma(dW[c], gzv[c], o.x);
-                        dB[c] += gzv[c];
+                        for (int c = 0; c < (G::REG ? EMAX : 1); c++) {
+                            float4 *wr = reinterpret_cast<float4 *>(mine + EMAX * DP + c * DP + lg * 4);
+                            float4 cur = *wr;
+                            f4fma(cur, gzv[c], o.x);
+                            *wr = cur;
+                        }
+                        if (lg == 0 && EMAX == 4) {
+                            float4 *br = reinterpret_cast<float4 *>(mine + 2 * EMAX * DP);
+                            float4 cur = *br;
+                            cur.x += gzv[0]; cur.y += gzv[EMAX > 1 ? 1 : 0]; cur.z += gzv[EMAX > 2 ? 2 : 0]; cur.w += gzv[EMAX > 3 ? 3 : 0];
+                            *br = cur;
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < (G::REG ? EMAX : 1); c++) {
+                            f4fma(dW[c], gzv[c], o.x);
+                            dB[c] += gzv[c];
+                        }
                     }
                     // embed_env: ONE read-modify-write of the LDS row the interaction's environment names -- a row set per
                     // group (smallest instance) or per wave, whose groups then take turns (in-order LDS operations of one
@@ -716,9 +748,9 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 accL2 = row16_sum(accL2); accL1 = row16_sum(accL1);
                 float *mine = red + grp * G::SLAB;
 #pragma unroll
-                for (int c = 0; c < (G::REG ? EMAX : 1); c++) {   // (the embed_env rows are there already)
-                    *reinterpret_cast<float4 *>(mine + EMAX * DP + c * DP + lg * 4) = dW[c];
-                    if (lg == 0) mine[2 * EMAX * DP + c] = dB[c];
+                for (int c = 0; c < ((G::REG && !STEP_LDS_DW) ? EMAX : 0); c++) {   // (the embed_env rows are there already)
+                    *reinterpret_cast<float4 *>(mine + EMAX * DP + c * DP + lg * 4) = dW[G::REG ? c : 0];
+                    if (lg == 0) mine[2 * EMAX * DP + c] = dB[G::REG ? c : 0];
                 }
                 if (lg == 0) {
                     float *ls = mine + 2 * EMAX * DP + EMAX;
@@ -770,8 +802,18 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             }
         }
         // ---- slices of one row meet through LDS: plain stores, fixed-order sum by the leader
+        auto slot_of = [&](int g) {
+            constexpr int GW = 64 / LG;   // groups per wave
+            return L::ALIAS ? lds + L::mv + (g / GW) * (4 * 64 * 4) + (g % GW) * 2 * DP : slots + g * 2 * DP;
+        };
+        float4 mi = f4zero(), vi = f4zero(), me = f4zero(), ve = f4zero();
+        if (L::ALIAS && dma && active && leader) {   // (the slices' partials overwrite the landing area next)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA pieces have landed
+            mi = mv_wave[0 * 64 + lane]; vi = mv_wave[1 * 64 + lane];
+            if (!pure) { me = mv_wave[2 * 64 + lane]; ve = mv_wave[3 * 64 + lane]; }
+        }
         if (slices > 1) {  // same for every slot of a round, idle slots included
-            float *mine = slots + grp * 2 * DP;
+            float *mine = slot_of(grp);
             *reinterpret_cast<float4 *>(mine + lg * 4) = gi;
             *reinterpret_cast<float4 *>(mine + DP + lg * 4) = ge;
         }
@@ -796,7 +838,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             if (active && leader) {
 #pragma unroll 4
                 for (int s = 1; s < slices; s++) {
-                    const float *oth_slot = slots + (grp + s) * 2 * DP;
+                    const float *oth_slot = slot_of(grp + s);
                     f4add(gi, *reinterpret_cast<const float4 *>(oth_slot + lg * 4));
                     f4add(ge, *reinterpret_cast<const float4 *>(oth_slot + DP + lg * 4));
                 }
@@ -814,8 +856,8 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 put4<VEC>(a.np[0], row, t.D, lg, gi);
                 if (!pure) put4<VEC>(a.np[2], row, t.D, lg, ge);
             } else {
-                float4 mi = f4zero(), vi = f4zero(), me = f4zero(), ve = f4zero();
-                if (dma) {
+                if (dma && L::ALIAS) {   // (taken out of the landing area above)
+                } else if (dma) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA pieces have landed
                     mi = mv_wave[0 * 64 + lane]; vi = mv_wave[1 * 64 + lane];
                     if (!pure) { me = mv_wave[2 * 64 + lane]; ve = mv_wave[3 * 64 + lane]; }
@@ -1353,6 +1395,9 @@ __device__ __forceinline__ void class_row(const StepArgs &a, int c, int (&q)[4])
 }
 
 // registers: the instances are held to 4 (E <= 4) / 3 workgroups per CU for launch 1 and 6 / 4 / 3 for launch 2
+#ifndef STEP_EVAL_WAVES_SMALL
+#define STEP_EVAL_WAVES_SMALL 3   // the smallest instance (D <= 64, E <= 4): 52 KB of LDS, <= 168 registers
+#endif
 #ifndef STEP_EVAL_WAVES
 #define STEP_EVAL_WAVES 2
 #endif
@@ -1360,7 +1405,7 @@ __device__ __forceinline__ void class_row(const StepArgs &a, int c, int (&q)[4])
 #define STEP_APPLY_WAVES 4
 #endif
 template <int LG, bool VEC, int EMAX>
-__global__ __launch_bounds__(kThreads, (STEP_NO_DMA && LG == 16 && EMAX <= 4) ? 3 : STEP_EVAL_WAVES) void mstep_eval_kernel(DevTables t, StepArgs a) {
+__global__ __launch_bounds__(kThreads, (LG == 16 && EMAX <= 4) ? STEP_EVAL_WAVES_SMALL : STEP_EVAL_WAVES) void mstep_eval_kernel(DevTables t, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // Workgroup b runs the tasks of class c = b % n_cls (XCD-affine order, InvPrefRowPlan), the j-th of them with
     // j = b / n_cls: its user jobs first, then its share of the untouched rows.  Every branch is workgroup-uniform.
@@ -1448,14 +1493,12 @@ __global__ __launch_bounds__(kThreads, EMAX <= 4 ? STEP_APPLY_WAVES : (EMAX <= 8
 inline int lanes_of(int D, bool vec) { return D <= 64 ? 16 : (D <= 128 ? 32 : 64); }
 inline int emax4_of(int E) { return E <= 4 ? 4 : (E <= 8 ? 8 : 16); }
 inline size_t slab_floats(int lg, int emax) { return (size_t)2 * emax * 4 * lg + emax + kLossSlots; }
-inline size_t eval_lds_bytes(int lg, int emax) {
-    const size_t DP = 4 * (size_t)lg, NG = kThreads / lg;
-    const bool reg = emax <= 8;
-    size_t fl = 2 * emax * DP + emax + NG * 2 * DP + kWaves * 4 * 64 * 4;
-    fl += reg ? ((lg == 16 && emax <= 4) ? NG : (size_t)kWaves) * slab_floats(lg, emax) : kWaves * kLossSlots;
-    if (!reg) fl += 2 * NG * 2 * DP;
-    if (emax > 4) fl += 2 * NG * (emax + 4);
-    return fl * sizeof(float);
+template <int LG>
+inline size_t eval_lds_floats(int emax) {
+    return emax <= 4 ? EvalLds<LG, 4>::total : (emax <= 8 ? EvalLds<LG, 8>::total : EvalLds<LG, 16>::total);
+}
+inline size_t eval_lds_bytes(int lg, int emax) {   // (the layout itself: EvalLds)
+    return sizeof(float) * (lg == 16 ? eval_lds_floats<16>(emax) : (lg == 32 ? eval_lds_floats<32>(emax) : eval_lds_floats<64>(emax)));
 }
 inline size_t apply_lds_bytes(int lg, int emax) {
     const size_t DP = 4 * (size_t)lg, NG = kThreads / lg;
@@ -1732,3 +1775,11 @@ int invpref_mstep_rows_adam_sched_hip(const InvPrefTables *tables, const InvPref
 }
 
 }  // extern "C"
+
+// (diagnostic, not declared in the header) resident workgroups per CU of the smallest launch-1 instance
+extern "C" int invpref_debug_eval_occupancy(void) {
+    int n = -1;
+    const size_t lds = eval_lds_bytes(16, 4);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mstep_eval_kernel<16, true, 4>, kThreads, lds) != hipSuccess) return -1;
+    return n * 1000 + (int)(lds / 1024);
+}

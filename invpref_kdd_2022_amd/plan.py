@@ -28,6 +28,7 @@ ITEM_BIT = 1 << 30     # stream_rows: a row of the item tables
 MODE_LIST = 7
 MAX_ROW_COUNT = 1 << 22
 TARGET_WORKGROUPS = 1536
+RESIDENT_SMALL = 768       # launch 1, rows <= 64 floats and <= 4 environments: three workgroups on each of 256 CUs
 
 
 class RowPlanStruct(C.Structure):
@@ -127,7 +128,7 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
                    factor_num: int = 64, per_slice: int | None = None, item_per_slice: int | None = None,
                    rounds_per_task: int | None = None, item_rounds_per_task: int | None = None, user_range=None,
                    n_classes: int | None = None, rows_per_stream_task: int | None = None,
-                   stream_split: float | None = None, push: bool | None = None) -> dict:
+                   stream_split: float | None = None, push: bool | None = None, env_num: int | None = None) -> dict:
     """users/items/scores: ONE minibatch (or this rank's slice of it); scores as the fp32 labels.
     factor_num: decides the row layout the plan is built for (lanes_of).
     per_slice / item_per_slice: interactions one group walks for a user / an item row (more interactions: more slices).
@@ -139,6 +140,10 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     the row's parameters and Adam moments are still in that XCD's L2 when the next step reads them (measured,
     tools/xcd_probe.py: a pure streaming step takes 8.4 us with a stable assignment and 11.5 us when the assignment
     moves to another XCD every step).  Speed only: any order gives the same results.
+    env_num: the model's environment count, if the caller knows it: rows of up to 64 floats with up to four environments
+    run launch 1's smallest instance, which fits THREE workgroups per CU (52 KB of LDS, <= 168 registers) -- the default
+    stream split then fills launch 1 up to that residency with untouched rows (measured at Yahoo shape: 18.9 us per step
+    with all of them in launch 1 against 19.5-20.4 us at the balanced split; tools/ab.sh).
     stream_split: share of the untouched rows that launch 1 streams (the rest goes to launch 2); default: what
     balances the two launches' row traffic.
     push: the "push" form of the item side (InvPrefRowPlan.push_slot): launch 1 stores every interaction's two
@@ -217,7 +222,10 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     if stream_split is None and 'INVPREF_PLAN_STREAM_SPLIT' in os.environ:
         stream_split = float(os.environ['INVPREF_PLAN_STREAM_SPLIT'])
     n_stream = len(stream_u) + len(stream_i)
+    fill_cap = 0   # launch 1 residency (workgroups) the default split fills with stream tasks; 0 = plain balance
     if stream_split is None:
+        if lanes == 16 and env_num is not None and env_num <= 4 and os.environ.get('INVPREF_PLAN_FILL', '1') == '1':
+            fill_cap = RESIDENT_SMALL
         # row moves (one row read or written in both tables of a side = 2): a touched or streamed row costs 12 (p, m, v
         # in, p', m', v' out), an interaction 4 gathered rows per launch; launch 1 also evaluates, hence the bias
         tu, ti = int((ucnt > 0).sum()), int((icnt > 0).sum())
@@ -238,6 +246,9 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         si = stream_i[icls[stream_i] == c] if len(stream_i) > 8 * 64 else (stream_i if c == 0 else stream_i[:0])
         rows = np.concatenate([stream_u[ucls[stream_u] == c], si | ITEM_BIT]).astype(np.int32)
         k = int(round(stream_split * len(rows)))
+        if fill_cap:   # (per class: the grid is n_classes x the longest class)
+            room = fill_cap // n_classes - -(-len(du_parts[-1]) // rounds_per_task)
+            k = min(len(rows), max(k, room * rows_per_stream_task))
         s1_parts.append(rows[:k])
         s2_parts.append(rows[k:])
     ub = ib = sb = 0
@@ -257,7 +268,8 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
                 push_slot=(np.argsort(pi, kind='stable').astype(np.int32) if push else None), push=bool(push),
                 stream_rows=np.concatenate(s1_parts + s2_parts).astype(np.int32), n_stream=sb,
                 rows_per_stream_task=rows_per_stream_task, rows_per_stream_task2=rows_per_stream_task2,
-                stream_split=stream_split, n_classes=n_classes, cls=cls)
+                stream_split=(sum(len(x) for x in s1_parts) / sb if (fill_cap and sb) else stream_split),
+                n_classes=n_classes, cls=cls)
 
 
 def launch_workgroups(plan: dict, launch: int) -> int:

@@ -345,7 +345,8 @@ class _InvPrefTrainManager:
         if hit == 1:                            # second sighting: invert the scatter pattern once (host side)
             hit = planlib.upload(planlib.build_row_plan(users.cpu().numpy(), items.cpu().numpy(),
                                                         scores.float().cpu().numpy(), self.model.user_num,
-                                                        self.model.item_num, factor_num=self.model.factor_num),
+                                                        self.model.item_num, factor_num=self.model.factor_num,
+                                                        env_num=getattr(self.model, 'env_num', 0)),
                                  self.device)
             self._batch_plans[key] = hit
         return hit
@@ -383,7 +384,8 @@ class _InvPrefTrainManager:
             for lo, n, *_ in self._raw_batches:
                 pl = planlib.build_row_plan(u[lo:lo + n], v[lo:lo + n], y[lo:lo + n], self.model.user_num,
                                             self.model.item_num, factor_num=self.model.factor_num,
-                                            user_range=self.shard.user_range(self.model.user_num))
+                                            user_range=self.shard.user_range(self.model.user_num),
+                                            env_num=getattr(self.model, 'env_num', 0))
                 self._plans.append(planlib.upload(pl, self.device))
             self.plan_build_s = time.perf_counter() - t0     # host-side, once per run (reported by bench.py)
         if self.use_plan and self.users_tensor.is_cuda:

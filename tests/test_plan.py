@@ -110,13 +110,24 @@ def test_plan_yahoo_like_batch():
 
 
 def test_default_plan_fits_one_residency_wave():
-    """both launches of a Yahoo-shaped step stay well inside one residency wave of workgroups (256 CUs x 3)"""
+    """both launches of a Yahoo-shaped step stay inside one residency wave of workgroups: two per CU in general, three
+    for launch 1 when the caller names at most four environments -- which the default split then fills with stream tasks"""
     d = synth.yahoo_like()
     for k in (0, 3, 8, 12):
         b = d[k * 8192:(k + 1) * 8192]
         p = planlib.build_row_plan(b[:, 0], b[:, 1], b[:, 2], 15400, 1000)
         assert planlib.launch_workgroups(p, 0) <= 640 and planlib.launch_workgroups(p, 1) <= 640
         assert 0.0 <= p['stream_split'] <= 1.0
+        q = check_plan(b[:, 0], b[:, 1], 15400, 1000, env_num=4)
+        assert planlib.launch_workgroups(p, 0) < planlib.launch_workgroups(q, 0) <= planlib.RESIDENT_SMALL
+        assert q['stream_split'] > 0.9 and planlib.launch_workgroups(q, 1) < planlib.launch_workgroups(p, 1)
+        r = planlib.build_row_plan(b[:, 0], b[:, 1], b[:, 2], 15400, 1000, env_num=8)   # other instances: the balanced split
+        assert r['stream_split'] == p['stream_split'] and planlib.launch_workgroups(r, 0) == planlib.launch_workgroups(p, 0)
+        r, r4 = (planlib.build_row_plan(b[:, 0], b[:, 1], b[:, 2], 15400, 1000, factor_num=128, env_num=e) for e in (None, 4))
+        assert r['stream_split'] == r4['stream_split']
+    g = synth.interactions(6, 400000, 100000, 1 << 18, implicit=True, zipf=False)   # jobs alone exceed the residency
+    q = planlib.build_row_plan(g[:, 0], g[:, 1], g[:, 2], 400000, 100000, env_num=4)
+    assert q['stream_split'] == planlib.build_row_plan(g[:, 0], g[:, 1], g[:, 2], 400000, 100000)['stream_split']
 
 
 @pytest.mark.parametrize('D', [30, 64, 128, 256])

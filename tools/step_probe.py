@@ -43,7 +43,7 @@ losses = torch.zeros(6, device=dev)
 coefs = (3.35, 9.99, 9.06, 3.13, 0.49, 1.9)
 flags = ops.flags_of(True, False, True, True, False)
 pls = [planlib.build_row_plan(data[k * B:(k + 1) * B, 0], data[k * B:(k + 1) * B, 1], data[k * B:(k + 1) * B, 2], U, I,
-                              factor_num=D) for k in range(nb)]
+                              factor_num=D, env_num=E) for k in range(nb)]
 plans = [planlib.upload(p, dev) for p in pls]
 Pn = sum(p.numel() for p in P)
 nbytes = B * (32 + 16 * D) + 24 * Pn

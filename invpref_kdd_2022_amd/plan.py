@@ -164,8 +164,23 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     # slice walks its interactions with the next gathers in flight, while every further slot, round and workgroup pays
     # its own start-up round trips), then more rounds per task.
     target = int(os.environ.get('INVPREF_PLAN_TARGET_WGS', str(TARGET_WORKGROUPS)))
+    def rounds_for(cnt, ps):   # group slots / ng: the rounds a side needs at `ps` interactions per slice
+        c = cnt[cnt > 0]
+        need = np.maximum(1, -(-c // ps))
+        return int(np.minimum(ng, 1 << np.ceil(np.log2(need)).astype(np.int64)).sum()) // ng + 1
+    if per_slice is None and 'INVPREF_PLAN_PER_SLICE' in os.environ:
+        per_slice = int(os.environ['INVPREF_PLAN_PER_SLICE'])
     if per_slice is None:
-        per_slice = int(os.environ.get('INVPREF_PLAN_PER_SLICE', str(2 if n <= 4 * ng * target // 3 else 16)))
+        # shortest slices while launch 1's jobs are resident at once (one latency chain: a Yahoo step); otherwise the
+        # shortest slice that costs no more than 5 % more rounds than 16 per slice does (measured at 32 768 Yahoo-shaped
+        # interactions: 6 per slice 33.5 us against 37.5 at 2 and 37.2 at 16; at 250 154: 16 per slice 118 us, 8: 135)
+        ucnt0 = np.bincount(users, minlength=1)
+        resident = RESIDENT_SMALL if (lanes == 16 and env_num is not None and env_num <= 4) else 512
+        if rounds_for(ucnt0, 2) <= resident:
+            per_slice = 2
+        else:
+            r16 = rounds_for(ucnt0, 16)
+            per_slice = next((ps for ps in (3, 4, 6, 8, 12) if rounds_for(ucnt0, ps) <= 1.05 * r16), 16)
     if push is None:
         env = os.environ.get('INVPREF_PLAN_PUSH')
         if env is not None:
@@ -185,10 +200,6 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         item_per_slice = int(os.environ.get('INVPREF_PLAN_ITEM_PER_SLICE',
                                             str(min(32, max(4 if push else 2, -(-n // (ng * 2 * target)))))))
 
-    def rounds_for(cnt, ps):   # group slots / ng: the rounds a side needs at `ps` interactions per slice
-        c = cnt[cnt > 0]
-        need = np.maximum(1, -(-c // ps))
-        return int(np.minimum(ng, 1 << np.ceil(np.log2(need)).astype(np.int64)).sum()) // ng + 1
     if rounds_per_task is None:
         rounds_per_task = int(os.environ.get('INVPREF_PLAN_ROUNDS', '0')) or \
             min(16, max(1, round(rounds_for(np.bincount(users, minlength=1), per_slice) / target)))

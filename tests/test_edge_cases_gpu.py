@@ -172,12 +172,15 @@ def test_random_plan_parameters_and_shapes(seed):
     try:
         lo = int(rs.randint(0, U)) if rs.randint(2) else 0
         user_range = (lo, int(rs.randint(lo, U)) + 1) if rs.randint(2) else None
-        pl = planlib.build_row_plan(u, v, y, U, I, factor_num=D, per_slice=int(rs.choice([1, 2, 3, 8, 16])),
+        defaults = rs.randint(3) == 0   # a third of the cases: the plan's own slice length / stream split (env_num given)
+        pl = planlib.build_row_plan(u, v, y, U, I, factor_num=D,
+                                    per_slice=None if defaults else int(rs.choice([1, 2, 3, 8, 16])),
                                     item_per_slice=int(rs.choice([1, 2, 3, 5, 40])),
                                     rounds_per_task=int(rs.choice([1, 1, 2, 3])),
                                     item_rounds_per_task=int(rs.choice([1, 1, 2, 3])),
-                                    n_classes=int(rs.choice([1, 3, 8])), stream_split=float(rs.choice([0.0, 0.4, 1.0])),
-                                    push=bool(rs.randint(2)),
+                                    n_classes=int(rs.choice([1, 3, 8])),
+                                    stream_split=None if defaults else float(rs.choice([0.0, 0.4, 1.0])),
+                                    push=bool(rs.randint(2)), env_num=E if defaults else None,
                                     user_range=user_range)
     finally:
         for k, val in old.items():

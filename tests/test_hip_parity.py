@@ -322,7 +322,8 @@ def test_plan_parameters_change_nothing_but_the_order_of_sums():
     for kw in (dict(per_slice=1, item_per_slice=1, n_classes=1, stream_split=0.0, push=False),
                dict(per_slice=2, item_per_slice=3, rounds_per_task=3, item_rounds_per_task=2, stream_split=1.0, push=True),
                dict(per_slice=64, item_per_slice=64, n_classes=3, push=False),
-               dict(per_slice=3, item_per_slice=5, push=True)):
+               dict(per_slice=3, item_per_slice=5, push=True),
+               dict(env_num=E)):   # the plan's own choices, launch 1 filled to its residency where that applies
         dp = planlib.upload(planlib.build_row_plan(z['u'], z['v'], z['y'], U, I, factor_num=D, **kw), DEV)
         rep = []
         for _ in range(2):

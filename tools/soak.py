@@ -1,4 +1,5 @@
 import os, sys
+EPOCHS = int(os.environ.get('SOAK_EPOCHS', '1700'))
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import numpy as np, torch
@@ -19,7 +20,7 @@ for ng in ('1', '0'):
     model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
     np.random.seed(3)
     mgr = ImplicitTrainManager(model=model, evaluator=Stub(), device=DEV, training_data=torch.from_numpy(data).to(DEV),
-                               batch_size=8192, epochs=1700, cluster_interval=10 ** 9, evaluate_interval=10 ** 9, lr=0.002,
+                               batch_size=8192, epochs=EPOCHS, cluster_interval=10 ** 9, evaluate_interval=10 ** 9, lr=0.002,
                                invariant_coe=3.35, env_aware_coe=9.99, env_coe=9.06, L2_coe=3.13, L1_coe=0.49, alpha=1.9,
                                use_class_re_weight=True, use_recommend_re_weight=False, cluster_use_random_sort=False)
     (losses, ep), _, (diffs, cnts, ce) = mgr.train(silent=True)
@@ -27,5 +28,5 @@ for ng in ('1', '0'):
     print('no_graph', ng, 'steps', mgr.state.step, 'final', tr[-1], 'diffs', diffs, 'finite', np.isfinite(tr).all())
     res.append((tr, diffs))
 d = np.abs(res[0][0] / res[1][0] - 1)
-print('max rel loss diff per 100 epochs:', np.round([d[i:i+100].max() for i in range(0, 1700, 100)], 6))
-print('BITWISE equal loss traces (graph vs eager, 1700 epochs):', bool((res[0][0] == res[1][0]).all()))
+print('max rel loss diff per 100 epochs:', np.round([d[i:i+100].max() for i in range(0, EPOCHS, 100)], 6))
+print('BITWISE equal loss traces (graph vs eager, %d epochs):' % EPOCHS, bool((res[0][0] == res[1][0]).all()))

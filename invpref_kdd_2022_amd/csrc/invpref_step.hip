@@ -641,13 +641,21 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                         f4add(cur, oo);
                         *erow = cur;
                     } else {
+                        // (the passes must stay separate instructions under separate lane masks: to the compiler the four
+                        //  conditions are mutually exclusive per THREAD and it would merge them into one unordered pass --
+                        //  two groups of a wave naming the same environment would then lose an update.  An opaque group
+                        //  number and a compiler barrier between the passes keep them apart.)
+                        int gsel = lane / LG;
+                        asm volatile("" : "+v"(gsel));
 #pragma unroll
-                        for (int g = 0; g < 64 / LG; g++)
-                            if (lane / LG == g) {
+                        for (int g = 0; g < 64 / LG; g++) {
+                            if (gsel == g) {
                                 float4 cur = *erow;
                                 f4add(cur, oo);
                                 *erow = cur;
                             }
+                            asm volatile("" ::: "memory");
+                        }
                     }
 #endif
                 } else {

@@ -820,6 +820,9 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             mi = mv_wave[0 * 64 + lane]; vi = mv_wave[1 * 64 + lane];
             if (!pure) { me = mv_wave[2 * 64 + lane]; ve = mv_wave[3 * 64 + lane]; }
         }
+        // (the reads above and the stores below are ordered ACROSS lanes only by instruction order: keep the compiler from
+        //  moving one over the other)
+        if (L::ALIAS) asm volatile("" ::: "memory");
         if (slices > 1) {  // same for every slot of a round, idle slots included
             float *mine = slot_of(grp);
             *reinterpret_cast<float4 *>(mine + lg * 4) = gi;

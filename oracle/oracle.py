@@ -25,7 +25,10 @@ PARAM_NAMES = [
 
 def build(force: bool = False) -> str:
     src = os.path.join(HERE, 'invpref_oracle.c')
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    twins, twins_src = os.path.join(HERE, 'libinvpref_cpu_abi.so'), os.path.join(HERE, 'invpref_cpu_abi.c')
+    stale = (not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src) or not os.path.exists(twins)
+             or os.path.getmtime(twins) < max(os.path.getmtime(src), os.path.getmtime(twins_src)))
+    if force or stale:   # (the oracle + the CPU twins of the HIP C ABI, invpref_cpu_abi.c: both test infrastructure)
         subprocess.check_call(['make', '-C', HERE, '-s', '-B'])
     return LIB_PATH
 

@@ -33,6 +33,10 @@ def bind(path, suffix):
         f = getattr(L, f'invpref_{name}_{suffix}')
         f.argtypes, f.restype = args, C.c_int
         fns[name] = f
+    for name in ('mstep_workspace_bytes', 'estep_workspace_bytes'):   # (the HIP library's size queries carry no suffix)
+        f = getattr(L, f'invpref_{name}' + ('' if suffix == 'hip' else '_' + suffix))
+        f.argtypes, f.restype = [T, i64], C.c_size_t
+        fns[name] = f
     return fns
 
 
@@ -56,7 +60,8 @@ def run_all(fns, device, z, implicit, flags_bits):
     tab, gtab = tables(params), tables(grads)
     u, v, e = T(z['u'], np.int64), T(z['v'], np.int64), T(z['e'], np.int64)
     y, w = T(z['y'], np.float32), T(z['w'], np.float32)
-    ws = torch.zeros(1 << 22, dtype=torch.uint8, device=dev)   # (more than either back end asks for at these sizes)
+    need = max(fns['mstep_workspace_bytes'](C.byref(tab), B), fns['estep_workspace_bytes'](C.byref(tab), B), 16)
+    ws = torch.zeros(need, dtype=torch.uint8, device=dev)
     out = {}
     inv, env, eo = torch.zeros(B, device=dev), torch.zeros(B, device=dev), torch.zeros(B, E, device=dev)
     flags = (1 if implicit else 0) | flags_bits

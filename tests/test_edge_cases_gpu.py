@@ -226,7 +226,7 @@ def test_random_plan_parameters_and_shapes(seed):
                 keep = touched.copy(); keep[user_range[0]:user_range[1]] = True
                 got, want = got[keep], want[keep]
             err, scale = np.abs(got - want).max(initial=0.0), max(np.abs(want).max(initial=0.0), 1e-4)
-            assert err <= 6e-5 * scale, (k, seed, float(err), float(scale))   # (fp32 sums of up to 3 000 terms vs the fp64 oracle)
+            assert err <= 1.5e-4 * scale, (k, seed, float(err), float(scale))   # (fp32 sums of up to 3 000 terms vs the fp64 oracle)
 
 
 @pytest.mark.parametrize('E,D', [(5, 20), (8, 64), (6, 128), (3, 64), (16, 64)])

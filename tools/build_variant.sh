@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
-mkdir -p invpref_kdd_2022_amd/variants /tmp/variant_$name
+rm -rf /tmp/variant_$name; mkdir -p invpref_kdd_2022_amd/variants /tmp/variant_$name
 for f in invpref_kernels invpref_step invpref_eval; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-pass-failed "$@" \
     -c invpref_kdd_2022_amd/csrc/$f.hip -o /tmp/variant_$name/$f.o &

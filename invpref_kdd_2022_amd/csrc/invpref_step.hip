@@ -14,9 +14,13 @@
 //   rows and their gradients in registers, gathers the partner item rows ONCE, evaluates every one of its
 //   interactions ONCE (forward + analytic backward of train.py:108-153, models.py:307-391) and stores a
 //   RECORD {g_p, g_q, env, gz[0..E)} per interaction for the item side; it finishes its own rows on the
-//   spot (Adam, or the gradient row for the multi-GPU path).  Everything that is a reduction ACROSS rows
-//   (gradients of embed_env / classifier, the five loss sums) is accumulated per workgroup and stored --
-//   plain stores -- as that workgroup's PARTIAL SLAB.
+//   spot (Adam, or the gradient row for the multi-GPU path).  (Push form, InvPrefRowPlan::push_slot: instead of the
+//   record it stores the interaction's two contribution rows to its item's gradient at the item-sorted slot, and
+//   launch 2 sums contiguous rows.)  Everything that is a reduction ACROSS rows (gradients of embed_env / classifier,
+//   the five loss sums) is accumulated per workgroup -- embed_env's by a read-modify-write of the LDS row the
+//   environment names, the classifier's in LDS rows (D <= 64, E <= 4: 154 registers, 50 KB, THREE workgroups per
+//   CU), in registers (E <= 8) or through LDS records (E = 16) -- and stored, plain stores, as that workgroup's
+//   PARTIAL SLAB.
 // Launch 2, mstep_apply_kernel  = [item jobs | the other untouched rows | fold blocks].  An item job
 //   gathers the partner user rows + the records and only multiplies and adds (no exp / log / classifier,
 //   few registers, several gathers in flight: long item slices are cheap, so there are no "hot rows").

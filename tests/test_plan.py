@@ -169,3 +169,20 @@ def test_plan_large_shapes():
     d = synth.interactions(5, 6040, 3706, 65536, implicit=True, zipf=False)
     p = check_plan(d[:, 0], d[:, 1], 6040, 3706, D=128)
     assert p['lanes_per_group'] == 32 and 500 < planlib.launch_workgroups(p, 0) < 4000
+
+
+def test_slice_length_of_mid_sized_launches_follows_the_makespan_estimate():
+    """launches of a few residencies: the default slice length is the shortest one within 2 % of the best list-scheduling
+    estimate (plan._launch1_makespan); a Yahoo step (jobs resident at once) keeps 2, a huge launch keeps the rounds rule"""
+    cnt = np.array([40] * 8 + [3] * 100)
+    few = planlib._launch1_makespan(cnt, 16, 16, 512, 8.0, 1.0)
+    assert few == 8.0 + 10                                  # everything resident: the longest task (40 = 4 slices of 10)
+    assert planlib._launch1_makespan(cnt, 16, 16, 1, 8.0, 1.0) > few   # one slot: the tasks queue
+    m = synth.interactions(5, 6040, 3706, 65536, implicit=True, zipf=False)
+    p = planlib.build_row_plan(m[:, 0], m[:, 1], m[:, 2], 6040, 3706, factor_num=128, env_num=8)
+    ucnt = np.bincount(m[:, 0])
+    est = {ps: planlib._launch1_makespan(ucnt, 8, ps, 512, 8.0, 2.1) for ps in (3, 4, 6, 8, 10, 12, 14, 16, 20)}
+    assert est[p['per_slice']] <= 1.02 * min(est.values())
+    assert all(est[ps] > 1.02 * min(est.values()) for ps in est if ps < p['per_slice'])
+    d = synth.yahoo_like()[:8192]
+    assert planlib.build_row_plan(d[:, 0], d[:, 1], d[:, 2], 15400, 1000, env_num=4)['per_slice'] == 2

@@ -1505,7 +1505,13 @@ __global__ __launch_bounds__(kThreads, EMAX <= 4 ? STEP_APPLY_WAVES : (EMAX <= 8
     }
 }
 
-inline int lanes_of(int D, bool vec) { return D <= 64 ? 16 : (D <= 128 ? 32 : 64); }
+inline int lanes_of(int D, bool vec) {
+    // (diagnostic: INVPREF_FORCE_LANES=32|64 runs narrower rows on a wider lane group -- what a row that fills more of
+    //  the wave costs at the same bytes; tools/README.md)
+    static const int forced = getenv("INVPREF_FORCE_LANES") ? atoi(getenv("INVPREF_FORCE_LANES")) : 0;
+    const int lg = D <= 64 ? 16 : (D <= 128 ? 32 : 64);
+    return forced > lg && forced <= 64 ? forced : lg;
+}
 inline int emax4_of(int E) { return E <= 4 ? 4 : (E <= 8 ? 8 : 16); }
 inline size_t slab_floats(int lg, int emax) { return (size_t)2 * emax * 4 * lg + emax + kLossSlots; }
 template <int LG>

@@ -50,7 +50,9 @@ CLASS_SHIFT = 6        # rows are dealt to the classes in blocks of 64
 
 def lanes_of(factor_num: int) -> int:
     """lanes that hold one row, one float4 each (invpref_rows_lanes_per_group)"""
-    return 16 if factor_num <= 64 else (32 if factor_num <= 128 else 64)
+    lg = 16 if factor_num <= 64 else (32 if factor_num <= 128 else 64)
+    forced = int(os.environ.get('INVPREF_FORCE_LANES', '0'))   # (diagnostic, as in csrc/invpref_step.hip)
+    return forced if lg < forced <= 64 else lg
 
 
 def stream_rows_default(factor_num: int) -> int:

@@ -24,7 +24,8 @@ EXPORTS = [
     'invpref_adam_schedule_fill', 'invpref_mstep_rows_adam_sched_hip', 'invpref_eval_topk_hip',
     'invpref_eval_error_sums_hip', 'invpref_mstep_rows_adam_profiled_hip', 'invpref_static_pop_workspace_bytes',
     'invpref_static_pop_hip', 'invpref_adam_ranges_hip', 'invpref_mstep_rows_grad_sched_hip',
-    'invpref_adam_ranges_sched_hip', 'invpref_rows_lanes_per_group',
+    'invpref_adam_ranges_sched_hip', 'invpref_rows_lanes_per_group', 'invpref_rows_defer_supported',
+    'invpref_mstep_rows_adam_deferred_hip', 'invpref_flush_deferred_hip',
 ]
 
 
@@ -94,6 +95,12 @@ def lib():
         L.invpref_mstep_rows_adam_sched_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), C.POINTER(Tables),
                                                         C.POINTER(Tables), vp, vp, vp, vp, i64, C.POINTER(Coefs), u32,
                                                         vp, C.POINTER(AdamSchedule), vp, C.c_size_t, vp]
+        L.invpref_mstep_rows_adam_deferred_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), C.POINTER(Tables),
+                                                           C.POINTER(Tables), vp, vp, vp, vp, i64, C.POINTER(Coefs), u32,
+                                                           vp, C.POINTER(AdamSchedule), vp, vp, C.c_size_t, vp]
+        L.invpref_rows_defer_supported.argtypes = [C.POINTER(Tables), vp]
+        L.invpref_flush_deferred_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), C.POINTER(Tables),
+                                                 C.POINTER(Tables), vp, C.POINTER(AdamSchedule), vp]
         L.invpref_eval_topk_hip.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
         L.invpref_eval_error_sums_hip.argtypes = [vp, vp, i64, vp, vp]
         L.invpref_mstep_rows_adam_profiled_hip.argtypes = L.invpref_mstep_rows_adam_hip.argtypes + [vp]
@@ -102,7 +109,7 @@ def lib():
         L.invpref_static_pop_workspace_bytes.restype = C.c_size_t
         L.invpref_static_pop_hip.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
         L.invpref_device_name.argtypes = [C.c_char_p, C.c_size_t]
-        if L.invpref_abi_version() != 3:
+        if L.invpref_abi_version() != 4:
             raise InvPrefError('libinvpref_hip.so ABI version mismatch')
         _lib = L
     return _lib

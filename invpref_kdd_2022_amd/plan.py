@@ -38,7 +38,8 @@ class RowPlanStruct(C.Structure):
                 ('user_desc', C.c_void_p), ('item_desc', C.c_void_p), ('user_round_iters', C.c_void_p),
                 ('user_list', C.c_void_p), ('item_list', C.c_void_p), ('n_stream', C.c_int32),
                 ('rows_per_stream_task', C.c_int32), ('stream_rows', C.c_void_p), ('n_classes', C.c_int32),
-                ('rows_per_stream_task2', C.c_int32), ('cls', C.c_int32 * 64), ('push_slot', C.c_void_p)]
+                ('rows_per_stream_task2', C.c_int32), ('cls', C.c_int32 * 64), ('push_slot', C.c_void_p),
+                ('defer_tail', C.c_int32 * 16)]
 
 
 ARRAYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list', 'stream_rows', 'push_slot')
@@ -282,6 +283,7 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         stream_split = min(1.0, max(0.0, s1 / n_stream)) if n_stream else 0.0
     du_parts, it_parts, di_parts, s1_parts, s2_parts = [], [], [], [], []
     cls = np.zeros((8, 8), np.int32)
+    defer_tail = np.zeros((8, 2), np.int32)
     for c in range(n_classes):
         d, it = _side_rounds(users[pu], ucols, user_num, ng, per_slice, rounds_per_task, 2,
                              skip=(ucnt == 0) | (ucls != c))
@@ -297,8 +299,13 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         if fill_cap:   # (per class: the grid is n_classes x the longest class)
             room = fill_cap // n_classes - -(-len(du_parts[-1]) // rounds_per_task)
             k = min(len(rows), max(k, room * rows_per_stream_task))
-        s1_parts.append(rows[:k])
-        s2_parts.append(rows[k:])
+        # inside each launch's share: item rows first, USER rows last -- a deferred step (InvPrefRowPlan.defer_tail)
+        # leaves that tail alone
+        for part, li in ((rows[:k], 0), (rows[k:], 1)):
+            is_user = (part & ITEM_BIT) == 0
+            part = np.concatenate([part[~is_user], part[is_user]])
+            defer_tail[c, li] = int(is_user.sum())
+            (s1_parts if li == 0 else s2_parts).append(part)
     ub = ib = sb = 0
     for c in range(n_classes):
         cls[c, 0], cls[c, 1] = ub, len(du_parts[c]); ub += len(du_parts[c])
@@ -317,15 +324,18 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
                 stream_rows=np.concatenate(s1_parts + s2_parts).astype(np.int32), n_stream=sb,
                 rows_per_stream_task=rows_per_stream_task, rows_per_stream_task2=rows_per_stream_task2,
                 stream_split=(sum(len(x) for x in s1_parts) / sb if (fill_cap and sb) else stream_split),
-                n_classes=n_classes, cls=cls)
+                n_classes=n_classes, cls=cls, defer_tail=defer_tail)
 
 
-def launch_workgroups(plan: dict, launch: int) -> int:
-    """task workgroups of launch 0 / 1: the classes' task lists interleaved, padded to the longest"""
+def launch_workgroups(plan: dict, launch: int, defer: bool = False) -> int:
+    """task workgroups of launch 0 / 1: the classes' task lists interleaved, padded to the longest
+    (defer: a deferred step does not stream the untouched user rows, InvPrefRowPlan.defer_tail)"""
     ncls, cls = int(plan['n_classes']), np.asarray(plan['cls'])
+    tail = np.asarray(plan['defer_tail'])[:, launch] if defer else np.zeros(8, np.int32)
     rpt = plan['user_rounds_per_task'] if launch == 0 else plan['item_rounds_per_task']
     spt = plan['rows_per_stream_task'] if launch == 0 else plan.get('rows_per_stream_task2', plan['rows_per_stream_task'])
-    return ncls * max(-(-int(cls[c, 4 * launch + 1]) // rpt) + -(-int(cls[c, 4 * launch + 3]) // spt) for c in range(ncls))
+    return ncls * max(-(-int(cls[c, 4 * launch + 1]) // rpt) + -(-(int(cls[c, 4 * launch + 3]) - int(tail[c])) // spt)
+                      for c in range(ncls))
 
 
 def plan_workgroups(plan: dict) -> int:
@@ -343,7 +353,8 @@ class DevicePlan:
     meta: torch.Tensor = None   # CPU int64[len(_fields_)]: struct fields in order, pointers as int32 offsets into buf
 
 
-_META_LEN = sum(64 if name == 'cls' else 1 for name, _ in RowPlanStruct._fields_)
+_ARRAY_FIELDS = {'cls': 64, 'defer_tail': 16}
+_META_LEN = sum(_ARRAY_FIELDS.get(name, 1) for name, _ in RowPlanStruct._fields_)
 
 
 def struct_from_meta(buf: torch.Tensor, meta: torch.Tensor) -> RowPlanStruct:
@@ -356,9 +367,10 @@ def struct_from_meta(buf: torch.Tensor, meta: torch.Tensor) -> RowPlanStruct:
     base, n = buf.data_ptr(), buf.numel()
     args, i = [], 0
     for name, ty in RowPlanStruct._fields_:
-        if name == 'cls':
-            args.append((C.c_int32 * 64)(*vals[i:i + 64]))
-            i += 64
+        if name in _ARRAY_FIELDS:
+            k = _ARRAY_FIELDS[name]
+            args.append((C.c_int32 * k)(*vals[i:i + k]))
+            i += k
             continue
         v = vals[i]
         i += 1
@@ -393,7 +405,8 @@ def upload(plan: dict, device) -> DevicePlan:
                        ptrs['user_round_iters'], ptrs['user_list'], ptrs['item_list'], plan['n_stream'],
                        plan['rows_per_stream_task'], ptrs['stream_rows'], int(plan['n_classes']),
                        int(plan.get('rows_per_stream_task2', 0)),
-                       (C.c_int32 * 64)(*cls.reshape(-1).tolist()), ptrs['push_slot'])
+                       (C.c_int32 * 64)(*cls.reshape(-1).tolist()), ptrs['push_slot'],
+                       (C.c_int32 * 16)(*np.asarray(plan.get('defer_tail', np.zeros((8, 2))), np.int32).reshape(-1).tolist()))
     meta = _meta_of(st, offs)
     return DevicePlan(st, [buf], plan_workgroups(plan), len(plan['user_desc']) + len(plan['item_desc']), buf,
                       torch.tensor(meta, dtype=torch.int64))

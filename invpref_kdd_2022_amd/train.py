@@ -388,6 +388,22 @@ class _InvPrefTrainManager:
                                             env_num=getattr(self.model, 'env_num', 0))
                 self._plans.append(planlib.upload(pl, self.device))
             self.plan_build_s = time.perf_counter() - t0     # host-side, once per run (reported by bench.py)
+        # Deferred dense Adam on untouched user rows (include/invpref_hip.h): inside a replayed run of
+        # epochs a user row the minibatch does not touch is left alone -- its zero-gradient updates are replayed, exactly,
+        # when it is next touched -- and a flush at the end of the run brings every row up to date.  Bit for bit the dense
+        # optimiser (tests/test_deferred_gpu.py), but OFF by default (INVPREF_DEFER=1 turns it on): measured at the Yahoo
+        # shape it is slower -- 25.3 us per step against 18.9 -- because the streamed rows were never on the step's
+        # critical chain while every replayed update is (about 0.45 us each, and rarely seen users are dozens of steps
+        # behind); with no update pending at all the step takes 19.40 us against 19.46 (profiles/r04/deferred_adam_ab.txt).
+        self._defer = False
+        if self.use_plan and self._plans and self.users_tensor.is_cuda and self._fused_seq() \
+                and os.environ.get('INVPREF_DEFER', '0') == '1':
+            self._defer = all(ops.defer_supported(st.p_views, dp) for dp in self._plans) \
+                and any(int(x) for dp in self._plans for x in dp.struct.defer_tail)
+        if self._defer and getattr(self, '_last_step', None) is None:
+            self._last_step = torch.zeros(self.model.user_num, dtype=torch.int32, device=self.device)
+            self._last_step_valid = None
+        self._defer_home = None
         if self.use_plan and self.users_tensor.is_cuda:
             # every plan shares ONE scratch (records + partial slabs; nothing carries over between steps): size it for
             # the largest BEFORE any graph capture bakes its address in
@@ -409,9 +425,16 @@ class _InvPrefTrainManager:
             # fused M-step + Adam: one pass, gradient never stored, parameters ping-pong
             st.step += 1
             sc = (self._sched['state'], self._sched['table'], st.step & 1) if sched else None
-            ops.mstep_rows_adam(st.p_views, st.p_views_alt, st.m_views, st.v_views, self._plans[k], be, by, bw, bn,
+            pv, pa, last = st.p_views, st.p_views_alt, None
+            if sched and self._defer_home is not None:
+                # deferred form: the user tables stay where the run found them and are updated in place
+                pv, pa, last = list(pv), list(pa), self._last_step
+                for i in self._user_tables:
+                    pv[i] = pa[i] = self._defer_home[i]
+            ops.mstep_rows_adam(pv, pa, st.m_views, st.v_views, self._plans[k], be, by, bw, bn,
                                 coefs, self._flags, lp, st.step, self.lr, self.workspace, pure=self._pure, sched=sc,
-                                mid_event=mid_event)   # (profiling: recorded between the step's two launches)
+                                mid_event=mid_event,   # (profiling: recorded between the step's two launches)
+                                last_step=last)
             st.swap()
             return
         st.step += 1
@@ -490,10 +513,24 @@ class _InvPrefTrainManager:
 
     def _issue_epochs(self, stream, sched: bool, n: int):
         self._epoch_losses[:n].zero_()
-        for j in range(n):
-            self._loss_slot = j
-            for k in range(self.batch_num):
-                self._raw_step(k, self._alpha_for(k), stream, sched=sched)
+        st = self.state
+        defer = bool(sched and getattr(self, '_defer', False))
+        self._defer_home = list(st.p_views) if defer else None
+        try:
+            for j in range(n):
+                self._loss_slot = j
+                for k in range(self.batch_num):
+                    self._raw_step(k, self._alpha_for(k), stream, sched=sched)
+            if defer:
+                # the run ends with every user row up to date in the CURRENT parameter buffer: nothing outside a replayed
+                # run ever sees a deferred row
+                home = list(st.p_views)
+                for i in self._user_tables:
+                    home[i] = self._defer_home[i]
+                ops.flush_deferred(home, st.p_views, st.m_views, st.v_views, self._last_step,
+                                   (self._sched['state'], self._sched['table'], (st.step + 1) & 1))
+        finally:
+            self._defer_home = None
         self._loss_slot = 0
 
     def train_a_epoch(self) -> dict:
@@ -558,7 +595,11 @@ class _InvPrefTrainManager:
                 self._graphs_agreed = None
                 self._loss_slot = 0
         if g is not None:
+            if getattr(self, '_defer', False) and self._last_step_valid != st.step:
+                self._last_step.fill_(st.step)     # (eager steps in between do not keep the row stamps)
             g.replay()
+            if getattr(self, '_defer', False):
+                self._last_step_valid = st.step + steps
             st.step += steps
             if steps % 2 and fused_seq:
                 st.swap()

@@ -101,9 +101,9 @@ int invpref_mstep_grad_hip(const InvPrefTables *tables, const InvPrefTables *gra
 /* ---- planned, atomic-free M-step ("row jobs"), two launches.  utils.mini_batch (utils.py:12-19) yields the same
  * contiguous, unshuffled slices every epoch, so the scatter pattern of a minibatch is inverted once into a plan
  * (built on the host, invpref_kdd_2022_amd/plan.py).  All arrays are device memory and are only read.
- *   group = the lanes that hold one embedding row, one float4 per lane: lanes_per_group = 16 / 32 / 64 for
- *           factor_num <= 64 / 128 / 256 (invpref_rows_lanes_per_group()); NG = 256 / lanes_per_group groups
- *           per workgroup;
+ *   group = the lanes that hold one embedding row: lanes_per_group = 16 / 16 / 32 for factor_num <= 64 / 128 / 256
+ *           (invpref_rows_lanes_per_group()) with 1 / 2 / 2 float4 per lane; NG = 256 / lanes_per_group groups per
+ *           workgroup;
  *   job   = one row of the user tables or of the item tables + the minibatch's interactions that touch it,
  *           cut into 1, 2, 4, ... NG equal slices (a power of two), one slice per group;
  *   round = the NG group slots of one workgroup; all jobs of a round have the same slice count; slices of a
@@ -157,7 +157,8 @@ typedef struct InvPrefRowPlan {
 /* Scratch of one planned step: the records + the partial slabs.  It needs no initialisation (every word is stored
  * before it is loaded) and carries nothing from one call to the next. */
 size_t invpref_rows_workspace_bytes(const InvPrefTables *tables, const InvPrefRowPlan *plan);
-/* lanes_per_group the kernels use for tables of this factor_num (16 / 32 / 64); a plan must be built for it. */
+/* lanes_per_group the kernels use for tables of this factor_num (16 / 16 / 32); a plan must be built for it.  Rows of
+ * more than 128 floats (32 lanes) take the pull form only: push_slot must be NULL. */
 int invpref_rows_lanes_per_group(const InvPrefTables *tables);
 
 /* same contract as invpref_mstep_grad_hip, except that EVERY row of every table of `grads` is

@@ -212,6 +212,7 @@ struct StepArgs {
     const int *push_slot;         // push form (InvPrefRowPlan::push_slot): [n] contribution slot of a minibatch position
     float *records;               // pull form: [n][4 + EMAX] records; push form: [n][2][DP] contribution rows
     float *slabs;                 // [launch-1 job tasks][slab_len] partial sums
+    float *slabs_ev;              // wide rows (step_wide.hpp, EVL2): [launch-2 item tasks][EMAX][DP] partial sums of embed_env's gradient
     int *sched_state;             // optional device int32[32]: two slots {step, base, SchedRow}, see InvPrefAdamSchedule
     int sched_slot;
     int *last_step;               // deferred dense Adam (launch 1, DEFER instances): [U] step of a user row's last update
@@ -1344,6 +1345,8 @@ struct FoldArgs {
     float *nEv, *nW, *nb;        // fused == 1: new parameters
     float *mEv, *mW, *mb, *vEv, *vW, *vb;
     int n_partials, n_task_wgs, fold_blocks;
+    const float *slabs_ev;       // EVL2: embed_env's partial sums come from launch 2's item tasks ...
+    int n_partials_ev;           // ... this many slabs of EMAX x DP floats
     float l2, l1;
     double inv_B, inv_BD2;       // 1 / Bnorm, 1 / (2 Bnorm D)
     float *losses6;
@@ -1352,10 +1355,9 @@ struct FoldArgs {
 };
 constexpr int kFoldCols = 16, kFoldSubs = kThreads / kFoldCols;   // a fold block: 16 columns x 16 sub-rows of partials
 
-template <int LG, int EMAX>
+template <int DP, int EMAX>
 __device__ __forceinline__ void fold_block(const DevTables &t, const StepArgs &a, const FoldArgs &f, int fb, float *lds) {
-    using G = Geo<LG, EMAX>;
-    constexpr int DP = G::DP, SLAB = G::SLAB, EDP = EMAX * DP;
+    constexpr int SLAB = 2 * EMAX * DP + EMAX + kLossSlots, EDP = EMAX * DP;
     double *part = reinterpret_cast<double *>(lds);   // [kFoldSubs][kFoldCols]
     const int colx = threadIdx.x % kFoldCols, sub = threadIdx.x / kFoldCols;
     const int idx = fb * kFoldCols + colx;
@@ -1380,8 +1382,10 @@ __device__ __forceinline__ void fold_block(const DevTables &t, const StepArgs &a
     }
     // this thread's column of the partials sub, sub + kFoldSubs, ...: 8 loads in flight together (clamped, not
     // guarded), summed in partial order in fp64
-    const float *col = a.slabs + (mine ? idx : 0);
-    const int np = f.n_partials;
+    const bool from_ev = f.slabs_ev != nullptr && mine && idx < EDP;   // (embed_env's columns: launch 2's slabs)
+    const float *col = from_ev ? f.slabs_ev + idx : a.slabs + (mine ? idx : 0);
+    const int np = from_ev ? f.n_partials_ev : f.n_partials;
+    const int64_t stride = from_ev ? EDP : SLAB;
     double acc = 0.0;
 #ifndef STEP_FOLD_CH
 #define STEP_FOLD_CH 32
@@ -1390,7 +1394,7 @@ __device__ __forceinline__ void fold_block(const DevTables &t, const StepArgs &a
     for (int s0 = sub; s0 < np; s0 += CH * kFoldSubs) {
         float x[CH];
 #pragma unroll
-        for (int j = 0; j < CH; j++) x[j] = col[(int64_t)min(s0 + j * kFoldSubs, np - 1) * SLAB];
+        for (int j = 0; j < CH; j++) x[j] = col[(int64_t)min(s0 + j * kFoldSubs, np - 1) * stride];
 #pragma unroll
         for (int j = 0; j < CH; j++) acc += (s0 + j * kFoldSubs < np) ? (double)x[j] : 0.0;
     }
@@ -1425,7 +1429,6 @@ __device__ __forceinline__ void fold_block(const DevTables &t, const StepArgs &a
     sl[idx - 2 * EDP - EMAX] = v;
 }
 
-template <int LG, int EMAX>
 __device__ __forceinline__ void fold_losses(const DevTables &t, const StepArgs &a, const FoldArgs &f, float *lds) {
     // called by the block that holds the loss columns, after fold_block and a barrier
     const double *sl = reinterpret_cast<const double *>(lds) + kFoldSubs * kFoldCols;
@@ -1527,11 +1530,11 @@ __global__ __launch_bounds__(kThreads, EMAX <= 4 ? STEP_APPLY_WAVES : (EMAX <= 8
         }
         STAMP(0);
 #ifndef DBG_NO_FOLD
-        fold_block<LG, EMAX>(t, a, f, fb, lds);
+        fold_block<4 * LG, EMAX>(t, a, f, fb, lds);
         constexpr int loss0 = 2 * EMAX * 4 * LG + EMAX;
         if (fb == loss0 / kFoldCols) {   // (workgroup-uniform)
             __syncthreads();
-            fold_losses<LG, EMAX>(t, a, f, lds);
+            fold_losses(t, a, f, lds);
         }
 #endif
         STAMP(7);
@@ -1623,27 +1626,44 @@ __global__ __launch_bounds__(kThreads) void flush_deferred_kernel(FlushArgs f) {
     if (lane == 0 && from <= t_done) f.last_step[row] = t_done;
 }
 
-inline int lanes_of(int D, bool vec) {
-    // (diagnostic: INVPREF_FORCE_LANES=32|64 runs narrower rows on a wider lane group -- what a row that fills more of
-    //  the wave costs at the same bytes; tools/README.md)
-    static const int forced = getenv("INVPREF_FORCE_LANES") ? atoi(getenv("INVPREF_FORCE_LANES")) : 0;
-    const int lg = D <= 64 ? 16 : (D <= 128 ? 32 : 64);
-    return forced > lg && forced <= 64 ? forced : lg;
-}
+#include "step_wide.hpp"
+
+// The row layout and the kernel family of a shape.  Rows of up to 64 floats with up to four environments (Yahoo, Coat,
+// the PureMF baselines) run the latency-tuned kernels above (16 lanes x 1 float4); everything else the wide ones
+// (step_wide.hpp): 16 lanes x 1 or 2 float4 up to 128 floats, 32 lanes x 2 float4 up to 256, class counts 8 or 16.
+struct Shape {
+    int lg, nc, dp, emax;
+    bool wide, evl2;   // evl2: embed_env's outer product runs in launch 2 (pull form only) and a third launch folds
+};
 inline int emax4_of(int E) { return E <= 4 ? 4 : (E <= 8 ? 8 : 16); }
-inline size_t slab_floats(int lg, int emax) { return (size_t)2 * emax * 4 * lg + emax + kLossSlots; }
-template <int LG>
-inline size_t eval_lds_floats(int emax) {
-    return emax <= 4 ? EvalLds<LG, 4>::total : (emax <= 8 ? EvalLds<LG, 8>::total : EvalLds<LG, 16>::total);
+inline Shape shape_of(int D, int E) {
+    Shape s;
+    s.lg = D <= 128 ? 16 : 32;
+    s.nc = D <= 64 ? 1 : 2;
+    s.dp = 4 * s.lg * s.nc;
+    const int e4 = emax4_of(E);
+    s.wide = !(s.nc == 1 && e4 == 4);
+    s.emax = s.wide ? (e4 < 8 ? 8 : e4) : 4;
+    s.evl2 = s.lg == 32;
+    return s;
 }
-inline size_t eval_lds_bytes(int lg, int emax) {   // (the layout itself: EvalLds)
-    return sizeof(float) * (lg == 16 ? eval_lds_floats<16>(emax) : (lg == 32 ? eval_lds_floats<32>(emax) : eval_lds_floats<64>(emax)));
+inline int lanes_of(int D) { return D <= 128 ? 16 : 32; }
+inline size_t slab_floats(const Shape &s) { return (size_t)2 * s.emax * s.dp + s.emax + kLossSlots; }
+inline size_t eval_lds_bytes(const Shape &s) {
+    if (!s.wide) return sizeof(float) * EvalLds<16, 4>::total;
+    // (the layout itself: WGeo / WGeo::Img in step_wide.hpp)
+    const size_t ng = kThreads / s.lg;
+    const size_t live = (size_t)2 * s.emax * s.dp + 16 + ng * 2 * s.dp + 2 * ng * (s.emax + 4);
+    const size_t len = (size_t)(s.evl2 ? 1 : 2) * s.emax * s.dp;
+    const size_t nimg = 4 * len <= 10240 ? 4 : (2 * len <= 10240 ? 2 : 1);
+    const size_t tail = nimg * len > live ? nimg * len : live;
+    return sizeof(float) * (tail + kWaves * (s.emax + kLossSlots));
 }
-inline size_t apply_lds_bytes(int lg, int emax) {
-    const size_t DP = 4 * (size_t)lg, NG = kThreads / lg;
-    const size_t job = (2 * emax * DP + NG * 2 * DP + kWaves * 4 * 64 * 4) * sizeof(float);
-    const size_t fold = (kFoldSubs * kFoldCols + kLossSlots) * sizeof(double);
-    return job > fold ? job : fold;
+inline size_t fold_lds_bytes() { return (kFoldSubs * kFoldCols + kLossSlots) * sizeof(double); }
+inline size_t apply_lds_bytes(const Shape &s) {
+    const size_t DP = s.dp, NG = kThreads / s.lg;
+    const size_t job = (2 * s.emax * DP + NG * 2 * DP + (s.wide ? 0 : kWaves * 4 * 64 * 4)) * sizeof(float);
+    return job > fold_lds_bytes() ? job : fold_lds_bytes();
 }
 
 template <typename K>
@@ -1652,10 +1672,17 @@ int ensure_lds(K kernel, size_t bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-inline size_t record_floats(const InvPrefRowPlan *plan, int lg, int emax) {
+inline size_t record_floats(const InvPrefRowPlan *plan, const Shape &s) {
     // pull form: a record of 4 + EMAX floats per interaction; push form: two padded contribution rows
-    const size_t per = plan->push_slot ? (size_t)8 * lg : (size_t)4 + emax;
+    const size_t per = plan->push_slot ? (size_t)2 * s.dp : (size_t)4 + s.emax;
     return ((size_t)(plan->n > 0 ? plan->n : 1) * per + 63) & ~(size_t)63;
+}
+inline size_t workspace_floats(const InvPrefRowPlan *plan, const Shape &s) {
+    // records | launch 1's partial slabs | (evl2) launch 2's partial slabs of embed_env's gradient
+    const size_t np = (size_t)(plan->n_user_rounds / plan->user_rounds_per_task);
+    const size_t ni = (size_t)(plan->n_item_rounds / plan->item_rounds_per_task);
+    return record_floats(plan, s) + slab_floats(s) * (np > 0 ? np : 1) +
+           (s.evl2 ? (size_t)s.emax * s.dp * (ni > 0 ? ni : 1) : 0);
 }
 
 inline int plan_tasks(const InvPrefRowPlan *plan, int launch, int *task_wgs, bool defer = false) {
@@ -1711,8 +1738,8 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
             dst[i][2] = src[i]->embed_user_env_aware; dst[i][3] = src[i]->embed_item_env_aware;
         }
     }
-    const int lg = lanes_of(t.D, vec), emax = emax4_of(t.E);
-    const int NG = kThreads / lg;
+    const Shape shp = shape_of(t.D, t.E);
+    const int lg = shp.lg, emax = shp.emax;
     // ---- the plan
     if (plan->lanes_per_group != lg) return INVPREF_EINVAL;   // built for another row layout
     if (plan->n < 0 || plan->n_user_rounds < 0 || plan->n_item_rounds < 0 || plan->user_rounds_per_task <= 0 ||
@@ -1732,7 +1759,7 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
         if (tables->embed_user_invariant != new_tables->embed_user_invariant ||
             tables->embed_user_env_aware != new_tables->embed_user_env_aware)
             return INVPREF_EINVAL;
-        if (!vec || lg != 16 || emax != 4) return INVPREF_EUNSUPPORTED;
+        if (!vec || shp.wide) return INVPREF_EUNSUPPORTED;
     }
     for (int c = 0; c < ncls; c++) {
         const int32_t *q = plan->cls[c];
@@ -1745,10 +1772,10 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
             return INVPREF_EINVAL;
     }
     const int n_partials = plan->n_user_rounds / plan->user_rounds_per_task;
-    const size_t slab = slab_floats(lg, emax);
-    const size_t rec_floats = record_floats(plan, lg, emax);
-    if (workspace_bytes < sizeof(float) * (rec_floats + slab * (size_t)(n_partials > 0 ? n_partials : 1)))
-        return INVPREF_EWORKSPACE;
+    const size_t slab = slab_floats(shp);
+    const size_t rec_floats = record_floats(plan, shp);
+    if (workspace_bytes < sizeof(float) * workspace_floats(plan, shp)) return INVPREF_EWORKSPACE;
+    if (shp.evl2 && plan->push_slot) return INVPREF_EINVAL;   // rows on 32 lanes: pull form only (step_wide.hpp)
     StepScalars k;
     k.ca = coefs->invariant_coe; k.cb = coefs->env_aware_coe; k.cc = coefs->env_coe; k.alpha = coefs->alpha;
     k.invB = 1.0f / (float)batch_norm;
@@ -1757,6 +1784,7 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a.envs = envs; a.weights = weights; a.k = k; a.flags = flags; a.fused = fused; a.ad = ad;
     a.rows_per_stream_task = plan->rows_per_stream_task; a.n_cls = ncls;
     a.records = (float *)workspace; a.slabs = (float *)workspace + rec_floats;
+    a.slabs_ev = a.slabs + slab * (size_t)(n_partials > 0 ? n_partials : 1);
     a.push_slot = plan->push_slot;
     a.sched_state = sched ? sched->state : nullptr;
     a.sched_slot = sched ? (sched->slot & 1) : 0;
@@ -1769,7 +1797,7 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     int wg1 = 0, wg2 = 0;
     plan_tasks(plan, 0, &wg1, defer);
     plan_tasks(plan, 1, &wg2, defer);
-    const size_t lds1 = eval_lds_bytes(lg, emax), lds2 = apply_lds_bytes(lg, emax);
+    const size_t lds1 = eval_lds_bytes(shp), lds2 = apply_lds_bytes(shp);
     if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return INVPREF_EUNSUPPORTED;
     // launch 1
     StepArgs a1 = a;
@@ -1806,6 +1834,40 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     f.sched_table = sched ? reinterpret_cast<const SchedRow *>(sched->table) : nullptr;
     f.sched_n = sched ? sched->n : 0;
     const int grid2 = wg2 + f.fold_blocks + 1;
+    if (shp.evl2) { f.slabs_ev = a.slabs_ev; f.n_partials_ev = plan->n_item_rounds / plan->item_rounds_per_task; }
+    // wide rows / more than four environments (step_wide.hpp).  evl2: launch 2 = the item jobs alone (they produce embed_env's
+    // partial slabs), launch 3 = the fold blocks alone
+#define CALL_W(LGV, NCV, VECV, EMAXV, EV2)                                                                        \
+    do {                                                                                                          \
+        if ((rc = ensure_lds(mstep_eval_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>, lds1))) return rc;             \
+        if ((rc = ensure_lds(mstep_apply_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>, lds2))) return rc;            \
+        if (wg1 > 0)                                                                                              \
+            hipLaunchKernelGGL((mstep_eval_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>), dim3(wg1), dim3(kThreads), lds1, st, t, a1); \
+        if (profile_event && hipEventRecord((hipEvent_t)profile_event, st) != hipSuccess) return INVPREF_EINVAL; \
+        if (!EV2) {                                                                                               \
+            hipLaunchKernelGGL((mstep_apply_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>), dim3(grid2), dim3(kThreads), lds2, st, t, a2, f); \
+        } else {                                                                                                  \
+            if (wg2 > 0)                                                                                          \
+                hipLaunchKernelGGL((mstep_apply_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>), dim3(wg2), dim3(kThreads), lds2, st, t, a2, f); \
+            FoldArgs f3 = f;                                                                                      \
+            f3.n_task_wgs = 0;                                                                                    \
+            hipLaunchKernelGGL((mstep_apply_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>), dim3(f.fold_blocks + 1), dim3(kThreads), fold_lds_bytes(), st, t, a2, f3); \
+        }                                                                                                         \
+    } while (0)
+#define CALL_WE(LGV, NCV, VECV, EV2)                                                               \
+    do {                                                                                           \
+        if (emax == 8) CALL_W(LGV, NCV, VECV, 8, EV2); else CALL_W(LGV, NCV, VECV, 16, EV2);       \
+    } while (0)
+    if (shp.wide && !defer) {
+        if (vec) {
+            if (shp.lg == 32) CALL_WE(32, 2, true, true); else if (shp.nc == 2) CALL_WE(16, 2, true, false); else CALL_WE(16, 1, true, false);
+        } else {
+            if (shp.lg == 32) CALL_WE(32, 2, false, true); else if (shp.nc == 2) CALL_WE(16, 2, false, false); else CALL_WE(16, 1, false, false);
+        }
+        return (int)hipGetLastError();
+    }
+#undef CALL_WE
+#undef CALL_W
 #define CALL(LGV, VECV, EMAXV)                                                                                  \
     do {                                                                                                        \
         if ((rc = ensure_lds(mstep_eval_kernel<LGV, VECV, EMAXV>, lds1))) return rc;                            \
@@ -1814,10 +1876,6 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
             hipLaunchKernelGGL((mstep_eval_kernel<LGV, VECV, EMAXV>), dim3(wg1), dim3(kThreads), lds1, st, t, a1); \
         if (profile_event && hipEventRecord((hipEvent_t)profile_event, st) != hipSuccess) return INVPREF_EINVAL; \
         hipLaunchKernelGGL((mstep_apply_kernel<LGV, VECV, EMAXV>), dim3(grid2), dim3(kThreads), lds2, st, t, a2, f); \
-    } while (0)
-#define CALL_E(LGV, VECV)                                                                         \
-    do {                                                                                          \
-        if (emax == 4) CALL(LGV, VECV, 4); else if (emax == 8) CALL(LGV, VECV, 8); else CALL(LGV, VECV, 16); \
     } while (0)
     if (defer) {
         const size_t lds1d = lds1 + kDeferWin * sizeof(float2);
@@ -1828,11 +1886,10 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
         if (profile_event && hipEventRecord((hipEvent_t)profile_event, st) != hipSuccess) return INVPREF_EINVAL;
         hipLaunchKernelGGL((mstep_apply_kernel<16, true, 4>), dim3(grid2), dim3(kThreads), lds2, st, t, a2, f);
     } else if (!vec) {
-        if (lg == 16) CALL_E(16, false); else if (lg == 32) CALL_E(32, false); else CALL_E(64, false);
+        CALL(16, false, 4);
     } else {
-        if (lg == 16) CALL_E(16, true); else if (lg == 32) CALL_E(32, true); else CALL_E(64, true);
+        CALL(16, true, 4);
     }
-#undef CALL_E
 #undef CALL
     return (int)hipGetLastError();
 }
@@ -1857,16 +1914,15 @@ size_t invpref_rows_workspace_bytes(const InvPrefTables *tables, const InvPrefRo
     if (check_tables(tables, tables && !tables->embed_user_env_aware) || !plan || plan->n < 0 || plan->n_user_rounds < 0 ||
         plan->user_rounds_per_task <= 0)
         return 0;
-    const int lg = plan->lanes_per_group, emax = emax4_of((int)tables->env_num);
-    if (lg != 16 && lg != 32 && lg != 64) return 0;
-    const size_t rec_floats = record_floats(plan, lg, emax);
-    const size_t np = (size_t)(plan->n_user_rounds / plan->user_rounds_per_task);
-    return sizeof(float) * (rec_floats + slab_floats(lg, emax) * (np > 0 ? np : 1));
+    if (plan->item_rounds_per_task <= 0 || plan->n_item_rounds < 0) return 0;
+    const Shape shp = shape_of((int)tables->factor_num, (int)tables->env_num);
+    if (plan->lanes_per_group != shp.lg) return 0;
+    return sizeof(float) * workspace_floats(plan, shp);
 }
 
 int invpref_rows_lanes_per_group(const InvPrefTables *tables) {
     if (!tables || tables->factor_num <= 0 || tables->factor_num > INVPREF_MAX_FACTORS) return INVPREF_EUNSUPPORTED;
-    return lanes_of((int)tables->factor_num, true);
+    return lanes_of((int)tables->factor_num);
 }
 
 int invpref_mstep_rows_grad_hip(const InvPrefTables *tables, const InvPrefTables *grads, const InvPrefRowPlan *plan,
@@ -1957,8 +2013,7 @@ int invpref_rows_defer_supported(const InvPrefTables *tables, const InvPrefRowPl
     if (!tables || !plan) return 0;
     const bool pure = tables->embed_user_env_aware == nullptr;
     if (check_tables(tables, pure)) return 0;
-    return plan->push_slot && vec_ok(tables) && lanes_of((int)tables->factor_num, true) == 16 &&
-           emax4_of((int)tables->env_num) == 4;
+    return plan->push_slot && vec_ok(tables) && !shape_of((int)tables->factor_num, (int)tables->env_num).wide;
 }
 
 int invpref_flush_deferred_hip(const InvPrefTables *home, const InvPrefTables *dst, const InvPrefTables *exp_avg,
@@ -1989,7 +2044,7 @@ int invpref_flush_deferred_hip(const InvPrefTables *home, const InvPrefTables *d
 // (diagnostic, not declared in the header) resident workgroups per CU of the smallest launch-1 instance
 extern "C" int invpref_debug_eval_occupancy(void) {
     int n = -1;
-    const size_t lds = eval_lds_bytes(16, 4);
+    const size_t lds = eval_lds_bytes(shape_of(64, 4));
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mstep_eval_kernel<16, true, 4>, kThreads, lds) != hipSuccess) return -1;
     return n * 1000 + (int)(lds / 1024);
 }

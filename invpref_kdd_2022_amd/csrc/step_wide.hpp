@@ -1,0 +1,968 @@
+// step_wide.hpp -- the planned M-step for rows of more than 64 floats and / or more than four environments
+// (MovieLens: D = 128, E = 8; MIND: D = 256, E = 16).  Included by invpref_step.hip inside its anonymous namespace.
+//
+// Round 3 gave every row ONE float4 per lane (32 / 64 lanes per row): an interaction then occupied half a wave or a
+// whole one, and the per-interaction chain -- row reductions, softmax, the loss terms, some 300 instructions -- was paid
+// per wave; the E x D outer products (gradients of the classifier and of embed_env) sat in registers or went through
+// LDS records with a barrier per interaction.  Measured: the same rows cost 41 -> 63 -> 204 us on 16 / 32 / 64 lanes.
+// Here:
+//   * a row lives on 16 lanes x 2 float4 (D <= 128) or 32 lanes x 2 float4 (D <= 256): four (two) interactions
+//     share a wave's instruction stream again;
+//   * the two outer products  dW += gz (x) x  and  dEv += onehot(env) (x) o  are GEMM-shaped across the wave's
+//     interactions and run on the matrix cores: v_mfma_f32_16x16x4_f32, fp32 in, fp32 accumulate -- bit for bit an
+//     fmaf chain over the wave's (up to) four interactions, so the step stays bitwise reproducible.  The operands
+//     need no data movement: the A operand A[m][k] sits on lane m + 16 k, which IS "class m of the interaction on
+//     lane quarter k" in the class-per-lane softmax layout; the B operand B[k][n] on lane n + 16 k is component c of
+//     float4 chunk j of that interaction's row -- one MFMA per (chunk, component); the accumulators (4 registers per
+//     tile, classes on rows) stay in registers for the whole task and meet in LDS once, at its end.
+//     (32 lanes per row: a lane quarter holds HALF a row, so each tile takes the A operand masked to one half.)
+//   * D <= 128: both products in launch 1 (64 accumulator registers).  D <= 256: the classifier's in launch 1, embed_env's
+//     in launch 2's item jobs (EVL2; they hold Qa[v], gather Pa[u] and read g_q / env from the record: pull form only),
+//     whose partial slabs a third, tiny launch folds.
+// Arithmetic of one interaction: eval_wide() == eval_interaction() (models.py:307-326, :206-209; train.py:108-153).
+#pragma once
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef WIDE_UE
+#define WIDE_UE 2      // interactions in flight per group (launch 1)
+#endif
+#ifndef WIDE_WAVES_16_2_8
+#define WIDE_WAVES_16_2_8 2
+#endif
+#ifndef WIDE_UE_16_2_8
+#define WIDE_UE_16_2_8 2
+#endif
+#ifndef WIDE_U_EVL2_16
+#define WIDE_U_EVL2_16 1   // launch 2 of the D <= 256, E = 16 instance (its slots hold 16 class gradients each)
+#endif
+#ifndef WIDE_FENCE
+#define WIDE_FENCE 1   // scheduling fences inside the classifier loops of two-chunk rows (register pressure)
+#endif
+
+// per-instance launch-1 configuration: workgroups per CU the kernel is compiled for (registers: 512 / waves per SIMD)
+// and the interactions each group keeps in flight
+template <int LG, int NC, int EMAX>
+struct WideCfg {
+    static constexpr int WAVES = (LG == 16 && NC == 2 && EMAX == 8) ? WIDE_WAVES_16_2_8 : 2;
+    static constexpr int UE = (LG == 16 && NC == 2 && EMAX == 8) ? WIDE_UE_16_2_8 : ((NC == 2 && LG == 16 && EMAX == 16) ? 1 : WIDE_UE);
+};
+
+template <int LG, int NC, int EMAX>
+struct WGeo {
+    static constexpr int NG = kThreads / LG;          // groups (rows in flight) per workgroup
+    static constexpr int DP = 4 * LG * NC;            // padded row length
+    static constexpr int RS = 4 + EMAX;               // floats per record: g_p, g_q, env bits, 0, gz[EMAX]
+    static constexpr int SLAB = 2 * EMAX * DP + EMAX + kLossSlots;   // dEv | dW | db | loss sums
+    static constexpr int HALVES = LG / 16;            // 16-lane pieces of a group = MFMA k slots a row spans
+    static constexpr int TILES = NC * HALVES;         // column tiles of a table: 16 float4 columns x 16 classes each
+    // LDS of launch 1 (floats)
+    static constexpr int sEv = 0, sW = EMAX * DP, sb = 2 * EMAX * DP, slots = sb + 16;
+    static constexpr int gzs = slots + NG * 2 * DP;                  // [2][NG][EMAX + 4] class gradients of a group
+    static constexpr int live_end = gzs + 2 * NG * (EMAX + 4);
+    // task end: the waves' accumulator tiles meet in NIMG LDS images laid over everything above (nobody reads it any
+    // more); wave w adds into image w % NIMG in turn w / NIMG.  EVL2 = true halves the image (classifier only).
+    template <bool EVL2> struct Img {
+        static constexpr int LEN = (EVL2 ? 1 : 2) * EMAX * DP;
+        static constexpr int N = 4 * LEN <= 10240 ? 4 : (2 * LEN <= 10240 ? 2 : 1);
+        static constexpr int tail = (N * LEN > live_end ? N * LEN : live_end);   // [kWaves][EMAX + kLossSlots] db | loss sums
+        static constexpr int total = tail + kWaves * (EMAX + kLossSlots);
+    };
+    // LDS of launch 2: sEv | sW | slots
+    static constexpr int apply_total = 2 * EMAX * DP + NG * 2 * DP;
+};
+
+template <int LG, int NC, bool VEC>
+__device__ __forceinline__ void load_row(float4 (&r)[NC], const float *__restrict__ base, int row, int D, int lg) {
+#pragma unroll
+    for (int j = 0; j < NC; j++) r[j] = row4<VEC>(base, row, D, lg + LG * j);
+}
+template <int LG, int NC, bool VEC, int MODE = 0>
+__device__ __forceinline__ void store_row(float *__restrict__ base, int row, int D, int lg, const float4 (&r)[NC]) {
+#pragma unroll
+    for (int j = 0; j < NC; j++) put4<VEC, MODE>(base, row, D, lg + LG * j, r[j]);
+}
+template <int LG, int NC>
+__device__ __forceinline__ void lds_row(float4 (&r)[NC], const float *tab, int e, int lg) {
+    constexpr int DP = 4 * LG * NC;
+#pragma unroll
+    for (int j = 0; j < NC; j++) r[j] = *reinterpret_cast<const float4 *>(tab + e * DP + 4 * (lg + LG * j));
+}
+
+// ---- forward + analytic backward of ONE interaction on a lane group of LG lanes x NC float4 (M-step arithmetic:
+// hardware exp / log / rcp).  One class per lane: lane c of the group (c < E <= 16) ends up with class c's logit.
+template <int NC>
+struct WEval {
+    float g_p, g_q, li, le, lcls, gz_lane;
+    float4 x[NC], gx[NC];   // x = Pu*Qi ; gx = sum_c gz_c W_c
+};
+template <int LG, int NC, int EMAX>
+__device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], const float4 (&qi)[NC],
+                                          const float4 (&pa)[NC], const float4 (&qa)[NC], const float4 (&ev)[NC],
+                                          const float *sW, const float *sb, float *gzs, int E, int e, float y, float cw_rec,
+                                          float cw_cls, const StepScalars &k, bool implicit, bool pure, int lg, bool has) {
+    // `has` = false (an empty slot of a lock-step iteration): the arithmetic runs on the slot's stale -- finite -- rows
+    // and every gradient scalar is forced to zero, so that everything downstream contributes nothing; no branch.
+    constexpr int DP = 4 * LG * NC;
+    float ps = 0.f, qs = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+        o.x[j] = f4mul(pu[j], qi[j]);
+        ps += (o.x[j].x + o.x[j].y) + (o.x[j].z + o.x[j].w);
+        qs += dot4(f4mul(pa[j], qa[j]), ev[j]);
+    }
+    const float p = group_sum<LG>(ps);
+    const float q = group_sum<LG>(qs);
+    if (implicit) {
+        const float sp = f_sigmoid(p), sq = f_sigmoid(q), sv = sp * sq;
+        o.li = f_bce(sp, y);
+        o.le = f_bce(sv, y);
+        const float d_inv = k.ca * cw_rec * f_dbce(sp, y);
+        const float d_env = k.cb * cw_rec * f_dbce(sv, y);
+        o.g_p = (d_inv + d_env * sq) * (sp * (1.f - sp));
+        o.g_q = d_env * sp * (sq * (1.f - sq));
+    } else {
+        const float s2 = p + q;
+        o.li = (p - y) * (p - y);
+        o.le = (s2 - y) * (s2 - y);
+        const float d_env = k.cb * cw_rec * 2.f * (s2 - y);
+        o.g_p = k.ca * cw_rec * 2.f * (p - y) + d_env;
+        o.g_q = d_env;
+    }
+    if (!has) o.g_p = o.g_q = o.li = o.le = 0.f;
+    o.lcls = 0.f;
+    o.gz_lane = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC; j++) o.gx[j] = f4zero();
+    if (pure) return;   // PureMF: no classifier
+#ifdef WIDE_DIAG_NOCLS
+    return;
+#endif
+    // all EMAX class dot products per lane (rows c >= E are staged as zeros), then ONE reduce-scatter butterfly: lane l of
+    // the group ends up with the logit of class l & (EMAX - 1)
+    float part[EMAX];
+#pragma unroll
+    for (int c = 0; c < EMAX; c++) {
+        // (a scheduling fence per four classes: left alone the compiler requests every W row of the loop up front and
+        //  the kernel spills; two waves per SIMD cover the LDS latency instead)
+        if (WIDE_FENCE && NC > 1 && (c & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC; j++) s += dot4(o.x[j], *reinterpret_cast<const float4 *>(sW + c * DP + 4 * (lg + LG * j)));
+        part[c] = s;
+    }
+    if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);
+    const float zred = group_sum_above<LG, EMAX>(class_butterfly<EMAX>(part, lg), lg);
+    const float zmine = lg < E ? zred + sb[lg & (EMAX - 1)] : -__builtin_inff();
+    const float mxl = group_max<LG>(zmine);
+    const float ez = lg < E ? f_exp(zmine - mxl) : 0.f;
+    const float rsel = f_rcp(group_sum<LG>(ez));
+    const float gzl = (lg < E && has) ? k.cc * cw_cls * (ez * rsel - (lg == e ? 1.f : 0.f)) : 0.f;
+    o.gz_lane = gzl;
+    // every lane needs every gz_c for the backward: through the group's LDS words (in-order LDS operations of one wave)
+    if (lg < EMAX) gzs[lg] = gzl;
+    if (lg == e) gzs[EMAX + 1] = -f_log(ez * rsel);   // (lane e holds the picked class: its loss term)
+    WAVE_LDS_FENCE();
+    o.lcls = has ? gzs[EMAX + 1] : 0.f;
+#pragma unroll
+    for (int c4 = 0; c4 < EMAX; c4 += 4) {
+        if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);
+        const float4 g4 = *reinterpret_cast<const float4 *>(gzs + c4);
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+            const float *wr = sW + c4 * DP + 4 * (lg + LG * j);
+            f4fma(o.gx[j], g4.x, *reinterpret_cast<const float4 *>(wr));
+            f4fma(o.gx[j], g4.y, *reinterpret_cast<const float4 *>(wr + DP));
+            f4fma(o.gx[j], g4.z, *reinterpret_cast<const float4 *>(wr + 2 * DP));
+            f4fma(o.gx[j], g4.w, *reinterpret_cast<const float4 *>(wr + 3 * DP));
+        }
+    }
+}
+
+// acc[tile][component] += A (x) B over the wave's lane quarters: tile (j, h) covers the float4 columns
+// (lane & 15) + 16 h + LG j; a row on 32 lanes spans two quarters, so the A operand is masked to the quarter's half.
+template <int LG, int NC>
+__device__ __forceinline__ void outer_mfma(f32x4 (&acc)[NC * (LG / 16)][4], float a, const float4 (&b)[NC], int lane) {
+    constexpr int HALVES = LG / 16;
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+#pragma unroll
+        for (int h = 0; h < HALVES; h++) {
+            const float ah = (HALVES == 1 || ((lane >> 4) & 1) == h) ? a : 0.f;
+            f32x4 (&t)[4] = acc[j * HALVES + h];
+            t[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah, b[j].x, t[0], 0, 0, 0);
+            t[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah, b[j].y, t[1], 0, 0, 0);
+            t[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah, b[j].z, t[2], 0, 0, 0);
+            t[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah, b[j].w, t[3], 0, 0, 0);
+        }
+    }
+}
+// EMAX = 8 pads the class dimension of a tile to 16 rows: rows 8 .. 15 of the SAME accumulators then take embed_env's
+// product (its one-hot A operand moved to lanes 8 .. 15 of the quarter) -- half the accumulator registers
+template <int EMAX, bool EVL2>
+struct Shared { static constexpr bool value = EMAX == 8 && !EVL2; };
+
+// one wave's accumulator tiles into (first = true: over) the workgroup's [EMAX][DP] LDS image: lane l, register r of a
+// tile hold class 4 (l >> 4) + r at float4 column (l & 15) + 16 h + LG j -- the four components are the four MFMAs
+template <int LG, int NC, int EMAX, bool SHARED = false>
+__device__ __forceinline__ void tiles_to_lds(float *img, const f32x4 (&acc)[NC * (LG / 16)][4], int lane, bool first) {
+    // (SHARED: img = embed_env's image, the classifier's follows it: accumulator rows 0 .. 7 are classifier classes,
+    //  rows 8 .. 15 environments)
+    constexpr int HALVES = LG / 16, DP = 4 * LG * NC;
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+#pragma unroll
+        for (int h = 0; h < HALVES; h++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int cls = 4 * (lane >> 4) + r;
+                if (SHARED || cls < EMAX) {
+                    const f32x4 (&t)[4] = acc[j * HALVES + h];
+                    const int rowi = SHARED ? (cls < 8 ? 8 + cls : cls - 8) : cls;   // image row: [dEv: 8 rows][dW: 8 rows]
+                    float4 *dst = reinterpret_cast<float4 *>(img + rowi * DP + 4 * ((lane & 15) + 16 * h + LG * j));
+                    float4 v = make_float4(t[0][r], t[1][r], t[2][r], t[3][r]);
+                    if (!first) { const float4 cur = *dst; v.x += cur.x; v.y += cur.y; v.z += cur.z; v.w += cur.w; }
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================
+// launch 1: rounds of USER jobs
+// =====================================================================================
+template <int LG, int NC, bool VEC, int EMAX, bool EVL2>
+__device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArgs &a, int r0, int nr, int slab_index, float *lds) {
+    using G = WGeo<LG, NC, EMAX>;
+    constexpr int NG = G::NG, DP = G::DP, RS = G::RS, TILES = G::TILES;
+    // interactions in flight per group: what the instance's register budget allows (WideCfg)
+    constexpr int UE = WideCfg<LG, NC, EMAX>::UE;
+    using IM = typename G::template Img<EVL2>;
+    float *sEv = lds + G::sEv, *sW = lds + G::sW, *sb = lds + G::sb, *slots = lds + G::slots, *tail = lds + IM::tail;
+    const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool implicit = a.flags & INVPREF_IMPLICIT;
+    const bool rw_rec = a.flags & INVPREF_REWEIGHT_REC, rw_cls = a.flags & INVPREF_REWEIGHT_CLS;
+    const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
+    const bool pure = a.flags & INVPREF_PURE_MF;
+    const bool push = a.push_slot != nullptr;
+    StepScalars k = a.k;
+    if (a.sched_state) {  // scheduled alpha (train.py:214-217) under graph replay
+        const float al = sched_slot_ptr(a.sched_state, a.sched_slot)->alpha;
+        if (al == al) k.alpha = al;
+    }
+    const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
+
+    STAMP(0);
+    int4 d = a.desc[(r0 * NG + grp) * 2], d1 = a.desc[(r0 * NG + grp) * 2 + 1];
+    STAMP(1);
+
+    constexpr bool SH = Shared<EMAX, EVL2>::value;   // one accumulator set for both products
+    f32x4 accW[TILES][4], accE[(EVL2 || SH) ? 1 : TILES][4];
+#pragma unroll
+    for (int i = 0; i < TILES; i++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) accW[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < ((EVL2 || SH) ? 1 : TILES); i++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) accE[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dBacc = 0.f;   // lane c of every group: sum of gz_c
+    float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
+    int it_total = 0;    // parity of the gz words
+    float *slab = a.slabs + (int64_t)slab_index * G::SLAB;
+
+    for (int r = r0; r < r0 + nr; r++) {
+        const int4 dd = d, dd1 = d1;
+        const int row = dd.x, meta = dd.y;
+        const bool active = row >= 0, leader = meta & 1;
+        const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
+        const int nsmp = active ? (mode == 7 ? dd.w - dd.z : mode) : 0;
+        const int iters = a.round_iters[r];   // the round's longest slice: the loop (and its MFMAs) is workgroup-uniform
+        if (r == r0) STAMP(2);
+        auto sample_at = [&](int sidx) {
+            USample sm;
+            if (mode == 7) {
+                const int4 q = a.ulist[dd.z + sidx];
+                sm.oth = q.x; sm.ps = q.y; sm.y = __builtin_bit_cast(float, q.z);
+            } else if (sidx == 0) { sm.oth = dd.z; sm.ps = dd.w; sm.y = __builtin_bit_cast(float, dd1.x); }
+            else { sm.oth = dd1.y; sm.ps = dd1.z; sm.y = __builtin_bit_cast(float, dd1.w); }
+            return sm;
+        };
+        float4 oi[NC], oe[NC], gi[NC], ge[NC];
+#pragma unroll
+        for (int j = 0; j < NC; j++) oi[j] = oe[j] = gi[j] = ge[j] = f4zero();
+        {   // (an idle slot reads row 0 rather than branching around the loads)
+            const int rowc = active ? row : 0;
+            load_row<LG, NC, VEC>(oi, t.Pu, rowc, t.D, lg);
+            if (!pure) load_row<LG, NC, VEC>(oe, t.Pa, rowc, t.D, lg);
+        }
+        struct Slot {
+            float4 qi[NC], qa[NC];
+            USample sm;
+            int e, cs;
+            float w;
+        };
+        Slot sl[UE];
+        USample idn[UE];
+        auto gather = [&](Slot &q, const USample &sm) {
+            q.sm = sm;
+#ifdef WIDE_DIAG_HOT   // (what-if build: every gather hits the same few rows -- what the launch costs without gather latency)
+            const int oth = sm.oth & 15;
+#else
+            const int oth = sm.oth;
+#endif
+            load_row<LG, NC, VEC>(q.qi, t.Qi, oth, t.D, lg);
+            if (!pure) {
+                load_row<LG, NC, VEC>(q.qa, t.Qa, oth, t.D, lg);
+                q.e = (int)a.envs[sm.ps];
+            }
+            if (rw_rec || rw_cls) q.w = a.weights[sm.ps];
+            if (push) q.cs = a.push_slot[sm.ps];
+        };
+#pragma unroll
+        for (int j = 0; j < UE; j++) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) sl[j].qi[c] = sl[j].qa[c] = f4zero();
+            sl[j].sm = USample{0, 0, 0.f};
+            sl[j].e = sl[j].cs = 0;
+            sl[j].w = 1.f;
+            idn[j] = USample{0, 0, 0.f};
+            if (j < nsmp) gather(sl[j], sample_at(j));
+        }
+#pragma unroll
+        for (int j = 0; j < UE; j++)
+            if (UE + j < nsmp) idn[j] = sample_at(UE + j);
+        if (r == r0) {
+            // the two small tables are staged HERE, behind the first round's gathers: a load -> store loop in front of
+            // them would put the tables' round trip ahead of the rows' on the task's critical chain
+            stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
+            stage_small(sW, t.W, t.E, t.D, EMAX, DP);
+            if (threadIdx.x < 16) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
+            __syncthreads();
+            STAMP(3);
+        }
+
+        auto step = [&](const Slot &q, bool has) {
+            // branch-free: an empty slot (the round's longest slice sets the trip count) evaluates its stale rows with
+            // every gradient scalar forced to zero (eval_wide) and stores nothing
+            if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);   // (the unrolled slots' evaluations stay apart)
+            float *gzs = lds + G::gzs + ((it_total & 1) * NG + grp) * (EMAX + 4);
+            const int e = q.e;
+            const float w_rec = rw_rec ? q.w : 1.f, w_cls = rw_cls ? q.w : 1.f;
+            float4 ev[NC];
+            lds_row<LG, NC>(ev, sEv, e, lg);
+            WEval<NC> o;
+            eval_wide<LG, NC, EMAX>(o, oi, q.qi, oe, q.qa, ev, sW, sb, gzs, t.E, e, q.sm.y, w_rec * k.invB, w_cls * k.invB, k,
+                                    implicit, pure, lg, has);
+            float s2 = 0.f, s1 = 0.f;
+            float *cr = a.records + (unsigned)q.cs * (unsigned)(2 * DP);
+            float4 boo[EVL2 ? 1 : NC];
+#pragma unroll
+            for (int j = 0; j < NC; j++) {
+                float4 gip;
+                gip.x = o.g_p - k.alpha * o.gx[j].x; gip.y = o.g_p - k.alpha * o.gx[j].y;
+                gip.z = o.g_p - k.alpha * o.gx[j].z; gip.w = o.g_p - k.alpha * o.gx[j].w;
+                f4add(gi[j], f4mul(gip, q.qi[j]));
+                f4fma(ge[j], o.g_q, f4mul(q.qa[j], ev[j]));
+#ifdef WIDE_DIAG_NOSTORE
+                if (false) {
+#else
+                if (push && has) {   // the interaction's two contribution rows to its ITEM's gradient, at the item-sorted slot
+#endif
+                    *reinterpret_cast<float4 *>(cr + 4 * (lg + LG * j)) = f4mul(gip, oi[j]);
+                    *reinterpret_cast<float4 *>(cr + DP + 4 * (lg + LG * j)) = f4scale(o.g_q, f4mul(oe[j], ev[j]));
+                }
+                if constexpr (!EVL2) {
+                    // o = g_q Pa*Qa (+ env regulariser): the interaction's term of embed_env's gradient
+                    float4 oo = f4scale(o.g_q, f4mul(oe[j], q.qa[j]));
+                    if (reg_env && has) f4add(oo, reg_term(ev[j], 2.f * k.r2, 2.f * k.r1));
+                    boo[j] = oo;
+                }
+                // regulariser REPORTS over the item rows of the interaction (env rows weigh double)
+                s2 += f4sq(q.qi[j]) + f4sq(q.qa[j]);
+                s1 += f4abs(q.qi[j]) + f4abs(q.qa[j]);
+                if (reg_env) { s2 += 2.f * f4sq(ev[j]); s1 += 2.f * f4abs(ev[j]); }
+            }
+            if (!push && has) {   // pull form: the record the item side consumes
+                float *rec_g = a.records + (unsigned)q.sm.ps * (unsigned)RS;
+                if (lg == 0) *reinterpret_cast<float4 *>(rec_g) = make_float4(o.g_p, o.g_q, __builtin_bit_cast(float, e), 0.f);
+                if (lg < EMAX) rec_g[4 + lg] = o.gz_lane;
+            }
+            accL2 += has ? s2 : 0.f;
+            accL1 += has ? s1 : 0.f;
+            if (lg == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; accLc += o.lcls * w_cls; }
+            // A operands: class (lane & 15) of this interaction; rows on 32 lanes read it back from the group's words
+            const int lc = lane & 15;
+            const float a_gz = LG == 16 ? o.gz_lane : ((lc < EMAX && !pure) ? gzs[lc] : 0.f);
+            if (lg < 16) dBacc += o.gz_lane;
+            if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);
+#ifndef WIDE_DIAG_NOMFMA
+            outer_mfma<LG, NC>(accW, a_gz, o.x, lane);
+#endif
+#ifndef WIDE_DIAG_NOMFMA
+            if constexpr (SH) outer_mfma<LG, NC>(accW, (has && lc == e + 8) ? 1.f : 0.f, boo, lane);
+            else if constexpr (!EVL2) outer_mfma<LG, NC>(accE, (has && lc == e) ? 1.f : 0.f, boo, lane);
+#endif
+            if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);
+            it_total++;
+        };
+        for (int s = 0; s < iters; s += UE) {
+#pragma unroll
+            for (int j = 0; j < UE; j++) {
+                if (s + j < iters) step(sl[j], s + j < nsmp);
+                if (s + UE + j < nsmp) gather(sl[j], idn[j]);
+                if (s + 2 * UE + j < nsmp) idn[j] = sample_at(s + 2 * UE + j);
+            }
+        }
+        if (r == r0) STAMP(4);
+        if (r + 1 < r0 + nr) { d = a.desc[((r + 1) * NG + grp) * 2]; d1 = a.desc[((r + 1) * NG + grp) * 2 + 1]; }
+        const float cnt = (float)(meta >> 9);
+        if (active && leader) {   // regulariser reports: the user's rows count once per interaction
+            float s2 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NC; j++) { s2 += f4sq(oi[j]) + f4sq(oe[j]); s1 += f4abs(oi[j]) + f4abs(oe[j]); }
+            accL2 += cnt * s2;
+            accL1 += cnt * s1;
+        }
+        // the row's Adam moments are requested here -- the interaction slots' registers are free again -- and fly under
+        // the slices' meeting
+        float4 mm[2][NC], vv[2][NC];
+#pragma unroll
+        for (int tb = 0; tb < 2; tb++)
+#pragma unroll
+            for (int j = 0; j < NC; j++) mm[tb][j] = vv[tb][j] = f4zero();
+        constexpr bool EARLY_MV = LG == 16;   // (rows on 32 lanes: no registers to spare across the meeting)
+        if (EARLY_MV && active && leader && a.fused) {
+#pragma unroll
+            for (int tb = 0; tb < 2; tb++) {
+                if (tb == 1 && pure) break;
+                load_row<LG, NC, VEC>(mm[tb], a.m[2 * tb], row, t.D, lg);
+                load_row<LG, NC, VEC>(vv[tb], a.v[2 * tb], row, t.D, lg);
+            }
+        }
+        // ---- slices of one row meet through LDS: plain stores, fixed-order sum by the leader
+        if (slices > 1) {  // same for every slot of a round, idle slots included
+            float *mine = slots + grp * 2 * DP;
+#pragma unroll
+            for (int j = 0; j < NC; j++) {
+                *reinterpret_cast<float4 *>(mine + 4 * (lg + LG * j)) = gi[j];
+                *reinterpret_cast<float4 *>(mine + DP + 4 * (lg + LG * j)) = ge[j];
+            }
+            __syncthreads();
+            if (active && leader) {
+#pragma unroll 2
+                for (int s = 1; s < slices; s++) {
+                    const float *oth = slots + (grp + s) * 2 * DP;
+#pragma unroll
+                    for (int j = 0; j < NC; j++) {
+                        f4add(gi[j], *reinterpret_cast<const float4 *>(oth + 4 * (lg + LG * j)));
+                        f4add(ge[j], *reinterpret_cast<const float4 *>(oth + DP + 4 * (lg + LG * j)));
+                    }
+                }
+            }
+            __syncthreads();  // the slots are rewritten by the next round
+        }
+        if (r == r0) STAMP(5);
+        // ---- the leader finishes the row
+        if (active && leader) {
+            if (cnt != 0.f) {
+#pragma unroll
+                for (int j = 0; j < NC; j++) {
+                    f4fma(gi[j], cnt, reg_term(oi[j], k.r2, k.r1));
+                    f4fma(ge[j], cnt, reg_term(oe[j], k.r2, k.r1));
+                }
+            }
+            if (!a.fused) {
+                store_row<LG, NC, VEC>(a.np[0], row, t.D, lg, gi);
+                if (!pure) store_row<LG, NC, VEC>(a.np[2], row, t.D, lg, ge);
+            } else {
+#pragma unroll
+                for (int tb = 0; tb < 2; tb++) {
+                    if (tb == 1 && pure) break;
+                    if (!EARLY_MV) {
+                        load_row<LG, NC, VEC>(mm[tb], a.m[2 * tb], row, t.D, lg);
+                        load_row<LG, NC, VEC>(vv[tb], a.v[2 * tb], row, t.D, lg);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NC; j++) adam4(tb ? oe[j] : oi[j], tb ? ge[j] : gi[j], mm[tb][j], vv[tb][j], ad);
+                    store_row<LG, NC, VEC>(a.np[2 * tb], row, t.D, lg, tb ? oe : oi);
+                    store_row<LG, NC, VEC>(a.m[2 * tb], row, t.D, lg, mm[tb]);
+                    store_row<LG, NC, VEC>(a.v[2 * tb], row, t.D, lg, vv[tb]);
+                }
+            }
+        }
+    }
+    STAMP(6);
+    // ---- the task's partial sums: the waves' accumulator tiles meet in NIMG LDS images (wave w adds into image
+    // w % NIMG in turn w / NIMG: fixed order), laid over the staged tables and the slots -- nobody reads those any more --
+    // and leave, summed, as the workgroup's partial slab
+    accLi = wave_sum_valu(accLi); accLe = wave_sum_valu(accLe); accLc = wave_sum_valu(accLc);
+    accL2 = wave_sum_valu(accL2); accL1 = wave_sum_valu(accL1);
+    if (LG == 16) dBacc = xor16_sum(dBacc);
+    dBacc = xor32_sum(dBacc);                 // lanes 0 .. 15 of the wave: class `lane`, summed over the wave's groups
+    __syncthreads();
+    constexpr int NIMG = IM::N, ILEN = IM::LEN;
+    {   // db | loss sums: one line per wave
+        float *mine = tail + wave * (EMAX + kLossSlots);
+        if (lane < EMAX) mine[lane] = dBacc;
+        if (lane == 0) {
+            float *ls = mine + EMAX;
+            ls[0] = accLi; ls[1] = accLe; ls[2] = accLc; ls[3] = accL2; ls[4] = accL1; ls[5] = ls[6] = ls[7] = 0.f;
+        }
+    }
+#pragma unroll 1
+    for (int turn = 0; turn < kWaves / NIMG; turn++) {
+        if (wave / NIMG == turn) {
+            float *img = lds + (wave % NIMG) * ILEN;        // [dEv: EMAX][DP] | [dW: EMAX][DP]   (EVL2: dW alone)
+            if constexpr (SH) tiles_to_lds<LG, NC, EMAX, true>(img, accW, lane, turn == 0);
+            else {
+                if constexpr (!EVL2) tiles_to_lds<LG, NC, EMAX>(img, accE, lane, turn == 0);
+                tiles_to_lds<LG, NC, EMAX>(img + (EVL2 ? 0 : EMAX * DP), accW, lane, turn == 0);
+            }
+        }
+        __syncthreads();
+    }
+    {
+        float *dst = slab + (EVL2 ? EMAX * DP : 0);   // (EVL2: the embed_env part of this slab is never read)
+        for (int i = threadIdx.x; i < ILEN / 4; i += kThreads) {
+            float4 v = *reinterpret_cast<const float4 *>(lds + 4 * i);
+#pragma unroll
+            for (int q = 1; q < NIMG; q++) f4add(v, *reinterpret_cast<const float4 *>(lds + q * ILEN + 4 * i));
+            *reinterpret_cast<float4 *>(dst + 4 * i) = v;
+        }
+        if (threadIdx.x < EMAX + kLossSlots) {
+            const int i = threadIdx.x;
+            slab[2 * EMAX * DP + i] = ((tail[i] + tail[(EMAX + kLossSlots) + i]) + tail[2 * (EMAX + kLossSlots) + i]) +
+                                      tail[3 * (EMAX + kLossSlots) + i];
+        }
+    }
+    STAMP(7);
+}
+
+// =====================================================================================
+// launch 2, pull form: rounds of ITEM jobs -- partner user rows + record, multiply-add only; EVL2: embed_env's outer
+// product as well (the job owns Qa[v], gathers Pa[u], the record holds g_q and the environment)
+// =====================================================================================
+template <int LG, int NC, bool VEC, int EMAX, bool EVL2>
+__device__ __forceinline__ void item_task_wide(const DevTables &t, const StepArgs &a, int r0, int nr, int slab_index, float *lds) {
+    using G = WGeo<LG, NC, EMAX>;
+    constexpr int NG = G::NG, DP = G::DP, RS = G::RS, TILES = G::TILES;
+    constexpr int U = (EVL2 && EMAX == 16) ? WIDE_U_EVL2_16 : 2;   // interactions in flight per group
+    float *sEv = lds, *sW = sEv + EMAX * DP, *slots = sW + EMAX * DP;
+    const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool pure = a.flags & INVPREF_PURE_MF;
+    const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
+    StepScalars k = a.k;
+    if (a.sched_state) {
+        const float al = sched_slot_ptr(a.sched_state, a.sched_slot)->alpha;
+        if (al == al) k.alpha = al;
+    }
+    const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
+    STAMP(0);
+    int4 d = a.desc[(r0 * NG + grp) * 2], d1 = a.desc[(r0 * NG + grp) * 2 + 1];
+    STAMP(1);
+    f32x4 accE[EVL2 ? TILES : 1][4];
+#pragma unroll
+    for (int i = 0; i < (EVL2 ? TILES : 1); i++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) accE[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < r0 + nr; r++) {
+        const int4 dd = d, dd1 = d1;
+        if (r + 1 < r0 + nr) { d = a.desc[((r + 1) * NG + grp) * 2]; d1 = a.desc[((r + 1) * NG + grp) * 2 + 1]; }
+        const int row = dd.x, meta = dd.y;
+        const bool active = row >= 0, leader = meta & 1;
+        const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
+        const int nsmp = active ? (mode == 7 ? dd.w - dd.z : mode) : 0;
+        // EVL2: the loop carries MFMAs, so it runs to the longest slice of the WAVE (two groups of 32 lanes)
+        int iters = nsmp;
+        if (EVL2) {
+            int mx = 0;
+#pragma unroll
+            for (int g = 0; g < 64 / LG; g++) mx = max(mx, __builtin_amdgcn_readlane(nsmp, g * LG));
+            iters = mx;
+        }
+        if (r == r0) STAMP(2);
+        // (the job's own rows are needed when the row is finished -- and Qa[v] by embed_env's product, EVL2: they are
+        //  requested there, not held across the loop)
+        float4 oi[NC], oe[NC], gi[NC], ge[NC];
+#pragma unroll
+        for (int j = 0; j < NC; j++) oi[j] = oe[j] = gi[j] = ge[j] = f4zero();
+        if (EVL2 && !pure) load_row<LG, NC, VEC>(oe, t.Qa, active ? row : 0, t.D, lg);
+        auto ids_at = [&](int sidx) {
+            if (mode == 7) return a.ilist[dd.z + sidx];
+            if (sidx == 0) return make_int2(dd.z, dd.w);
+            if (sidx == 1) return make_int2(dd1.x, dd1.y);
+            return make_int2(dd1.z, dd1.w);
+        };
+        struct In {
+            float4 pu[NC], pa[NC], r0;
+            float4 gz[EMAX / 4];
+        };
+        auto fetch = [&](In &in, int2 id) {
+            load_row<LG, NC, VEC>(in.pu, t.Pu, id.x, t.D, lg);
+            const float *rec = a.records + (unsigned)id.y * (unsigned)RS;
+            in.r0 = *reinterpret_cast<const float4 *>(rec);
+            if (!pure) {
+                load_row<LG, NC, VEC>(in.pa, t.Pa, id.x, t.D, lg);
+#pragma unroll
+                for (int c4 = 0; c4 < EMAX / 4; c4++) in.gz[c4] = *reinterpret_cast<const float4 *>(rec + 4 + c4 * 4);
+            }
+        };
+        auto consume = [&](const In &in, bool has) {
+            if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);   // (the unrolled slots stay apart)
+            float a_one = 0.f;
+            float4 boo[EVL2 ? NC : 1];
+#pragma unroll
+            for (int j = 0; j < (EVL2 ? NC : 1); j++) boo[j] = f4zero();
+            if (has) {
+                const float g_p = in.r0.x, g_q = in.r0.y;
+                const int e = __builtin_bit_cast(int, in.r0.z);
+#pragma unroll
+                for (int j = 0; j < NC; j++) {
+                    float4 gx = f4zero();
+                    if (!pure) {
+#pragma unroll
+                        for (int c4 = 0; c4 < EMAX / 4; c4++) {
+                            if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);
+                            const float *wr = sW + (c4 * 4) * DP + 4 * (lg + LG * j);
+                            f4fma(gx, in.gz[c4].x, *reinterpret_cast<const float4 *>(wr));
+                            f4fma(gx, in.gz[c4].y, *reinterpret_cast<const float4 *>(wr + DP));
+                            f4fma(gx, in.gz[c4].z, *reinterpret_cast<const float4 *>(wr + 2 * DP));
+                            f4fma(gx, in.gz[c4].w, *reinterpret_cast<const float4 *>(wr + 3 * DP));
+                        }
+                        const float4 ev = *reinterpret_cast<const float4 *>(sEv + e * DP + 4 * (lg + LG * j));
+                        f4fma(ge[j], g_q, f4mul(in.pa[j], ev));
+                        if (EVL2) {
+                            float4 oo = f4scale(g_q, f4mul(in.pa[j], oe[j]));
+                            if (reg_env) f4add(oo, reg_term(ev, 2.f * k.r2, 2.f * k.r1));
+                            boo[EVL2 ? j : 0] = oo;
+                        }
+                    }
+                    float4 gip;
+                    gip.x = g_p - k.alpha * gx.x; gip.y = g_p - k.alpha * gx.y;
+                    gip.z = g_p - k.alpha * gx.z; gip.w = g_p - k.alpha * gx.w;
+                    f4add(gi[j], f4mul(gip, in.pu[j]));
+                }
+                a_one = (lane & 15) == e ? 1.f : 0.f;
+            }
+            if constexpr (EVL2) outer_mfma<LG, NC>(accE, a_one, boo, lane);
+        };
+        In nx[U];
+        int2 idn[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) nx[j].pu[c] = nx[j].pa[c] = f4zero();
+            nx[j].r0 = f4zero();
+#pragma unroll
+            for (int c4 = 0; c4 < EMAX / 4; c4++) nx[j].gz[c4] = f4zero();
+            idn[j] = make_int2(0, 0);
+            if (j < nsmp) fetch(nx[j], ids_at(j));
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++)
+            if (U + j < nsmp) idn[j] = ids_at(U + j);
+        if (r == r0) {   // (staged behind the first round's gathers, see user_task_wide)
+            stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
+            stage_small(sW, t.W, t.E, t.D, EMAX, DP);
+            __syncthreads();
+            STAMP(3);
+        }
+        for (int s = 0; s < iters; s += U) {
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                if (s + j < iters) consume(nx[j], s + j < nsmp);
+                if (s + U + j < nsmp) fetch(nx[j], idn[j]);
+                if (s + 2 * U + j < nsmp) idn[j] = ids_at(s + 2 * U + j);
+            }
+        }
+        if (r == r0) STAMP(4);
+        if (slices > 1) {
+            float *mine = slots + grp * 2 * DP;
+#pragma unroll
+            for (int j = 0; j < NC; j++) {
+                *reinterpret_cast<float4 *>(mine + 4 * (lg + LG * j)) = gi[j];
+                *reinterpret_cast<float4 *>(mine + DP + 4 * (lg + LG * j)) = ge[j];
+            }
+            __syncthreads();
+            if (active && leader) {
+#pragma unroll 2
+                for (int s = 1; s < slices; s++) {
+                    const float *oth = slots + (grp + s) * 2 * DP;
+#pragma unroll
+                    for (int j = 0; j < NC; j++) {
+                        f4add(gi[j], *reinterpret_cast<const float4 *>(oth + 4 * (lg + LG * j)));
+                        f4add(ge[j], *reinterpret_cast<const float4 *>(oth + DP + 4 * (lg + LG * j)));
+                    }
+                }
+            }
+            if (r + 1 < r0 + nr) __syncthreads();
+        }
+        if (r == r0) STAMP(5);
+        if (active && leader) {
+            load_row<LG, NC, VEC>(oi, t.Qi, row, t.D, lg);
+            if (!EVL2 && !pure) load_row<LG, NC, VEC>(oe, t.Qa, row, t.D, lg);
+            const float cnt = (float)(meta >> 9);
+            if (cnt != 0.f) {
+#pragma unroll
+                for (int j = 0; j < NC; j++) {
+                    f4fma(gi[j], cnt, reg_term(oi[j], k.r2, k.r1));
+                    f4fma(ge[j], cnt, reg_term(oe[j], k.r2, k.r1));
+                }
+            }
+            if (!a.fused) {
+                store_row<LG, NC, VEC>(a.np[1], row, t.D, lg, gi);
+                if (!pure) store_row<LG, NC, VEC>(a.np[3], row, t.D, lg, ge);
+            } else {
+#pragma unroll
+                for (int tb = 0; tb < 2; tb++) {
+                    if (tb == 1 && pure) break;
+                    float4 m[NC], v[NC];
+                    load_row<LG, NC, VEC>(m, a.m[2 * tb + 1], row, t.D, lg);
+                    load_row<LG, NC, VEC>(v, a.v[2 * tb + 1], row, t.D, lg);
+#pragma unroll
+                    for (int j = 0; j < NC; j++) adam4(tb ? oe[j] : oi[j], tb ? ge[j] : gi[j], m[j], v[j], ad);
+                    store_row<LG, NC, VEC>(a.np[2 * tb + 1], row, t.D, lg, tb ? oe : oi);
+                    store_row<LG, NC, VEC>(a.m[2 * tb + 1], row, t.D, lg, m);
+                    store_row<LG, NC, VEC>(a.v[2 * tb + 1], row, t.D, lg, v);
+                }
+            }
+        }
+    }
+    STAMP(6);
+    if constexpr (EVL2) {
+        // the item task's partial sums of embed_env's gradient: the waves' tiles meet over the staged tables, in wave order
+        __syncthreads();
+        float *img = lds;
+#pragma unroll 1
+        for (int w = 0; w < kWaves; w++) {
+            if (wave == w) tiles_to_lds<LG, NC, EMAX>(img, accE, lane, w == 0);
+            __syncthreads();
+        }
+        float *slab = a.slabs_ev + (int64_t)slab_index * (EMAX * DP);
+        for (int i = threadIdx.x; i < EMAX * DP; i += kThreads) slab[i] = img[i];
+    }
+}
+
+// launch 2, push form: an item job sums the CONTIGUOUS contribution rows launch 1 stored for its row
+template <int LG, int NC, bool VEC, int EMAX>
+__device__ __forceinline__ void item_task_push_wide(const DevTables &t, const StepArgs &a, int r0, int nr, float *lds) {
+    using G = WGeo<LG, NC, EMAX>;
+    constexpr int DP = G::DP, NG = G::NG;
+    constexpr int PCH = 2;   // contribution-row pairs in flight per group
+    float *slots = lds;      // [NG][2][DP] slice partials
+    const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG;
+    const bool pure = a.flags & INVPREF_PURE_MF;
+    const StepScalars k = a.k;
+    const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
+    STAMP(0);
+    int4 d = a.desc[(r0 * NG + grp) * 2];
+    STAMP(1);
+    for (int r = r0; r < r0 + nr; r++) {
+        const int4 dd = d;
+        if (r + 1 < r0 + nr) d = a.desc[((r + 1) * NG + grp) * 2];
+        const int row = dd.x, meta = dd.y;
+        const bool active = row >= 0, leader = meta & 1;
+        const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
+        const int nsmp = (active && mode == 7) ? dd.w - dd.z : 0;
+        if (r == r0) STAMP(2);
+        float4 oi[NC], oe[NC], gi[NC], ge[NC];
+#pragma unroll
+        for (int j = 0; j < NC; j++) oi[j] = oe[j] = gi[j] = ge[j] = f4zero();
+        {
+            const int rowc = active ? row : 0;
+            load_row<LG, NC, VEC>(oi, t.Qi, rowc, t.D, lg);
+            if (!pure) load_row<LG, NC, VEC>(oe, t.Qa, rowc, t.D, lg);
+        }
+        const float *base = a.records + (unsigned)dd.z * (unsigned)(2 * DP);
+        float4 ci[PCH][NC], ce[PCH][NC];
+        auto fetch = [&](int s0) {   // contribution rows s0 .. s0 + PCH of the slice (clamped: no branch around a load)
+#pragma unroll
+            for (int q = 0; q < PCH; q++) {
+                const int sj = s0 + q < nsmp ? s0 + q : (nsmp > 0 ? nsmp - 1 : 0);
+                const float *p = nsmp > 0 ? base + (unsigned)sj * (unsigned)(2 * DP) : a.records;
+#pragma unroll
+                for (int j = 0; j < NC; j++) {
+                    ci[q][j] = *reinterpret_cast<const float4 *>(p + 4 * (lg + LG * j));
+                    if (!pure) ce[q][j] = *reinterpret_cast<const float4 *>(p + DP + 4 * (lg + LG * j));
+                }
+            }
+        };
+        fetch(0);
+        if (r == r0) STAMP(3);
+        for (int s0 = 0; s0 < nsmp; s0 += PCH) {
+#pragma unroll
+            for (int q = 0; q < PCH; q++) {
+                const bool has = s0 + q < nsmp;
+#pragma unroll
+                for (int j = 0; j < NC; j++) {
+                    f4add(gi[j], has ? ci[q][j] : f4zero());
+                    if (!pure) f4add(ge[j], has ? ce[q][j] : f4zero());
+                }
+            }
+            if (s0 + PCH < nsmp) fetch(s0 + PCH);
+        }
+        if (r == r0) STAMP(4);
+        if (slices > 1) {
+            float *mine = slots + grp * 2 * DP;
+#pragma unroll
+            for (int j = 0; j < NC; j++) {
+                *reinterpret_cast<float4 *>(mine + 4 * (lg + LG * j)) = gi[j];
+                *reinterpret_cast<float4 *>(mine + DP + 4 * (lg + LG * j)) = ge[j];
+            }
+            __syncthreads();
+            if (active && leader) {
+#pragma unroll 2
+                for (int s = 1; s < slices; s++) {
+                    const float *oth = slots + (grp + s) * 2 * DP;
+#pragma unroll
+                    for (int j = 0; j < NC; j++) {
+                        f4add(gi[j], *reinterpret_cast<const float4 *>(oth + 4 * (lg + LG * j)));
+                        f4add(ge[j], *reinterpret_cast<const float4 *>(oth + DP + 4 * (lg + LG * j)));
+                    }
+                }
+            }
+            if (r + 1 < r0 + nr) __syncthreads();
+        }
+        if (r == r0) STAMP(5);
+        if (active && leader) {
+            const float cnt = (float)(meta >> 9);
+            if (cnt != 0.f) {
+#pragma unroll
+                for (int j = 0; j < NC; j++) {
+                    f4fma(gi[j], cnt, reg_term(oi[j], k.r2, k.r1));
+                    f4fma(ge[j], cnt, reg_term(oe[j], k.r2, k.r1));
+                }
+            }
+            if (!a.fused) {
+                store_row<LG, NC, VEC>(a.np[1], row, t.D, lg, gi);
+                if (!pure) store_row<LG, NC, VEC>(a.np[3], row, t.D, lg, ge);
+            } else {
+#pragma unroll
+                for (int tb = 0; tb < 2; tb++) {
+                    if (tb == 1 && pure) break;
+                    float4 m[NC], v[NC];
+                    load_row<LG, NC, VEC>(m, a.m[2 * tb + 1], row, t.D, lg);
+                    load_row<LG, NC, VEC>(v, a.v[2 * tb + 1], row, t.D, lg);
+#pragma unroll
+                    for (int j = 0; j < NC; j++) adam4(tb ? oe[j] : oi[j], tb ? ge[j] : gi[j], m[j], v[j], ad);
+                    store_row<LG, NC, VEC>(a.np[2 * tb + 1], row, t.D, lg, tb ? oe : oi);
+                    store_row<LG, NC, VEC>(a.m[2 * tb + 1], row, t.D, lg, m);
+                    store_row<LG, NC, VEC>(a.v[2 * tb + 1], row, t.D, lg, v);
+                }
+            }
+        }
+    }
+    STAMP(6);
+}
+
+// untouched rows: the dense-Adam step with a zero gradient (stream_task for rows of NC float4 per lane, one row of both
+// tables per group in flight)
+template <int LG, int NC, bool VEC>
+__device__ __forceinline__ void stream_task_wide(const DevTables &t, const StepArgs &a, const int *rows, int n) {
+    constexpr int NG = kThreads / LG;
+    const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG;
+    const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
+    const bool pure = a.flags & INVPREF_PURE_MF;
+    float4 z[NC];
+#pragma unroll
+    for (int j = 0; j < NC; j++) z[j] = f4zero();
+    if (!a.fused) {   // gradient form: the untouched rows' gradient is a row of zeros
+        for (int i = grp; i < n; i += NG) {
+            const int rid = rows[i], side = (rid >> 30) & 1, row = rid & 0x3fffffff;
+            store_row<LG, NC, VEC>(side ? a.np[1] : a.np[0], row, t.D, lg, z);
+            if (!pure) store_row<LG, NC, VEC>(side ? a.np[3] : a.np[2], row, t.D, lg, z);
+        }
+        return;
+    }
+    for (int i = grp; i < n; i += NG) {   // (workgroup-uniform trip count up to the last, partial, pass)
+        const int rid = rows[i], side = (rid >> 30) & 1, row = rid & 0x3fffffff;
+        float4 p[2][NC], m[2][NC], v[2][NC];
+#pragma unroll
+        for (int tb = 0; tb < 2; tb++) {
+            if (tb == 1 && pure) break;
+            load_row<LG, NC, VEC>(p[tb], tb ? (side ? t.Qa : t.Pa) : (side ? t.Qi : t.Pu), row, t.D, lg);
+            load_row<LG, NC, VEC>(m[tb], side ? a.m[2 * tb + 1] : a.m[2 * tb], row, t.D, lg);
+            load_row<LG, NC, VEC>(v[tb], side ? a.v[2 * tb + 1] : a.v[2 * tb], row, t.D, lg);
+        }
+#pragma unroll
+        for (int tb = 0; tb < 2; tb++) {
+            if (tb == 1 && pure) break;
+#pragma unroll
+            for (int j = 0; j < NC; j++) adam4(p[tb][j], f4zero(), m[tb][j], v[tb][j], ad);
+            store_row<LG, NC, VEC, STEP_STREAM_ST>(side ? a.np[2 * tb + 1] : a.np[2 * tb], row, t.D, lg, p[tb]);
+            store_row<LG, NC, VEC, STEP_STREAM_ST>(side ? a.m[2 * tb + 1] : a.m[2 * tb], row, t.D, lg, m[tb]);
+            store_row<LG, NC, VEC, STEP_STREAM_ST>(side ? a.v[2 * tb + 1] : a.v[2 * tb], row, t.D, lg, v[tb]);
+        }
+    }
+}
+
+// ---- the two kernels
+template <int LG, int NC, bool VEC, int EMAX, bool EVL2>
+__global__ __launch_bounds__(kThreads, (WideCfg<LG, NC, EMAX>::WAVES)) void mstep_eval_wide_kernel(DevTables t, StepArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int ncls = a.n_cls;
+    const int c = (int)blockIdx.x % ncls;
+    int j = (int)blockIdx.x / ncls;
+    int q[4];
+    class_row(a, c, q);
+    const int rpt = a.rounds_per_task, spt = a.rows_per_stream_task;
+    const int tj = (q[1] + rpt - 1) / rpt;
+    if (j < tj) {
+        user_task_wide<LG, NC, VEC, EMAX, EVL2>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), q[0] / rpt + j, lds);
+        return;
+    }
+    j -= tj;
+    if (j * spt < q[3]) {
+        STAMP(0);
+        stream_task_wide<LG, NC, VEC>(t, a, a.stream_rows + q[2] + j * spt, min(spt, q[3] - j * spt));
+        STAMP(7);
+    }
+}
+
+template <int LG, int NC, bool VEC, int EMAX, bool EVL2>
+__global__ __launch_bounds__(kThreads, (NC > 1 || EMAX > 8) ? 2 : 3) void mstep_apply_wide_kernel(DevTables t, StepArgs a, FoldArgs f) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x >= f.n_task_wgs) {
+        const int fb = (int)blockIdx.x - f.n_task_wgs;
+        if (fb == f.fold_blocks) {   // the device-side schedule moves on (see mstep_apply_kernel)
+            if (a.sched_state && a.fused && threadIdx.x == 0) {
+                const int *cur = a.sched_state + 16 * a.sched_slot;
+                int *nxt = a.sched_state + 16 * (a.sched_slot ^ 1);
+                const int next = cur[0] + 1, base = cur[1], idx = next - base;
+                nxt[0] = next;
+                nxt[1] = base;
+                if (idx >= 0 && idx < f.sched_n) *reinterpret_cast<SchedRow *>(nxt + 2) = f.sched_table[idx];
+            }
+            return;
+        }
+        STAMP(0);
+        constexpr int DP = 4 * LG * NC;
+        fold_block<DP, EMAX>(t, a, f, fb, lds);
+        constexpr int loss0 = 2 * EMAX * DP + EMAX;
+        if (fb == loss0 / kFoldCols) {   // (workgroup-uniform)
+            __syncthreads();
+            fold_losses(t, a, f, lds);
+        }
+        STAMP(7);
+        return;
+    }
+    const int ncls = a.n_cls;
+    const int c = (int)blockIdx.x % ncls;
+    int j = (int)blockIdx.x / ncls;
+    int q[4];
+    class_row(a, c, q);
+    const int rpt = a.rounds_per_task, spt = a.rows_per_stream_task;
+    const int tj = (q[1] + rpt - 1) / rpt;
+    if (j < tj) {
+        if (a.push_slot) item_task_push_wide<LG, NC, VEC, EMAX>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), lds);
+        else item_task_wide<LG, NC, VEC, EMAX, EVL2>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), q[0] / rpt + j, lds);
+        return;
+    }
+    j -= tj;
+    if (j * spt < q[3]) {
+        STAMP(0);
+        stream_task_wide<LG, NC, VEC>(t, a, a.stream_rows + q[2] + j * spt, min(spt, q[3] - j * spt));
+        STAMP(7);
+    }
+}

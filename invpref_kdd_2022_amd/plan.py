@@ -50,10 +50,14 @@ CLASS_SHIFT = 6        # rows are dealt to the classes in blocks of 64
 
 
 def lanes_of(factor_num: int) -> int:
-    """lanes that hold one row, one float4 each (invpref_rows_lanes_per_group)"""
-    lg = 16 if factor_num <= 64 else (32 if factor_num <= 128 else 64)
-    forced = int(os.environ.get('INVPREF_FORCE_LANES', '0'))   # (diagnostic, as in csrc/invpref_step.hip)
-    return forced if lg < forced <= 64 else lg
+    """lanes that hold one row (invpref_rows_lanes_per_group): 16 lanes x 1 float4 up to 64 floats, 16 x 2 up to 128,
+    32 x 2 up to 256 (csrc/step_wide.hpp: an interaction shares its wave with three / one other)"""
+    return 16 if factor_num <= 128 else 32
+
+
+def padded_row(factor_num: int) -> int:
+    """floats of a padded row (contribution rows, LDS images): 64 / 128 / 256"""
+    return 64 if factor_num <= 64 else (128 if factor_num <= 128 else 256)
 
 
 def stream_rows_default(factor_num: int) -> int:
@@ -183,6 +187,8 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     lanes = lanes_of(factor_num)
     ng = THREADS // lanes
     n = len(users)
+    # the latency-tuned kernel instance (rows of up to 64 floats, up to four environments): three workgroups per CU
+    small = factor_num <= 64 and env_num is not None and env_num <= 4
     # Defaults: a launch wants about TARGET_WORKGROUPS job workgroups -- enough to fill 256 CUs a few times over, few
     # enough that the per-workgroup partial slabs of launch 1 stay a small share of the step's bytes.  A Yahoo step
     # (8 192 interactions) is one latency chain and gets the shortest slices (2 interactions); larger minibatches are
@@ -201,7 +207,7 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         # shortest slice that costs no more than 5 % more rounds than 16 per slice does (measured at 32 768 Yahoo-shaped
         # interactions: 6 per slice 33.5 us against 37.5 at 2 and 37.2 at 16; at 250 154: 16 per slice 118 us, 8: 135)
         ucnt0 = np.bincount(users, minlength=1)
-        resident = RESIDENT_SMALL if (lanes == 16 and env_num is not None and env_num <= 4) else 512
+        resident = RESIDENT_SMALL if small else 512
         if rounds_for(ucnt0, 2) <= resident:
             per_slice = 2
         else:
@@ -226,10 +232,14 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
             # rows are a small share of the bytes (a 1/8 MIND minibatch 457 vs 534); it loses on cache-exceeding launches
             # whose rows dominate (2^20 interactions over 500 000 rows: 768 vs 732)
             p_floats = 2 * (user_num + item_num) * factor_num
-            contrib = n * 4 * lanes * 16                            # two padded rows written and read per interaction
+            contrib = n * padded_row(factor_num) * 16               # two padded rows written and read per interaction
             total = n * (32 + 16 * factor_num) + 24 * p_floats       # algorithmic bytes of the step
             resident = 20 * p_floats + contrib // 2 <= 200e6       # p, p', m, v, g-free: five flat buffers + the rows
             push = n > 0 and (resident or contrib <= 0.2 * total)
+    if lanes == 32:
+        # rows of more than 128 floats: embed_env's outer product runs in launch 2's item jobs, which need the partner
+        # rows and the records -- the pull form (csrc/step_wide.hpp, EVL2)
+        push = False
     if item_per_slice is None:
         # (push form: a slice's contribution rows are contiguous and leave in one burst of up to four: measured 4 > 2, 3)
         item_per_slice = int(os.environ.get('INVPREF_PLAN_ITEM_PER_SLICE',
@@ -239,9 +249,10 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         rounds_per_task = int(os.environ.get('INVPREF_PLAN_ROUNDS', '0')) or \
             min(16, max(1, round(rounds_for(np.bincount(users, minlength=1), per_slice) / target)))
     if item_rounds_per_task is None:
-        # (rows of up to 1 KB, pull form: an item task first stages two [E, D] tables of up to 16 KB each and a workgroup
-        #  holds only four rows -- fewer, longer tasks: MIND-shaped steps 1 030 -> 956 us at 8 rounds per task instead of 2)
-        few = lanes == 64 and not push
+        # (rows of up to 1 KB, pull form: an item task first stages two [E, D] tables of up to 16 KB each, holds only eight
+        #  rows and leaves a 16 KB partial slab of embed_env's gradient -- fewer, longer tasks: MIND-shaped steps 898 -> 769 us
+        #  at 8 rounds per task instead of 1)
+        few = lanes == 32
         item_rounds_per_task = int(os.environ.get('INVPREF_PLAN_ITEM_ROUNDS', '0')) or \
             min(16, max(1, round(rounds_for(np.bincount(items, minlength=1), item_per_slice) / (target if few else 4 * target))))
     if rows_per_stream_task is None:
@@ -273,7 +284,7 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     n_stream = len(stream_u) + len(stream_i)
     fill_cap = 0   # launch 1 residency (workgroups) the default split fills with stream tasks; 0 = plain balance
     if stream_split is None:
-        if lanes == 16 and env_num is not None and env_num <= 4 and os.environ.get('INVPREF_PLAN_FILL', '1') == '1':
+        if small and os.environ.get('INVPREF_PLAN_FILL', '1') == '1':
             fill_cap = RESIDENT_SMALL
         # row moves (one row read or written in both tables of a side = 2): a touched or streamed row costs 12 (p, m, v
         # in, p', m', v' out), an interaction 4 gathered rows per launch; launch 1 also evaluates, hence the bias

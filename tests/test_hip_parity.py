@@ -279,14 +279,14 @@ def test_rows_path_mind_shape_g5():
 
 def test_rows_path_movielens_shape_default_plan():
     """MovieLens-class step (U=6 040, I=3 706, E=8, D=128, B=65 536) through the planned fused
-    pass with the DEFAULT plan parameters for that minibatch size (32-lane groups, 16 interactions per slice,
-    8 rounds per task) against oracle gradient + oracle Adam."""
+    pass with the DEFAULT plan parameters for that minibatch size (16-lane groups of two float4 per lane,
+    csrc/step_wide.hpp) against oracle gradient + oracle Adam."""
     U, I, E, D, B = 6040, 3706, 8, 128, 65536
     data = synth.interactions(31, U, I, B, implicit=True, zipf=False)
     tabs = synth.tables(32, U, I, E, D, std=0.1)
     envs = np.random.RandomState(33).randint(0, E, B).astype(np.int64)
     pl = planlib.build_row_plan(data[:, 0], data[:, 1], data[:, 2], U, I, factor_num=D)
-    assert pl['lanes_per_group'] == 32 and len(pl['item_desc']) > 0
+    assert pl['lanes_per_group'] == 16 and len(pl['item_desc']) > 0
     dp = planlib.upload(pl, DEV)
     P = dev_params(tabs)
     P2, M, V = ([torch.zeros_like(p) for p in P] for _ in range(3))

@@ -168,7 +168,7 @@ def test_plan_empty_and_single():
 def test_plan_large_shapes():
     d = synth.interactions(5, 6040, 3706, 65536, implicit=True, zipf=False)
     p = check_plan(d[:, 0], d[:, 1], 6040, 3706, D=128)
-    assert p['lanes_per_group'] == 32 and 500 < planlib.launch_workgroups(p, 0) < 4000
+    assert p['lanes_per_group'] == 16 and 500 < planlib.launch_workgroups(p, 0) < 4000
 
 
 def test_slice_length_of_mid_sized_launches_follows_the_makespan_estimate():
@@ -181,7 +181,7 @@ def test_slice_length_of_mid_sized_launches_follows_the_makespan_estimate():
     m = synth.interactions(5, 6040, 3706, 65536, implicit=True, zipf=False)
     p = planlib.build_row_plan(m[:, 0], m[:, 1], m[:, 2], 6040, 3706, factor_num=128, env_num=8)
     ucnt = np.bincount(m[:, 0])
-    est = {ps: planlib._launch1_makespan(ucnt, 8, ps, 512, 8.0, 2.1) for ps in (3, 4, 6, 8, 10, 12, 14, 16, 20)}
+    est = {ps: planlib._launch1_makespan(ucnt, 16, ps, 512, 8.0, 2.1) for ps in (3, 4, 6, 8, 10, 12, 14, 16, 20)}
     assert est[p['per_slice']] <= 1.02 * min(est.values())
     assert all(est[ps] > 1.02 * min(est.values()) for ps in est if ps < p['per_slice'])
     d = synth.yahoo_like()[:8192]

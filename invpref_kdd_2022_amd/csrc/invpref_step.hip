@@ -212,6 +212,7 @@ struct StepArgs {
     const int *push_slot;         // push form (InvPrefRowPlan::push_slot): [n] contribution slot of a minibatch position
     float *records;               // pull form: [n][4 + EMAX] records; push form: [n][2][DP] contribution rows
     float *slabs;                 // [launch-1 job tasks][slab_len] partial sums
+    int n_rec;                    // wide rows: interactions of the minibatch = index of the spare record / contribution-row pair
     float *slabs_ev;              // wide rows (step_wide.hpp, EVL2): [launch-2 item tasks][EMAX][DP] partial sums of embed_env's gradient
     int *sched_state;             // optional device int32[32]: two slots {step, base, SchedRow}, see InvPrefAdamSchedule
     int sched_slot;
@@ -1674,8 +1675,9 @@ int ensure_lds(K kernel, size_t bytes) {
 
 inline size_t record_floats(const InvPrefRowPlan *plan, const Shape &s) {
     // pull form: a record of 4 + EMAX floats per interaction; push form: two padded contribution rows
+    // (+ 1: the spare one an empty slot of a lock-step iteration stores to, step_wide.hpp)
     const size_t per = plan->push_slot ? (size_t)2 * s.dp : (size_t)4 + s.emax;
-    return ((size_t)(plan->n > 0 ? plan->n : 1) * per + 63) & ~(size_t)63;
+    return ((size_t)((plan->n > 0 ? plan->n : 0) + 1) * per + 63) & ~(size_t)63;
 }
 inline size_t workspace_floats(const InvPrefRowPlan *plan, const Shape &s) {
     // records | launch 1's partial slabs | (evl2) launch 2's partial slabs of embed_env's gradient
@@ -1785,6 +1787,7 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a.rows_per_stream_task = plan->rows_per_stream_task; a.n_cls = ncls;
     a.records = (float *)workspace; a.slabs = (float *)workspace + rec_floats;
     a.slabs_ev = a.slabs + slab * (size_t)(n_partials > 0 ? n_partials : 1);
+    a.n_rec = plan->n;
     a.push_slot = plan->push_slot;
     a.sched_state = sched ? sched->state : nullptr;
     a.sched_slot = sched ? (sched->slot & 1) : 0;
@@ -1859,7 +1862,9 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
         if (emax == 8) CALL_W(LGV, NCV, VECV, 8, EV2); else CALL_W(LGV, NCV, VECV, 16, EV2);       \
     } while (0)
     if (shp.wide && !defer) {
-        if (vec) {
+        // (the wide kernels' vector form is for FULL rows only -- factor_num 64 / 128 / 256: no clamps or selects behind a
+        //  load; any other row length takes their element-wise form)
+        if (vec && t.D == shp.dp) {
             if (shp.lg == 32) CALL_WE(32, 2, true, true); else if (shp.nc == 2) CALL_WE(16, 2, true, false); else CALL_WE(16, 1, true, false);
         } else {
             if (shp.lg == 32) CALL_WE(32, 2, false, true); else if (shp.nc == 2) CALL_WE(16, 2, false, false); else CALL_WE(16, 1, false, false);

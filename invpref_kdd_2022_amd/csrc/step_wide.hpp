@@ -38,6 +38,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef WIDE_FENCE
 #define WIDE_FENCE 1   // scheduling fences inside the classifier loops of two-chunk rows (register pressure)
 #endif
+#ifndef WIDE_FENCE_MASK
+// what may still cross a fence of the classifier loops: ALU (0x1 | VALU 0x2 | SALU 0x4 | transcendental 0x400) -- the
+// loss chains interleave with the LDS waits -- but no memory instruction: the W-row reads stay where they are
+#define WIDE_FENCE_MASK 0x407
+#endif
 
 // per-instance launch-1 configuration: workgroups per CU the kernel is compiled for (registers: 512 / waves per SIMD)
 // and the interactions each group keeps in flight
@@ -71,15 +76,54 @@ struct WGeo {
     static constexpr int apply_total = 2 * EMAX * DP + NG * 2 * DP;
 };
 
+// diagnostic build (-DWIDE_DIAG_TRACE, tools/wide_trace.py): shader-clock stamps of the first steps of one wave, written
+// behind the phase stamps of the stamp buffer
+#ifdef WIDE_DIAG_TRACE
+#define WTRACE(tag)                                                                                           \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (a.stamps && blockIdx.x == 40 && threadIdx.x == 0 && wtrace_n < 120) {                             \
+            a.stamps[100000 + wtrace_n] = ((unsigned long long)(tag) << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull); \
+            wtrace_n++;                                                                                       \
+        }                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
+#else
+#define WTRACE(tag) do { } while (0)
+#endif
+
+// VEC in this file = FULL rows: factor_num == DP (64 / 128 / 256) and 16-byte aligned tables.  A full row is loaded with
+// nothing behind the load -- no clamp, no zero-select: an instruction on the loaded value right behind the load makes the
+// compiler wait for it on the spot, which turned every prefetch of a lock-step iteration into a blocking round trip.
+// Other row lengths take the element-wise form (VEC = false).
 template <int LG, int NC, bool VEC>
 __device__ __forceinline__ void load_row(float4 (&r)[NC], const float *__restrict__ base, int row, int D, int lg) {
 #pragma unroll
-    for (int j = 0; j < NC; j++) r[j] = row4<VEC>(base, row, D, lg + LG * j);
+    for (int j = 0; j < NC; j++) {
+        if (VEC) {
+            constexpr unsigned DPB = 16u * LG * NC;   // bytes of a row
+            r[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + (unsigned)row * DPB + 16u * (unsigned)(lg + LG * j));
+        } else {
+            r[j] = row4<false>(base, row, D, lg + LG * j);
+        }
+    }
 }
 template <int LG, int NC, bool VEC, int MODE = 0>
 __device__ __forceinline__ void store_row(float *__restrict__ base, int row, int D, int lg, const float4 (&r)[NC]) {
 #pragma unroll
-    for (int j = 0; j < NC; j++) put4<VEC, MODE>(base, row, D, lg + LG * j, r[j]);
+    for (int j = 0; j < NC; j++) {
+        if (VEC) {
+            constexpr unsigned DPB = 16u * LG * NC;
+            float4 *dst = reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + (unsigned)row * DPB + 16u * (unsigned)(lg + LG * j));
+            if (MODE == 0) *dst = r[j];
+            else {
+                v4f val = {r[j].x, r[j].y, r[j].z, r[j].w};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(val) : "memory");
+            }
+        } else {
+            put4<false, MODE>(base, row, D, lg + LG * j, r[j]);
+        }
+    }
 }
 template <int LG, int NC>
 __device__ __forceinline__ void lds_row(float4 (&r)[NC], const float *tab, int e, int lg) {
@@ -144,13 +188,13 @@ __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], 
     for (int c = 0; c < EMAX; c++) {
         // (a scheduling fence per four classes: left alone the compiler requests every W row of the loop up front and
         //  the kernel spills; two waves per SIMD cover the LDS latency instead)
-        if (WIDE_FENCE && NC > 1 && (c & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+        if (WIDE_FENCE && NC > 1 && (c & 3) == 0) __builtin_amdgcn_sched_barrier(WIDE_FENCE_MASK);
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < NC; j++) s += dot4(o.x[j], *reinterpret_cast<const float4 *>(sW + c * DP + 4 * (lg + LG * j)));
         part[c] = s;
     }
-    if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);
+    if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(WIDE_FENCE_MASK);
     const float zred = group_sum_above<LG, EMAX>(class_butterfly<EMAX>(part, lg), lg);
     const float zmine = lg < E ? zred + sb[lg & (EMAX - 1)] : -__builtin_inff();
     const float mxl = group_max<LG>(zmine);
@@ -165,7 +209,7 @@ __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], 
     o.lcls = has ? gzs[EMAX + 1] : 0.f;
 #pragma unroll
     for (int c4 = 0; c4 < EMAX; c4 += 4) {
-        if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);
+        if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(WIDE_FENCE_MASK);
         const float4 g4 = *reinterpret_cast<const float4 *>(gzs + c4);
 #pragma unroll
         for (int j = 0; j < NC; j++) {
@@ -270,6 +314,9 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
     float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
     int it_total = 0;    // parity of the gz words
     float *slab = a.slabs + (int64_t)slab_index * G::SLAB;
+#ifdef WIDE_DIAG_TRACE
+    int wtrace_n = 0;
+#endif
 
     for (int r = r0; r < r0 + nr; r++) {
         const int4 dd = d, dd1 = d1;
@@ -279,14 +326,17 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
         const int nsmp = active ? (mode == 7 ? dd.w - dd.z : mode) : 0;
         const int iters = a.round_iters[r];   // the round's longest slice: the loop (and its MFMAs) is workgroup-uniform
         if (r == r0) STAMP(2);
-        auto sample_at = [&](int sidx) {
-            USample sm;
-            if (mode == 7) {
-                const int4 q = a.ulist[dd.z + sidx];
-                sm.oth = q.x; sm.ps = q.y; sm.y = __builtin_bit_cast(float, q.z);
-            } else if (sidx == 0) { sm.oth = dd.z; sm.ps = dd.w; sm.y = __builtin_bit_cast(float, dd1.x); }
-            else { sm.oth = dd1.y; sm.ps = dd1.z; sm.y = __builtin_bit_cast(float, dd1.w); }
-            return sm;
+        // The slice's interactions come from the sorted list (mode 7) or, up to two of them, from the descriptor itself.
+        // Every load of the loop below is UNCONDITIONAL -- list indices are clamped into the slice, so a finished slice
+        // re-reads its last interaction (cache hits) and an idle slot reads entry 0 -- because a load under a divergent
+        // branch is waited for at the join, and a wait inside a lock-step iteration stops the whole prefetch pipeline.
+        // (the inline form is read back from the descriptor's own words -- 3 ints per interaction from word 2 on -- so that
+        //  both forms are ONE load from a selected address, with nothing to select behind it)
+        const int lo = dd.z, hi1 = max(dd.w - 1, dd.z);
+        const int *dwords = reinterpret_cast<const int *>(a.desc + (r * NG + grp) * 2);
+        auto list_at = [&](int sidx) {
+            const int *src = mode == 7 ? reinterpret_cast<const int *>(a.ulist + min(lo + sidx, hi1)) : dwords + 2 + 3 * min(sidx, 1);
+            return USample{src[0], src[1], __builtin_bit_cast(float, src[2])};
         };
         float4 oi[NC], oe[NC], gi[NC], ge[NC];
 #pragma unroll
@@ -298,40 +348,39 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
         }
         struct Slot {
             float4 qi[NC], qa[NC];
-            USample sm;
-            int e, cs;
-            float w;
+            int ps, e, cs;
+            float y, w;
         };
         Slot sl[UE];
         USample idn[UE];
         auto gather = [&](Slot &q, const USample &sm) {
-            q.sm = sm;
+            q.ps = sm.ps;
+            q.y = sm.y;
 #ifdef WIDE_DIAG_HOT   // (what-if build: every gather hits the same few rows -- what the launch costs without gather latency)
             const int oth = sm.oth & 15;
 #else
             const int oth = sm.oth;
 #endif
             load_row<LG, NC, VEC>(q.qi, t.Qi, oth, t.D, lg);
+            const unsigned pso = (unsigned)sm.ps;   // (32-bit offsets: one address register, no 64-bit pair to copy into)
             if (!pure) {
                 load_row<LG, NC, VEC>(q.qa, t.Qa, oth, t.D, lg);
-                q.e = (int)a.envs[sm.ps];
+                q.e = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.envs) + pso * 8u);   // low word of the int64 id
             }
-            if (rw_rec || rw_cls) q.w = a.weights[sm.ps];
-            if (push) q.cs = a.push_slot[sm.ps];
+            if (rw_rec || rw_cls) q.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + pso * 4u);
+            if (push) q.cs = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.push_slot) + pso * 4u);
         };
 #pragma unroll
         for (int j = 0; j < UE; j++) {
 #pragma unroll
             for (int c = 0; c < NC; c++) sl[j].qi[c] = sl[j].qa[c] = f4zero();
-            sl[j].sm = USample{0, 0, 0.f};
-            sl[j].e = sl[j].cs = 0;
+            sl[j].ps = sl[j].e = sl[j].cs = 0;
+            sl[j].y = 0.f;
             sl[j].w = 1.f;
-            idn[j] = USample{0, 0, 0.f};
-            if (j < nsmp) gather(sl[j], sample_at(j));
+            gather(sl[j], list_at(j));
         }
 #pragma unroll
-        for (int j = 0; j < UE; j++)
-            if (UE + j < nsmp) idn[j] = sample_at(UE + j);
+        for (int j = 0; j < UE; j++) idn[j] = list_at(UE + j);
         if (r == r0) {
             // the two small tables are staged HERE, behind the first round's gathers: a load -> store loop in front of
             // them would put the tables' round trip ahead of the rows' on the task's critical chain
@@ -347,15 +396,28 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             // every gradient scalar forced to zero (eval_wide) and stores nothing
             if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);   // (the unrolled slots' evaluations stay apart)
             float *gzs = lds + G::gzs + ((it_total & 1) * NG + grp) * (EMAX + 4);
+            WTRACE(1);
             const int e = q.e;
             const float w_rec = rw_rec ? q.w : 1.f, w_cls = rw_cls ? q.w : 1.f;
             float4 ev[NC];
             lds_row<LG, NC>(ev, sEv, e, lg);
+#ifdef WIDE_DIAG_TRACE
+            {   // (force the slot's rows and the env row to have arrived)
+                float probe = q.qi[0].x + q.qa[NC - 1].w + ev[0].x;
+                asm volatile("" :: "v"(probe));
+            }
+            WTRACE(2);
+#endif
             WEval<NC> o;
-            eval_wide<LG, NC, EMAX>(o, oi, q.qi, oe, q.qa, ev, sW, sb, gzs, t.E, e, q.sm.y, w_rec * k.invB, w_cls * k.invB, k,
+            eval_wide<LG, NC, EMAX>(o, oi, q.qi, oe, q.qa, ev, sW, sb, gzs, t.E, e, q.y, w_rec * k.invB, w_cls * k.invB, k,
                                     implicit, pure, lg, has);
+#ifdef WIDE_DIAG_TRACE
+            { float probe = o.gx[0].x + o.g_p + o.lcls; asm volatile("" :: "v"(probe)); }
+            WTRACE(3);
+#endif
             float s2 = 0.f, s1 = 0.f;
-            float *cr = a.records + (unsigned)q.cs * (unsigned)(2 * DP);
+            // (an empty slot stores to the spare row / record behind the minibatch's: the loop's stores are unconditional too)
+            float *cr = a.records + (unsigned)(has ? q.cs : a.n_rec) * (unsigned)(2 * DP);
             float4 boo[EVL2 ? 1 : NC];
 #pragma unroll
             for (int j = 0; j < NC; j++) {
@@ -367,7 +429,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
 #ifdef WIDE_DIAG_NOSTORE
                 if (false) {
 #else
-                if (push && has) {   // the interaction's two contribution rows to its ITEM's gradient, at the item-sorted slot
+                if (push) {   // the interaction's two contribution rows to its ITEM's gradient, at the item-sorted slot
 #endif
                     *reinterpret_cast<float4 *>(cr + 4 * (lg + LG * j)) = f4mul(gip, oi[j]);
                     *reinterpret_cast<float4 *>(cr + DP + 4 * (lg + LG * j)) = f4scale(o.g_q, f4mul(oe[j], ev[j]));
@@ -383,10 +445,17 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
                 s1 += f4abs(q.qi[j]) + f4abs(q.qa[j]);
                 if (reg_env) { s2 += 2.f * f4sq(ev[j]); s1 += 2.f * f4abs(ev[j]); }
             }
-            if (!push && has) {   // pull form: the record the item side consumes
-                float *rec_g = a.records + (unsigned)q.sm.ps * (unsigned)RS;
-                if (lg == 0) *reinterpret_cast<float4 *>(rec_g) = make_float4(o.g_p, o.g_q, __builtin_bit_cast(float, e), 0.f);
-                if (lg < EMAX) rec_g[4 + lg] = o.gz_lane;
+            if (!push) {
+                // pull form: the record {g_p, g_q, env, 0, gz[EMAX]} the item side consumes -- one word per lane, every lane
+                // (lanes beyond the record repeat its last word), so that the store is one unconditional wave instruction
+                float *rec_g = a.records + (unsigned)(has ? q.ps : a.n_rec) * (unsigned)RS;
+                const float gzw = pure ? 0.f : gzs[min(max(lg - 4, 0), EMAX - 1)];
+                const float val = lg >= 4 ? gzw : (lg == 0 ? o.g_p : (lg == 1 ? o.g_q : (lg == 2 ? __builtin_bit_cast(float, e) : 0.f)));
+                rec_g[min(lg, RS - 1)] = val;
+                if (RS > LG) {   // (E = 16 on 16 lanes: the record's last words)
+                    const int wi = min(lg, RS - LG - 1);
+                    rec_g[LG + wi] = pure ? 0.f : gzs[LG - 4 + wi];
+                }
             }
             accL2 += has ? s2 : 0.f;
             accL1 += has ? s1 : 0.f;
@@ -395,6 +464,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             const int lc = lane & 15;
             const float a_gz = LG == 16 ? o.gz_lane : ((lc < EMAX && !pure) ? gzs[lc] : 0.f);
             if (lg < 16) dBacc += o.gz_lane;
+            WTRACE(4);
             if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);
 #ifndef WIDE_DIAG_NOMFMA
             outer_mfma<LG, NC>(accW, a_gz, o.x, lane);
@@ -404,14 +474,16 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             else if constexpr (!EVL2) outer_mfma<LG, NC>(accE, (has && lc == e) ? 1.f : 0.f, boo, lane);
 #endif
             if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);
+            WTRACE(5);
             it_total++;
         };
         for (int s = 0; s < iters; s += UE) {
 #pragma unroll
             for (int j = 0; j < UE; j++) {
                 if (s + j < iters) step(sl[j], s + j < nsmp);
-                if (s + UE + j < nsmp) gather(sl[j], idn[j]);
-                if (s + 2 * UE + j < nsmp) idn[j] = sample_at(s + 2 * UE + j);
+                gather(sl[j], idn[j]);
+                idn[j] = list_at(s + 2 * UE + j);
+                WTRACE(6);
             }
         }
         if (r == r0) STAMP(4);
@@ -588,11 +660,13 @@ __device__ __forceinline__ void item_task_wide(const DevTables &t, const StepArg
 #pragma unroll
         for (int j = 0; j < NC; j++) oi[j] = oe[j] = gi[j] = ge[j] = f4zero();
         if (EVL2 && !pure) load_row<LG, NC, VEC>(oe, t.Qa, active ? row : 0, t.D, lg);
+        // every load of the loop is unconditional (see user_task_wide): list indices clamped into the slice; the inline form
+        // (up to three (user row, position) pairs from word 2 of the descriptor) is read back from the descriptor's words
+        const int lo = dd.z, hi1 = max(dd.w - 1, dd.z);
+        const int2 *dpairs = reinterpret_cast<const int2 *>(a.desc + (r * NG + grp) * 2);
         auto ids_at = [&](int sidx) {
-            if (mode == 7) return a.ilist[dd.z + sidx];
-            if (sidx == 0) return make_int2(dd.z, dd.w);
-            if (sidx == 1) return make_int2(dd1.x, dd1.y);
-            return make_int2(dd1.z, dd1.w);
+            const int2 *src = mode == 7 ? a.ilist + min(lo + sidx, hi1) : dpairs + 1 + min(sidx, 2);
+            return *src;
         };
         struct In {
             float4 pu[NC], pa[NC], r0;
@@ -656,12 +730,10 @@ __device__ __forceinline__ void item_task_wide(const DevTables &t, const StepArg
             nx[j].r0 = f4zero();
 #pragma unroll
             for (int c4 = 0; c4 < EMAX / 4; c4++) nx[j].gz[c4] = f4zero();
-            idn[j] = make_int2(0, 0);
-            if (j < nsmp) fetch(nx[j], ids_at(j));
+            fetch(nx[j], ids_at(j));
         }
 #pragma unroll
-        for (int j = 0; j < U; j++)
-            if (U + j < nsmp) idn[j] = ids_at(U + j);
+        for (int j = 0; j < U; j++) idn[j] = ids_at(U + j);
         if (r == r0) {   // (staged behind the first round's gathers, see user_task_wide)
             stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
             stage_small(sW, t.W, t.E, t.D, EMAX, DP);
@@ -672,8 +744,8 @@ __device__ __forceinline__ void item_task_wide(const DevTables &t, const StepArg
 #pragma unroll
             for (int j = 0; j < U; j++) {
                 if (s + j < iters) consume(nx[j], s + j < nsmp);
-                if (s + U + j < nsmp) fetch(nx[j], idn[j]);
-                if (s + 2 * U + j < nsmp) idn[j] = ids_at(s + 2 * U + j);
+                fetch(nx[j], idn[j]);
+                idn[j] = ids_at(s + 2 * U + j);
             }
         }
         if (r == r0) STAMP(4);

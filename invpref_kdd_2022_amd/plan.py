@@ -242,8 +242,11 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         push = False
     if item_per_slice is None:
         # (push form: a slice's contribution rows are contiguous and leave in one burst of up to four: measured 4 > 2, 3)
+        # (wide rows, push form, minibatches of several residencies: longer item slices, fewer item workgroups -- MovieLens-
+        #  shaped steps 66.7 -> 64.9 us at 16 per slice instead of 4)
+        floor = (16 if (factor_num > 64 and n > 16384) else 4) if push else 2
         item_per_slice = int(os.environ.get('INVPREF_PLAN_ITEM_PER_SLICE',
-                                            str(min(32, max(4 if push else 2, -(-n // (ng * 2 * target)))))))
+                                            str(min(32, max(floor, -(-n // (ng * 2 * target)))))))
 
     if rounds_per_task is None:
         rounds_per_task = int(os.environ.get('INVPREF_PLAN_ROUNDS', '0')) or \
@@ -254,7 +257,7 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         #  at 8 rounds per task instead of 1)
         few = lanes == 32
         item_rounds_per_task = int(os.environ.get('INVPREF_PLAN_ITEM_ROUNDS', '0')) or \
-            min(16, max(1, round(rounds_for(np.bincount(items, minlength=1), item_per_slice) / (target if few else 4 * target))))
+            min(16, max(1, round(rounds_for(np.bincount(items, minlength=1), item_per_slice) / (target // 2 if few else 4 * target))))
     if rows_per_stream_task is None:
         rows_per_stream_task = int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', str(stream_rows_default(factor_num))))
     rows_per_stream_task2 = int(os.environ.get('INVPREF_PLAN_STREAM_ROWS2', str(rows_per_stream_task)))  # one iteration of a workgroup

@@ -143,8 +143,13 @@ __device__ __forceinline__ float4 reg_term(float4 p, float r2, float r1) {   // 
 // more): a load takes the table's base from scalar registers and ONE vector register of offset instead of a 64-bit
 // address pair.  Lanes beyond D read a clamped address and select zero: no branch around the load (a load under a
 // branch is waited for at the join).
-template <bool VEC>
+// FULL (rows of exactly 64 floats on 16 lanes, 16-byte aligned tables): the load and nothing else.  The clamp-and-select
+// form below puts an instruction on the loaded value right behind the load; where the next loads sit behind a branch the
+// compiler then waits for the data on the spot (found in round 4: the job's own rows, then each gather slot in turn, were
+// separate round trips on the step's critical chain).
+template <bool VEC, bool FULL = false>
 __device__ __forceinline__ float4 row4(const float *__restrict__ base, int row, int D, int lg) {
+    if (FULL) return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + ((unsigned)row * 256u + (unsigned)lg * 16u));
     const unsigned i0 = (unsigned)lg * 4u;
     if (VEC) {
         const bool ok = i0 < (unsigned)D;
@@ -162,8 +167,18 @@ __device__ __forceinline__ float4 row4(const float *__restrict__ base, int row, 
 }
 typedef float v4f __attribute__((ext_vector_type(4)));
 // MODE 0: plain store; 1: write-through (sc1: the line leaves the XCD's L2 at once instead of at the end of the kernel)
-template <bool VEC, int MODE = 0>
+template <bool VEC, int MODE = 0, bool FULL = false>
 __device__ __forceinline__ void put4(float *__restrict__ base, int row, int D, int lg, float4 r) {
+    if (FULL) {
+        // (ONE 32-bit offset from the table's base: the base stays in scalar registers)
+        float4 *dst = reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + ((unsigned)row * 256u + (unsigned)lg * 16u));
+        if (MODE == 0) *dst = r;
+        else {
+            v4f val = {r.x, r.y, r.z, r.w};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(val) : "memory");
+        }
+        return;
+    }
     const int i0 = lg * 4;
     if (VEC) {
         const unsigned boff = ((unsigned)row * (unsigned)D + (unsigned)i0) * 4u;
@@ -434,7 +449,7 @@ struct USample {
 #ifndef STEP_ROW_ST
 #define STEP_ROW_ST 0   // (A/B knob: 1 = write-through stores for the rows the jobs finish)
 #endif
-template <int LG, bool VEC, int EMAX, bool DEFER>
+template <int LG, bool VEC, int EMAX, bool DEFER, bool FULL>
 __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a, int r0, int nr, int slab_index, float *lds) {
     using G = Geo<LG, EMAX>;
     // interactions in flight per group (measured: 2 for the D <= 64, E <= 4 instances -- a third slot only costs registers
@@ -515,10 +530,19 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
         const int nsmp = active ? (mode == 7 ? dd.w - dd.z : mode) : 0;
         const int iters = G::REG ? nsmp : a.round_iters[r];
         if (r == r0) STAMP(2);
-        // sample sidx of the slice: inline in the descriptor (up to two) or one 16-byte load from the sorted list
+        // sample sidx of the slice: inline in the descriptor (up to two) or one 16-byte load from the sorted list.
+        // FULL instances fetch it with ONE unconditional load from a selected address (list index clamped into the slice;
+        // the inline form read back from the descriptor's own words, 3 ints per interaction from word 2 on): every gather of
+        // the task is then issued without a branch around it and without an instruction on loaded data behind it -- a load
+        // under a divergent branch is waited for at the join, which made each gather slot a round trip of its own.
+        const int s_lo = dd.z, s_hi1 = max(dd.w - 1, dd.z);
+        const int *dwords = reinterpret_cast<const int *>(a.desc + (r * NG + grp) * 2);
         auto sample_at = [&](int sidx) {
             USample sm;
-            if (mode == 7) {
+            if (FULL) {   // (the refills of the interaction loop: list form; inline slices never get there)
+                const int *src = mode == 7 ? reinterpret_cast<const int *>(a.ulist + min(s_lo + sidx, s_hi1)) : dwords + 2 + 3 * min(sidx, 1);
+                sm.oth = src[0]; sm.ps = src[1]; sm.y = __builtin_bit_cast(float, src[2]);
+            } else if (mode == 7) {
                 const int4 q = a.ulist[dd.z + sidx];
                 sm.oth = q.x; sm.ps = q.y; sm.y = __builtin_bit_cast(float, q.z);
             } else if (sidx == 0) { sm.oth = dd.z; sm.ps = dd.w; sm.y = __builtin_bit_cast(float, dd1.x); }
@@ -532,14 +556,14 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
         int pend_from = 0x7fffffff;                                              // DEFER: first step the row has not seen yet
         {   // (an idle slot reads row 0 rather than branching around the loads)
             const int rowc = active ? row : 0;
-            oi = row4<VEC>(t.Pu, rowc, t.D, lg);
-            if (!pure) oe = row4<VEC>(t.Pa, rowc, t.D, lg);
+            oi = row4<VEC, FULL>(t.Pu, rowc, t.D, lg);
+            if (!pure) oe = row4<VEC, FULL>(t.Pa, rowc, t.D, lg);
             if (DEFER) {
                 // every slice of the row replays for itself (it needs the up-to-date row for its evaluations)
                 const int ls = a.last_step[rowc];
                 if (active) pend_from = ls + 1;
-                dmi = row4<VEC>(a.m[0], rowc, t.D, lg); dvi = row4<VEC>(a.v[0], rowc, t.D, lg);
-                if (!pure) { dme = row4<VEC>(a.m[2], rowc, t.D, lg); dve = row4<VEC>(a.v[2], rowc, t.D, lg); }
+                dmi = row4<VEC, FULL>(a.m[0], rowc, t.D, lg); dvi = row4<VEC, FULL>(a.v[0], rowc, t.D, lg);
+                if (!pure) { dme = row4<VEC, FULL>(a.m[2], rowc, t.D, lg); dve = row4<VEC, FULL>(a.v[2], rowc, t.D, lg); }
             }
         }
         // UE interactions in flight per group, each in a register slot of its own: the slot just consumed is refilled
@@ -554,9 +578,19 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
         USample idn[UE];   // (list form: the ids run UE interactions ahead of the rows)
         auto gather = [&](Slot &q, const USample &sm) {
             q.sm = sm;
-            q.qi = row4<VEC>(t.Qi, sm.oth, t.D, lg);
+            q.qi = row4<VEC, FULL>(t.Qi, sm.oth, t.D, lg);
+            if (FULL) {   // (32-bit offsets: one address register each, nothing to copy a loaded index into)
+                const unsigned pso = (unsigned)sm.ps;
+                if (!pure) {
+                    q.qa = row4<VEC, FULL>(t.Qa, sm.oth, t.D, lg);
+                    q.e = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.envs) + pso * 8u);   // low word of the int64 id
+                }
+                if (rw_rec || rw_cls) q.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + pso * 4u);
+                if (push) q.cs = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.push_slot) + pso * 4u);
+                return;
+            }
             if (!pure) {
-                q.qa = row4<VEC>(t.Qa, sm.oth, t.D, lg);
+                q.qa = row4<VEC, FULL>(t.Qa, sm.oth, t.D, lg);
                 q.e = (int)a.envs[sm.ps];
             }
             if (rw_rec || rw_cls) q.w = a.weights[sm.ps];
@@ -569,11 +603,36 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             sl[j].e = sl[j].cs = 0;
             sl[j].w = 1.f;
             idn[j] = USample{0, 0, 0.f};
-            if (j < nsmp) gather(sl[j], sample_at(j));
         }
+        if (FULL) {
+            // the first interactions' ids: inline ones straight from the descriptor's registers; listed ones (only if some
+            // group of the WAVE has a list: a uniform branch) with every list entry requested BEFORE the first row load
+            // hangs on one -- ids, then rows: two round trips, not one per slot
+            USample ls[2 * UE];
 #pragma unroll
-        for (int j = 0; j < UE; j++)
-            if (UE + j < nsmp) idn[j] = sample_at(UE + j);
+            for (int j = 0; j < 2 * UE; j++) ls[j] = USample{0, 0, 0.f};
+            if (__builtin_amdgcn_ballot_w64(mode == 7) != 0) {
+#pragma unroll
+                for (int j = 0; j < 2 * UE; j++) {
+                    const int4 q = a.ulist[min(s_lo + j, s_hi1)];
+                    ls[j] = USample{q.x, q.y, __builtin_bit_cast(float, q.z)};
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < UE; j++) {
+                USample sm = ls[j];
+                if (mode != 7) sm = j == 0 ? USample{dd.z, dd.w, __builtin_bit_cast(float, dd1.x)} : USample{dd1.y, dd1.z, __builtin_bit_cast(float, dd1.w)};
+                gather(sl[j], sm);
+                idn[j] = ls[UE + j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < UE; j++)
+                if (j < nsmp) gather(sl[j], sample_at(j));
+#pragma unroll
+            for (int j = 0; j < UE; j++)
+                if (UE + j < nsmp) idn[j] = sample_at(UE + j);
+        }
 #ifndef STEP_DMA_LATE
         if (dma) {
             // each lane sends its 16-byte piece of the row's four moment rows straight to LDS; the destination of a
@@ -795,8 +854,8 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
 #pragma unroll
             for (int j = 0; j < UE; j++) {
                 if (s + j < iters) step(sl[j], s + j < nsmp);   // (E > 8: `iters` is uniform, the barrier inside is too)
-                if (s + UE + j < nsmp) gather(sl[j], idn[j]);
-                if (s + 2 * UE + j < nsmp) idn[j] = sample_at(s + 2 * UE + j);
+                if (FULL || s + UE + j < nsmp) gather(sl[j], idn[j]);
+                if (FULL || s + 2 * UE + j < nsmp) idn[j] = sample_at(s + 2 * UE + j);
             }
         }
         if (r == r0) STAMP(4);
@@ -926,8 +985,8 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 f4fma(ge, cnt, reg_term(oe, k.r2, k.r1));
             }
             if (!a.fused) {
-                put4<VEC>(a.np[0], row, t.D, lg, gi);
-                if (!pure) put4<VEC>(a.np[2], row, t.D, lg, ge);
+                put4<VEC, 0, FULL>(a.np[0], row, t.D, lg, gi);
+                if (!pure) put4<VEC, 0, FULL>(a.np[2], row, t.D, lg, ge);
             } else {
                 if ((dma || DEFER) && L::ALIAS) {   // (taken out of the landing area above)
                 } else if (dma) {
@@ -935,18 +994,18 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                     mi = mv_wave[0 * 64 + lane]; vi = mv_wave[1 * 64 + lane];
                     if (!pure) { me = mv_wave[2 * 64 + lane]; ve = mv_wave[3 * 64 + lane]; }
                 } else {
-                    mi = row4<VEC>(a.m[0], row, t.D, lg); vi = row4<VEC>(a.v[0], row, t.D, lg);
-                    if (!pure) { me = row4<VEC>(a.m[2], row, t.D, lg); ve = row4<VEC>(a.v[2], row, t.D, lg); }
+                    mi = row4<VEC, FULL>(a.m[0], row, t.D, lg); vi = row4<VEC, FULL>(a.v[0], row, t.D, lg);
+                    if (!pure) { me = row4<VEC, FULL>(a.m[2], row, t.D, lg); ve = row4<VEC, FULL>(a.v[2], row, t.D, lg); }
                 }
                 adam4(oi, gi, mi, vi, ad);
-                put4<VEC, STEP_ROW_ST>(a.np[0], row, t.D, lg, oi);
-                put4<VEC, STEP_ROW_ST>(a.m[0], row, t.D, lg, mi);
-                put4<VEC, STEP_ROW_ST>(a.v[0], row, t.D, lg, vi);
+                put4<VEC, STEP_ROW_ST, FULL>(a.np[0], row, t.D, lg, oi);
+                put4<VEC, STEP_ROW_ST, FULL>(a.m[0], row, t.D, lg, mi);
+                put4<VEC, STEP_ROW_ST, FULL>(a.v[0], row, t.D, lg, vi);
                 if (!pure) {
                     adam4(oe, ge, me, ve, ad);
-                    put4<VEC, STEP_ROW_ST>(a.np[2], row, t.D, lg, oe);
-                    put4<VEC, STEP_ROW_ST>(a.m[2], row, t.D, lg, me);
-                    put4<VEC, STEP_ROW_ST>(a.v[2], row, t.D, lg, ve);
+                    put4<VEC, STEP_ROW_ST, FULL>(a.np[2], row, t.D, lg, oe);
+                    put4<VEC, STEP_ROW_ST, FULL>(a.m[2], row, t.D, lg, me);
+                    put4<VEC, STEP_ROW_ST, FULL>(a.v[2], row, t.D, lg, ve);
                 }
                 if (DEFER && lg == 0) a.last_step[row] = tcur;   // up to date as of this step
             }
@@ -968,7 +1027,7 @@ struct IIn {
 #ifndef STEP_ITEM_DEPTH
 #define STEP_ITEM_DEPTH 2
 #endif
-template <int LG, bool VEC, int EMAX>
+template <int LG, bool VEC, int EMAX, bool FULL>
 __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a, int r0, int nr, float *lds) {
     using G = Geo<LG, EMAX>;
     constexpr int U = EMAX <= 4 ? STEP_ITEM_DEPTH : 2;   // interactions in flight per group
@@ -1003,8 +1062,8 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
         float4 oi = f4zero(), oe = f4zero(), gi = f4zero(), ge = f4zero();
         {   // (an idle slot reads row 0 rather than branching around the loads)
             const int rowc = active ? row : 0;
-            oi = row4<VEC>(t.Qi, rowc, t.D, lg);
-            if (!pure) oe = row4<VEC>(t.Qa, rowc, t.D, lg);
+            oi = row4<VEC, FULL>(t.Qi, rowc, t.D, lg);
+            if (!pure) oe = row4<VEC, FULL>(t.Qa, rowc, t.D, lg);
         }
         // interaction sidx of the slice: (user row, position) inline (up to three) or from the sorted list
         auto ids_at = [&](int sidx) {
@@ -1014,11 +1073,11 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
             return make_int2(dd1.z, dd1.w);
         };
         auto fetch = [&](IIn &in, float4 (&gzv)[EMAX / 4], int2 id) {
-            in.pu = row4<VEC>(t.Pu, id.x, t.D, lg);
+            in.pu = row4<VEC, FULL>(t.Pu, id.x, t.D, lg);
             const float *rec = a.records + (unsigned)id.y * (unsigned)RS;
             in.r0 = *reinterpret_cast<const float4 *>(rec);
             if (!pure) {
-                in.pa = row4<VEC>(t.Pa, id.x, t.D, lg);
+                in.pa = row4<VEC, FULL>(t.Pa, id.x, t.D, lg);
 #pragma unroll
                 for (int c4 = 0; c4 < EMAX / 4; c4++) gzv[c4] = *reinterpret_cast<const float4 *>(rec + 4 + c4 * 4);
             }
@@ -1102,8 +1161,8 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
                 f4fma(ge, cnt, reg_term(oe, k.r2, k.r1));
             }
             if (!a.fused) {
-                put4<VEC>(a.np[1], row, t.D, lg, gi);
-                if (!pure) put4<VEC>(a.np[3], row, t.D, lg, ge);
+                put4<VEC, 0, FULL>(a.np[1], row, t.D, lg, gi);
+                if (!pure) put4<VEC, 0, FULL>(a.np[3], row, t.D, lg, ge);
             } else {
                 float4 mi = f4zero(), vi = f4zero(), me = f4zero(), ve = f4zero();
                 if (dma) {
@@ -1111,18 +1170,18 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
                     mi = mv_wave[0 * 64 + lane]; vi = mv_wave[1 * 64 + lane];
                     if (!pure) { me = mv_wave[2 * 64 + lane]; ve = mv_wave[3 * 64 + lane]; }
                 } else {
-                    mi = row4<VEC>(a.m[1], row, t.D, lg); vi = row4<VEC>(a.v[1], row, t.D, lg);
-                    if (!pure) { me = row4<VEC>(a.m[3], row, t.D, lg); ve = row4<VEC>(a.v[3], row, t.D, lg); }
+                    mi = row4<VEC, FULL>(a.m[1], row, t.D, lg); vi = row4<VEC, FULL>(a.v[1], row, t.D, lg);
+                    if (!pure) { me = row4<VEC, FULL>(a.m[3], row, t.D, lg); ve = row4<VEC, FULL>(a.v[3], row, t.D, lg); }
                 }
                 adam4(oi, gi, mi, vi, ad);
-                put4<VEC, STEP_ROW_ST>(a.np[1], row, t.D, lg, oi);
-                put4<VEC, STEP_ROW_ST>(a.m[1], row, t.D, lg, mi);
-                put4<VEC, STEP_ROW_ST>(a.v[1], row, t.D, lg, vi);
+                put4<VEC, STEP_ROW_ST, FULL>(a.np[1], row, t.D, lg, oi);
+                put4<VEC, STEP_ROW_ST, FULL>(a.m[1], row, t.D, lg, mi);
+                put4<VEC, STEP_ROW_ST, FULL>(a.v[1], row, t.D, lg, vi);
                 if (!pure) {
                     adam4(oe, ge, me, ve, ad);
-                    put4<VEC, STEP_ROW_ST>(a.np[3], row, t.D, lg, oe);
-                    put4<VEC, STEP_ROW_ST>(a.m[3], row, t.D, lg, me);
-                    put4<VEC, STEP_ROW_ST>(a.v[3], row, t.D, lg, ve);
+                    put4<VEC, STEP_ROW_ST, FULL>(a.np[3], row, t.D, lg, oe);
+                    put4<VEC, STEP_ROW_ST, FULL>(a.m[3], row, t.D, lg, me);
+                    put4<VEC, STEP_ROW_ST, FULL>(a.v[3], row, t.D, lg, ve);
                 }
             }
         }
@@ -1134,7 +1193,7 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
 // [a, b) of the slice, read from the descriptor alone): no partner gathers, no records, no classifier rows -- every load of
 // a slice of up to PCH interactions leaves in one burst.  Chosen by the plan for minibatches whose contribution rows are a
 // small share of the step's bytes (they cost one extra row write + read per interaction and table).
-template <int LG, bool VEC, int EMAX>
+template <int LG, bool VEC, int EMAX, bool FULL>
 __device__ __forceinline__ void item_task_push(const DevTables &t, const StepArgs &a, int r0, int nr, float *lds) {
     using G = Geo<LG, EMAX>;
     constexpr int DP = G::DP, NG = G::NG;
@@ -1162,8 +1221,8 @@ __device__ __forceinline__ void item_task_push(const DevTables &t, const StepArg
         float4 oi, oe = f4zero(), gi = f4zero(), ge = f4zero();
         {
             const int rowc = active ? row : 0;
-            oi = row4<VEC>(t.Qi, rowc, t.D, lg);
-            if (!pure) oe = row4<VEC>(t.Qa, rowc, t.D, lg);
+            oi = row4<VEC, FULL>(t.Qi, rowc, t.D, lg);
+            if (!pure) oe = row4<VEC, FULL>(t.Qa, rowc, t.D, lg);
         }
         const float *base = a.records + (unsigned)dd.z * (unsigned)(2 * DP) + lg * 4;
         float4 ci[PCH], ce[PCH];
@@ -1222,8 +1281,8 @@ __device__ __forceinline__ void item_task_push(const DevTables &t, const StepArg
                 f4fma(ge, cnt, reg_term(oe, k.r2, k.r1));
             }
             if (!a.fused) {
-                put4<VEC>(a.np[1], row, t.D, lg, gi);
-                if (!pure) put4<VEC>(a.np[3], row, t.D, lg, ge);
+                put4<VEC, 0, FULL>(a.np[1], row, t.D, lg, gi);
+                if (!pure) put4<VEC, 0, FULL>(a.np[3], row, t.D, lg, ge);
             } else {
                 float4 mi = f4zero(), vi = f4zero(), me = f4zero(), ve = f4zero();
                 if (dma) {
@@ -1231,18 +1290,18 @@ __device__ __forceinline__ void item_task_push(const DevTables &t, const StepArg
                     mi = mv_wave[0 * 64 + lane]; vi = mv_wave[1 * 64 + lane];
                     if (!pure) { me = mv_wave[2 * 64 + lane]; ve = mv_wave[3 * 64 + lane]; }
                 } else {
-                    mi = row4<VEC>(a.m[1], row, t.D, lg); vi = row4<VEC>(a.v[1], row, t.D, lg);
-                    if (!pure) { me = row4<VEC>(a.m[3], row, t.D, lg); ve = row4<VEC>(a.v[3], row, t.D, lg); }
+                    mi = row4<VEC, FULL>(a.m[1], row, t.D, lg); vi = row4<VEC, FULL>(a.v[1], row, t.D, lg);
+                    if (!pure) { me = row4<VEC, FULL>(a.m[3], row, t.D, lg); ve = row4<VEC, FULL>(a.v[3], row, t.D, lg); }
                 }
                 adam4(oi, gi, mi, vi, ad);
-                put4<VEC, STEP_ROW_ST>(a.np[1], row, t.D, lg, oi);
-                put4<VEC, STEP_ROW_ST>(a.m[1], row, t.D, lg, mi);
-                put4<VEC, STEP_ROW_ST>(a.v[1], row, t.D, lg, vi);
+                put4<VEC, STEP_ROW_ST, FULL>(a.np[1], row, t.D, lg, oi);
+                put4<VEC, STEP_ROW_ST, FULL>(a.m[1], row, t.D, lg, mi);
+                put4<VEC, STEP_ROW_ST, FULL>(a.v[1], row, t.D, lg, vi);
                 if (!pure) {
                     adam4(oe, ge, me, ve, ad);
-                    put4<VEC, STEP_ROW_ST>(a.np[3], row, t.D, lg, oe);
-                    put4<VEC, STEP_ROW_ST>(a.m[3], row, t.D, lg, me);
-                    put4<VEC, STEP_ROW_ST>(a.v[3], row, t.D, lg, ve);
+                    put4<VEC, STEP_ROW_ST, FULL>(a.np[3], row, t.D, lg, oe);
+                    put4<VEC, STEP_ROW_ST, FULL>(a.m[3], row, t.D, lg, me);
+                    put4<VEC, STEP_ROW_ST, FULL>(a.v[3], row, t.D, lg, ve);
                 }
             }
         }
@@ -1274,7 +1333,7 @@ __device__ __forceinline__ void stream_delay() {
 // (Tried in round 3: two register sets with the next rows' loads issued before the current rows' stores, so that a task
 //  of several iterations would be one round trip + work -- 128-row tasks in launch 1 ran 23-28 us per step against
 //  19.4: the rows per CU, not the iterations' round trips, pace these workgroups.  One iteration per task it is.)
-template <int LG, bool VEC>
+template <int LG, bool VEC, bool FULL>
 __device__ __forceinline__ void stream_task(const DevTables &t, const StepArgs &a, const int *rows, int n) {
     constexpr int R = 2, NG = kThreads / LG;
     const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG;
@@ -1283,8 +1342,8 @@ __device__ __forceinline__ void stream_task(const DevTables &t, const StepArgs &
     if (!a.fused) {   // gradient form: the untouched rows' gradient is a row of zeros
         for (int i = grp; i < n; i += NG) {
             const int rid = rows[i], side = (rid >> 30) & 1, row = rid & 0x3fffffff;
-            put4<VEC>(side ? a.np[1] : a.np[0], row, t.D, lg, f4zero());
-            if (!pure) put4<VEC>(side ? a.np[3] : a.np[2], row, t.D, lg, f4zero());
+            put4<VEC, 0, FULL>(side ? a.np[1] : a.np[0], row, t.D, lg, f4zero());
+            if (!pure) put4<VEC, 0, FULL>(side ? a.np[3] : a.np[2], row, t.D, lg, f4zero());
         }
         return;
     }
@@ -1310,9 +1369,9 @@ __device__ __forceinline__ void stream_task(const DevTables &t, const StepArgs &
                 const float *T = (q & 1) ? (s ? t.Qa : t.Pa) : (s ? t.Qi : t.Pu);
                 const float *M = (q & 1) ? (s ? a.m[3] : a.m[2]) : (s ? a.m[1] : a.m[0]);
                 const float *V = (q & 1) ? (s ? a.v[3] : a.v[2]) : (s ? a.v[1] : a.v[0]);
-                S.p[q] = row4<VEC>(T, S.row[q >> 1], t.D, lg);
-                S.m[q] = row4<VEC>(M, S.row[q >> 1], t.D, lg);
-                S.v[q] = row4<VEC>(V, S.row[q >> 1], t.D, lg);
+                S.p[q] = row4<VEC, FULL>(T, S.row[q >> 1], t.D, lg);
+                S.m[q] = row4<VEC, FULL>(M, S.row[q >> 1], t.D, lg);
+                S.v[q] = row4<VEC, FULL>(V, S.row[q >> 1], t.D, lg);
             }
         }
     };
@@ -1325,9 +1384,9 @@ __device__ __forceinline__ void stream_task(const DevTables &t, const StepArgs &
                 float *NP = (q & 1) ? (s ? a.np[3] : a.np[2]) : (s ? a.np[1] : a.np[0]);
                 float *M = (q & 1) ? (s ? a.m[3] : a.m[2]) : (s ? a.m[1] : a.m[0]);
                 float *V = (q & 1) ? (s ? a.v[3] : a.v[2]) : (s ? a.v[1] : a.v[0]);
-                put4<VEC, STEP_STREAM_ST>(NP, S.row[q >> 1], t.D, lg, S.p[q]);
-                put4<VEC, STEP_STREAM_ST>(M, S.row[q >> 1], t.D, lg, S.m[q]);
-                put4<VEC, STEP_STREAM_ST>(V, S.row[q >> 1], t.D, lg, S.v[q]);
+                put4<VEC, STEP_STREAM_ST, FULL>(NP, S.row[q >> 1], t.D, lg, S.p[q]);
+                put4<VEC, STEP_STREAM_ST, FULL>(M, S.row[q >> 1], t.D, lg, S.m[q]);
+                put4<VEC, STEP_STREAM_ST, FULL>(V, S.row[q >> 1], t.D, lg, S.v[q]);
             }
         }
     };
@@ -1480,7 +1539,7 @@ __device__ __forceinline__ void class_row(const StepArgs &a, int c, int (&q)[4])
 #ifndef STEP_APPLY_WAVES
 #define STEP_APPLY_WAVES 4
 #endif
-template <int LG, bool VEC, int EMAX, bool DEFER = false>
+template <int LG, bool VEC, int EMAX, bool DEFER = false, bool FULL = false>
 __global__ __launch_bounds__(kThreads, (LG == 16 && EMAX <= 4) ? STEP_EVAL_WAVES_SMALL : STEP_EVAL_WAVES) void mstep_eval_kernel(DevTables t, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // Workgroup b runs the tasks of class c = b % n_cls (XCD-affine order, InvPrefRowPlan), the j-th of them with
@@ -1494,7 +1553,7 @@ __global__ __launch_bounds__(kThreads, (LG == 16 && EMAX <= 4) ? STEP_EVAL_WAVES
     const int tj = (q[1] + rpt - 1) / rpt;
     if (j < tj) {
 #ifndef DBG_NO_JOBS
-        user_task<LG, VEC, EMAX, DEFER>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), q[0] / rpt + j, lds);
+        user_task<LG, VEC, EMAX, DEFER, FULL>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), q[0] / rpt + j, lds);
 #endif
         return;
     }
@@ -1503,14 +1562,14 @@ __global__ __launch_bounds__(kThreads, (LG == 16 && EMAX <= 4) ? STEP_EVAL_WAVES
         STAMP(0);
 #ifndef DBG_NO_STREAM
         stream_delay<STEP_STREAM_DELAY1>();
-        stream_task<LG, VEC>(t, a, a.stream_rows + q[2] + j * spt, min(spt, q[3] - j * spt));
+        stream_task<LG, VEC, FULL>(t, a, a.stream_rows + q[2] + j * spt, min(spt, q[3] - j * spt));
 #endif
         STAMP(7);
     }
 }
 
-template <int LG, bool VEC, int EMAX>
-__global__ __launch_bounds__(kThreads, EMAX <= 4 ? STEP_APPLY_WAVES : (EMAX <= 8 ? 4 : 3)) void mstep_apply_kernel(DevTables t, StepArgs a, FoldArgs f) {
+template <int LG, bool VEC, int EMAX, bool FULL = false>
+__global__ __launch_bounds__(kThreads, FULL ? 3 : STEP_APPLY_WAVES) void mstep_apply_kernel(DevTables t, StepArgs a, FoldArgs f) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if ((int)blockIdx.x >= f.n_task_wgs) {
         const int fb = (int)blockIdx.x - f.n_task_wgs;
@@ -1550,8 +1609,8 @@ __global__ __launch_bounds__(kThreads, EMAX <= 4 ? STEP_APPLY_WAVES : (EMAX <= 8
     const int tj = (q[1] + rpt - 1) / rpt;
     if (j < tj) {
 #ifndef DBG_NO_JOBS
-        if (a.push_slot) item_task_push<LG, VEC, EMAX>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), lds);
-        else item_task<LG, VEC, EMAX>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), lds);
+        if (a.push_slot) item_task_push<LG, VEC, EMAX, FULL>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), lds);
+        else item_task<LG, VEC, EMAX, FULL>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), lds);
 #endif
         return;
     }
@@ -1560,7 +1619,7 @@ __global__ __launch_bounds__(kThreads, EMAX <= 4 ? STEP_APPLY_WAVES : (EMAX <= 8
         STAMP(0);
 #ifndef DBG_NO_STREAM
         stream_delay<STEP_STREAM_DELAY2>();
-        stream_task<LG, VEC>(t, a, a.stream_rows + q[2] + j * spt, min(spt, q[3] - j * spt));
+        stream_task<LG, VEC, FULL>(t, a, a.stream_rows + q[2] + j * spt, min(spt, q[3] - j * spt));
 #endif
         STAMP(7);
     }
@@ -1882,6 +1941,7 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
         if (profile_event && hipEventRecord((hipEvent_t)profile_event, st) != hipSuccess) return INVPREF_EINVAL; \
         hipLaunchKernelGGL((mstep_apply_kernel<LGV, VECV, EMAXV>), dim3(grid2), dim3(kThreads), lds2, st, t, a2, f); \
     } while (0)
+    const bool full = vec && t.D == 64;   // rows of exactly 64 floats: loads with nothing behind them (row4<VEC, FULL>)
     if (defer) {
         const size_t lds1d = lds1 + kDeferWin * sizeof(float2);
         if ((rc = ensure_lds(mstep_eval_kernel<16, true, 4, true>, lds1d))) return rc;
@@ -1890,6 +1950,13 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
             hipLaunchKernelGGL((mstep_eval_kernel<16, true, 4, true>), dim3(wg1), dim3(kThreads), lds1d, st, t, a1);
         if (profile_event && hipEventRecord((hipEvent_t)profile_event, st) != hipSuccess) return INVPREF_EINVAL;
         hipLaunchKernelGGL((mstep_apply_kernel<16, true, 4>), dim3(grid2), dim3(kThreads), lds2, st, t, a2, f);
+    } else if (full) {
+        if ((rc = ensure_lds(mstep_eval_kernel<16, true, 4, false, true>, lds1))) return rc;
+        if ((rc = ensure_lds(mstep_apply_kernel<16, true, 4, true>, lds2))) return rc;
+        if (wg1 > 0)
+            hipLaunchKernelGGL((mstep_eval_kernel<16, true, 4, false, true>), dim3(wg1), dim3(kThreads), lds1, st, t, a1);
+        if (profile_event && hipEventRecord((hipEvent_t)profile_event, st) != hipSuccess) return INVPREF_EINVAL;
+        hipLaunchKernelGGL((mstep_apply_kernel<16, true, 4, true>), dim3(grid2), dim3(kThreads), lds2, st, t, a2, f);
     } else if (!vec) {
         CALL(16, false, 4);
     } else {
@@ -2050,6 +2117,6 @@ int invpref_flush_deferred_hip(const InvPrefTables *home, const InvPrefTables *d
 extern "C" int invpref_debug_eval_occupancy(void) {
     int n = -1;
     const size_t lds = eval_lds_bytes(shape_of(64, 4));
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mstep_eval_kernel<16, true, 4>, kThreads, lds) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mstep_eval_kernel<16, true, 4, false, true>, kThreads, lds) != hipSuccess) return -1;
     return n * 1000 + (int)(lds / 1024);
 }

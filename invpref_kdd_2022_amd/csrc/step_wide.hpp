@@ -102,7 +102,7 @@ __device__ __forceinline__ void load_row(float4 (&r)[NC], const float *__restric
     for (int j = 0; j < NC; j++) {
         if (VEC) {
             constexpr unsigned DPB = 16u * LG * NC;   // bytes of a row
-            r[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + (unsigned)row * DPB + 16u * (unsigned)(lg + LG * j));
+            r[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + ((unsigned)row * DPB + 16u * (unsigned)(lg + LG * j)));
         } else {
             r[j] = row4<false>(base, row, D, lg + LG * j);
         }
@@ -114,7 +114,7 @@ __device__ __forceinline__ void store_row(float *__restrict__ base, int row, int
     for (int j = 0; j < NC; j++) {
         if (VEC) {
             constexpr unsigned DPB = 16u * LG * NC;
-            float4 *dst = reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + (unsigned)row * DPB + 16u * (unsigned)(lg + LG * j));
+            float4 *dst = reinterpret_cast<float4 *>(reinterpret_cast<char *>(base) + ((unsigned)row * DPB + 16u * (unsigned)(lg + LG * j)));
             if (MODE == 0) *dst = r[j];
             else {
                 v4f val = {r[j].x, r[j].y, r[j].z, r[j].w};

@@ -441,6 +441,49 @@ def roofline_large(dev):
     return head
 
 
+def estep_random_sort_timing(dev, n=20):
+    """The reference's DEFAULT E-step path (cluster_use_random_sort=True, train.py:24, :192-196) against the plain one at
+    the Yahoo shape.  Device time per E-step + stat_envs (HIP events on the launch stream) with the permutation indices
+    drawn beforehand: what the device does is a 250 KB index copy, the unranking and the E-step; the host's share -- the
+    reference's own np.random.randint call per minibatch, same numpy stream -- is timed apart (in a training loop it runs
+    while the GPU is still busy with the epochs enqueued before it)."""
+    import torch
+    out = {}
+    for rs in (False, True):
+        mgr = build_manager(dev, 0, 1)
+        mgr.cluster_use_random_sort = rs
+        mgr.train_epochs(1)
+        mgr.prepare_graphs([1])
+        host_s = 0.0
+        if rs:
+            t0 = time.perf_counter()
+            draws = [mgr._eps_index() for _ in range(n + 3)]
+            host_s = (time.perf_counter() - t0) / (n + 3)
+            mgr._eps_index = lambda: draws.pop()
+        for _ in range(3):
+            mgr.cluster(sync=False); mgr.stat_envs(sync=False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(int(2e7))   # (the stream stays backlogged for the whole loop: the events are stamped by the GPU, not while it waits for the host)
+        e0.record()
+        for _ in range(n):
+            mgr.cluster(sync=False); mgr.stat_envs(sync=False)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        if rs:
+            out.update(estep_random_sort_ms=ms, estep_random_sort_host_draw_ms=host_s * 1e3)
+        else:
+            out['estep_plain_ms'] = ms
+        del mgr
+        torch.cuda.empty_cache()
+    out['ratio'] = out['estep_random_sort_ms'] / out['estep_plain_ms']
+    out['note'] = ('device time of cluster(sync=False) + stat_envs(sync=False), graph-replayed; random sort = index copy (1 B per '
+                   'interaction) + unranking on the device + the same E-step; host draws = np.random.randint per minibatch, the '
+                   'reference\'s own numpy stream')
+    return out
+
+
 def eval_timing(dev):
     """ImplicitTestManager.evaluate() on the Yahoo test shape (5 400 test users x 1 000 items,
     top-k 3/5/7, test batch 1 024: Yahoo_InvPref_Implicit.py:43-48); the reference's CPU path took 4.8 s per call in

@@ -337,6 +337,20 @@ int invpref_estep_hip(const InvPrefTables *tables, const int64_t *users, const i
                       float *class_weights, float *sample_weights, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* The same E-step with the reference's DEFAULT tie-break (cluster_use_random_sort=True: train.py:86-92 builds all E!
+ * permutations of eps_base = [1e-10, 1e-11, ...] in itertools.permutations order, train.py:192-196 adds row
+ * np.random.randint(0, E!) to every interaction's distances) WITHOUT the E! x E table and without an N x E table of
+ * gathered rows: perm_index[i] (device; index_bytes = 1, 4 or 8 bytes per entry, unsigned / int32 / int64 -- wide enough
+ * for E! - 1) is the permutation row drawn for interaction i and eps_base (HOST, float[env_num]) the vector that is
+ * permuted; the row is unranked on the device.  Bit for bit the result of invpref_estep_hip on the gathered rows.
+ * perm_index may also be PINNED HOST memory the device can address (hipHostMalloc): up to seven environments the kernel
+ * reads every workgroup's indices in one burst, so no copy is needed in front of it. */
+int invpref_estep_perm_hip(const InvPrefTables *tables, const int64_t *users, const int64_t *items, const float *scores,
+                           int64_t N, uint32_t flags, const void *perm_index, int index_bytes, const float *eps_base,
+                           const int64_t *old_envs, int64_t *new_envs, int64_t *counts, int64_t *diff,
+                           float *class_weights, float *sample_weights, void *workspace, size_t workspace_bytes,
+                           void *stream);
+
 /* ---- stat_envs alone (train.py:268-280), e.g. before the first epoch (train.py:297). */
 int invpref_stat_envs_hip(const int64_t *envs, int64_t N, int64_t env_num, int64_t *counts, float *class_weights,
                           float *sample_weights, void *workspace, size_t workspace_bytes, void *stream);

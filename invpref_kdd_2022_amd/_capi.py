@@ -25,7 +25,7 @@ EXPORTS = [
     'invpref_eval_error_sums_hip', 'invpref_mstep_rows_adam_profiled_hip', 'invpref_static_pop_workspace_bytes',
     'invpref_static_pop_hip', 'invpref_adam_ranges_hip', 'invpref_mstep_rows_grad_sched_hip',
     'invpref_adam_ranges_sched_hip', 'invpref_rows_lanes_per_group', 'invpref_rows_defer_supported',
-    'invpref_mstep_rows_adam_deferred_hip', 'invpref_flush_deferred_hip',
+    'invpref_mstep_rows_adam_deferred_hip', 'invpref_flush_deferred_hip', 'invpref_estep_perm_hip',
 ]
 
 
@@ -74,6 +74,8 @@ def lib():
         L.invpref_adam_hip.argtypes = [vp, vp, vp, vp, i64, i64, f64, f64, f64, f64, C.c_int, vp]
         L.invpref_estep_hip.argtypes = [C.POINTER(Tables), vp, vp, vp, i64, u32, vp, vp, vp, vp, vp, vp, vp, vp,
                                         C.c_size_t, vp]
+        L.invpref_estep_perm_hip.argtypes = [C.POINTER(Tables), vp, vp, vp, i64, u32, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp,
+                                             vp, C.c_size_t, vp]
         L.invpref_stat_envs_hip.argtypes = [vp, i64, i64, vp, vp, vp, vp, C.c_size_t, vp]
         L.invpref_sample_weights_hip.argtypes = [vp, i64, vp, i64, i64, vp, vp, vp]
         L.invpref_backward_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), vp, vp, vp, i64, u32, C.c_float, vp,

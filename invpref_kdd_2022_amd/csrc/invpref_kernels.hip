@@ -543,11 +543,56 @@ __global__ __launch_bounds__(256) void adam_ranges_kernel(float *__restrict__ p,
 // =====================================================================================
 // E-step  (train.py:169-202, :235-259): argmin_e dist_e, lowest index on ties
 // =====================================================================================
+// ---- cluster_use_random_sort (train.py:86-92, :192-196): the reference builds the E! x E table of all permutations of
+// [1e-10, 1e-11, ...] (itertools.permutations order) and adds row np.random.randint(0, E!) to every interaction's
+// distances.  Here only the drawn INDEX travels to the device (1, 4 or 8 bytes per interaction); one lane per
+// interaction unranks it -- factorial-base digits, then the d-th element still available, position by position -- into
+// sixteen 4-bit element numbers, which the E-step's lanes turn into their tie-break term.
+struct EpsBase { float v[INVPREF_MAX_ENVS]; };
+struct Factorials { unsigned long long f[INVPREF_MAX_ENVS]; };   // f[k] = k!
+__device__ __forceinline__ unsigned long long unrank_packed(unsigned long long r, int E, const Factorials &fac) {
+    unsigned avail = (1u << E) - 1u;
+    unsigned long long out = 0;
+#pragma unroll
+    for (int pos = 0; pos < INVPREF_MAX_ENVS; pos++) {
+        if (pos < E) {
+            unsigned long long f = 1;   // (E - 1 - pos)!  -- a masked select: no run-time index into the by-value table
+#pragma unroll
+            for (int k = 0; k < INVPREF_MAX_ENVS; k++) f = (k == E - 1 - pos) ? fac.f[k] : f;
+            const unsigned d = (unsigned)(r / f);
+            r -= (unsigned long long)d * f;
+            // the d-th (0-based) element still available, in increasing order
+            unsigned seen = 0, pick = 0;
+#pragma unroll
+            for (int b = 0; b < INVPREF_MAX_ENVS; b++) {
+                const bool on = (avail >> b) & 1u;
+                pick = (on && seen == d) ? (unsigned)b : pick;
+                seen += on ? 1u : 0u;
+            }
+            avail &= ~(1u << pick);
+            out |= (unsigned long long)pick << (4 * pos);
+        }
+    }
+    return out;
+}
+template <typename IT>
+__global__ __launch_bounds__(256) void eps_unrank_kernel(const IT *__restrict__ idx, int64_t N, int E, Factorials fac,
+                                                         unsigned long long *__restrict__ packed) {
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < N; s += (int64_t)gridDim.x * blockDim.x)
+        packed[s] = unrank_packed((unsigned long long)idx[s], E, fac);
+}
+// up to seven environments (7! = 5 040 rows): the E-step's workgroups unrank EVERY row of the permutation table into LDS
+// once (4 bytes each) and look an interaction's row up there -- no unranking launch, no packed rows through memory
+constexpr int kEpsTableMaxE = 7, kEpsTableMaxRows = 5040;
+
 template <int NC, bool VEC>
 __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const int64_t *__restrict__ users,
                                                            const int64_t *__restrict__ items,
                                                            const float *__restrict__ scores, int64_t N, uint32_t flags,
                                                            const float *__restrict__ eps_rows,
+                                                           const unsigned long long *__restrict__ eps_packed, EpsBase eps_base,
+                                                           const void *__restrict__ eps_index, int eps_index_bytes,
+                                                           int eps_rows_n, Factorials fac,
                                                            const int64_t *old_envs, int64_t *new_envs,
                                                            int *__restrict__ slabs) {
     // (old_envs and new_envs may be the SAME buffer -- cluster() updates the assignments in place -- so neither
@@ -556,13 +601,33 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
     constexpr int DP = NC * 64;
     float *sEv = lds;
     int *cnt = reinterpret_cast<int *>(lds + t.E * DP);  // [E + 1]
+    float *sbase = lds + t.E * DP + INVPREF_MAX_ENVS + 1;  // [16] the tie-break vector (train.py:86-92), eps_packed form
     stage_table(sEv, t.Ev, t.E, t.D, DP);
     for (int i = threadIdx.x; i <= t.E; i += blockDim.x) cnt[i] = 0;
+    unsigned *stab = reinterpret_cast<unsigned *>(sbase + INVPREF_MAX_ENVS);   // [E!] packed permutation rows (E <= 7)
+    if (eps_packed || eps_index) {
+#pragma unroll
+        for (int k = 0; k < INVPREF_MAX_ENVS; k++)   // (static indices: a by-value argument indexed at run time goes to scratch)
+            if (threadIdx.x == k) sbase[k] = eps_base.v[k];
+    }
+    // A workgroup walks ONE contiguous block of interactions, 16 per pass (any split gives the same per-interaction results).
+    // That makes its permutation indices one contiguous byte range, fetched here in one burst -- the index array may be
+    // PINNED HOST memory (the managers hand their staging buffer over as it is: no copy engine, no copy node in the graph),
+    // and a burst of whole lines is what the link moves well.
+    const int64_t rows_per_block = blockDim.x / kRow;
+    const int64_t chunk = ((N + gridDim.x - 1) / gridDim.x + rows_per_block - 1) / rows_per_block * rows_per_block;
+    const int64_t s_begin = blockIdx.x * chunk, s_end = min(N, s_begin + chunk);
+    unsigned *sidx = stab + eps_rows_n;   // [chunk] the block's permutation rows (E <= 7)
+    if (eps_index) {
+        for (int i = threadIdx.x; i < eps_rows_n; i += blockDim.x) stab[i] = (unsigned)unrank_packed((unsigned long long)i, t.E, fac);
+        for (int64_t i = threadIdx.x; s_begin + i < s_end; i += blockDim.x)
+            sidx[i] = eps_index_bytes == 1 ? (unsigned)reinterpret_cast<const uint8_t *>(eps_index)[s_begin + i]
+                                            : (unsigned)reinterpret_cast<const int32_t *>(eps_index)[s_begin + i];
+    }
     __syncthreads();
     const int l16 = threadIdx.x & 15;
-    const int64_t rows_per_block = blockDim.x / kRow;
     const bool implicit = flags & INVPREF_IMPLICIT;
-    for (int64_t s = blockIdx.x * rows_per_block + (threadIdx.x >> 4); s < N; s += gridDim.x * rows_per_block) {
+    for (int64_t s = s_begin + (threadIdx.x >> 4); s < s_end; s += rows_per_block) {
         const int64_t u = users[s], v = items[s];
         const float y = scores[s];
         float4 pu[NC], qi[NC], pa[NC], qa[NC];
@@ -587,6 +652,11 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
         if (implicit) dist = c_bce(sp * c_sigmoid(qmine), y);
         else { const float r = (p + qmine) - y; dist = r * r; }
         if (eps_rows && l16 < t.E) dist = dist + eps_rows[s * t.E + l16];
+        // train.py:192-196 with the row's permutation unranked on the device: position l16 of permutation row idx[s] of
+        // the tie-break vector is element (packed >> 4 l16) & 15 of it (eps_unrank_kernel)
+        if (eps_packed && l16 < t.E) dist = dist + sbase[(eps_packed[s] >> (4 * l16)) & 15ull];
+        if (eps_index && l16 < t.E)   // (E <= 7: the row looked up in the workgroup's LDS table)
+            dist = dist + sbase[(stab[sidx[s - s_begin]] >> (4 * l16)) & 15u];
         // argmin with the lowest index among equal minima (torch.argmin; the sequential `dist < best` scan)
         // A NaN distance wins, the first one if there are several (torch.argmin's LessOrNan; only reachable with
         // NaN parameters) -- row16_min ignores NaNs, so the lowest NaN lane is found separately.
@@ -977,9 +1047,9 @@ int invpref_adam_ranges_sched_hip(float *param, float *grad, float *exp_avg, flo
 }
 
 size_t invpref_estep_workspace_bytes(const InvPrefTables *tables, int64_t N) {
-    (void)N;
+    // count slabs of the workgroups | (invpref_estep_perm_hip) one packed permutation per interaction
     const int64_t E = tables ? tables->env_num : INVPREF_MAX_ENVS;
-    return sizeof(int) * (size_t)(E + 1) * kEstepMaxBlocks;
+    return sizeof(int) * (size_t)(E + 1) * kEstepMaxBlocks + sizeof(unsigned long long) * (size_t)(N > 0 ? N : 0);
 }
 
 int invpref_stat_envs_hip(const int64_t *envs, int64_t N, int64_t env_num, int64_t *counts, float *class_weights,
@@ -1010,10 +1080,11 @@ int invpref_sample_weights_hip(const int64_t *envs, int64_t N_local, const int64
     return (int)hipGetLastError();
 }
 
-int invpref_estep_hip(const InvPrefTables *tables, const int64_t *users, const int64_t *items, const float *scores,
-                      int64_t N, uint32_t flags, const float *eps_rows, const int64_t *old_envs, int64_t *new_envs,
-                      int64_t *counts, int64_t *diff, float *class_weights, float *sample_weights, void *workspace,
-                      size_t workspace_bytes, void *stream) {
+static int estep_launch(const InvPrefTables *tables, const int64_t *users, const int64_t *items, const float *scores,
+                        int64_t N, uint32_t flags, const float *eps_rows, const void *perm_index, int index_bytes,
+                        const float *eps_base_host, const int64_t *old_envs, int64_t *new_envs, int64_t *counts,
+                        int64_t *diff, float *class_weights, float *sample_weights, void *workspace,
+                        size_t workspace_bytes, void *stream) {
     int rc = check_tables(tables);
     if (rc) return rc;
     if (N <= 0 || !users || !items || !scores || !new_envs || !counts || !diff || !workspace) return INVPREF_EINVAL;
@@ -1022,12 +1093,45 @@ int invpref_estep_hip(const InvPrefTables *tables, const int64_t *users, const i
     const bool vec = vec_ok(tables);
     const int nc = vec ? nc_of(t.D) : 4;
     const int nb = estep_blocks(N);
-    const size_t lds = sizeof(float) * ((size_t)t.E * nc * 64) + sizeof(int) * (t.E + 1);
+    const size_t lds = sizeof(float) * ((size_t)t.E * nc * 64 + INVPREF_MAX_ENVS + 1 + INVPREF_MAX_ENVS);
     hipStream_t st = (hipStream_t)stream;
     int *slabs = (int *)workspace;
+    unsigned long long *eps_packed = nullptr;
+    EpsBase eps_base{};
+    Factorials fac{};
+    fac.f[0] = 1;
+    for (int k = 1; k < INVPREF_MAX_ENVS; k++) fac.f[k] = fac.f[k - 1] * (unsigned long long)k;
+    const void *eps_index = nullptr;   // E <= 7: looked up in the kernel's own LDS table
+    int eps_rows_n = 0;
+    size_t lds_extra = 0;
+    if (perm_index) {
+        if (eps_rows || !eps_base_host || (index_bytes != 1 && index_bytes != 4 && index_bytes != 8)) return INVPREF_EINVAL;
+        // (an index type must be able to hold E! - 1)
+        if ((index_bytes == 1 && t.E > 5) || (index_bytes == 4 && t.E > 12)) return INVPREF_EINVAL;
+        for (int k = 0; k < t.E; k++) eps_base.v[k] = eps_base_host[k];
+    }
+    if (perm_index && t.E <= kEpsTableMaxE && index_bytes != 8) {
+        eps_index = perm_index;
+        eps_rows_n = (int)fac.f[t.E];
+        const int64_t rpb = kEstepThreads / kRow, chunk = ((N + nb - 1) / nb + rpb - 1) / rpb * rpb;
+        lds_extra = sizeof(unsigned) * ((size_t)eps_rows_n + (size_t)chunk);
+        if (lds + lds_extra > 64 * 1024) return INVPREF_EUNSUPPORTED;   // (2^24 interactions and more: use the packed form)
+    } else if (perm_index) {
+        eps_packed = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(workspace) +
+                                                           sizeof(int) * (size_t)(t.E + 1) * kEstepMaxBlocks);
+        int64_t ub = (N + 255) / 256;
+        if (ub > 4096) ub = 4096;
+        if (index_bytes == 1)
+            hipLaunchKernelGGL(eps_unrank_kernel<uint8_t>, dim3((unsigned)ub), dim3(256), 0, st, (const uint8_t *)perm_index, N, t.E, fac, eps_packed);
+        else if (index_bytes == 4)
+            hipLaunchKernelGGL(eps_unrank_kernel<int32_t>, dim3((unsigned)ub), dim3(256), 0, st, (const int32_t *)perm_index, N, t.E, fac, eps_packed);
+        else
+            hipLaunchKernelGGL(eps_unrank_kernel<int64_t>, dim3((unsigned)ub), dim3(256), 0, st, (const int64_t *)perm_index, N, t.E, fac, eps_packed);
+    }
 #define ECALL(NCV, VECV)                                                                                          \
-    hipLaunchKernelGGL((estep_assign_kernel<NCV, VECV>), dim3(nb), dim3(kEstepThreads), lds, st, t, users, items, \
-                       scores, N, flags, eps_rows, old_envs, new_envs, slabs)
+    hipLaunchKernelGGL((estep_assign_kernel<NCV, VECV>), dim3(nb), dim3(kEstepThreads), lds + lds_extra, st, t, users, items, \
+                       scores, N, flags, eps_rows, eps_packed, eps_base, eps_index, index_bytes, eps_rows_n, fac, old_envs, \
+                       new_envs, slabs)
     if (!vec) { ECALL(4, false); } else if (nc == 1) { ECALL(1, true); } else if (nc == 2) { ECALL(2, true); } else { ECALL(4, true); }
 #undef ECALL
     hipError_t err = hipGetLastError();
@@ -1037,6 +1141,24 @@ int invpref_estep_hip(const InvPrefTables *tables, const int64_t *users, const i
     hipLaunchKernelGGL(stat_envs_kernel, dim3((unsigned)nb2), dim3(256), 0, st, new_envs, N, t.E, slabs, nb, counts, diff,
                        class_weights, sample_weights);
     return (int)hipGetLastError();
+}
+
+int invpref_estep_hip(const InvPrefTables *tables, const int64_t *users, const int64_t *items, const float *scores,
+                      int64_t N, uint32_t flags, const float *eps_rows, const int64_t *old_envs, int64_t *new_envs,
+                      int64_t *counts, int64_t *diff, float *class_weights, float *sample_weights, void *workspace,
+                      size_t workspace_bytes, void *stream) {
+    return estep_launch(tables, users, items, scores, N, flags, eps_rows, nullptr, 0, nullptr, old_envs, new_envs, counts,
+                        diff, class_weights, sample_weights, workspace, workspace_bytes, stream);
+}
+
+int invpref_estep_perm_hip(const InvPrefTables *tables, const int64_t *users, const int64_t *items, const float *scores,
+                           int64_t N, uint32_t flags, const void *perm_index, int index_bytes, const float *eps_base,
+                           const int64_t *old_envs, int64_t *new_envs, int64_t *counts, int64_t *diff,
+                           float *class_weights, float *sample_weights, void *workspace, size_t workspace_bytes,
+                           void *stream) {
+    if (!perm_index) return INVPREF_EINVAL;
+    return estep_launch(tables, users, items, scores, N, flags, nullptr, perm_index, index_bytes, eps_base, old_envs,
+                        new_envs, counts, diff, class_weights, sample_weights, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

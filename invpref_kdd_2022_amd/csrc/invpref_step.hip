@@ -443,6 +443,9 @@ struct USample {
 // launch 1: rounds of USER jobs.  Per interaction: gather the item rows, evaluate, accumulate the user rows'
 // gradients in registers, store the record for the item side, accumulate the E x D / loss sums.
 // =====================================================================================
+#ifndef STEP_STAGE_LATE
+#define STEP_STAGE_LATE 1   // (A/B knob, FULL instances: the small tables staged behind the first gathers)
+#endif
 #ifndef STEP_EVAL_DEPTH
 #define STEP_EVAL_DEPTH 3
 #endif
@@ -484,9 +487,11 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
     // the first round's descriptor goes out before anything else: every gather below hangs on it
     int4 d, d1;
     first_desc<LG>(a.desc, r0, grp, d, d1);
-    stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
-    stage_small(sW, t.W, t.E, t.D, EMAX, DP);
-    if (threadIdx.x < EMAX) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
+    if (!STEP_STAGE_LATE || !FULL) {
+        stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
+        stage_small(sW, t.W, t.E, t.D, EMAX, DP);
+        if (threadIdx.x < EMAX) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
+    }
     // DEFER: this step's number, and the Adam scalars of the kDeferWin steps before it staged in LDS
     int tcur = 0, sbase = 0;
     float2 *swin = reinterpret_cast<float2 *>(lds + L::total);
@@ -648,7 +653,17 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             }
         }
 #endif
-        if (r == r0) { __syncthreads(); STAMP(3); }  // staged tables visible (the gathers above are in flight)
+        if (r == r0) {
+            if (STEP_STAGE_LATE && FULL) {
+                // the two small tables are staged HERE, behind the first round's gathers: their load -> LDS-store loop in
+                // front of the descriptor's use put a round trip of its own ahead of the gathers
+                stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
+                stage_small(sW, t.W, t.E, t.D, EMAX, DP);
+                if (threadIdx.x < EMAX) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
+            }
+            __syncthreads();   // staged tables visible (the gathers above are in flight)
+            STAMP(3);
+        }
         if (DEFER) {
             // Deferred dense Adam: steps pend_from .. cur - 1 did not touch this row, so their updates -- gradient exactly
             // zero, the step's own scalars from the schedule table -- were never applied.  They are replayed here, in

@@ -114,18 +114,22 @@ def adam_ranges_(param, grad, exp_avg, exp_avg_sq, offsets, lengths, step: int, 
 
 def estep(params: Sequence[torch.Tensor], users, items, scores, implicit: bool, old_envs: Optional[torch.Tensor],
           workspace: Workspace, eps_rows: Optional[torch.Tensor] = None, new_envs: Optional[torch.Tensor] = None,
-          want_weights: bool = True):
+          want_weights: bool = True, perm_index: Optional[torch.Tensor] = None, eps_base=None):
     """cluster() + stat_envs() (train.py:235-259, :268-280) over all given interactions.
     Returns (new_envs int64[N], counts int64[E], diff int64[1], class_w fp32[E], sample_w fp32[N]).
-    new_envs may be the same tensor as old_envs (in-place update, `estep_assign_`)."""
+    new_envs may be the same tensor as old_envs (in-place update, `estep_assign_`).
+    eps_rows: the tie-break rows of train.py:192-196 already gathered per interaction ([N, E] fp32) -- or perm_index
+    (uint8 / int32 / int64 [N]: the permutation row drawn for every interaction) + eps_base (the E floats that are
+    permuted): the row is unranked on the device."""
     _gpu(users, *params)
     t = make_tables(params)
     ws = workspace.get(lib().invpref_estep_workspace_bytes(C.byref(t), users.numel()))
     if new_envs is not None and old_envs is not None and new_envs.data_ptr() == old_envs.data_ptr():
         counts, diff, cw, sw = _o().estep_assign_(list(params), users, items, scores, new_envs, bool(implicit), eps_rows,
-                                                  bool(want_weights), ws)
+                                                  bool(want_weights), ws, perm_index, eps_base)
         return new_envs, counts, diff, (cw if want_weights else None), (sw if want_weights else None)
-    out, counts, diff = _o().estep_assign(list(params), users, items, scores, old_envs, bool(implicit), eps_rows, ws)
+    out, counts, diff = _o().estep_assign(list(params), users, items, scores, old_envs, bool(implicit), eps_rows, ws,
+                                          perm_index, eps_base)
     if new_envs is not None:
         new_envs.copy_(out)
         out = new_envs

@@ -325,11 +325,35 @@ def _adam_ranges_fake(param, grad, exp_avg, exp_avg_sq, offsets, lengths, step, 
 
 
 # ------------------------------------------------------------------------------------------------ E-step
-def _estep_call(tables, users, items, scores, implicit, eps_rows, old_envs, new_envs, want_weights, workspace):
+_PERM_BYTES = {torch.uint8: 1, torch.int32: 4, torch.int64: 8}
+
+
+def _estep_call(tables, users, items, scores, implicit, eps_rows, old_envs, new_envs, want_weights, workspace,
+                perm_index=None, eps_base=None):
     t = make_tables(tables)
     N = users.numel()
     dev = users.device
     _f32(scores, 'scores'); _f32(eps_rows, 'eps_rows')
+    if perm_index is not None:
+        # train.py:192-196 with the permutation row unranked on the device (invpref_estep_perm_hip)
+        if eps_rows is not None or eps_base is None or len(eps_base) != t.env_num or perm_index.dtype not in _PERM_BYTES \
+                or perm_index.numel() != N:
+            raise InvPrefError('perm_index: one uint8 / int32 / int64 permutation row per interaction + eps_base[env_num]')
+        if not (perm_index.is_cuda or (perm_index.is_pinned() and t.env_num <= 7)) or not perm_index.is_contiguous():
+            raise InvPrefError('perm_index: a contiguous device tensor, or (up to 7 environments) pinned host memory')
+        if old_envs is not None:
+            _ids(old_envs, 'old_envs')
+        counts = torch.empty(t.env_num, dtype=torch.int64, device=dev)
+        diff = torch.zeros(1, dtype=torch.int64, device=dev)
+        cw = torch.empty(t.env_num if want_weights else 0, dtype=torch.float32, device=dev)
+        sw = torch.empty(N if want_weights else 0, dtype=torch.float32, device=dev)
+        base = (C.c_float * t.env_num)(*[float(x) for x in eps_base])
+        check(lib().invpref_estep_perm_hip(C.byref(t), ptr(_ids(users, 'users')), ptr(_ids(items, 'items')), ptr(scores), N,
+                                           _capi.IMPLICIT if implicit else 0, ptr(perm_index), _PERM_BYTES[perm_index.dtype],
+                                           base, ptr(old_envs), ptr(new_envs), ptr(counts), ptr(diff),
+                                           ptr(cw) if want_weights else None, ptr(sw) if want_weights else None,
+                                           ptr(workspace), workspace.numel(), stream_ptr()), 'invpref_estep_perm_hip')
+        return counts, diff, cw, sw
     if old_envs is not None:
         _ids(old_envs, 'old_envs')
     counts = torch.empty(t.env_num, dtype=torch.int64, device=dev)
@@ -345,35 +369,39 @@ def _estep_call(tables, users, items, scores, implicit, eps_rows, old_envs, new_
 
 
 _define('estep_assign(Tensor[] tables, Tensor users, Tensor items, Tensor scores, Tensor? old_envs, bool implicit, '
-        'Tensor? eps_rows, Tensor(a!) workspace) -> (Tensor, Tensor, Tensor)')
+        'Tensor? eps_rows, Tensor(a!) workspace, Tensor? perm_index=None, float[]? eps_base=None) -> (Tensor, Tensor, Tensor)')
 
 
 @_impl('estep_assign')
-def _estep_assign(tables, users, items, scores, old_envs, implicit, eps_rows, workspace):
+def _estep_assign(tables, users, items, scores, old_envs, implicit, eps_rows, workspace, perm_index=None, eps_base=None):
     new_envs = torch.empty(users.numel(), dtype=torch.int64, device=users.device)
-    counts, diff, _, _ = _estep_call(tables, users, items, scores, implicit, eps_rows, old_envs, new_envs, False, workspace)
+    counts, diff, _, _ = _estep_call(tables, users, items, scores, implicit, eps_rows, old_envs, new_envs, False, workspace,
+                                     perm_index, eps_base)
     return new_envs, counts, diff
 
 
 @_fake('estep_assign')
-def _estep_assign_fake(tables, users, items, scores, old_envs, implicit, eps_rows, workspace):
+def _estep_assign_fake(tables, users, items, scores, old_envs, implicit, eps_rows, workspace, perm_index=None, eps_base=None):
     i = dict(dtype=torch.int64, device=users.device)
     return torch.empty(users.numel(), **i), torch.empty(tables[4].shape[0], **i), torch.empty(1, **i)
 
 
 _define('estep_assign_(Tensor[] tables, Tensor users, Tensor items, Tensor scores, Tensor(a!) envs, bool implicit, '
-        'Tensor? eps_rows, bool want_weights, Tensor(b!) workspace) -> (Tensor, Tensor, Tensor, Tensor)')
+        'Tensor? eps_rows, bool want_weights, Tensor(b!) workspace, Tensor? perm_index=None, float[]? eps_base=None) '
+        '-> (Tensor, Tensor, Tensor, Tensor)')
 
 
 @_impl('estep_assign_')
-def _estep_assign_inplace(tables, users, items, scores, envs, implicit, eps_rows, want_weights, workspace):
+def _estep_assign_inplace(tables, users, items, scores, envs, implicit, eps_rows, want_weights, workspace, perm_index=None,
+                          eps_base=None):
     # envs is read (old assignment of row i) and written (new assignment of row i) by the same lane
     return _estep_call(tables, users, items, scores, implicit, eps_rows, _ids(envs, 'envs'), envs, want_weights,
-                       workspace)
+                       workspace, perm_index, eps_base)
 
 
 @_fake('estep_assign_')
-def _estep_assign_inplace_fake(tables, users, items, scores, envs, implicit, eps_rows, want_weights, workspace):
+def _estep_assign_inplace_fake(tables, users, items, scores, envs, implicit, eps_rows, want_weights, workspace,
+                               perm_index=None, eps_base=None):
     E, N, dev = tables[4].shape[0], users.numel(), users.device
     return (torch.empty(E, dtype=torch.int64, device=dev), torch.empty(1, dtype=torch.int64, device=dev),
             torch.empty(E if want_weights else 0, dtype=torch.float32, device=dev),

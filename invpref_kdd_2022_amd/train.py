@@ -706,41 +706,59 @@ class _InvPrefTrainManager:
         return r
 
     # ------------------------------------------------------------------ E-step
-    def _eps_rows(self, n_rows: int) -> torch.Tensor:
-        """train.py:86-92,192-196: per batch, np.random.randint picks a permutation of the eps vector
-        per row.  The E! x E table is not materialised: row r is unranked on the fly."""
-        out = np.empty((n_rows, self.envs_num), np.float32)
-        done = 0
-        if self._eps_rows_cnt <= 40320:
-            table = np.array(list(itertools.permutations(self._eps_base)), dtype=np.float32)
+    def _perm_index_dtype(self):
+        """the narrowest type that holds E! - 1: what travels to the device per interaction"""
+        return np.uint8 if self.envs_num <= 5 else (np.int32 if self.envs_num <= 12 else np.int64)
+
+    def _eps_index(self) -> np.ndarray:
+        """train.py:192-196: per batch, np.random.randint picks one of the E! permutations of the eps vector per row --
+        the same draws from the same numpy stream as the reference.  Only the INDEX is kept (1 / 4 / 8 bytes per
+        interaction); neither the E! x E table of train.py:86-92 nor an N x E table of gathered rows is built: the E-step
+        unranks the row on the device (invpref_estep_perm_hip)."""
+        parts = []
         for k in range(self.batch_num):
             glen = self.shard.global_batch_len(k)
             idx = np.random.randint(0, self._eps_rows_cnt, glen)  # same numpy stream as the reference
-            idx = self.shard.select_in_batch(k, idx)
-            if self._eps_rows_cnt <= 40320:
-                out[done:done + len(idx)] = table[idx]
-            else:
-                out[done:done + len(idx)] = _unrank_permutations(idx, self._eps_base)
-            done += len(idx)
-        return torch.from_numpy(out).to(self.device)
+            parts.append(self.shard.select_in_batch(k, idx))
+        return np.concatenate(parts).astype(self._perm_index_dtype(), copy=False)
+
+    def _eps_index_device(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """the drawn indices on the device, through a pinned staging buffer (a plain asynchronous copy)"""
+        idx = self._eps_index()
+        cuda = self.device.type == 'cuda'
+        stage = getattr(self, '_eps_stage', None)
+        if stage is None or stage.numel() != len(idx) or stage.dtype != torch.from_numpy(idx[:0]).dtype:
+            stage = self._eps_stage = torch.empty(len(idx), dtype=torch.from_numpy(idx[:0]).dtype, pin_memory=cuda)
+            self._eps_stage_done = None
+        if self._eps_stage_done is not None:
+            self._eps_stage_done.synchronize()    # (the previous E-step's copy has left the staging buffer)
+        stage.numpy()[:] = idx
+        if out is None:
+            out = stage.to(self.device, non_blocking=True)
+        else:
+            out.copy_(stage, non_blocking=True)
+        if cuda:
+            self._eps_stage_done = torch.cuda.Event()
+            self._eps_stage_done.record()
+        return out
 
     def cluster(self, sync: bool = True):
         """train.py:235-259 (+ the stat_envs that always follows it is fused in: train.py:330).
         sync=False: no read-back, returns diff_num as a device int64[1] tensor."""
         self.model.eval()
-        eps = self._eps_rows(self.users_tensor.shape[0]) if self.cluster_use_random_sort else None
         if self.world_size == 1 and self.use_graph and self.envs.is_cuda and not torch.cuda.is_current_stream_capturing():
             # one HIP-graph replay instead of a handful of eager launches behind the Python operator layer (the
-            # host-side cost of those was several times the 40 us the kernels take); the per-row eps rows of
+            # host-side cost of those was several times the 40 us the kernels take); the permutation indices of
             # train.py:192-196 are host random numbers: they are copied into the buffer the graph reads
-            counts, diff, cw, sw = self._cluster_replay(eps)
+            counts, diff, cw, sw = self._cluster_replay(self.cluster_use_random_sort)
             self._pending_stat = (counts, cw, sw)
             return int(diff.item()) if sync else diff.clone()
+        perm = self._eps_index_device() if self.cluster_use_random_sort else None
         # new assignments overwrite self.envs in place (the kernel reads old_envs[i] before writing i)
         new, counts, diff, cw, sw = ops.estep(self.state.p_views, self.users_tensor, self.items_tensor,
                                               self.scores_tensor, self.implicit, self.envs, self.workspace,
-                                              eps_rows=eps, new_envs=self.envs,
-                                              want_weights=(self.world_size == 1))
+                                              new_envs=self.envs, want_weights=(self.world_size == 1),
+                                              perm_index=perm, eps_base=self._eps_base.tolist() if perm is not None else None)
         if self.world_size > 1:
             cd = torch.cat([counts, diff])
             all_reduce_sum_(cd, self.process_group)
@@ -757,13 +775,21 @@ class _InvPrefTrainManager:
         key = (self.state.p_views[0].data_ptr(), self.envs.data_ptr(), self.users_tensor.data_ptr(), with_eps)
         ent = self._estep_graphs.get(key)
         if ent is None:
-            eps_buf = torch.zeros(self.users_tensor.shape[0], self.envs_num, dtype=torch.float32, device=self.device) \
-                if with_eps else None
+            # (the buffer the captured E-step reads its permutation indices from, 1 / 4 / 8 bytes per interaction: up to
+            #  seven environments PINNED HOST memory the kernel reads in place -- no copy in front of the replay --
+            #  otherwise a device buffer the staging buffer is copied into)
+            eps_buf = None
+            if with_eps:
+                dt = torch.from_numpy(np.zeros(0, self._perm_index_dtype())).dtype
+                n_loc = self.users_tensor.shape[0]
+                eps_buf = torch.zeros(n_loc, dtype=dt, pin_memory=True) if self.envs_num <= 7 \
+                    else torch.zeros(n_loc, dtype=dt, device=self.device)
 
             def run():
                 _, counts, diff, cw, sw = ops.estep(self.state.p_views, self.users_tensor, self.items_tensor,
                                                     self.scores_tensor, self.implicit, self.envs, self.workspace,
-                                                    eps_rows=eps_buf, new_envs=self.envs, want_weights=True)
+                                                    new_envs=self.envs, want_weights=True, perm_index=eps_buf,
+                                                    eps_base=self._eps_base.tolist() if with_eps else None)
                 return counts, diff, cw, sw
             # sizes the workspace outside the capture (envs is restored: the warm-up is not an E-step)
             keep = self.envs.clone()
@@ -776,23 +802,33 @@ class _InvPrefTrainManager:
             ent = self._estep_graphs[key] = (g, eps_buf, outs)
         return ent
 
-    def _cluster_replay(self, eps):
+    def _cluster_replay(self, with_eps: bool):
         """One graph per parameter buffer (the fused M-step ping-pongs between two) and per interaction-array set."""
-        g, eps_buf, outs = self._estep_graph(eps is not None)
-        if eps_buf is not None:
-            eps_buf.copy_(eps)
+        g, eps_buf, outs = self._estep_graph(with_eps)
+        if eps_buf is not None and not eps_buf.is_cuda:
+            # this E-step's draws (host numpy stream, like the reference) straight into the pinned buffer the graph reads
+            done = getattr(self, '_eps_read_done', None)
+            if done is not None:
+                done.synchronize()                 # (the previous replay has read the buffer)
+            eps_buf.numpy()[:] = self._eps_index()
+        elif eps_buf is not None:
+            self._eps_index_device(out=eps_buf)
         g.replay()
+        if eps_buf is not None and not eps_buf.is_cuda:
+            self._eps_read_done = torch.cuda.Event()
+            self._eps_read_done.record()
         return outs
 
     def cluster_a_batch(self, batch_users_tensor, batch_items_tensor, batch_scores_tensor) -> torch.Tensor:
         """train.py:169-202 for one batch (single-rank semantics)."""
-        eps = None
+        perm = None
         if self.cluster_use_random_sort:
             idx = np.random.randint(0, self._eps_rows_cnt, batch_users_tensor.shape[0])
-            eps = torch.from_numpy(_unrank_permutations(idx, self._eps_base)).to(self.device)
+            perm = torch.from_numpy(idx.astype(self._perm_index_dtype(), copy=False)).to(self.device)
         new, _, _, _, _ = ops.estep(self.state.p_views, batch_users_tensor.contiguous(),
                                     batch_items_tensor.contiguous(), batch_scores_tensor.float().contiguous(),
-                                    self.implicit, None, self.workspace, eps_rows=eps, want_weights=False)
+                                    self.implicit, None, self.workspace, want_weights=False, perm_index=perm,
+                                    eps_base=self._eps_base.tolist() if perm is not None else None)
         return new
 
     def stat_envs(self, sync: bool = True):

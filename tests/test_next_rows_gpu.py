@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from invpref_kdd_2022_amd import ops, plan as planlib
+from invpref_kdd_2022_amd import ops, plan as planlib, synth
 from invpref_kdd_2022_amd.baseline import (PURE_LOSS_KEYS, BasicExplicitTrainManager, BasicImplicitTrainManager,
                                            BasicUniformImplicitTrainManager, PureExplicitMatrixFactorization,
                                            PureMatrixFactorization)
@@ -210,3 +210,36 @@ def test_static_pop_manager_vs_reference():
     assert le == [1, 2, 3, 4] and te == [0, 2, 4] and ce == [3] and se == [2, 4] and len(d) == 1
     assert set(stat.keys()) == set(ops.POP_KEYS) and len(stat[ops.POP_KEYS[0]][0]) == 2
     assert mgr.epochs == 4
+
+
+@pytest.mark.parametrize('E', [2, 4, 5, 8, 13])
+def test_estep_unranks_the_permutation_rows_on_the_device(E):
+    """cluster_use_random_sort (train.py:86-92, :192-196) with only the drawn permutation INDEX on the device: the E-step's
+    assignments, counts and weights equal, bit for bit, those of the E-step fed the gathered N x E rows of
+    itertools.permutations order (built here with the manager's host-side unranking, pinned to itertools by a CPU test)."""
+    import math
+    from invpref_kdd_2022_amd.train import _unrank_permutations
+    U, I, D, N = 300, 200, 64, 20000
+    rs = np.random.RandomState(E)
+    tabs = synth.tables(E + 1, U, I, E, D, std=0.3)
+    u, v = rs.randint(0, U, N), rs.randint(0, I, N)
+    y = rs.randint(0, 2, N).astype(np.float32)
+    # every distance of a row ties (no env-aware part) and the permuted vector is large enough to survive the fp32 sum
+    # (the reference's own 1e-10 .. 1e-25 are below one ulp of the distances: SURVEY 7), so the tie-break decides every row
+    for k in ('embed_user_env_aware.weight', 'embed_item_env_aware.weight', 'embed_env.weight'):
+        tabs[k] = np.zeros_like(tabs[k])
+    base = np.array([1e-2 * (0.5 ** i) for i in range(E)], dtype=np.float32)
+    idx = rs.randint(0, math.factorial(E), N)
+    dt = np.uint8 if E <= 5 else (np.int32 if E <= 12 else np.int64)
+    P = [torch.from_numpy(tabs[k]).to(DEV) for k in ops.PARAM_NAMES]
+    ws = ops.Workspace(DEV)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)   # noqa: E731
+    old = dev(rs.randint(0, E, N).astype(np.int64))
+    rows = dev(_unrank_permutations(idx, base))
+    a = ops.estep(P, dev(u), dev(v), dev(y), True, old, ws, eps_rows=rows)
+    b = ops.estep(P, dev(u), dev(v), dev(y), True, old, ws, perm_index=dev(idx.astype(dt)), eps_base=base.tolist())
+    for x, z in zip(a, b):
+        np.testing.assert_array_equal(x.cpu().numpy(), z.cpu().numpy())
+    # the tie-break really decided rows: without it everything ties at environment 0
+    plain = ops.estep(P, dev(u), dev(v), dev(y), True, old, ws)[0].cpu().numpy()
+    assert (plain == 0).all() and (a[0].cpu().numpy() != 0).any()

@@ -1,0 +1,50 @@
+/* invpref_plan.h -- C ABI of the host-side row-plan builder (libinvpref_ingest.so; plain C, no GPU involved).
+ *
+ * The planned M-step (include/invpref_hip.h: InvPrefRowPlan) needs the scatter pattern of every minibatch inverted
+ * once.  The reference's minibatches are static (utils.mini_batch, utils.py:12-19: contiguous, unshuffled slices of the
+ * resident interaction tensors), so this is set-up work, but it stands in front of the first planned step: 31 plans of a
+ * Yahoo-shaped run took 0.35 s in numpy and a 2^24-interaction plan minutes.  This builder produces THE SAME arrays as
+ * invpref_kdd_2022_amd/plan.py's numpy reference implementation, byte for byte (tests/test_plan_native.py), from the
+ * same resolved parameters: two stable counting sorts, one pass per XCD class and side, no Python in the loop.
+ *
+ * Returns an opaque handle; the arrays are read out with invpref_plan_array() (int32 each, owned by the handle) and the
+ * handle is released with invpref_plan_free().  invpref_plan_build_many() builds the plans of many minibatches
+ * (consecutive slices of the same interaction arrays) on a thread pool. */
+#ifndef INVPREF_PLAN_H
+#define INVPREF_PLAN_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct InvPrefPlanParams {
+    int32_t lanes_per_group;          /* 16 / 32: NG = 256 / lanes_per_group group slots per round */
+    int32_t per_slice, item_per_slice;
+    int32_t rounds_per_task, item_rounds_per_task;
+    int32_t n_classes;                /* 1 .. 8 */
+    int32_t rows_per_stream_task;
+    int32_t push;                     /* item side in push form: no inline interactions, push_slot produced */
+    int32_t user_lo, user_hi;         /* untouched user rows outside [user_lo, user_hi) are not streamed; (0, user_num) = all */
+    int32_t fill_cap;                 /* launch-1 residency the stream split fills (0: plain split) */
+    double stream_split;              /* share of a class's untouched rows streamed by launch 1 */
+} InvPrefPlanParams;
+
+typedef struct InvPrefHostPlan InvPrefHostPlan;
+
+/* which: 0 user_desc [rounds][NG][8] | 1 item_desc | 2 user_round_iters | 3 user_list [n][4] | 4 item_list [n][2] |
+ *        5 stream_rows | 6 push_slot (length 0 without push) | 7 cls [8][8] | 8 defer_tail [8][2] */
+InvPrefHostPlan *invpref_plan_build(const int64_t *users, const int64_t *items, const float *scores, int64_t n,
+                                    int64_t user_num, int64_t item_num, const InvPrefPlanParams *params);
+int64_t invpref_plan_array(const InvPrefHostPlan *plan, int32_t which, const int32_t **data);
+void invpref_plan_free(InvPrefHostPlan *plan);
+
+/* plans of `count` minibatches: minibatch k = interactions [offsets[k], offsets[k + 1]) with parameters params[k];
+ * out[k] receives its handle (NULL on failure).  n_threads <= 0: one per hardware thread (at most 16). */
+int invpref_plan_build_many(const int64_t *users, const int64_t *items, const float *scores, const int64_t *offsets,
+                            int32_t count, int64_t user_num, int64_t item_num, const InvPrefPlanParams *params,
+                            InvPrefHostPlan **out, int32_t n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

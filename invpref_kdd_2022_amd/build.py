@@ -12,6 +12,7 @@ LIB = os.path.join(PKG, 'libinvpref_hip.so')
 OBJDIR = os.path.join(PKG, 'build')
 INGEST_LIB = os.path.join(PKG, 'libinvpref_ingest.so')   # host-only data ingest (include/invpref_ingest.h)
 INGEST_SRC = os.path.join(CSRC, 'invpref_ingest.cpp')
+PLAN_SRC = os.path.join(CSRC, 'invpref_plan.cpp')        # host-only row-plan builder (include/invpref_plan.h), same library
 SOURCES = ['invpref_kernels.hip', 'invpref_step.hip', 'invpref_eval.hip']
 HEADERS = ['canon_math.hpp', 'kernel_common.hpp', os.path.join('..', '..', 'include', 'invpref_hip.h')]
 # -ffp-contract=off: every fma of the canonical arithmetic is written explicitly
@@ -35,11 +36,11 @@ def needs_build() -> bool:
 
 
 def build_ingest(force: bool = False, verbose: bool = False) -> str:
-    hdr = os.path.join(PKG, '..', 'include', 'invpref_ingest.h')
-    if force or not os.path.exists(INGEST_LIB) or \
-            os.path.getmtime(INGEST_LIB) < max(os.path.getmtime(INGEST_SRC), os.path.getmtime(hdr)):
+    deps = [INGEST_SRC, PLAN_SRC, os.path.join(PKG, '..', 'include', 'invpref_ingest.h'),
+            os.path.join(PKG, '..', 'include', 'invpref_plan.h')]
+    if force or not os.path.exists(INGEST_LIB) or os.path.getmtime(INGEST_LIB) < max(os.path.getmtime(d) for d in deps):
         cxx = shutil.which('g++') or _hipcc()
-        cmd = [cxx, '-O2', '-std=c++17', '-shared', '-fPIC', '-pthread', '-Wall', INGEST_SRC, '-o', INGEST_LIB]
+        cmd = [cxx, '-O2', '-std=c++17', '-shared', '-fPIC', '-pthread', '-Wall', INGEST_SRC, PLAN_SRC, '-o', INGEST_LIB]
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)

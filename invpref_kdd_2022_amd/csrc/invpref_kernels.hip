@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void eps_unrank_kernel(const IT *__restrict__ 
 }
 // up to seven environments (7! = 5 040 rows): the E-step's workgroups unrank EVERY row of the permutation table into LDS
 // once (4 bytes each) and look an interaction's row up there -- no unranking launch, no packed rows through memory
-constexpr int kEpsTableMaxE = 7, kEpsTableMaxRows = 5040;
+constexpr int kEpsTableMaxE = 7;
 
 template <int NC, bool VEC>
 __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const int64_t *__restrict__ users,

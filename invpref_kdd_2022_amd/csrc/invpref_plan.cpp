@@ -1,0 +1,319 @@
+// Host-side row-plan builder (include/invpref_plan.h): the native twin of invpref_kdd_2022_amd/plan.py's numpy reference
+// implementation (build_row_plan / _side_rounds), producing the same int32 arrays byte for byte from the same resolved
+// parameters.  Two stable counting sorts, then one pass per XCD class and side; build_many runs minibatches on threads.
+// (The reference's seam: utils.mini_batch, utils.py:12-19 -- the minibatches are the same contiguous slices every epoch.)
+#include "../../include/invpref_plan.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+struct InvPrefHostPlan {
+    std::vector<int32_t> arr[9];
+};
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int32_t kItemBit = 1 << 30;
+constexpr int kModeList = 7;
+constexpr int kClassShift = 6;
+
+struct Side {
+    int64_t n_rows = 0;
+    std::vector<int64_t> cnt, ptr;       // per row: interactions, first position in the sorted order
+    std::vector<int32_t> perm;           // sorted position -> minibatch position (stable counting sort by row)
+    std::vector<int32_t> own;            // sorted position -> row
+};
+
+void sort_side(const int64_t *rows, int64_t n, int64_t n_rows, Side &s) {
+    s.n_rows = n_rows;
+    s.cnt.assign((size_t)n_rows, 0);
+    for (int64_t i = 0; i < n; i++) s.cnt[(size_t)rows[i]]++;
+    s.ptr.assign((size_t)n_rows + 1, 0);
+    for (int64_t r = 0; r < n_rows; r++) s.ptr[(size_t)r + 1] = s.ptr[(size_t)r] + s.cnt[(size_t)r];
+    s.perm.resize((size_t)n);
+    s.own.resize((size_t)n);
+    std::vector<int64_t> at(s.ptr.begin(), s.ptr.end() - 1);
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t r = rows[i], j = at[(size_t)r]++;
+        s.perm[(size_t)j] = (int32_t)i;
+        s.own[(size_t)j] = (int32_t)r;
+    }
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// plan.py: _side_rounds for the rows of class `cls_id` (skip = untouched rows and rows of other classes)
+void side_rounds(const Side &s, int64_t n, const int32_t *const *cols, int w, int ng, int per_slice, int pad_to, int inl_max,
+                 const std::vector<int32_t> &class_rows, std::vector<int32_t> &desc, std::vector<int32_t> &iters) {
+    // the class's touched rows (increasing) by slice count (a power of two up to ng)
+    std::vector<std::vector<int32_t>> by_g;
+    int lg_max = 0;
+    while ((1 << lg_max) < ng) lg_max++;
+    by_g.resize((size_t)lg_max + 1);
+    for (int32_t r : class_rows) {
+        const int64_t c = s.cnt[(size_t)r];
+        const int64_t need = std::max<int64_t>(1, cdiv(c, per_slice));
+        int lg = 0;
+        while (((int64_t)1 << lg) < need) lg++;
+        by_g[(size_t)std::min(lg, lg_max)].push_back(r);
+    }
+    size_t total_rounds = 0;
+    for (int lg = lg_max; lg >= 0; lg--) total_rounds += (size_t)cdiv((int64_t)by_g[(size_t)lg].size(), ng >> lg);
+    desc.reserve(desc.size() + (total_rounds + (size_t)pad_to) * (size_t)ng * 8);
+    iters.reserve(iters.size() + total_rounds + (size_t)pad_to);
+    const size_t slot_w = 8;
+    for (int lg = lg_max; lg >= 0; lg--) {
+        std::vector<int32_t> &rows = by_g[(size_t)lg];
+        if (rows.empty()) continue;
+        const int g = 1 << lg;
+        std::stable_sort(rows.begin(), rows.end(), [&](int32_t a, int32_t b) { return s.cnt[(size_t)a] > s.cnt[(size_t)b]; });
+        const int per_round = ng / g;
+        const int64_t n_rounds = cdiv((int64_t)rows.size(), per_round);
+        const size_t base = desc.size(), ibase = iters.size();
+        desc.resize(base + (size_t)n_rounds * ng * slot_w, 0);
+        iters.resize(ibase + (size_t)n_rounds, 0);
+        for (int64_t rr = 0; rr < n_rounds; rr++)
+            for (int sl = 0; sl < ng; sl++) {
+                int32_t *d = desc.data() + base + ((size_t)rr * ng + sl) * slot_w;
+                d[0] = -1;
+                d[1] = g << 1;   // idle slots still tell the round's slice count (sync decision)
+            }
+        for (size_t i = 0; i < rows.size(); i++) {
+            const int64_t row = rows[i], rnd = (int64_t)i / per_round, first = ((int64_t)i % per_round) * g;
+            const int64_t c = s.cnt[(size_t)row], p0 = s.ptr[(size_t)row], p1 = s.ptr[(size_t)row + 1];
+            const int64_t sl = std::max<int64_t>(cdiv(c, g), 1);
+            for (int k = 0; k < g; k++) {
+                const int64_t j0 = std::min(p0 + k * sl, p1), j1 = std::min(j0 + sl, p1), m = j1 - j0;
+                const int64_t mode = m <= inl_max ? m : kModeList;
+                const int64_t meta = (k == 0 ? 1 : 0) | ((int64_t)g << 1) | (mode << 6) | (c << 9);
+                int32_t *d = desc.data() + base + ((size_t)rnd * ng + (size_t)(first + k)) * slot_w;
+                d[0] = (int32_t)row;
+                d[1] = (int32_t)meta;
+                if (n > 0) {
+                    const bool inl = mode != kModeList;
+                    d[2] = inl ? 0 : (int32_t)j0;
+                    d[3] = inl ? 0 : (int32_t)j1;
+                    for (int q = 0; q < inl_max; q++) {
+                        const int64_t jq = std::min(j0 + q, n - 1);
+                        if (inl && m > q)
+                            for (int cc = 0; cc < w; cc++) d[2 + q * w + cc] = cols[cc][(size_t)jq];
+                    }
+                }
+                int32_t &it = iters[ibase + (size_t)rnd];
+                it = std::max(it, (int32_t)m);
+            }
+        }
+    }
+}
+
+// the rounds of ONE class (into arrays of their own), padded to a multiple of pad_to rounds with idle rounds
+void class_rounds(const Side &s, int64_t n, const int32_t *const *cols, int w, int ng, int per_slice, int pad_to, int inl_max,
+                  const std::vector<int32_t> &class_rows, std::vector<int32_t> &d, std::vector<int32_t> &it) {
+    side_rounds(s, n, cols, w, ng, per_slice, pad_to, inl_max, class_rows, d, it);
+    const int64_t have = (int64_t)it.size();
+    const int64_t pad = ((-have) % pad_to + pad_to) % pad_to;
+    for (int64_t p = 0; p < pad; p++) {
+        for (int sl = 0; sl < ng; sl++) {
+            const int32_t slot[8] = {-1, 1 << 1, 0, 0, 0, 0, 0, 0};
+            d.insert(d.end(), slot, slot + 8);
+        }
+        it.push_back(0);
+    }
+}
+
+// run fn(0 .. count - 1) on up to `threads` threads
+template <typename F>
+void parallel_for(int count, int threads, F fn) {
+    threads = std::max(1, std::min(threads, count));
+    if (threads == 1) {
+        for (int i = 0; i < count; i++) fn(i);
+        return;
+    }
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= count) return;
+            fn(i);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+}
+
+InvPrefHostPlan *build(const int64_t *users, const int64_t *items, const float *scores, int64_t n, int64_t U, int64_t I,
+                       const InvPrefPlanParams &p, int threads) {
+    if (n < 0 || U <= 0 || I <= 0 || p.n_classes < 1 || p.n_classes > 8 || p.per_slice < 1 || p.item_per_slice < 1 ||
+        p.rounds_per_task < 1 || p.item_rounds_per_task < 1 || p.rows_per_stream_task < 1 ||
+        (p.lanes_per_group != 16 && p.lanes_per_group != 32 && p.lanes_per_group != 64) || (n > 0 && (!users || !items || !scores)))
+        return nullptr;
+    for (int64_t i = 0; i < n; i++)
+        if (users[i] < 0 || users[i] >= U || items[i] < 0 || items[i] >= I) return nullptr;
+    const int ng = kThreads / p.lanes_per_group, ncls = p.n_classes;
+    // a big minibatch spreads its independent pieces (two sides, then 2 x n_classes round lists) over threads
+    const int nt = n >= (1 << 18) ? std::max(1, threads) : 1;
+    Side us, is;
+    std::vector<int32_t> u_oth((size_t)n), u_pos((size_t)n), u_y((size_t)n), i_oth((size_t)n), i_pos((size_t)n);
+    parallel_for(2, nt, [&](int side) {
+        if (side == 0) {
+            sort_side(users, n, U, us);
+            for (int64_t j = 0; j < n; j++) {   // the sorted list's columns
+                const int32_t pu = us.perm[(size_t)j];
+                u_oth[(size_t)j] = (int32_t)items[pu];
+                u_pos[(size_t)j] = pu;
+                std::memcpy(&u_y[(size_t)j], scores + pu, 4);
+            }
+        } else {
+            sort_side(items, n, I, is);
+            for (int64_t j = 0; j < n; j++) {
+                const int32_t pi = is.perm[(size_t)j];
+                i_oth[(size_t)j] = (int32_t)users[pi];
+                i_pos[(size_t)j] = pi;
+            }
+        }
+    });
+    InvPrefHostPlan *hp = new InvPrefHostPlan();
+    std::vector<int32_t> &ud = hp->arr[0], &id = hp->arr[1], &uit = hp->arr[2];
+    const int32_t *ucols[3] = {u_oth.data(), u_pos.data(), u_y.data()};
+    const int32_t *icols[2] = {i_oth.data(), i_pos.data()};
+    // touched rows of every class, in increasing order
+    std::vector<std::vector<int32_t>> urows((size_t)ncls), irows((size_t)ncls);
+    for (int64_t r = 0; r < U; r++)
+        if (us.cnt[(size_t)r]) urows[(size_t)((r >> kClassShift) % ncls)].push_back((int32_t)r);
+    for (int64_t r = 0; r < I; r++)
+        if (is.cnt[(size_t)r]) irows[(size_t)((r >> kClassShift) % ncls)].push_back((int32_t)r);
+    std::vector<std::vector<int32_t>> cd((size_t)(2 * ncls)), cit((size_t)(2 * ncls));
+    parallel_for(2 * ncls, nt, [&](int q) {
+        const int c = q >> 1;
+        if ((q & 1) == 0)
+            class_rounds(us, n, ucols, 3, ng, p.per_slice, p.rounds_per_task, 2, urows[(size_t)c], cd[(size_t)q], cit[(size_t)q]);
+        else
+            class_rounds(is, n, icols, 2, ng, p.item_per_slice, p.item_rounds_per_task, p.push ? 0 : 3, irows[(size_t)c],
+                         cd[(size_t)q], cit[(size_t)q]);
+    });
+    int32_t cls[8][8];
+    std::memset(cls, 0, sizeof(cls));
+    int32_t defer_tail[8][2];
+    std::memset(defer_tail, 0, sizeof(defer_tail));
+    // untouched rows: streamed, no job
+    std::vector<int32_t> stream_u, stream_i;
+    for (int64_t r = 0; r < U; r++)
+        if (us.cnt[(size_t)r] == 0 && r >= p.user_lo && r < p.user_hi) stream_u.push_back((int32_t)r);
+    for (int64_t r = 0; r < I; r++)
+        if (is.cnt[(size_t)r] == 0) stream_i.push_back((int32_t)r);
+    std::vector<std::vector<int32_t>> s1((size_t)ncls), s2((size_t)ncls);
+    int32_t ub = 0, ib = 0;
+    std::vector<int32_t> n_ur((size_t)ncls), n_ir((size_t)ncls);
+    // every class's untouched rows: users, then items (a few untouched item rows are not worth one tiny task per class:
+    // class 0 streams them all then)
+    std::vector<std::vector<int32_t>> srows((size_t)ncls);
+    for (int32_t r : stream_u) srows[(size_t)((r >> kClassShift) % ncls)].push_back(r);
+    for (int32_t r : stream_i) srows[(size_t)(stream_i.size() > 8 * 64 ? (r >> kClassShift) % ncls : 0)].push_back(r | kItemBit);
+    for (int c = 0; c < ncls; c++) {
+        n_ur[(size_t)c] = (int32_t)cit[(size_t)(2 * c)].size();
+        n_ir[(size_t)c] = (int32_t)cit[(size_t)(2 * c + 1)].size();
+        ud.insert(ud.end(), cd[(size_t)(2 * c)].begin(), cd[(size_t)(2 * c)].end());
+        uit.insert(uit.end(), cit[(size_t)(2 * c)].begin(), cit[(size_t)(2 * c)].end());
+        id.insert(id.end(), cd[(size_t)(2 * c + 1)].begin(), cd[(size_t)(2 * c + 1)].end());
+        std::vector<int32_t>().swap(cd[(size_t)(2 * c)]);
+        std::vector<int32_t>().swap(cd[(size_t)(2 * c + 1)]);
+        const std::vector<int32_t> &rows = srows[(size_t)c];
+        int64_t k = (int64_t)std::nearbyint(p.stream_split * (double)rows.size());   // (Python's round(): ties to even)
+        if (p.fill_cap) {   // (per class: the grid is n_classes x the longest class)
+            const int64_t room = p.fill_cap / ncls - cdiv(n_ur[(size_t)c], p.rounds_per_task);
+            k = std::min<int64_t>((int64_t)rows.size(), std::max<int64_t>(k, room * p.rows_per_stream_task));
+        }
+        k = std::max<int64_t>(0, std::min<int64_t>(k, (int64_t)rows.size()));
+        // inside each launch's share: item rows first, USER rows last (InvPrefRowPlan.defer_tail)
+        for (int li = 0; li < 2; li++) {
+            const int64_t a = li == 0 ? 0 : k, b = li == 0 ? k : (int64_t)rows.size();
+            std::vector<int32_t> &dst = li == 0 ? s1[(size_t)c] : s2[(size_t)c];
+            int32_t nu = 0;
+            for (int64_t q = a; q < b; q++)
+                if (rows[(size_t)q] & kItemBit) dst.push_back(rows[(size_t)q]);
+            for (int64_t q = a; q < b; q++)
+                if (!(rows[(size_t)q] & kItemBit)) { dst.push_back(rows[(size_t)q]); nu++; }
+            defer_tail[c][li] = nu;
+        }
+    }
+    for (int c = 0; c < ncls; c++) {
+        cls[c][0] = ub; cls[c][1] = n_ur[(size_t)c]; ub += n_ur[(size_t)c];
+        cls[c][4] = ib; cls[c][5] = n_ir[(size_t)c]; ib += n_ir[(size_t)c];
+    }
+    int32_t sb = 0;
+    for (int c = 0; c < ncls; c++) { cls[c][2] = sb; cls[c][3] = (int32_t)s1[(size_t)c].size(); sb += cls[c][3]; }
+    for (int c = 0; c < ncls; c++) { cls[c][6] = sb; cls[c][7] = (int32_t)s2[(size_t)c].size(); sb += cls[c][7]; }
+    std::vector<int32_t> &ul = hp->arr[3], &il = hp->arr[4], &sr = hp->arr[5], &ps = hp->arr[6];
+    ul.resize((size_t)n * 4);
+    il.resize((size_t)n * 2);
+    for (int64_t j = 0; j < n; j++) {
+        ul[(size_t)j * 4 + 0] = u_oth[(size_t)j]; ul[(size_t)j * 4 + 1] = u_pos[(size_t)j];
+        ul[(size_t)j * 4 + 2] = u_y[(size_t)j]; ul[(size_t)j * 4 + 3] = 0;
+        il[(size_t)j * 2 + 0] = i_oth[(size_t)j]; il[(size_t)j * 2 + 1] = i_pos[(size_t)j];
+    }
+    for (int c = 0; c < ncls; c++) sr.insert(sr.end(), s1[(size_t)c].begin(), s1[(size_t)c].end());
+    for (int c = 0; c < ncls; c++) sr.insert(sr.end(), s2[(size_t)c].begin(), s2[(size_t)c].end());
+    if (p.push) {
+        ps.resize((size_t)n);
+        for (int64_t j = 0; j < n; j++) ps[(size_t)is.perm[(size_t)j]] = (int32_t)j;   // argsort of the item order
+    }
+    hp->arr[7].assign(&cls[0][0], &cls[0][0] + 64);
+    hp->arr[8].assign(&defer_tail[0][0], &defer_tail[0][0] + 16);
+    return hp;
+}
+
+}  // namespace
+
+extern "C" {
+
+InvPrefHostPlan *invpref_plan_build(const int64_t *users, const int64_t *items, const float *scores, int64_t n,
+                                    int64_t user_num, int64_t item_num, const InvPrefPlanParams *params) {
+    if (!params) return nullptr;
+    try {
+        const int hw = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        return build(users, items, scores, n, user_num, item_num, *params, hw);
+    } catch (...) {
+        return nullptr;
+    }
+}
+
+int64_t invpref_plan_array(const InvPrefHostPlan *plan, int32_t which, const int32_t **data) {
+    if (!plan || which < 0 || which > 8) return -1;
+    if (data) *data = plan->arr[which].data();
+    return (int64_t)plan->arr[which].size();
+}
+
+void invpref_plan_free(InvPrefHostPlan *plan) { delete plan; }
+
+int invpref_plan_build_many(const int64_t *users, const int64_t *items, const float *scores, const int64_t *offsets,
+                            int32_t count, int64_t user_num, int64_t item_num, const InvPrefPlanParams *params,
+                            InvPrefHostPlan **out, int32_t n_threads) {
+    if (!offsets || !params || !out || count < 0) return -1;
+    int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    nt = std::max(1, std::min(nt, (int)count));
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int k = next.fetch_add(1);
+            if (k >= count) return;
+            const int64_t lo = offsets[k], n = offsets[k + 1] - lo;
+            out[k] = invpref_plan_build(users + lo, items + lo, scores + lo, n, user_num, item_num, params + k);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    for (int k = 0; k < count; k++)
+        if (!out[k]) return -2;
+    return 0;
+}
+
+}  // extern "C"

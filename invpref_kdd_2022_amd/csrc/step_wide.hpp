@@ -297,7 +297,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
     const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
 
     STAMP(0);
-    int4 d = a.desc[(r0 * NG + grp) * 2], d1 = a.desc[(r0 * NG + grp) * 2 + 1];
+    int4 d = a.desc[(r0 * NG + grp) * 2];   // (the inline interactions of the descriptor's second half are read back from memory)
     STAMP(1);
 
     constexpr bool SH = Shared<EMAX, EVL2>::value;   // one accumulator set for both products
@@ -319,7 +319,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
 #endif
 
     for (int r = r0; r < r0 + nr; r++) {
-        const int4 dd = d, dd1 = d1;
+        const int4 dd = d;
         const int row = dd.x, meta = dd.y;
         const bool active = row >= 0, leader = meta & 1;
         const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
@@ -487,7 +487,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             }
         }
         if (r == r0) STAMP(4);
-        if (r + 1 < r0 + nr) { d = a.desc[((r + 1) * NG + grp) * 2]; d1 = a.desc[((r + 1) * NG + grp) * 2 + 1]; }
+        if (r + 1 < r0 + nr) d = a.desc[((r + 1) * NG + grp) * 2];
         const float cnt = (float)(meta >> 9);
         if (active && leader) {   // regulariser reports: the user's rows count once per interaction
             float s2 = 0.f, s1 = 0.f;
@@ -631,7 +631,7 @@ __device__ __forceinline__ void item_task_wide(const DevTables &t, const StepArg
     }
     const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
     STAMP(0);
-    int4 d = a.desc[(r0 * NG + grp) * 2], d1 = a.desc[(r0 * NG + grp) * 2 + 1];
+    int4 d = a.desc[(r0 * NG + grp) * 2];   // (the inline interactions of the descriptor's second half are read back from memory)
     STAMP(1);
     f32x4 accE[EVL2 ? TILES : 1][4];
 #pragma unroll
@@ -639,8 +639,8 @@ __device__ __forceinline__ void item_task_wide(const DevTables &t, const StepArg
 #pragma unroll
         for (int c = 0; c < 4; c++) accE[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int r = r0; r < r0 + nr; r++) {
-        const int4 dd = d, dd1 = d1;
-        if (r + 1 < r0 + nr) { d = a.desc[((r + 1) * NG + grp) * 2]; d1 = a.desc[((r + 1) * NG + grp) * 2 + 1]; }
+        const int4 dd = d;
+        if (r + 1 < r0 + nr) d = a.desc[((r + 1) * NG + grp) * 2];
         const int row = dd.x, meta = dd.y;
         const bool active = row >= 0, leader = meta & 1;
         const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;

@@ -154,11 +154,116 @@ def _launch1_makespan(cnt, ng: int, per_slice: int, resident: int, c0: float, ti
     return max(slots) if durs else 0.0
 
 
+class PlanParamsStruct(C.Structure):
+    """struct InvPrefPlanParams (include/invpref_plan.h)"""
+    _fields_ = [('lanes_per_group', C.c_int32), ('per_slice', C.c_int32), ('item_per_slice', C.c_int32),
+                ('rounds_per_task', C.c_int32), ('item_rounds_per_task', C.c_int32), ('n_classes', C.c_int32),
+                ('rows_per_stream_task', C.c_int32), ('push', C.c_int32), ('user_lo', C.c_int32), ('user_hi', C.c_int32),
+                ('fill_cap', C.c_int32), ('stream_split', C.c_double)]
+
+
+_NATIVE = None
+_NATIVE_ARRAYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list', 'stream_rows', 'push_slot', 'cls',
+                  'defer_tail')
+
+
+def _native_lib():
+    """the host library with the native plan builder (include/invpref_plan.h), or None when it is not built"""
+    global _NATIVE
+    if _NATIVE is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libinvpref_ingest.so')
+        try:
+            L = C.CDLL(path)
+            L.invpref_plan_build.restype = C.c_void_p
+            L.invpref_plan_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                             C.POINTER(PlanParamsStruct)]
+            L.invpref_plan_array.restype = C.c_int64
+            L.invpref_plan_array.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(C.c_int32))]
+            L.invpref_plan_free.argtypes = [C.c_void_p]
+            L.invpref_plan_build_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                                                  C.c_int64, C.POINTER(PlanParamsStruct), C.POINTER(C.c_void_p), C.c_int32]
+            _NATIVE = L
+        except (OSError, AttributeError):
+            _NATIVE = False
+    return _NATIVE or None
+
+
+def _params_struct(r: dict) -> PlanParamsStruct:
+    return PlanParamsStruct(r['lanes'], r['per_slice'], r['item_per_slice'], r['rounds_per_task'], r['item_rounds_per_task'],
+                            r['n_classes'], r['rows_per_stream_task'], int(r['push']), r['user_lo'], r['user_hi'], r['fill_cap'],
+                            r['stream_split'])
+
+
+def _plan_from_handle(L, h, r: dict) -> dict:
+    """the plan dict build_row_plan returns, from a native handle (which is released)"""
+    out = {}
+    try:
+        for which, name in enumerate(_NATIVE_ARRAYS):
+            ptr = C.POINTER(C.c_int32)()
+            ln = L.invpref_plan_array(h, which, C.byref(ptr))
+            out[name] = np.ctypeslib.as_array(ptr, shape=(ln,)).copy() if ln > 0 else np.zeros(0, np.int32)
+    finally:
+        L.invpref_plan_free(h)
+    ng = THREADS // r['lanes']
+    cls = out['cls'].reshape(8, 8)
+    sb = int(cls[:, 3].sum() + cls[:, 7].sum())
+    return dict(n=r['n'], lanes_per_group=r['lanes'], factor_num=r['factor_num'], per_slice=r['per_slice'],
+                item_per_slice=r['item_per_slice'], user_rounds_per_task=r['rounds_per_task'],
+                item_rounds_per_task=r['item_rounds_per_task'], user_desc=out['user_desc'].reshape(-1, ng, 8),
+                item_desc=out['item_desc'].reshape(-1, ng, 8), user_round_iters=out['user_round_iters'],
+                user_list=out['user_list'], item_list=out['item_list'],
+                push_slot=(out['push_slot'] if r['push'] else None), push=r['push'], stream_rows=out['stream_rows'], n_stream=sb,
+                rows_per_stream_task=r['rows_per_stream_task'], rows_per_stream_task2=r['rows_per_stream_task2'],
+                stream_split=(float(cls[:, 3].sum()) / sb if (r['fill_cap'] and sb) else r['stream_split']),
+                n_classes=r['n_classes'], cls=cls.copy(), defer_tail=out['defer_tail'].reshape(8, 2).copy())
+
+
+def _native_build(users, items, scores, user_num, item_num, r: dict) -> dict:
+    L = _native_lib()
+    users, items = np.ascontiguousarray(users, np.int64), np.ascontiguousarray(items, np.int64)
+    scores = np.ascontiguousarray(scores, np.float32)
+    ps = _params_struct(r)
+    h = L.invpref_plan_build(users.ctypes.data, items.ctypes.data, scores.ctypes.data, len(users), user_num, item_num,
+                             C.byref(ps))
+    if not h:
+        raise ValueError('native plan builder: invalid arguments (row ids out of range?)')
+    return _plan_from_handle(L, h, r)
+
+
+def build_row_plans(users: np.ndarray, items: np.ndarray, scores: np.ndarray, offsets, user_num: int, item_num: int,
+                    threads: int = 0, **kw) -> list:
+    """The plans of many minibatches -- minibatch k = interactions [offsets[k], offsets[k + 1]) of the same arrays, what
+    utils.mini_batch (utils.py:12-19) yields -- each with build_row_plan's parameters resolved for it; the arrays are built
+    by the native builder on a thread pool (one call).  Falls back to build_row_plan per minibatch without the library."""
+    users, items = np.ascontiguousarray(users, np.int64), np.ascontiguousarray(items, np.int64)
+    scores = np.ascontiguousarray(scores, np.float32)
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    nb = len(offsets) - 1
+    L = _native_lib()
+    if L is None or kw.get('native') is False or os.environ.get('INVPREF_PLAN_NATIVE', '1') == '0':
+        return [build_row_plan(users[offsets[k]:offsets[k + 1]], items[offsets[k]:offsets[k + 1]],
+                               scores[offsets[k]:offsets[k + 1]], user_num, item_num, **kw) for k in range(nb)]
+    kw.pop('native', None)
+    res = [build_row_plan(users[offsets[k]:offsets[k + 1]], items[offsets[k]:offsets[k + 1]], scores[offsets[k]:offsets[k + 1]],
+                          user_num, item_num, _resolve_only=True, **kw) for k in range(nb)]
+    params = (PlanParamsStruct * nb)(*[_params_struct(r) for r in res])
+    handles = (C.c_void_p * nb)()
+    rc = L.invpref_plan_build_many(users.ctypes.data, items.ctypes.data, scores.ctypes.data, offsets.ctypes.data, nb, user_num,
+                                   item_num, params, handles, int(threads))
+    if rc != 0:
+        for h in handles:
+            if h:
+                L.invpref_plan_free(h)
+        raise ValueError('native plan builder: invalid arguments (row ids out of range?)')
+    return [_plan_from_handle(L, handles[k], res[k]) for k in range(nb)]
+
+
 def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, user_num: int, item_num: int,
                    factor_num: int = 64, per_slice: int | None = None, item_per_slice: int | None = None,
                    rounds_per_task: int | None = None, item_rounds_per_task: int | None = None, user_range=None,
                    n_classes: int | None = None, rows_per_stream_task: int | None = None,
-                   stream_split: float | None = None, push: bool | None = None, env_num: int | None = None) -> dict:
+                   stream_split: float | None = None, push: bool | None = None, env_num: int | None = None,
+                   native: bool | None = None, _resolve_only: bool = False) -> dict:
     """users/items/scores: ONE minibatch (or this rank's slice of it); scores as the fp32 labels.
     factor_num: decides the row layout the plan is built for (lanes_of).
     per_slice / item_per_slice: interactions one group walks for a user / an item row (more interactions: more slices).
@@ -267,11 +372,6 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         raise ValueError(f'a row with {max(ucnt.max(), icnt.max())} interactions in one minibatch overflows the job descriptor')
     if max(user_num, item_num) >= ITEM_BIT:
         raise ValueError('too many rows')
-    pu = np.argsort(users, kind='stable')
-    pi = np.argsort(items, kind='stable')
-    ybits = scores.view(np.int32)
-    ucols = (items[pu].astype(np.int32), pu.astype(np.int32), ybits[pu])
-    icols = (users[pi].astype(np.int32), pi.astype(np.int32))
     untouched_u = ucnt == 0
     if user_range is not None:
         untouched_u[:user_range[0]] = False
@@ -281,7 +381,6 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     if n_classes is None:
         n_classes = int(os.environ.get('INVPREF_PLAN_CLASSES', str(N_CLASSES)))
     n_classes = max(1, min(8, n_classes))
-    ucls, icls = row_class(np.arange(user_num), n_classes), row_class(np.arange(item_num), n_classes)
     if stream_split is None and 'INVPREF_PLAN_STREAM_SPLIT' in os.environ:
         stream_split = float(os.environ['INVPREF_PLAN_STREAM_SPLIT'])
     n_stream = len(stream_u) + len(stream_i)
@@ -295,6 +394,26 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         bias = float(os.environ.get('INVPREF_PLAN_EVAL_COST', '3.0'))
         s1 = (12.0 * ti - 12.0 * tu - bias * n + 12.0 * n_stream) / 24.0
         stream_split = min(1.0, max(0.0, s1 / n_stream)) if n_stream else 0.0
+    # ---- every parameter is resolved: the arrays themselves come from the native builder (csrc/invpref_plan.cpp, the same
+    # arrays byte for byte: tests/test_plan_native.py) unless INVPREF_PLAN_NATIVE=0 or `_resolve_only`
+    resolved = dict(lanes=lanes, per_slice=int(per_slice), item_per_slice=int(item_per_slice),
+                    rounds_per_task=int(rounds_per_task), item_rounds_per_task=int(item_rounds_per_task),
+                    n_classes=int(n_classes), rows_per_stream_task=int(rows_per_stream_task),
+                    rows_per_stream_task2=int(rows_per_stream_task2), stream_split=float(stream_split), fill_cap=int(fill_cap),
+                    push=bool(push), user_lo=0 if user_range is None else int(user_range[0]),
+                    user_hi=int(user_num) if user_range is None else int(user_range[1]), factor_num=factor_num, n=n)
+    if _resolve_only:
+        return resolved
+    if native is None:
+        native = os.environ.get('INVPREF_PLAN_NATIVE', '1') != '0'
+    if native and _native_lib() is not None:
+        return _native_build(users, items, scores, user_num, item_num, resolved)
+    pu = np.argsort(users, kind='stable')
+    pi = np.argsort(items, kind='stable')
+    ybits = scores.view(np.int32)
+    ucols = (items[pu].astype(np.int32), pu.astype(np.int32), ybits[pu])
+    icols = (users[pi].astype(np.int32), pi.astype(np.int32))
+    ucls, icls = row_class(np.arange(user_num), n_classes), row_class(np.arange(item_num), n_classes)
     du_parts, it_parts, di_parts, s1_parts, s2_parts = [], [], [], [], []
     cls = np.zeros((8, 8), np.int32)
     defer_tail = np.zeros((8, 2), np.int32)

@@ -340,9 +340,14 @@ class _InvPrefTrainManager:
         if hit is None:
             if len(self._batch_plans) >= self._BATCH_PLAN_CACHE_MAX:
                 self._batch_plans.clear()
-            self._batch_plans[key] = 1          # first sighting: remember it, run plan-free
-            return None
-        if hit == 1:                            # second sighting: invert the scatter pattern once (host side)
+            # first sighting: with the native builder a plan costs about a millisecond (and the ids' trip to the host), so it
+            # is made at once -- INVPREF_BATCH_PLAN_AT=2 waits for the second sighting (a caller that never repeats a
+            # minibatch pays nothing for plans it would not reuse) and runs the first one plan-free
+            if os.environ.get('INVPREF_BATCH_PLAN_AT', '1') != '1' or planlib._native_lib() is None:
+                self._batch_plans[key] = 1
+                return None
+            hit = 1
+        if hit == 1:                            # invert the scatter pattern once (host side)
             hit = planlib.upload(planlib.build_row_plan(users.cpu().numpy(), items.cpu().numpy(),
                                                         scores.float().cpu().numpy(), self.model.user_num,
                                                         self.model.item_num, factor_num=self.model.factor_num,
@@ -380,13 +385,18 @@ class _InvPrefTrainManager:
             t0 = time.perf_counter()
             u, v = self.users_tensor.cpu().numpy(), self.items_tensor.cpu().numpy()
             y = self.scores_tensor.cpu().numpy()
-            self._plans = []
-            for lo, n, *_ in self._raw_batches:
-                pl = planlib.build_row_plan(u[lo:lo + n], v[lo:lo + n], y[lo:lo + n], self.model.user_num,
-                                            self.model.item_num, factor_num=self.model.factor_num,
-                                            user_range=self.shard.user_range(self.model.user_num),
-                                            env_num=getattr(self.model, 'env_num', 0))
-                self._plans.append(planlib.upload(pl, self.device))
+            # every minibatch's plan in one call: parameters resolved per minibatch, the arrays built natively on a thread
+            # pool (csrc/invpref_plan.cpp; plan.py's numpy builder is the reference implementation, INVPREF_PLAN_NATIVE=0)
+            offs = np.array([b[0] for b in self._raw_batches] + [self._raw_batches[-1][0] + self._raw_batches[-1][1]], np.int64)
+            contiguous = all(offs[k] + self._raw_batches[k][1] == offs[k + 1] for k in range(len(self._raw_batches)))
+            kw = dict(factor_num=self.model.factor_num, user_range=self.shard.user_range(self.model.user_num),
+                      env_num=getattr(self.model, 'env_num', 0))
+            if contiguous:
+                pls = planlib.build_row_plans(u, v, y, offs, self.model.user_num, self.model.item_num, **kw)
+            else:
+                pls = [planlib.build_row_plan(u[lo:lo + n], v[lo:lo + n], y[lo:lo + n], self.model.user_num,
+                                              self.model.item_num, **kw) for lo, n, *_ in self._raw_batches]
+            self._plans = [planlib.upload(pl, self.device) for pl in pls]
             self.plan_build_s = time.perf_counter() - t0     # host-side, once per run (reported by bench.py)
         # Deferred dense Adam on untouched user rows (include/invpref_hip.h): inside a replayed run of
         # epochs a user row the minibatch does not touch is left alone -- its zero-gradient updates are replayed, exactly,

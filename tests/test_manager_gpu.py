@@ -95,11 +95,14 @@ def test_g4_yahoo_like_trajectory_through_manager():
     assert sum(cnts[0].values()) == len(data)
 
 
-def test_reference_loop_through_train_a_batch_is_planned_from_its_second_epoch():
+@pytest.mark.parametrize('plan_at', ['1', '2'])
+def test_reference_loop_through_train_a_batch_is_planned_from_its_second_epoch(monkeypatch, plan_at):
     """The reference's own epoch loop (train.py:204-233: `for batch in mini_batch(...)`: train_a_batch on slices of the
-    resident tensors) driven from outside the manager: the first epoch runs plan-free (float-atomic scatter-add), every
-    later one the planned fused step -- the row plans are cached by the identity of the slices -- and the losses follow the
-    reference's recorded trajectory (golden g4) at 1e-5."""
+    resident tensors) driven from outside the manager: every minibatch runs the planned fused step from its FIRST sighting
+    (the native plan builder makes that cheap; INVPREF_BATCH_PLAN_AT=2: the first epoch plan-free -- float-atomic
+    scatter-add -- and planned from the second) -- the row plans are cached by the identity of the slices -- and the losses
+    follow the reference's recorded trajectory (golden g4) at 1e-5."""
+    monkeypatch.setenv('INVPREF_BATCH_PLAN_AT', plan_at)
     z = np.load(os.path.join(G, 'g4_yahoo_like_traj.npz'))
     U, I, E, D, bs, epochs, seed = [int(x) for x in z['meta']]
     data = synth.yahoo_like(seed)
@@ -119,14 +122,14 @@ def test_reference_loop_through_train_a_batch_is_planned_from_its_second_epoch()
                                   mgr.sample_weights[sl], mgr.alpha)
             rows.append([d[k] for k in LOSS_KEYS])
         trace.append(np.mean(np.array(rows, np.float64), axis=0))
-        assert mgr.planned_batch_steps == ep * len(rows)      # epoch 0 plan-free, then every step planned
+        assert mgr.planned_batch_steps == (ep + (plan_at == '1')) * len(rows)   # (plan_at 2: epoch 0 plan-free)
     np.testing.assert_allclose(np.array(trace)[:, [0, 1, 2, 5]], z['loss_trace'][:3, [0, 1, 2, 5]], rtol=1e-5)
     # a tensor written in place is a different minibatch: its plan is not reused
     mgr.scores_tensor[:bs] = 1 - mgr.scores_tensor[:bs]
     before = mgr.planned_batch_steps
     mgr.train_a_batch(mgr.users_tensor[:bs], mgr.items_tensor[:bs], mgr.scores_tensor[:bs], mgr.envs[:bs],
                       mgr.sample_weights[:bs], mgr.alpha)
-    assert mgr.planned_batch_steps == before
+    assert mgr.planned_batch_steps == before + (plan_at == '1')   # (a new minibatch: planned anew, or plan-free once)
 
 
 def test_g12_train_control_flow_matches_reference():

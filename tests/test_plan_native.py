@@ -1,0 +1,77 @@
+"""CPU: the native row-plan builder (csrc/invpref_plan.cpp, include/invpref_plan.h) produces the arrays of plan.py's numpy
+reference implementation BYTE FOR BYTE -- every array of the plan, over a randomised sweep of shapes and plan parameters,
+the Yahoo / MovieLens / MIND-shaped defaults, and the many-minibatch entry point."""
+import numpy as np
+import pytest
+
+from invpref_kdd_2022_amd import build, plan as planlib, synth
+
+KEYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list', 'stream_rows', 'push_slot', 'cls', 'defer_tail')
+SCALARS = ('n', 'lanes_per_group', 'per_slice', 'item_per_slice', 'user_rounds_per_task', 'item_rounds_per_task', 'n_stream',
+           'rows_per_stream_task', 'rows_per_stream_task2', 'n_classes', 'push', 'stream_split')
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _lib():
+    build.build_ingest()
+    assert planlib._native_lib() is not None
+
+
+def same(a: dict, b: dict):
+    for k in SCALARS:
+        assert a[k] == b[k], k
+    for k in KEYS:
+        if a[k] is None or b[k] is None:
+            assert a[k] is None and b[k] is None, k
+            continue
+        x, y = np.asarray(a[k]), np.asarray(b[k])
+        assert x.shape == y.shape and x.dtype == y.dtype == np.int32, k
+        np.testing.assert_array_equal(x, y, err_msg=k)
+
+
+@pytest.mark.parametrize('seed', range(60))
+def test_native_plan_equals_numpy_plan_on_random_shapes(seed):
+    rs = np.random.RandomState(2000 + seed)
+    U, I = int(rs.choice([3, 17, 60, 300, 5000])), int(rs.choice([2, 9, 40, 150, 2000]))
+    D = int(rs.choice([4, 30, 64, 100, 128, 256]))
+    B = int(rs.choice([0, 1, 15, 16, 17, 100, 700, 3000, 20000]))
+    u = rs.randint(0, U, B) if rs.randint(2) else rs.randint(0, max(1, U // 8), B)
+    v = rs.randint(0, I, B)
+    y = rs.randint(0, 5, B).astype(np.float32)
+    lo = int(rs.randint(0, U)) if rs.randint(2) else 0
+    kw = dict(factor_num=D, user_range=(lo, int(rs.randint(lo, U)) + 1) if rs.randint(2) else None)
+    if rs.randint(3):   # explicit parameters; otherwise the plan's own defaults
+        kw.update(per_slice=int(rs.choice([1, 2, 3, 8, 16])), item_per_slice=int(rs.choice([1, 2, 3, 5, 40])),
+                  rounds_per_task=int(rs.choice([1, 2, 3])), item_rounds_per_task=int(rs.choice([1, 2, 3])),
+                  n_classes=int(rs.choice([1, 3, 8])), stream_split=float(rs.choice([0.0, 0.37, 0.5, 1.0])),
+                  push=bool(rs.randint(2)), rows_per_stream_task=int(rs.choice([1, 16, 200])))
+    else:
+        kw.update(env_num=int(rs.choice([1, 4, 8, 16])))
+    same(planlib.build_row_plan(u, v, y, U, I, native=True, **kw), planlib.build_row_plan(u, v, y, U, I, native=False, **kw))
+
+
+@pytest.mark.parametrize('shape', [(15400, 1000, 4, 64, 8192, True), (6040, 3706, 8, 128, 65536, False),
+                                   (50000, 51283, 16, 256, 32768, False)], ids=['yahoo', 'movielens', 'mind_share'])
+def test_native_plan_equals_numpy_plan_at_the_bench_shapes(shape):
+    U, I, E, D, B, zipf = shape
+    d = synth.yahoo_like()[:B] if zipf else synth.interactions(3, U, I, B, implicit=True)
+    kw = dict(factor_num=D, env_num=E)
+    same(planlib.build_row_plan(d[:, 0], d[:, 1], d[:, 2], U, I, native=True, **kw),
+         planlib.build_row_plan(d[:, 0], d[:, 1], d[:, 2], U, I, native=False, **kw))
+
+
+def test_many_minibatches_in_one_call():
+    d = synth.yahoo_like()
+    n = len(d)
+    offs = np.arange(0, n + 8192, 8192).clip(max=n)
+    many = planlib.build_row_plans(d[:, 0], d[:, 1], d[:, 2], offs, 15400, 1000, factor_num=64, env_num=4)
+    assert len(many) == len(offs) - 1 == 31
+    for k in (0, 7, 30):
+        lo, hi = offs[k], offs[k + 1]
+        same(many[k], planlib.build_row_plan(d[lo:hi, 0], d[lo:hi, 1], d[lo:hi, 2], 15400, 1000, factor_num=64, env_num=4,
+                                             native=False))
+
+
+def test_native_builder_rejects_out_of_range_rows():
+    with pytest.raises(ValueError):
+        planlib.build_row_plan(np.array([5]), np.array([0]), np.array([1.0], np.float32), 3, 3, native=True)

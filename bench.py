@@ -176,7 +176,9 @@ def cpu_baseline():
             'value_one_core': CLUSTER_INTERVAL * N_PER_GPU / (CLUSTER_INTERVAL * tm1 + te1)}
 
 
-def build_manager(dev, rank, world, shard_mode=None):
+def build_manager(dev, rank, world, shard_mode=None, random_sort=True):
+    """random_sort: the reference's DEFAULT E-step path (cluster_use_random_sort=True, train.py:24, :192-196): every E-step
+    draws a permutation index per interaction on the host (the reference's own numpy stream) and the device unranks it."""
     import numpy as np
     import torch
     from invpref_kdd_2022_amd import synth
@@ -192,7 +194,7 @@ def build_manager(dev, rank, world, shard_mode=None):
     mgr = ImplicitTrainManager(
         model=model, evaluator=StubEvaluator(), device=dev, training_data=torch.from_numpy(data).to(dev),
         batch_size=B_PER_GPU * world, epochs=10 ** 9, cluster_interval=CLUSTER_INTERVAL, evaluate_interval=10 ** 9,
-        use_class_re_weight=True, use_recommend_re_weight=False, cluster_use_random_sort=False,
+        use_class_re_weight=True, use_recommend_re_weight=False, cluster_use_random_sort=random_sort,
         rank=rank, world_size=world, **YAHOO)
     mgr.stat_envs()
     return mgr
@@ -425,18 +427,22 @@ def other_configs(dev):
 def roofline_large(dev):
     """SURVEY.md 8(d) "Roofline launch": the same fused step on cache-exceeding launches -- uniformly random interactions
     over tables of 400 000 users x 100 000 items (256 MB .. 1 GB per flat buffer, four to five buffers: far beyond the
-    256 MiB Infinity Cache), D in {64, 128, 256} with E = 4 / 8 / 16.  INVPREF_BENCH_LARGE_LOG2N (default 22 / 21 / 20 for
-    the three row lengths; 24 = SURVEY's size where the host-side plan build is affordable)."""
-    res = {}
-    forced = os.environ.get('INVPREF_BENCH_LARGE_LOG2N')
-    for Dl, El, lg in ((64, 4, 22), (128, 8, 21), (256, 16, 20)):
-        lg = int(forced) if forced else lg
-        r = step_bench(dev, 400000, 100000, El, Dl, 1 << lg, 2, seed=5 + Dl)
+    256 MiB Infinity Cache), D in {64, 128, 256} with E = 4 / 8 / 16, 2^24 interactions per launch (SURVEY's size;
+    INVPREF_BENCH_LARGE_LOG2N for another; the plan of such a launch is a few seconds of native host work)."""
+    res, small = {}, {}
+    lg = int(os.environ.get('INVPREF_BENCH_LARGE_LOG2N', '24'))   # SURVEY 8(d): one launch over 2^24 uniform-random rows
+    keep = ('frac', 'achieved', 'ms_per_step', 'algorithmic_bytes_per_step', 'shape', 'plan_build_s')
+    for Dl, El, lg_r03 in ((64, 4, 22), (128, 8, 21), (256, 16, 20)):
+        r = step_bench(dev, 400000, 100000, El, Dl, 1 << lg, 1, seed=5 + Dl)
         r['kernel'] = 'the fused M-step + Adam step (same kernels as the headline)'
         res[f'D{Dl}_E{El}'] = r
+        # (the sizes rounds 2 and 3 reported -- 2^22 / 2^21 / 2^20 interactions, two minibatches -- for continuity: with 10 to
+        #  40 times fewer interactions per table row the Adam stream weighs more and the evaluation less)
+        small[f'D{Dl}_E{El}'] = {kk: vv for kk, vv in step_bench(dev, 400000, 100000, El, Dl, 1 << lg_r03, 2, seed=5 + Dl).items()
+                                 if kk in keep}
     head = dict(res['D64_E4'])
-    head['sweep'] = {k: {kk: v[kk] for kk in ('frac', 'achieved', 'ms_per_step', 'algorithmic_bytes_per_step', 'shape')}
-                     for k, v in res.items()}
+    head['sweep'] = {k: {kk: v[kk] for kk in keep} for k, v in res.items()}
+    head['sweep_r03_sizes'] = small
     head['traffic'] = None
     return head
 
@@ -484,14 +490,10 @@ def estep_random_sort_timing(dev, n=20):
     return out
 
 
-def eval_timing(dev):
-    """SURVEY §8(f)-1: ImplicitTestManager.evaluate() on the Yahoo test shape (5 400 test users x 1 000 items,
-    top-k 3/5/7, test batch 1 024: Yahoo_InvPref_Implicit.py:43-48); the reference's CPU path took 4.8 s per call in
-    the survey container (SURVEY.md §6)."""
+def yahoo_test_loader():
+    """a data-loader stand-in of the Yahoo test shape: 5 400 test users x 1 000 items, 1 .. 32 train items to mask and 10
+    ground-truth items per user (Yahoo_InvPref_Implicit.py:43-48 evaluates top-k 3/5/7 in test batches of 1 024)"""
     import numpy as np
-    import torch
-    from invpref_kdd_2022_amd.evaluate import ImplicitTestManager
-    from invpref_kdd_2022_amd.models import InvPrefImplicit
     rs = np.random.RandomState(11)
     users = sorted(rs.choice(U, 5400, replace=False).tolist())
     mask = {u: set(rs.choice(I, rs.randint(1, 33), replace=False).tolist()) for u in users}
@@ -504,8 +506,81 @@ def eval_timing(dev):
         @staticmethod
         def user_mask_items(u):
             return mask[u]
+    return Loader()
+
+
+def end_to_end(dev, env_num, factor_num, epochs=200):
+    """What a user of the reference's Yahoo driver waits for (Yahoo_InvPref_Implicit.py:24-41, main(): :56-159; the loop:
+    train.py:282-342): manager construction, train(silent=True) for `epochs` epochs (the reference runs 1 000) with the real
+    ImplicitTestManager every 10 epochs, the E-step every 5 with the reference's default random tie-break -- wall seconds
+    from the constructor to train()'s return, split into where they go, and interactions per second over that wall."""
+    import numpy as np
+    import torch
+    from invpref_kdd_2022_amd import synth
+    from invpref_kdd_2022_amd.evaluate import ImplicitTestManager
+    from invpref_kdd_2022_amd.models import InvPrefImplicit
+    from invpref_kdd_2022_amd.train import ImplicitTrainManager
+    data = torch.from_numpy(synth.interactions(SEED, U, I, N_PER_GPU, implicit=True)).to(dev)
+    tabs = synth.tables(SEED + 7, U, I, env_num, factor_num)
+    loader = yahoo_test_loader()
+    torch.cuda.synchronize()
+    spent = {'evaluation': 0.0, 'graph_capture': 0.0}
+
+    def timed(fn, key):
+        def wrapped(*a, **k):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            out = fn(*a, **k)
+            torch.cuda.synchronize()
+            spent[key] += time.perf_counter() - t
+            return out
+        return wrapped
+    t0 = time.perf_counter()
+    model = InvPrefImplicit(U, I, env_num, factor_num, reg_only_embed=True, reg_env_embed=False)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in tabs.items()})
+    evaluator = ImplicitTestManager(model, loader, test_batch_size=1024, top_k_list=[3, 5, 7], use_item_pool=False)
+    np.random.seed(SEED)
+    mgr = ImplicitTrainManager(model=model, evaluator=evaluator, device=dev, training_data=data, batch_size=B_PER_GPU,
+                               epochs=epochs, cluster_interval=CLUSTER_INTERVAL, evaluate_interval=10,
+                               use_class_re_weight=True, use_recommend_re_weight=False, test_begin_epoch=0, **YAHOO)
+    evaluator.evaluate = timed(evaluator.evaluate, 'evaluation')
+    cap_graph, cap_estep = mgr._graph_for, mgr._estep_graph
+
+    def graph_for(n):   # (time only the calls that capture)
+        return cap_graph(n) if mgr._graph_key(n) in mgr._graphs else timed(cap_graph, 'graph_capture')(n)
+
+    def estep_graph(with_eps):
+        key = (mgr.state.p_views[0].data_ptr(), mgr.envs.data_ptr(), mgr.users_tensor.data_ptr(), with_eps)
+        return cap_estep(with_eps) if key in mgr._estep_graphs else timed(cap_estep, 'graph_capture')(with_eps)
+    mgr._graph_for, mgr._estep_graph = graph_for, estep_graph
+    t_ctor = time.perf_counter() - t0
+    (losses, _), (tests, test_epochs), (diffs, _, cluster_epochs) = mgr.train(silent=True)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    assert len(losses) == epochs and len(tests) == epochs // 10 + 1 and len(diffs) == epochs // CLUSTER_INTERVAL
+    assert all(np.isfinite(list(d.values())).all() for d in losses)
+    plan_s = float(getattr(mgr, 'plan_build_s', 0.0))
+    rest = wall - t_ctor - spent['evaluation'] - spent['graph_capture'] - plan_s
+    return {'wall_s': wall, 'epochs': epochs, 'interactions_per_s_over_wall': epochs * N_PER_GPU / wall,
+            'split_s': {'construction': t_ctor, 'plan_build': plan_s, 'graph_capture': spent['graph_capture'],
+                        'evaluation': spent['evaluation'], 'training_and_readbacks': rest},
+            'evaluations': len(tests), 'e_steps': len(diffs), 'env_num': env_num, 'factor_num': factor_num,
+            'cluster_use_random_sort': True,
+            'note': 'train(silent=True): epochs enqueued in runs up to the next evaluate / cluster event, losses / diff_num / '
+                    'env counts read back once at the end; the reference runs 1 000 epochs of this (same cadence)'}
+
+
+def eval_timing(dev):
+    """SURVEY §8(f)-1: ImplicitTestManager.evaluate() on the Yahoo test shape (5 400 test users x 1 000 items,
+    top-k 3/5/7, test batch 1 024: Yahoo_InvPref_Implicit.py:43-48); the reference's CPU path took 4.8 s per call in
+    the survey container (SURVEY.md §6)."""
+    import torch
+    from invpref_kdd_2022_amd.evaluate import ImplicitTestManager
+    from invpref_kdd_2022_amd.models import InvPrefImplicit
+    loader = yahoo_test_loader()
+    users = loader.all_test_users_by_sorted_list
     model = InvPrefImplicit(U, I, E, D).to(dev)
-    tm = ImplicitTestManager(model, Loader(), test_batch_size=1024, top_k_list=[3, 5, 7], use_item_pool=False)
+    tm = ImplicitTestManager(model, loader, test_batch_size=1024, top_k_list=[3, 5, 7], use_item_pool=False)
     tm.evaluate()                       # builds the CSR arrays from the python sets once
     torch.cuda.synchronize()
     ts = []
@@ -545,7 +620,16 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
 
-    # N > 1: BASELINE.json configs[3] as written -- row-sharded, whole flat gradient all-reduced
+    # N > 1: BASELINE.json configs[3] as written -- interactions row-sharded, ONE all-reduce of the whole flat gradient
+    # buffer per optimiser step; the reduce-scatter form and the user-sharded layout are timed after it
+    rccl_ranks = None
+    if world > 1:
+        os.environ['INVPREF_EXCHANGE'] = 'allreduce'
+        probe = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(probe)            # (through the backend the run uses: RCCL unless rehearsing on gloo)
+        torch.cuda.synchronize()
+        rccl_ranks = int(probe.item()) if torch.distributed.get_backend() == 'nccl' else 0
+        assert int(probe.item()) == torch.distributed.get_world_size() == world
     mgr = build_manager(dev, rank, world, 'rows' if world > 1 else None)
     dt, steps, warm_steps, graphs = timed_run(mgr, world, args.steps, args.warmup)
     inter = steps * B_PER_GPU * world
@@ -573,6 +657,13 @@ def main():
         knames = [kname]
         what = 'the whole optimiser step: gradient pass + all-reduce + stand-alone Adam'
     achieved = nbytes / (ms_step_dev * 1e-3) / 1e9
+    # the second byte model: what the step would have to move if user rows the minibatch does not touch
+    # were left alone (the exact deferred form exists -- INVPREF_DEFER=1, tests/test_deferred_gpu.py -- and measures
+    # SLOWER: profiles/r04/deferred_adam_ab.txt; the headline runs the dense form, so `frac` uses the dense bytes)
+    untouched = 0.0
+    if fused and getattr(mgr, '_plans', None):
+        untouched = sum(int(x) for dp in mgr._plans for x in dp.struct.defer_tail) / len(mgr._plans)
+    nbytes_touched = nbytes - 24 * 2 * D * untouched
     traffic, traffic_stamp = pmc_traffic_bytes(knames) if world == 1 else (None, None)
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_profile': traffic_stamp,
@@ -587,7 +678,12 @@ def main():
                               'roofline_large is the cache-exceeding launch',
                 'rocprofv3_avg_launch_ms': rocprof_avg_ms(knames) if world == 1 else None,   # (the committed profiles are 1-GPU runs)
                 'rocprofv3_note': 'sum of the average durations of the kernels of one step in the committed profile of this command',
-                'GBs_at_survey_unfused_pricing': bytes_survey / (ms_step_dev * 1e-3) / 1e9}
+                'GBs_at_survey_unfused_pricing': bytes_survey / (ms_step_dev * 1e-3) / 1e9,
+                'touched_rows_model': {'bytes_per_launch': nbytes_touched, 'untouched_user_rows_per_step': untouched,
+                                       'achieved': nbytes_touched / (ms_step_dev * 1e-3) / 1e9,
+                                       'frac': nbytes_touched / (ms_step_dev * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       'note': 'untouched user rows not counted (what deferred Adam would move); the run '
+                                               'itself is the dense form'}}
     out = {
         'metric': 'training interactions/sec, Yahoo-implicit InvPref', 'value': value, 'unit': 'interactions/s',
         'n_gpus': world, 'steps': steps, 'steps_requested': args.steps, 'warmup': warm_steps,
@@ -601,19 +697,21 @@ def main():
         'timed_path': 'graph' if graphs else 'eager', 'plan_build_s': getattr(mgr, 'plan_build_s', None),
         'roofline': roofline, 'detail': detail,
     }
+    out['rccl_ranks'] = rccl_ranks    # ranks that took part in an RCCL all-reduce in front of the run (None: single GPU)
     if world > 1:
-        # beside the headline (rows, reduce-scatter -> slice Adam -> all-gather): the literal all-reduce form of
-        # BASELINE.json configs[3], and the xGMI-first user-sharded layout
-        out['config']['parallelism'] = (f'rows-sharded x{world}, exchange {mgr.exchange}: '
-                                        + ('reduce-scatter(grad) + all-gather(param), ' if mgr.exchange == 'scatter' else '1 all-reduce, ')
-                                        + f'{4 * mgr.state.cap} B of flat buffer per step')
+        # the headline is the literal form BASELINE.json configs[3] names (rows + one all-reduce); beside it: the same
+        # split with the exchange as reduce-scatter -> Adam on the rank's slice -> all-gather, and the xGMI-first
+        # user-sharded layout.  UNMEASURED on hardware until a SCALE record exists.
+        out['config']['parallelism'] = (f'rows-sharded x{world}, exchange {mgr.exchange}: 1 all-reduce of the flat gradient per '
+                                        f'optimiser step ({4 * (mgr.state.n + 8 - mgr._ar_lo)} B)')
         del mgr
         torch.cuda.empty_cache()
-        os.environ['INVPREF_EXCHANGE'] = 'allreduce'
+        os.environ['INVPREF_EXCHANGE'] = 'scatter'
         mgr_a = build_manager(dev, rank, world, 'rows')
         dt_a, steps_a, _, _ = timed_run(mgr_a, world, args.steps, args.warmup)
-        out['detail']['rows_allreduce'] = {'value': steps_a * B_PER_GPU * world / dt_a, 'ms_per_step': dt_a / steps_a * 1e3,
-                                           'steps': steps_a, 'all_reduce_bytes': 4 * (mgr_a.state.n + 8 - mgr_a._ar_lo)}
+        out['detail']['rows_scatter'] = {'value': steps_a * B_PER_GPU * world / dt_a, 'ms_per_step': dt_a / steps_a * 1e3,
+                                         'steps': steps_a, 'exchange': 'reduce-scatter(grad) + all-gather(param)',
+                                         'flat_buffer_bytes': 4 * mgr_a.state.cap}
         del mgr_a
         torch.cuda.empty_cache()
         os.environ.pop('INVPREF_EXCHANGE', None)
@@ -627,6 +725,12 @@ def main():
         out['roofline_large'] = roofline_large(dev)
         out['detail']['configs'] = other_configs(dev)
         out['detail']['evaluation'] = eval_timing(dev)
+        est = estep_random_sort_timing(dev)
+        out['detail']['estep_random_sort_ms'] = est['estep_random_sort_ms']
+        out['detail']['estep_random_sort'] = est
+        out['detail']['end_to_end'] = {
+            'reference_yahoo_config_E2_D40': end_to_end(dev, 2, 40),
+            'baseline_config_E4_D64': end_to_end(dev, E, D)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     if rank == 0:

@@ -38,6 +38,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef WIDE_FENCE
 #define WIDE_FENCE 1   // scheduling fences inside the classifier loops of two-chunk rows (register pressure)
 #endif
+#ifndef WIDE_MFMA_FENCE
+#define WIDE_MFMA_FENCE 1   // (A/B knob) a fence between the row updates / stores and the MFMA block
+#endif
 #ifndef WIDE_FENCE_MASK
 // what may still cross a fence of the classifier loops: ALU (0x1 | VALU 0x2 | SALU 0x4 | transcendental 0x400) -- the
 // loss chains interleave with the LDS waits -- but no memory instruction: the W-row reads stay where they are
@@ -465,7 +468,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             const float a_gz = LG == 16 ? o.gz_lane : ((lc < EMAX && !pure) ? gzs[lc] : 0.f);
             if (lg < 16) dBacc += o.gz_lane;
             WTRACE(4);
-            if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);
+            if (WIDE_FENCE && WIDE_MFMA_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);
 #ifndef WIDE_DIAG_NOMFMA
             outer_mfma<LG, NC>(accW, a_gz, o.x, lane);
 #endif

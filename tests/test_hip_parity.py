@@ -128,8 +128,9 @@ def test_estep_yahoo_shape_bit_exact_and_golden(kind):
     assert int(diff.item()) == od
     ref = z['new_envs'].astype(np.int64)
     mism = np.nonzero(new != ref)[0]
-    assert set(mism.tolist()) <= set(z['low_margin_rows'].tolist())  # vs reference: only rounding-level rows
-    assert len(mism) <= 40
+    # vs the reference's own assignments on this fixture (healthy margins: SURVEY 8(c) G2): every one of the 250 154 rows
+    # (measured: HIP == oracle bitwise, oracle == reference on all rows, both kinds)
+    assert len(mism) == 0
 
 
 def test_stat_envs_and_sample_weights():

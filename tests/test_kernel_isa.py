@@ -1,0 +1,58 @@
+"""CPU: what the compiler made of the step kernels (device assembly of csrc/invpref_step.hip, cross-compiled for gfx950 --
+no GPU needed).  The planned M-step's instances must stay free of scratch MEMORY traffic in their loops (a dispatch that
+needs scratch costs microseconds, a spill inside the interaction loop a multiple of that), the wide-row instances must keep
+their outer products on the matrix cores, and rows on 32 lanes their cross-row exchanges on v_permlane16_swap (inline
+assembly, csrc/invpref_step.hip: permlane16_swap -- hipcc's builtin mis-compiles)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+
+
+@pytest.fixture(scope='module')
+def kernels():
+    import kernel_regs
+    if not os.path.exists('/opt/rocm/bin/hipcc'):
+        pytest.skip('hipcc not available')
+    text = kernel_regs.listing()
+    return {k['name']: k for k in kernel_regs.kernels(text)}, text
+
+
+def test_full_row_instances_have_no_scratch_traffic(kernels):
+    ks, _ = kernels
+    assert len(ks) >= 25
+    # the instances the bench configurations run: Yahoo (16 lanes x 1 float4, E <= 4, full rows), MovieLens (16 x 2, E = 8),
+    # and every 16-lane wide instance on full rows
+    for name in ('mstep_eval_kernel<16, true, 4, false, true>', 'mstep_apply_kernel<16, true, 4, true>',
+                 'mstep_eval_wide_kernel<16, 2, true, 8, false>', 'mstep_apply_wide_kernel<16, 2, true, 8, false>',
+                 'mstep_eval_wide_kernel<16, 1, true, 8, false>', 'mstep_eval_wide_kernel<16, 1, true, 16, false>',
+                 'mstep_eval_wide_kernel<16, 2, true, 16, false>', 'mstep_apply_wide_kernel<32, 2, true, 16, true>'):
+        assert ks[name]['scratch_ops'] == 0, (name, ks[name])
+    # rows on 32 lanes (MIND: 256 accumulator + row registers): a handful of loop-invariant values may sit in scratch, none
+    # of them inside the interaction loop (depth 2)
+    for name in ('mstep_eval_wide_kernel<32, 2, true, 16, true>', 'mstep_eval_wide_kernel<32, 2, true, 8, true>'):
+        assert ks[name]['scratch_ops'] <= 24, (name, ks[name])
+    # the latency-tuned Yahoo instance keeps three workgroups per CU: at most 168 registers
+    assert ks['mstep_eval_kernel<16, true, 4, false, true>']['vgpr'] <= 168
+
+
+def test_wide_instances_run_their_outer_products_on_mfma(kernels):
+    ks, text = kernels
+    for name, k in ks.items():
+        if name.startswith('mstep_eval_wide_kernel'):
+            assert k['mfma'] >= 16, (name, k['mfma'])       # both unrolled slots: >= 2 x 8 tiles
+        if name.startswith(('mstep_eval_kernel', 'mstep_apply_kernel')):
+            assert k['mfma'] == 0, name
+    assert 'v_mfma_f32_16x16x4_f32' in text
+    # rows on 32 lanes reduce across the wave's 16-lane rows with v_permlane16_swap (VALU, no LDS round trip)
+    mangled = [m for m in re.findall(r'^(_ZN\S*mstep_eval_wide_kernelILi32\S*):', text, re.M)]
+    assert mangled
+    for m in mangled:
+        i = text.index(m + ':')
+        body = text[i:text.index('.Lfunc_end', i)]
+        assert 'v_permlane16_swap_b32' in body, m

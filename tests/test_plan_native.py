@@ -75,3 +75,18 @@ def test_many_minibatches_in_one_call():
 def test_native_builder_rejects_out_of_range_rows():
     with pytest.raises(ValueError):
         planlib.build_row_plan(np.array([5]), np.array([0]), np.array([1.0], np.float32), 3, 3, native=True)
+
+
+def test_plan_header_symbols_are_exported():
+    """every function include/invpref_plan.h declares is exported by libinvpref_ingest.so; the params struct has the C layout"""
+    import ctypes as C
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = re.sub(r'/\*.*?\*/', '', open(os.path.join(root, 'include', 'invpref_plan.h')).read(), flags=re.S)
+    names = set(re.findall(r'\b(invpref_plan_\w+)\s*\(', code))
+    assert names == {'invpref_plan_build', 'invpref_plan_array', 'invpref_plan_free', 'invpref_plan_build_many'}
+    L = C.CDLL(build.INGEST_LIB)
+    for n in names:
+        assert hasattr(L, n), n
+    assert C.sizeof(planlib.PlanParamsStruct) == 11 * 4 + 4 + 8   # 11 int32, padding, one double

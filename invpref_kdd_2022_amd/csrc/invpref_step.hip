@@ -360,37 +360,8 @@ __device__ __forceinline__ void eval_interaction(Eval<EMAX> &o, float4 pu, float
             // (read again rather than held across the softmax: 16 registers at the kernel's pressure peak)
             f4fma(o.gx, o.gz[c], *reinterpret_cast<const float4 *>(sW + c * DP + lg * 4));
         }
-    } else {
-        // larger classifiers keep ONE class per lane: the logit of class c is a group-uniform value after the
-        // row reduction, lane c keeps it; max / sum of the softmax are group reductions, one exp per lane
-        // all EMAX class dot products per lane (rows c >= E are staged as zeros), then ONE reduce-scatter butterfly:
-        // lane l ends up with the logit of class l & (EMAX - 1)
-        float part[EMAX > 4 ? EMAX : 1];
-#pragma unroll
-        for (int c = 0; c < (EMAX > 4 ? EMAX : 1); c++)
-            part[c] = dot4(o.x, *reinterpret_cast<const float4 *>(sW + c * DP + lg * 4));
-        const float zred = group_sum_above<LG, EMAX>(class_butterfly<(EMAX > 4 ? EMAX : 1)>(part, lg), lg);
-        const float zmine = lg < E ? zred + sb[lg & (EMAX - 1)] : -__builtin_inff();
-        const float mxl = group_max<LG>(zmine);
-        const float ez = lg < E ? f_exp(zmine - mxl) : 0.f;
-        const float rsel = f_rcp(group_sum<LG>(ez));
-        const float gzl = lg < E ? k.cc * cw_cls * (ez * rsel - (lg == e ? 1.f : 0.f)) : 0.f;
-        o.gz_lane = gzl;
-        // every lane needs every gz_c for the backward: through the group's LDS record (in-order LDS operations
-        // of one wave: no barrier), which the E x D accumulation reads as well
-        if (lg < EMAX) gzs[lg] = gzl;
-        if (lg == e) gzs[EMAX + 1] = -f_log(ez * rsel);   // (lane e holds the picked class: its loss term)
-        WAVE_LDS_FENCE();
-        o.lcls = gzs[EMAX + 1];
-#pragma unroll
-        for (int c4 = 0; c4 < EMAX; c4 += 4) {
-            const float4 g4 = *reinterpret_cast<const float4 *>(gzs + c4);
-            f4fma(o.gx, g4.x, *reinterpret_cast<const float4 *>(sW + (c4 + 0) * DP + lg * 4));
-            f4fma(o.gx, g4.y, *reinterpret_cast<const float4 *>(sW + (c4 + 1) * DP + lg * 4));
-            f4fma(o.gx, g4.z, *reinterpret_cast<const float4 *>(sW + (c4 + 2) * DP + lg * 4));
-            f4fma(o.gx, g4.w, *reinterpret_cast<const float4 *>(sW + (c4 + 3) * DP + lg * 4));
-        }
     }
+    // (more than four classes: one class per lane, eval_wide in step_wide.hpp)
 }
 
 // stage a small [E][D] table into LDS as [EMAX][DP], zero padded (an absent table, INVPREF_PURE_MF, stages zeros)
@@ -455,6 +426,9 @@ struct USample {
 template <int LG, bool VEC, int EMAX, bool DEFER, bool FULL>
 __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a, int r0, int nr, int slab_index, float *lds) {
     using G = Geo<LG, EMAX>;
+    // (rows of more than 64 floats and more than four environments run step_wide.hpp; the branches of this function for
+    //  other layouts are compile-time dead)
+    static_assert(LG == 16 && EMAX == 4, "user_task: the 16-lane, four-environment instances only");
     // interactions in flight per group (measured: 2 for the D <= 64, E <= 4 instances -- a third slot only costs registers
     // there -- and for E > 8, whose per-interaction barrier paces the groups anyway; 3 for the other larger rows)
     constexpr int UE = !G::REG ? 1 : ((LG == 16 && EMAX <= 4 && STEP_EVAL_DEPTH > 2) ? 2 : STEP_EVAL_DEPTH);
@@ -771,33 +745,11 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                     // embed_env: ONE read-modify-write of the LDS row the interaction's environment names -- a row set per
                     // group (smallest instance) or per wave, whose groups then take turns (in-order LDS operations of one
                     // wave: fixed order, no barrier) -- instead of a select + add per class on registers
-                    float4 *erow = reinterpret_cast<float4 *>(red + (G::DIRECT ? grp : wave) * G::SLAB + e * DP + lg * 4);
-                    if (G::DIRECT || LG == 64) {
-                        float4 cur = *erow;
-                        f4add(cur, oo);
-                        *erow = cur;
-                    } else {
-                        // (the passes must stay separate instructions under separate lane masks: to the compiler the four
-                        //  conditions are mutually exclusive per THREAD and it would merge them into one unordered pass --
-                        //  two groups of a wave naming the same environment would then lose an update.  An opaque group
-                        //  number and a compiler barrier between the passes keep them apart.)
-                        int gsel = lane / LG;
-                        asm volatile("" : "+v"(gsel));
-#pragma unroll
-                        for (int g = 0; g < 64 / LG; g++) {
-                            if (gsel == g) {
-                                float4 cur = *erow;
-                                f4add(cur, oo);
-                                *erow = cur;
-                            }
-                            asm volatile("" ::: "memory");
-                        }
-                    }
+                    float4 *erow = reinterpret_cast<float4 *>(red + grp * G::SLAB + e * DP + lg * 4);
+                    float4 cur = *erow;
+                    f4add(cur, oo);
+                    *erow = cur;
 #endif
-                } else {
-                    float *rx = lds + L::rec + (((it_total & 1) * NG + grp) * 2) * DP;
-                    *reinterpret_cast<float4 *>(rx + lg * 4) = o.x;
-                    *reinterpret_cast<float4 *>(rx + DP + lg * 4) = oo;
                 }
                 // regulariser REPORTS over the item rows of the interaction (env rows weigh double: 1/(BD) vs 1/(2BD))
                 float s2 = f4sq(q.qi) + f4sq(q.qa), s1 = f4abs(q.qi) + f4abs(q.qa);
@@ -805,46 +757,6 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 accL2 += s2;
                 accL1 += s1;
                 if (lg == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; accLc += o.lcls * w_cls; }
-            }
-            if (!G::REG) {
-                // E > 8: every thread adds the NG records of this iteration into the outputs it OWNS (one column,
-                // a strided set of classes).  Branch-free: an empty record slot holds env id -1, its stale x / o /
-                // gz are masked by selects.  Double-buffered: one barrier per iteration.
-                if (lg == 0) gzs[EMAX] = __builtin_bit_cast(float, has ? e : -1);
-                __syncthreads();
-                const float *recx = lds + L::rec + ((it_total & 1) * NG * 2) * DP;
-                const float *recz = lds + L::recs + ((it_total & 1) * NG) * (EMAX + 4);
-                if (threadIdx.x < G::CG * DP) {
-                    constexpr int BATCH = G::CPT > 8 ? 2 : (NG < 4 ? NG : 4);   // records whose LDS reads are in flight together
-#pragma unroll 1
-                    for (int g0 = 0; g0 < NG; g0 += BATCH) {
-                        int er[BATCH];
-                        float xr[BATCH], orr[BATCH], gr[BATCH][G::CPT];
-#pragma unroll
-                        for (int b = 0; b < BATCH; b++) {
-                            const float *rs = recz + (g0 + b) * (EMAX + 4);
-                            er[b] = __builtin_bit_cast(int, rs[EMAX]);
-                            xr[b] = recx[((g0 + b) * 2) * DP + d_own];
-                            orr[b] = recx[((g0 + b) * 2 + 1) * DP + d_own];
-#pragma unroll
-                            for (int i = 0; i < G::CPT; i++) gr[b][i] = rs[(cg + G::CG * i) & (EMAX - 1)];
-                        }
-#pragma unroll
-                        for (int b = 0; b < BATCH; b++) {
-                            const bool ok = er[b] >= 0;
-                            const float xv = ok ? xr[b] : 0.f;
-#pragma unroll
-                            for (int i = 0; i < G::CPT; i++) {
-                                const float gzc = ok ? gr[b][i] : 0.f;
-                                oW[G::REG ? 0 : i] = __builtin_fmaf(gzc, xv, oW[G::REG ? 0 : i]);
-                            }
-                            // embed_env: ONE read-modify-write of the row the record's environment names (this thread's
-                            // column; one thread per column) instead of a select + add per class
-                            if (ok && cg == 0) sdE[er[b] * DP + d_own] += orr[b];
-                            if (threadIdx.x < EMAX) oB1 += ok ? recz[(g0 + b) * (EMAX + 4) + threadIdx.x] : 0.f;
-                        }
-                    }
-                }
             }
             if (EMAX > 4) it_total++;
         };

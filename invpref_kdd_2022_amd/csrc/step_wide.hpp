@@ -38,6 +38,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef WIDE_FENCE
 #define WIDE_FENCE 1   // scheduling fences inside the classifier loops of two-chunk rows (register pressure)
 #endif
+#ifndef WIDE_PUSH_DEPTH
+#define WIDE_PUSH_DEPTH 4   // (measured at the MovieLens shape: 66.7 -> 66.0 us against 2)
+#endif
 #ifndef WIDE_MFMA_FENCE
 #define WIDE_MFMA_FENCE 1   // (A/B knob) a fence between the row updates / stores and the MFMA block
 #endif
@@ -824,7 +827,7 @@ template <int LG, int NC, bool VEC, int EMAX>
 __device__ __forceinline__ void item_task_push_wide(const DevTables &t, const StepArgs &a, int r0, int nr, float *lds) {
     using G = WGeo<LG, NC, EMAX>;
     constexpr int DP = G::DP, NG = G::NG;
-    constexpr int PCH = 2;   // contribution-row pairs in flight per group
+    constexpr int PCH = WIDE_PUSH_DEPTH;   // contribution-row pairs in flight per group
     float *slots = lds;      // [NG][2][DP] slice partials
     const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG;
     const bool pure = a.flags & INVPREF_PURE_MF;

@@ -56,14 +56,14 @@ def summarise(dirs, dest, keep=lambda k: True, by_dir=False):
             for r in csv.DictReader(open(fs[0])):
                 if keep(r['Kernel_Name']):
                     k=r['Kernel_Name']
-                    tag=(os.path.basename(d)+' ' if by_dir else '')+(k.split('(')[1].split('::')[-1][:56] if k.startswith('void (') else k[:60])+' grid '+r['Grid_Size']
+                    tag=(os.path.basename(d)+' ' if by_dir else '')+(k.split('(')[1].split('::')[-1][:56] if k.startswith('void (') else k[:60])
                     acc[(tag, r['Counter_Name'])].append(float(r['Counter_Value']))
             for k,v in sorted(acc.items()):
                 f.write(f'"{k[0]}",{k[1]},{len(v)},{sum(v)/len(v):.1f}\n')
 for n in ('fetch','write'):
-    summarise([out+'/pmc_'+n], out+f'/pmc_{n}_summary.csv')
-    summarise(sorted(glob.glob(out+f'/large_pmc_{n}_*')), out+f'/large_pmc_{n}_summary.csv', keep=lambda k: 'mstep_' in k, by_dir=True)
-summarise(sorted(glob.glob(out+'/extra_*')), out+'/pmc_extra_summary.csv', keep=lambda k: 'mstep_' in k or 'estep' in k)
+    summarise([out+'/pmc_'+n], out+f'/pmc_{n}_summary.csv', keep=lambda k: 'mstep_' in k or 'estep' in k)
+    summarise(sorted(d for d in glob.glob(out+f'/large_pmc_{n}_*') if os.path.isdir(d)), out+f'/large_pmc_{n}_summary.csv', keep=lambda k: 'mstep_' in k, by_dir=True)
+summarise(sorted(d for d in glob.glob(out+'/extra_*') if os.path.isdir(d)), out+'/pmc_extra_summary.csv', keep=lambda k: 'mstep_' in k or 'estep' in k)
 summarise(sorted(d for d in glob.glob(out+'/wide_*') if os.path.isdir(d)), out+'/pmc_wide_instances_summary.csv', keep=lambda k: 'mstep_' in k, by_dir=True)
 for src,dst in (('stats','rocprofv3_kernel_stats_bench_graph.csv'),('stats_eager','rocprofv3_kernel_stats_bench_eager_steps.csv')):
     fs=glob.glob(out+'/'+src+'/*/*kernel_stats.csv')

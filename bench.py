@@ -449,34 +449,38 @@ def roofline_large(dev):
 
 def estep_random_sort_timing(dev, n=20):
     """The reference's DEFAULT E-step path (cluster_use_random_sort=True, train.py:24, :192-196) against the plain one at
-    the Yahoo shape.  Device time per E-step + stat_envs (HIP events on the launch stream) with the permutation indices
-    drawn beforehand: what the device does is a 250 KB index copy, the unranking and the E-step; the host's share -- the
-    reference's own np.random.randint call per minibatch, same numpy stream -- is timed apart (in a training loop it runs
-    while the GPU is still busy with the epochs enqueued before it)."""
+    the Yahoo shape: device time of the captured E-step (+ the count / weight half of stat_envs) per replay -- HIP events
+    around each replay, the permutation indices already in the pinned buffer the kernel reads -- and, apart, the host's
+    share: the reference's own np.random.randint call per minibatch (same numpy stream), which in a training loop runs
+    while the GPU is still busy with the epochs enqueued before it."""
+    import numpy as np
     import torch
     out = {}
     for rs in (False, True):
-        mgr = build_manager(dev, 0, 1)
-        mgr.cluster_use_random_sort = rs
+        mgr = build_manager(dev, 0, 1, random_sort=rs)
         mgr.train_epochs(1)
         mgr.prepare_graphs([1])
+        g, eps_buf, _ = mgr._estep_graph(rs)
         host_s = 0.0
         if rs:
             t0 = time.perf_counter()
-            draws = [mgr._eps_index() for _ in range(n + 3)]
-            host_s = (time.perf_counter() - t0) / (n + 3)
-            mgr._eps_index = lambda: draws.pop()
-        for _ in range(3):
-            mgr.cluster(sync=False); mgr.stat_envs(sync=False)
+            draws = [mgr._eps_index() for _ in range(4)]
+            host_s = (time.perf_counter() - t0) / 4
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for i in range(n + 3):
+            if rs:
+                torch.cuda.synchronize()                       # (the previous replay has read the buffer)
+                if eps_buf.is_cuda:
+                    eps_buf.copy_(torch.from_numpy(draws[i % 4]))
+                else:
+                    eps_buf.numpy()[:] = draws[i % 4]
+            if i >= 3:
+                ev[i - 3][0].record()
+            g.replay()
+            if i >= 3:
+                ev[i - 3][1].record()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda._sleep(int(2e7))   # (the stream stays backlogged for the whole loop: the events are stamped by the GPU, not while it waits for the host)
-        e0.record()
-        for _ in range(n):
-            mgr.cluster(sync=False); mgr.stat_envs(sync=False)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / n
+        ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
         if rs:
             out.update(estep_random_sort_ms=ms, estep_random_sort_host_draw_ms=host_s * 1e3)
         else:
@@ -484,9 +488,9 @@ def estep_random_sort_timing(dev, n=20):
         del mgr
         torch.cuda.empty_cache()
     out['ratio'] = out['estep_random_sort_ms'] / out['estep_plain_ms']
-    out['note'] = ('device time of cluster(sync=False) + stat_envs(sync=False), graph-replayed; random sort = index copy (1 B per '
-                   'interaction) + unranking on the device + the same E-step; host draws = np.random.randint per minibatch, the '
-                   'reference\'s own numpy stream')
+    out['note'] = ('device time of one replay of the captured E-step (estep_assign_kernel + stat_envs_kernel), median of %d; '
+                   'random sort = 1 byte of permutation index per interaction read from pinned host memory + the row looked up '
+                   'in an LDS table; host draws = np.random.randint per minibatch, the reference\'s own numpy stream' % n)
     return out
 
 

@@ -620,7 +620,25 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
     unsigned *sidx = stab + eps_rows_n;   // [chunk] the block's permutation rows (E <= 7)
     if (eps_index) {
         for (int i = threadIdx.x; i < eps_rows_n; i += blockDim.x) stab[i] = (unsigned)unrank_packed((unsigned long long)i, t.E, fac);
-        for (int64_t i = threadIdx.x; s_begin + i < s_end; i += blockDim.x)
+        // 16 bytes per lane (16 one-byte or 4 four-byte indices; the block starts on a multiple of 16 interactions): on
+        // host-coherent memory every lane's access is a transaction of its own, so they had better be few and wide
+        const int per = eps_index_bytes == 1 ? 16 : 4;
+        const int64_t n_here = s_end - s_begin, n_vec = ((reinterpret_cast<uintptr_t>(eps_index) & 15) == 0) ? n_here / per : 0;
+        const char *base = reinterpret_cast<const char *>(eps_index) + s_begin * eps_index_bytes;
+        for (int64_t i = threadIdx.x; i < n_vec; i += blockDim.x) {
+            const uint4 v = reinterpret_cast<const uint4 *>(base)[i];
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (eps_index_bytes == 1) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) sidx[i * 16 + k * 4 + b] = (w[k] >> (8 * b)) & 255u;
+                } else {
+                    sidx[i * 4 + k] = w[k];
+                }
+            }
+        }
+        for (int64_t i = n_vec * per + threadIdx.x; i < n_here; i += blockDim.x)   // (the block's tail / an unaligned array)
             sidx[i] = eps_index_bytes == 1 ? (unsigned)reinterpret_cast<const uint8_t *>(eps_index)[s_begin + i]
                                             : (unsigned)reinterpret_cast<const int32_t *>(eps_index)[s_begin + i];
     }

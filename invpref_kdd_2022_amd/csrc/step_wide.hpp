@@ -38,6 +38,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef WIDE_FENCE
 #define WIDE_FENCE 1   // scheduling fences inside the classifier loops of two-chunk rows (register pressure)
 #endif
+#ifndef WIDE_STEP_FENCE_MASK
+#define WIDE_STEP_FENCE_MASK 0   // what may cross the fences between two lock-step iterations (0x8: the MFMA block)
+#endif
 #ifndef WIDE_PUSH_DEPTH
 #define WIDE_PUSH_DEPTH 4   // (measured at the MovieLens shape: 66.7 -> 66.0 us against 2)
 #endif
@@ -400,7 +403,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
         auto step = [&](const Slot &q, bool has) {
             // branch-free: an empty slot (the round's longest slice sets the trip count) evaluates its stale rows with
             // every gradient scalar forced to zero (eval_wide) and stores nothing
-            if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);   // (the unrolled slots' evaluations stay apart)
+            if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(WIDE_STEP_FENCE_MASK);   // (the unrolled slots' evaluations stay apart)
             float *gzs = lds + G::gzs + ((it_total & 1) * NG + grp) * (EMAX + 4);
             WTRACE(1);
             const int e = q.e;
@@ -479,7 +482,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             if constexpr (SH) outer_mfma<LG, NC>(accW, (has && lc == e + 8) ? 1.f : 0.f, boo, lane);
             else if constexpr (!EVL2) outer_mfma<LG, NC>(accE, (has && lc == e) ? 1.f : 0.f, boo, lane);
 #endif
-            if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);
+            if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(WIDE_STEP_FENCE_MASK);
             WTRACE(5);
             it_total++;
         };

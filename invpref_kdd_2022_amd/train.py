@@ -792,7 +792,8 @@ class _InvPrefTrainManager:
             if with_eps:
                 dt = torch.from_numpy(np.zeros(0, self._perm_index_dtype())).dtype
                 n_loc = self.users_tensor.shape[0]
-                eps_buf = torch.zeros(n_loc, dtype=dt, pin_memory=True) if self.envs_num <= 7 \
+                pinned = self.envs_num <= 7 and os.environ.get('INVPREF_EPS_PINNED', '1') != '0'   # (0: A/B, copy first)
+                eps_buf = torch.zeros(n_loc, dtype=dt, pin_memory=True) if pinned \
                     else torch.zeros(n_loc, dtype=dt, device=self.device)
 
             def run():

@@ -351,11 +351,18 @@ def step_bench(dev, Us, Is, Es, Ds, Bs, n_steps, zipf=False, seed=5, note=''):
     P2 = [torch.zeros_like(p) for p in P]
     M = [torch.zeros_like(p) for p in P]
     V = [torch.zeros_like(p) for p in P]
+    # (the interaction columns as the manager holds them: one contiguous array each)
+    cu, ci = np.ascontiguousarray(data[:, 0]), np.ascontiguousarray(data[:, 1])
+    cy = np.ascontiguousarray(data[:, 2].astype(np.float32))
     t0 = time.perf_counter()
-    plans = [planlib.upload(planlib.build_row_plan(data[k * Bs:(k + 1) * Bs, 0], data[k * Bs:(k + 1) * Bs, 1],
-                                                   data[k * Bs:(k + 1) * Bs, 2], Us, Is, factor_num=Ds, env_num=Es), dev)
-             for k in range(n_steps)]
-    plan_s = time.perf_counter() - t0
+    host_plans = [planlib.build_row_plan(cu[k * Bs:(k + 1) * Bs], ci[k * Bs:(k + 1) * Bs], cy[k * Bs:(k + 1) * Bs], Us, Is,
+                                         factor_num=Ds, env_num=Es) for k in range(n_steps)]
+    plan_s = (time.perf_counter() - t0) / n_steps
+    t0 = time.perf_counter()
+    plans = [planlib.upload(hp, dev) for hp in host_plans]
+    torch.cuda.synchronize()
+    upload_s = (time.perf_counter() - t0) / n_steps
+    del host_plans
     e = torch.from_numpy(rs.randint(0, Es, n_steps * Bs).astype(np.int64)).to(dev)
     yt = torch.from_numpy(data[:, 2].astype(np.float32)).to(dev)
     w = torch.rand(n_steps * Bs, device=dev)
@@ -397,7 +404,7 @@ def step_bench(dev, Us, Is, Es, Ds, Bs, n_steps, zipf=False, seed=5, note=''):
            'cache_resident': 16 * Pn < 200e6,
            'shape': {'users': Us, 'items': Is, 'envs': Es, 'factor_num': Ds, 'minibatch': Bs, 'minibatches': n_steps,
                      'ids': 'zipf' if zipf else 'uniform'},
-           'flat_buffer_MB': 4 * Pn / 1e6, 'plan_build_s': plan_s,
+           'flat_buffer_MB': 4 * Pn / 1e6, 'plan_build_s': plan_s, 'plan_upload_s': upload_s,
            'timing': f'HIP events around {reps} replays of a graph of {n_steps} fused steps (different minibatch plans, '
                      'ping-pong parameter buffers); whole step = both launches'}
     if note:
@@ -431,7 +438,7 @@ def roofline_large(dev):
     INVPREF_BENCH_LARGE_LOG2N for another; the plan of such a launch is a few seconds of native host work)."""
     res, small = {}, {}
     lg = int(os.environ.get('INVPREF_BENCH_LARGE_LOG2N', '24'))   # SURVEY 8(d): one launch over 2^24 uniform-random rows
-    keep = ('frac', 'achieved', 'ms_per_step', 'algorithmic_bytes_per_step', 'shape', 'plan_build_s')
+    keep = ('frac', 'achieved', 'ms_per_step', 'algorithmic_bytes_per_step', 'shape', 'plan_build_s', 'plan_upload_s')
     for Dl, El, lg_r03 in ((64, 4, 22), (128, 8, 21), (256, 16, 20)):
         r = step_bench(dev, 400000, 100000, El, Dl, 1 << lg, 1, seed=5 + Dl)
         r['kernel'] = 'the fused M-step + Adam step (same kernels as the headline)'

@@ -38,8 +38,13 @@ InvPrefHostPlan *invpref_plan_build(const int64_t *users, const int64_t *items, 
 int64_t invpref_plan_array(const InvPrefHostPlan *plan, int32_t which, const int32_t **data);
 void invpref_plan_free(InvPrefHostPlan *plan);
 
+/* interactions per row of one side (what np.bincount(rows, minlength=n_rows) returns), on threads: the plan's parameters
+ * (slice lengths, rounds per task) are chosen from these before the arrays are built.  0, -1 bad arguments, -2 a row id
+ * outside [0, n_rows). */
+int invpref_plan_row_counts(const int64_t *rows, int64_t n, int64_t n_rows, int64_t *counts);
+
 /* plans of `count` minibatches: minibatch k = interactions [offsets[k], offsets[k + 1]) with parameters params[k];
- * out[k] receives its handle (NULL on failure).  n_threads <= 0: one per hardware thread (at most 16). */
+ * out[k] receives its handle (NULL on failure).  n_threads <= 0: one per hardware thread (at most 32). */
 int invpref_plan_build_many(const int64_t *users, const int64_t *items, const float *scores, const int64_t *offsets,
                             int32_t count, int64_t user_num, int64_t item_num, const InvPrefPlanParams *params,
                             InvPrefHostPlan **out, int32_t n_threads);

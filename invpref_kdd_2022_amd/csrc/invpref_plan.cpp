@@ -6,49 +6,119 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
 struct InvPrefHostPlan {
     std::vector<int32_t> arr[9];
+    // the big arrays (lists, descriptors, push slots) live in UNINITIALISED storage: every element is written exactly once by
+    // the builder, and zero-filling 0.5 GB first costs as much as the sort itself
+    std::unique_ptr<int32_t[]> big[9];
+    size_t big_n[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int32_t *alloc(int which, size_t n) {
+        big[which].reset(new int32_t[n ? n : 1]);
+        big_n[which] = n;
+        return big[which].get();
+    }
 };
 
 namespace {
 
 constexpr int kThreads = 256;
+constexpr unsigned kMaxThreads = 32;   // host threads one build spreads over at most
 constexpr int32_t kItemBit = 1 << 30;
 constexpr int kModeList = 7;
 constexpr int kClassShift = 6;
 
+inline int64_t cdiv_i(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
 struct Side {
     int64_t n_rows = 0;
     std::vector<int64_t> cnt, ptr;       // per row: interactions, first position in the sorted order
-    std::vector<int32_t> perm;           // sorted position -> minibatch position (stable counting sort by row)
-    std::vector<int32_t> own;            // sorted position -> row
 };
 
-void sort_side(const int64_t *rows, int64_t n, int64_t n_rows, Side &s) {
+// run fn(0 .. count - 1) on up to `threads` threads
+template <typename F>
+void parallel_for(int count, int threads, F fn) {
+    threads = std::max(1, std::min(threads, count));
+    if (threads == 1) {
+        for (int i = 0; i < count; i++) fn(i);
+        return;
+    }
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= count) return;
+            fn(i);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+}
+
+// Stable counting sort of the minibatch by row, on `threads` threads: emit(i, j) is called once per interaction i with its
+// position j in the sorted order (equal rows keep their minibatch order).  Thread t counts and places the t-th contiguous
+// chunk of the minibatch; its first position inside a row is the row's start + what the chunks before it hold of that row.
+template <typename Emit>
+bool sort_side(const int64_t *rows, int64_t n, int64_t n_rows, Side &s, int threads, Emit emit) {
     s.n_rows = n_rows;
     s.cnt.assign((size_t)n_rows, 0);
-    for (int64_t i = 0; i < n; i++) s.cnt[(size_t)rows[i]]++;
     s.ptr.assign((size_t)n_rows + 1, 0);
-    for (int64_t r = 0; r < n_rows; r++) s.ptr[(size_t)r + 1] = s.ptr[(size_t)r] + s.cnt[(size_t)r];
-    s.perm.resize((size_t)n);
-    s.own.resize((size_t)n);
-    std::vector<int64_t> at(s.ptr.begin(), s.ptr.end() - 1);
-    for (int64_t i = 0; i < n; i++) {
-        const int64_t r = rows[i], j = at[(size_t)r]++;
-        s.perm[(size_t)j] = (int32_t)i;
-        s.own[(size_t)j] = (int32_t)r;
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n >> 16));
+    const int64_t chunk = T > 1 ? cdiv_i(n, T) : n;
+    std::vector<std::vector<int32_t>> at((size_t)T);
+    std::atomic<int> invalid{0};
+    parallel_for(T, T, [&](int t) {
+        std::vector<int32_t> &h = at[(size_t)t];
+        h.assign((size_t)n_rows, 0);
+        const int64_t a = std::min(n, t * chunk), b = std::min(n, a + chunk);
+        bool bad = false;
+        for (int64_t i = a; i < b; i++) {
+            const uint64_t r = (uint64_t)rows[i];
+            if (r < (uint64_t)n_rows) h[(size_t)r]++;
+            else bad = true;
+        }
+        if (bad) invalid.store(1);
+    });
+    if (invalid.load()) return false;   // a row id out of range
+    for (int64_t r = 0; r < n_rows; r++) {
+        int64_t c = 0;
+        for (int t = 0; t < T; t++) c += at[(size_t)t][(size_t)r];
+        s.cnt[(size_t)r] = c;
+        s.ptr[(size_t)r + 1] = s.ptr[(size_t)r] + c;
     }
+    parallel_for(T, T, [&](int blk) {   // counts -> first positions (rows split over the threads)
+        const int64_t rc = cdiv_i(n_rows, T), ra = std::min(n_rows, blk * rc), rb = std::min(n_rows, ra + rc);
+        for (int64_t r = ra; r < rb; r++) {
+            int64_t pos = s.ptr[(size_t)r];
+            for (int t = 0; t < T; t++) {
+                const int32_t c = at[(size_t)t][(size_t)r];
+                at[(size_t)t][(size_t)r] = (int32_t)pos;
+                pos += c;
+            }
+        }
+    });
+    parallel_for(T, T, [&](int t) {
+        std::vector<int32_t> &h = at[(size_t)t];
+        const int64_t a = std::min(n, t * chunk), b = std::min(n, a + chunk);
+        for (int64_t i = a; i < b; i++) emit(i, (int64_t)h[(size_t)rows[i]]++);
+    });
+    return true;
 }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // plan.py: _side_rounds for the rows of class `cls_id` (skip = untouched rows and rows of other classes)
-void side_rounds(const Side &s, int64_t n, const int32_t *const *cols, int w, int ng, int per_slice, int pad_to, int inl_max,
+void side_rounds(const Side &s, int64_t n, const int32_t *list, int stride, int w, int ng, int per_slice, int pad_to, int inl_max,
                  const std::vector<int32_t> &class_rows, std::vector<int32_t> &desc, std::vector<int32_t> &iters) {
     // the class's touched rows (increasing) by slice count (a power of two up to ng)
     std::vector<std::vector<int32_t>> by_g;
@@ -101,7 +171,7 @@ void side_rounds(const Side &s, int64_t n, const int32_t *const *cols, int w, in
                     for (int q = 0; q < inl_max; q++) {
                         const int64_t jq = std::min(j0 + q, n - 1);
                         if (inl && m > q)
-                            for (int cc = 0; cc < w; cc++) d[2 + q * w + cc] = cols[cc][(size_t)jq];
+                            for (int cc = 0; cc < w; cc++) d[2 + q * w + cc] = list[(size_t)jq * stride + cc];
                     }
                 }
                 int32_t &it = iters[ibase + (size_t)rnd];
@@ -112,9 +182,9 @@ void side_rounds(const Side &s, int64_t n, const int32_t *const *cols, int w, in
 }
 
 // the rounds of ONE class (into arrays of their own), padded to a multiple of pad_to rounds with idle rounds
-void class_rounds(const Side &s, int64_t n, const int32_t *const *cols, int w, int ng, int per_slice, int pad_to, int inl_max,
+void class_rounds(const Side &s, int64_t n, const int32_t *list, int stride, int w, int ng, int per_slice, int pad_to, int inl_max,
                   const std::vector<int32_t> &class_rows, std::vector<int32_t> &d, std::vector<int32_t> &it) {
-    side_rounds(s, n, cols, w, ng, per_slice, pad_to, inl_max, class_rows, d, it);
+    side_rounds(s, n, list, stride, w, ng, per_slice, pad_to, inl_max, class_rows, d, it);
     const int64_t have = (int64_t)it.size();
     const int64_t pad = ((-have) % pad_to + pad_to) % pad_to;
     for (int64_t p = 0; p < pad; p++) {
@@ -126,78 +196,74 @@ void class_rounds(const Side &s, int64_t n, const int32_t *const *cols, int w, i
     }
 }
 
-// run fn(0 .. count - 1) on up to `threads` threads
-template <typename F>
-void parallel_for(int count, int threads, F fn) {
-    threads = std::max(1, std::min(threads, count));
-    if (threads == 1) {
-        for (int i = 0; i < count; i++) fn(i);
-        return;
-    }
-    std::atomic<int> next{0};
-    auto work = [&]() {
-        for (;;) {
-            const int i = next.fetch_add(1);
-            if (i >= count) return;
-            fn(i);
-        }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < threads; t++) th.emplace_back(work);
-    work();
-    for (auto &t : th) t.join();
-}
-
 InvPrefHostPlan *build(const int64_t *users, const int64_t *items, const float *scores, int64_t n, int64_t U, int64_t I,
                        const InvPrefPlanParams &p, int threads) {
     if (n < 0 || U <= 0 || I <= 0 || p.n_classes < 1 || p.n_classes > 8 || p.per_slice < 1 || p.item_per_slice < 1 ||
         p.rounds_per_task < 1 || p.item_rounds_per_task < 1 || p.rows_per_stream_task < 1 ||
         (p.lanes_per_group != 16 && p.lanes_per_group != 32 && p.lanes_per_group != 64) || (n > 0 && (!users || !items || !scores)))
         return nullptr;
-    for (int64_t i = 0; i < n; i++)
-        if (users[i] < 0 || users[i] >= U || items[i] < 0 || items[i] >= I) return nullptr;
+    const bool timing = std::getenv("INVPREF_PLAN_TIMING") != nullptr;   // phase times on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[invpref_plan] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     const int ng = kThreads / p.lanes_per_group, ncls = p.n_classes;
-    // a big minibatch spreads its independent pieces (two sides, then 2 x n_classes round lists) over threads
+    // a big minibatch spreads its pieces (validation, the two sorts, then 2 x n_classes round lists) over threads
     const int nt = n >= (1 << 18) ? std::max(1, threads) : 1;
+    InvPrefHostPlan *hp = new InvPrefHostPlan();
+    std::vector<int32_t> &uit = hp->arr[2], &sr = hp->arr[5];
+    // the sorted lists are written where the sort places each interaction: user_list [n][4] = (item, position, label bits,
+    // 0), item_list [n][2] = (user, position); push_slot[position] = the interaction's slot in the item order
+    int32_t *const ul = hp->alloc(3, (size_t)n * 4), *const il = hp->alloc(4, (size_t)n * 2);
+    int32_t *const ps = p.push ? hp->alloc(6, (size_t)n) : nullptr;
+    lap("allocate lists");
     Side us, is;
-    std::vector<int32_t> u_oth((size_t)n), u_pos((size_t)n), u_y((size_t)n), i_oth((size_t)n), i_pos((size_t)n);
+    const int half = std::max(1, nt / 2);
+    bool ok[2] = {true, true};
     parallel_for(2, nt, [&](int side) {
         if (side == 0) {
-            sort_side(users, n, U, us);
-            for (int64_t j = 0; j < n; j++) {   // the sorted list's columns
-                const int32_t pu = us.perm[(size_t)j];
-                u_oth[(size_t)j] = (int32_t)items[pu];
-                u_pos[(size_t)j] = pu;
-                std::memcpy(&u_y[(size_t)j], scores + pu, 4);
-            }
+            int32_t *L = ul;
+            ok[0] = sort_side(users, n, U, us, half, [&](int64_t i, int64_t j) {
+                int32_t *d = L + (size_t)j * 4;
+                d[0] = (int32_t)items[i];
+                d[1] = (int32_t)i;
+                std::memcpy(d + 2, scores + i, 4);
+                d[3] = 0;
+            });
         } else {
-            sort_side(items, n, I, is);
-            for (int64_t j = 0; j < n; j++) {
-                const int32_t pi = is.perm[(size_t)j];
-                i_oth[(size_t)j] = (int32_t)users[pi];
-                i_pos[(size_t)j] = pi;
-            }
+            int32_t *L = il, *P = ps;
+            ok[1] = sort_side(items, n, I, is, half, [&](int64_t i, int64_t j) {
+                L[(size_t)j * 2] = (int32_t)users[i];
+                L[(size_t)j * 2 + 1] = (int32_t)i;
+                if (P) P[(size_t)i] = (int32_t)j;
+            });
         }
     });
-    InvPrefHostPlan *hp = new InvPrefHostPlan();
-    std::vector<int32_t> &ud = hp->arr[0], &id = hp->arr[1], &uit = hp->arr[2];
-    const int32_t *ucols[3] = {u_oth.data(), u_pos.data(), u_y.data()};
-    const int32_t *icols[2] = {i_oth.data(), i_pos.data()};
+    if (!ok[0] || !ok[1]) {
+        delete hp;
+        return nullptr;
+    }
+    lap("sort both sides");
     // touched rows of every class, in increasing order
     std::vector<std::vector<int32_t>> urows((size_t)ncls), irows((size_t)ncls);
     for (int64_t r = 0; r < U; r++)
         if (us.cnt[(size_t)r]) urows[(size_t)((r >> kClassShift) % ncls)].push_back((int32_t)r);
     for (int64_t r = 0; r < I; r++)
         if (is.cnt[(size_t)r]) irows[(size_t)((r >> kClassShift) % ncls)].push_back((int32_t)r);
+    lap("class rows");
     std::vector<std::vector<int32_t>> cd((size_t)(2 * ncls)), cit((size_t)(2 * ncls));
     parallel_for(2 * ncls, nt, [&](int q) {
         const int c = q >> 1;
         if ((q & 1) == 0)
-            class_rounds(us, n, ucols, 3, ng, p.per_slice, p.rounds_per_task, 2, urows[(size_t)c], cd[(size_t)q], cit[(size_t)q]);
+            class_rounds(us, n, ul, 4, 3, ng, p.per_slice, p.rounds_per_task, 2, urows[(size_t)c], cd[(size_t)q], cit[(size_t)q]);
         else
-            class_rounds(is, n, icols, 2, ng, p.item_per_slice, p.item_rounds_per_task, p.push ? 0 : 3, irows[(size_t)c],
+            class_rounds(is, n, il, 2, 2, ng, p.item_per_slice, p.item_rounds_per_task, p.push ? 0 : 3, irows[(size_t)c],
                          cd[(size_t)q], cit[(size_t)q]);
     });
+    lap("rounds of the classes");
     int32_t cls[8][8];
     std::memset(cls, 0, sizeof(cls));
     int32_t defer_tail[8][2];
@@ -219,11 +285,7 @@ InvPrefHostPlan *build(const int64_t *users, const int64_t *items, const float *
     for (int c = 0; c < ncls; c++) {
         n_ur[(size_t)c] = (int32_t)cit[(size_t)(2 * c)].size();
         n_ir[(size_t)c] = (int32_t)cit[(size_t)(2 * c + 1)].size();
-        ud.insert(ud.end(), cd[(size_t)(2 * c)].begin(), cd[(size_t)(2 * c)].end());
         uit.insert(uit.end(), cit[(size_t)(2 * c)].begin(), cit[(size_t)(2 * c)].end());
-        id.insert(id.end(), cd[(size_t)(2 * c + 1)].begin(), cd[(size_t)(2 * c + 1)].end());
-        std::vector<int32_t>().swap(cd[(size_t)(2 * c)]);
-        std::vector<int32_t>().swap(cd[(size_t)(2 * c + 1)]);
         const std::vector<int32_t> &rows = srows[(size_t)c];
         int64_t k = (int64_t)std::nearbyint(p.stream_split * (double)rows.size());   // (Python's round(): ties to even)
         if (p.fill_cap) {   // (per class: the grid is n_classes x the longest class)
@@ -250,20 +312,19 @@ InvPrefHostPlan *build(const int64_t *users, const int64_t *items, const float *
     int32_t sb = 0;
     for (int c = 0; c < ncls; c++) { cls[c][2] = sb; cls[c][3] = (int32_t)s1[(size_t)c].size(); sb += cls[c][3]; }
     for (int c = 0; c < ncls; c++) { cls[c][6] = sb; cls[c][7] = (int32_t)s2[(size_t)c].size(); sb += cls[c][7]; }
-    std::vector<int32_t> &ul = hp->arr[3], &il = hp->arr[4], &sr = hp->arr[5], &ps = hp->arr[6];
-    ul.resize((size_t)n * 4);
-    il.resize((size_t)n * 2);
-    for (int64_t j = 0; j < n; j++) {
-        ul[(size_t)j * 4 + 0] = u_oth[(size_t)j]; ul[(size_t)j * 4 + 1] = u_pos[(size_t)j];
-        ul[(size_t)j * 4 + 2] = u_y[(size_t)j]; ul[(size_t)j * 4 + 3] = 0;
-        il[(size_t)j * 2 + 0] = i_oth[(size_t)j]; il[(size_t)j * 2 + 1] = i_pos[(size_t)j];
+    {   // the classes' descriptor rounds, one after the other (copied on threads)
+        std::vector<size_t> off((size_t)(2 * ncls));
+        size_t tot[2] = {0, 0};
+        for (int q = 0; q < 2 * ncls; q++) { off[(size_t)q] = tot[q & 1]; tot[q & 1] += cd[(size_t)q].size(); }
+        int32_t *const dst[2] = {hp->alloc(0, tot[0]), hp->alloc(1, tot[1])};
+        parallel_for(2 * ncls, nt, [&](int q) {
+            if (!cd[(size_t)q].empty()) std::memcpy(dst[q & 1] + off[(size_t)q], cd[(size_t)q].data(), cd[(size_t)q].size() * 4);
+            std::vector<int32_t>().swap(cd[(size_t)q]);
+        });
     }
     for (int c = 0; c < ncls; c++) sr.insert(sr.end(), s1[(size_t)c].begin(), s1[(size_t)c].end());
     for (int c = 0; c < ncls; c++) sr.insert(sr.end(), s2[(size_t)c].begin(), s2[(size_t)c].end());
-    if (p.push) {
-        ps.resize((size_t)n);
-        for (int64_t j = 0; j < n; j++) ps[(size_t)is.perm[(size_t)j]] = (int32_t)j;   // argsort of the item order
-    }
+    lap("concatenate + stream rows");
     hp->arr[7].assign(&cls[0][0], &cls[0][0] + 64);
     hp->arr[8].assign(&defer_tail[0][0], &defer_tail[0][0] + 16);
     return hp;
@@ -277,7 +338,7 @@ InvPrefHostPlan *invpref_plan_build(const int64_t *users, const int64_t *items, 
                                     int64_t user_num, int64_t item_num, const InvPrefPlanParams *params) {
     if (!params) return nullptr;
     try {
-        const int hw = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        const int hw = (int)std::min<unsigned>(kMaxThreads, std::max(1u, std::thread::hardware_concurrency()));
         return build(users, items, scores, n, user_num, item_num, *params, hw);
     } catch (...) {
         return nullptr;
@@ -286,17 +347,46 @@ InvPrefHostPlan *invpref_plan_build(const int64_t *users, const int64_t *items, 
 
 int64_t invpref_plan_array(const InvPrefHostPlan *plan, int32_t which, const int32_t **data) {
     if (!plan || which < 0 || which > 8) return -1;
+    if (plan->big[which]) {
+        if (data) *data = plan->big[which].get();
+        return (int64_t)plan->big_n[which];
+    }
     if (data) *data = plan->arr[which].data();
     return (int64_t)plan->arr[which].size();
 }
 
 void invpref_plan_free(InvPrefHostPlan *plan) { delete plan; }
 
+int invpref_plan_row_counts(const int64_t *rows, int64_t n, int64_t n_rows, int64_t *counts) {
+    if (n < 0 || n_rows <= 0 || !counts || (n > 0 && !rows)) return -1;
+    const int hw = (int)std::min<unsigned>(kMaxThreads, std::max(1u, std::thread::hardware_concurrency()));
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(hw, n >> 18));
+    const int64_t chunk = cdiv_i(std::max<int64_t>(n, 1), T);
+    std::vector<std::vector<int32_t>> h((size_t)T);
+    std::atomic<int> invalid{0};
+    parallel_for(T, T, [&](int t) {
+        h[(size_t)t].assign((size_t)n_rows, 0);
+        const int64_t a = std::min(n, t * chunk), b = std::min(n, a + chunk);
+        for (int64_t i = a; i < b; i++) {
+            const uint64_t r = (uint64_t)rows[i];
+            if (r < (uint64_t)n_rows) h[(size_t)t][(size_t)r]++;
+            else invalid.store(1);
+        }
+    });
+    if (invalid.load()) return -2;
+    for (int64_t r = 0; r < n_rows; r++) {
+        int64_t c = 0;
+        for (int t = 0; t < T; t++) c += h[(size_t)t][(size_t)r];
+        counts[r] = c;
+    }
+    return 0;
+}
+
 int invpref_plan_build_many(const int64_t *users, const int64_t *items, const float *scores, const int64_t *offsets,
                             int32_t count, int64_t user_num, int64_t item_num, const InvPrefPlanParams *params,
                             InvPrefHostPlan **out, int32_t n_threads) {
     if (!offsets || !params || !out || count < 0) return -1;
-    int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(kMaxThreads, std::max(1u, std::thread::hardware_concurrency()));
     nt = std::max(1, std::min(nt, (int)count));
     std::atomic<int> next{0};
     auto work = [&]() {

@@ -180,6 +180,7 @@ def _native_lib():
             L.invpref_plan_array.restype = C.c_int64
             L.invpref_plan_array.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.POINTER(C.c_int32))]
             L.invpref_plan_free.argtypes = [C.c_void_p]
+            L.invpref_plan_row_counts.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
             L.invpref_plan_build_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                                   C.c_int64, C.POINTER(PlanParamsStruct), C.POINTER(C.c_void_p), C.c_int32]
             _NATIVE = L
@@ -194,16 +195,34 @@ def _params_struct(r: dict) -> PlanParamsStruct:
                             r['stream_split'])
 
 
+class _NativePlan:
+    """owner of a native plan handle: released when the last array that views its memory is gone"""
+
+    def __init__(self, L, h):
+        self.L, self.h = L, h
+
+    def __del__(self):
+        if self.h:
+            self.L.invpref_plan_free(self.h)
+            self.h = None
+
+
 def _plan_from_handle(L, h, r: dict) -> dict:
-    """the plan dict build_row_plan returns, from a native handle (which is released)"""
+    """the plan dict build_row_plan returns, from a native handle: the large arrays are VIEWS of the handle's memory (no
+    copy: a 2^24-interaction plan is 0.7 GB), kept alive by the arrays themselves; the small ones are copied"""
     out = {}
-    try:
-        for which, name in enumerate(_NATIVE_ARRAYS):
-            ptr = C.POINTER(C.c_int32)()
-            ln = L.invpref_plan_array(h, which, C.byref(ptr))
-            out[name] = np.ctypeslib.as_array(ptr, shape=(ln,)).copy() if ln > 0 else np.zeros(0, np.int32)
-    finally:
-        L.invpref_plan_free(h)
+    owner = _NativePlan(L, h)
+    for which, name in enumerate(_NATIVE_ARRAYS):
+        ptr = C.POINTER(C.c_int32)()
+        ln = L.invpref_plan_array(h, which, C.byref(ptr))
+        if ln <= 0:
+            out[name] = np.zeros(0, np.int32)
+        elif ln < (1 << 16):
+            out[name] = np.ctypeslib.as_array(ptr, shape=(ln,)).copy()
+        else:
+            buf = (C.c_int32 * ln).from_address(C.addressof(ptr.contents))
+            buf._owner = owner
+            out[name] = np.frombuffer(buf, dtype=np.int32)
     ng = THREADS // r['lanes']
     cls = out['cls'].reshape(8, 8)
     sb = int(cls[:, 3].sum() + cls[:, 7].sum())
@@ -301,6 +320,19 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     # slice walks its interactions with the next gathers in flight, while every further slot, round and workgroup pays
     # its own start-up round trips), then more rounds per task.
     target = int(os.environ.get('INVPREF_PLAN_TARGET_WGS', str(TARGET_WORKGROUPS)))
+    _cnt = {}
+    def counts(side):          # interactions per row of a side (one pass over the minibatch each, on first use)
+        if side not in _cnt:
+            rows, n_rows = (users, user_num) if side == 'u' else (items, item_num)
+            L = _native_lib() if (n >= (1 << 20) and rows.flags.c_contiguous) else None
+            if L is not None:       # (the same numbers as np.bincount, counted on threads)
+                out = np.empty(n_rows, np.int64)
+                if L.invpref_plan_row_counts(rows.ctypes.data, n, n_rows, out.ctypes.data) != 0:
+                    raise ValueError('row ids out of range')
+                _cnt[side] = out
+            else:
+                _cnt[side] = np.bincount(rows, minlength=n_rows)
+        return _cnt[side]
     def rounds_for(cnt, ps):   # group slots / ng: the rounds a side needs at `ps` interactions per slice
         c = cnt[cnt > 0]
         need = np.maximum(1, -(-c // ps))
@@ -311,7 +343,7 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         # shortest slices while launch 1's jobs are resident at once (one latency chain: a Yahoo step); otherwise the
         # shortest slice that costs no more than 5 % more rounds than 16 per slice does (measured at 32 768 Yahoo-shaped
         # interactions: 6 per slice 33.5 us against 37.5 at 2 and 37.2 at 16; at 250 154: 16 per slice 118 us, 8: 135)
-        ucnt0 = np.bincount(users, minlength=1)
+        ucnt0 = counts('u')
         resident = RESIDENT_SMALL if small else 512
         if rounds_for(ucnt0, 2) <= resident:
             per_slice = 2
@@ -355,19 +387,18 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
 
     if rounds_per_task is None:
         rounds_per_task = int(os.environ.get('INVPREF_PLAN_ROUNDS', '0')) or \
-            min(16, max(1, round(rounds_for(np.bincount(users, minlength=1), per_slice) / target)))
+            min(16, max(1, round(rounds_for(counts('u'), per_slice) / target)))
     if item_rounds_per_task is None:
         # (rows of up to 1 KB, pull form: an item task first stages two [E, D] tables of up to 16 KB each, holds only eight
         #  rows and leaves a 16 KB partial slab of embed_env's gradient -- fewer, longer tasks: MIND-shaped steps 898 -> 769 us
         #  at 8 rounds per task instead of 1)
         few = lanes == 32
         item_rounds_per_task = int(os.environ.get('INVPREF_PLAN_ITEM_ROUNDS', '0')) or \
-            min(16, max(1, round(rounds_for(np.bincount(items, minlength=1), item_per_slice) / (target // 2 if few else 4 * target))))
+            min(16, max(1, round(rounds_for(counts('i'), item_per_slice) / (target // 2 if few else 4 * target))))
     if rows_per_stream_task is None:
         rows_per_stream_task = int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', str(stream_rows_default(factor_num))))
     rows_per_stream_task2 = int(os.environ.get('INVPREF_PLAN_STREAM_ROWS2', str(rows_per_stream_task)))  # one iteration of a workgroup
-    ucnt = np.bincount(users, minlength=user_num)
-    icnt = np.bincount(items, minlength=item_num)
+    ucnt, icnt = counts('u'), counts('i')
     if n and max(ucnt.max(), icnt.max()) >= MAX_ROW_COUNT:
         raise ValueError(f'a row with {max(ucnt.max(), icnt.max())} interactions in one minibatch overflows the job descriptor')
     if max(user_num, item_num) >= ITEM_BIT:
@@ -525,12 +556,20 @@ def upload(plan: dict, device) -> DevicePlan:
             offs[k] = -1
             continue
         a = np.ascontiguousarray(plan[k], np.int32).reshape(-1)
-        pad = (-len(a)) % 4
-        parts.append(np.concatenate([a, np.zeros(pad, np.int32)]))
+        parts.append((off, a))
         offs[k] = off
-        off += len(a) + pad
-    parts.append(np.zeros(4, np.int32))   # (never an empty buffer)
-    buf = torch.from_numpy(np.concatenate(parts)).to(device)
+        off += len(a) + (-len(a)) % 4
+    total = off + 4                        # (never an empty buffer)
+    if total < (1 << 18):                  # a small plan: one host buffer, one copy
+        host = np.zeros(total, np.int32)
+        for o, a in parts:
+            host[o:o + len(a)] = a
+        buf = torch.from_numpy(host).to(device)
+    else:                                  # a large one (up to GBs): every array straight from where the builder left it
+        buf = torch.zeros(total, dtype=torch.int32, device=device)
+        for o, a in parts:
+            if len(a):
+                buf[o:o + len(a)].copy_(torch.from_numpy(a))
     ptrs = {k: (buf.data_ptr() + 4 * o if o >= 0 else None) for k, o in offs.items()}
     cls = np.asarray(plan['cls'], np.int32)
     st = RowPlanStruct(plan['n'], plan['lanes_per_group'], len(plan['user_desc']), len(plan['item_desc']),

@@ -85,8 +85,45 @@ def test_plan_header_symbols_are_exported():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = re.sub(r'/\*.*?\*/', '', open(os.path.join(root, 'include', 'invpref_plan.h')).read(), flags=re.S)
     names = set(re.findall(r'\b(invpref_plan_\w+)\s*\(', code))
-    assert names == {'invpref_plan_build', 'invpref_plan_array', 'invpref_plan_free', 'invpref_plan_build_many'}
+    assert names == {'invpref_plan_build', 'invpref_plan_array', 'invpref_plan_free', 'invpref_plan_build_many',
+                     'invpref_plan_row_counts'}
     L = C.CDLL(build.INGEST_LIB)
     for n in names:
         assert hasattr(L, n), n
     assert C.sizeof(planlib.PlanParamsStruct) == 11 * 4 + 4 + 8   # 11 int32, padding, one double
+
+
+def test_row_counts_match_bincount_and_reject_bad_ids():
+    """invpref_plan_row_counts == np.bincount(rows, minlength=n_rows), also over several threads' chunks"""
+    import ctypes as C
+    L = planlib._native_lib()
+    rs = np.random.RandomState(3)
+    for n, n_rows in ((0, 5), (1000, 37), ((1 << 20) + 123, 5000)):
+        rows = rs.randint(0, n_rows, n).astype(np.int64)
+        out = np.full(n_rows, -1, np.int64)
+        assert L.invpref_plan_row_counts(rows.ctypes.data, n, n_rows, out.ctypes.data) == 0
+        assert np.array_equal(out, np.bincount(rows, minlength=n_rows))
+    bad = np.array([0, 7, 2], np.int64)
+    out = np.zeros(5, np.int64)
+    assert L.invpref_plan_row_counts(bad.ctypes.data, 3, 5, out.ctypes.data) == -2
+    bad[1] = -1
+    assert L.invpref_plan_row_counts(bad.ctypes.data, 3, 5, out.ctypes.data) == -2
+
+
+def test_big_minibatch_on_threads_is_byte_identical():
+    """a minibatch large enough for the threaded sort (>= 2^18 interactions): same arrays as the numpy builder"""
+    rs = np.random.RandomState(11)
+    n, U, I = (1 << 18) + 777, 9000, 2500
+    users, items = rs.randint(0, U, n).astype(np.int64), (rs.zipf(1.3, n) % I).astype(np.int64)
+    scores = rs.randint(0, 2, n).astype(np.float32)
+    for D, E in ((64, 4), (128, 8), (256, 16)):
+        a = planlib.build_row_plan(users, items, scores, U, I, factor_num=D, env_num=E, native=True)
+        b = planlib.build_row_plan(users, items, scores, U, I, factor_num=D, env_num=E, native=False)
+        for k in b:
+            if isinstance(b[k], np.ndarray):
+                assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+            else:
+                assert a[k] == b[k] or (a[k] is None and b[k] is None), k
+    with pytest.raises(ValueError):
+        users[5] = U
+        planlib.build_row_plan(users, items, scores, U, I, native=True)

@@ -725,6 +725,16 @@ def main():
                                          'flat_buffer_bytes': 4 * mgr_a.state.cap}
         del mgr_a
         torch.cuda.empty_cache()
+        # the all-reduce over the rows each GLOBAL minibatch touches + the small tables only (packed on the device)
+        os.environ['INVPREF_EXCHANGE'] = 'packed'
+        mgr_p = build_manager(dev, rank, world, 'rows')
+        dt_p, steps_p, _, _ = timed_run(mgr_p, world, args.steps, args.warmup)
+        out['detail']['rows_packed'] = {'value': steps_p * B_PER_GPU * world / dt_p, 'ms_per_step': dt_p / steps_p * 1e3,
+                                        'steps': steps_p, 'exchange': 'pack touched rows -> 1 all-reduce -> unpack',
+                                        'all_reduce_bytes_mean': 4 * sum(mgr_p.packed_floats) / len(mgr_p.packed_floats),
+                                        'flat_gradient_bytes': 4 * mgr_p.state.n}
+        del mgr_p
+        torch.cuda.empty_cache()
         os.environ.pop('INVPREF_EXCHANGE', None)
         mgr_u = build_manager(dev, rank, world, 'users')
         dt_u, steps_u, _, _ = timed_run(mgr_u, world, args.steps, args.warmup)

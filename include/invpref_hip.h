@@ -310,6 +310,18 @@ int invpref_static_pop_hip(const int64_t *users, const int64_t *items, const int
                            const double *user_cnt_norm, const double *item_cnt_norm, double *out, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* ---- packed exchange of a row-sharded optimiser step (the reference is single-process: its
+ * loss.backward() / optimizer.step(), train.py:155-157, see the whole minibatch).  Only the rows of the four big tables
+ * that the GLOBAL minibatch touches carry a gradient; every other row is zero on every rank.  pack: copies those rows
+ * (row_offsets[r] = first float of row r inside `flat`, D floats each) and then flat[tail_offset, tail_offset + tail_len)
+ * (the small tables) into `packed` ((n_rows * D + tail_len) floats), which the caller all-reduces; unpack: the reverse copy.
+ * vec_ok != 0: every row offset is a multiple of 4 floats (float4 copies when D % 4 == 0 and the buffers are 16-byte
+ * aligned as well). */
+int invpref_pack_rows_hip(const float *flat, const int64_t *row_offsets, int64_t n_rows, int32_t D, int64_t tail_offset,
+                          int64_t tail_len, float *packed, int vec_ok, void *stream);
+int invpref_unpack_rows_hip(float *flat, const int64_t *row_offsets, int64_t n_rows, int32_t D, int64_t tail_offset,
+                            int64_t tail_len, const float *packed, int vec_ok, void *stream);
+
 /* ---- dense Adam: replaces optimizer.zero_grad() + optimizer.step() of torch.optim.Adam with
  * default betas/eps (train.py:41, :155-157) over one flat fp32 buffer of n parameters.
  * step is 1-based.  zero_grad != 0 also clears grad (the next step's zero_grad()).  The buffers need only be

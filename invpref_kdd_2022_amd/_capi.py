@@ -26,6 +26,7 @@ EXPORTS = [
     'invpref_static_pop_hip', 'invpref_adam_ranges_hip', 'invpref_mstep_rows_grad_sched_hip',
     'invpref_adam_ranges_sched_hip', 'invpref_rows_lanes_per_group', 'invpref_rows_defer_supported',
     'invpref_mstep_rows_adam_deferred_hip', 'invpref_flush_deferred_hip', 'invpref_estep_perm_hip',
+    'invpref_pack_rows_hip', 'invpref_unpack_rows_hip',
 ]
 
 
@@ -72,6 +73,8 @@ def lib():
         L.invpref_mstep_grad_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), vp, vp, vp, vp, vp, i64, i64,
                                              C.POINTER(Coefs), u32, vp, vp, C.c_size_t, vp]
         L.invpref_adam_hip.argtypes = [vp, vp, vp, vp, i64, i64, f64, f64, f64, f64, C.c_int, vp]
+        L.invpref_pack_rows_hip.argtypes = [vp, vp, i64, C.c_int32, i64, i64, vp, C.c_int, vp]
+        L.invpref_unpack_rows_hip.argtypes = [vp, vp, i64, C.c_int32, i64, i64, vp, C.c_int, vp]
         L.invpref_estep_hip.argtypes = [C.POINTER(Tables), vp, vp, vp, i64, u32, vp, vp, vp, vp, vp, vp, vp, vp,
                                         C.c_size_t, vp]
         L.invpref_estep_perm_hip.argtypes = [C.POINTER(Tables), vp, vp, vp, i64, u32, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp,

@@ -133,6 +133,7 @@ class _BasicTrainManager(_InvPrefTrainManager):
                                    self.world_size)
         else:
             self.shard = RowShard(n_total, batch_size, self.rank, self.world_size)
+        training_data_full = training_data
         if self.world_size > 1:
             training_data = training_data.index_select(0, self.shard.local_rows().to(training_data.device))
         self.users_tensor = training_data[:, 0].contiguous().to(self.device)
@@ -153,6 +154,8 @@ class _BasicTrainManager(_InvPrefTrainManager):
         self.state = FlatState(model.tables(), self.device,     # [user table | item table]: the shared part is last
                                chunks=self.world_size if self.exchange == 'scatter' else 1)
         self._setup_ranges(model)
+        if self.exchange == 'packed':
+            self._setup_packed(training_data_full[:, 0], training_data_full[:, 1])
         self.workspace = ops.Workspace(self.device)
         self._flags = ops.flags_of(self.implicit, False, False, True, False, dense_reg=False) | _capi.PURE_MF
         self.use_plan, self._plans = True, None

@@ -824,6 +824,61 @@ inline int estep_blocks(int64_t N) {
 }  // namespace
 
 // ===================================================================================== C ABI
+// ---- packed exchange of a row-sharded step: the rows of the flat gradient the GLOBAL minibatch touches --
+// every other row of the four big tables is zero on every rank -- and the flat buffer's tail (the small tables) are copied
+// into one contiguous buffer for the all-reduce (UNPACK = false) and back (UNPACK = true).  HBM-bound copies: one float4
+// per lane, consecutive lanes on consecutive float4 of a row.
+template <bool UNPACK, bool VEC>
+__global__ __launch_bounds__(256) void pack_rows_kernel(float *__restrict__ flat, const int64_t *__restrict__ row_offsets,
+                                                        int64_t n_rows, int32_t D, int64_t tail_offset, int64_t tail_len,
+                                                        float *__restrict__ packed) {
+    constexpr int W = VEC ? 4 : 1;
+    const int64_t per_row = D / W, body = n_rows * per_row, total = body + (tail_len + W - 1) / W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float *f, *q;
+        int cnt = W;
+        if (i < body) {
+            const int64_t r = i / per_row, c = i - r * per_row;
+            f = flat + row_offsets[r] + c * W;
+            q = packed + r * (int64_t)D + c * W;
+        } else {
+            const int64_t c = (i - body) * W;
+            f = flat + tail_offset + c;
+            q = packed + n_rows * (int64_t)D + c;
+            if (tail_len - c < W) cnt = (int)(tail_len - c);
+        }
+        if (VEC && cnt == 4) {
+            if (UNPACK) *reinterpret_cast<float4 *>(f) = *reinterpret_cast<const float4 *>(q);
+            else *reinterpret_cast<float4 *>(q) = *reinterpret_cast<const float4 *>(f);
+        } else {
+            for (int k = 0; k < cnt; k++) {
+                if (UNPACK) f[k] = q[k];
+                else q[k] = f[k];
+            }
+        }
+    }
+}
+
+static int pack_rows_launch(bool unpack, float *flat, const int64_t *row_offsets, int64_t n_rows, int32_t D,
+                            int64_t tail_offset, int64_t tail_len, float *packed, int vec_ok, void *stream) {
+    if (!flat || !packed || n_rows < 0 || D < 1 || tail_len < 0 || tail_offset < 0 || (n_rows > 0 && !row_offsets))
+        return INVPREF_EINVAL;
+    if (n_rows == 0 && tail_len == 0) return 0;
+    // float4 form: rows of whole float4 starting on 16-byte boundaries (the caller vouches for the row offsets: vec_ok)
+    const uintptr_t af = reinterpret_cast<uintptr_t>(flat), aq = reinterpret_cast<uintptr_t>(packed);
+    const bool vec = vec_ok && D % 4 == 0 && tail_offset % 4 == 0 && ((af | aq) & 15u) == 0;
+    const int64_t items = n_rows * (D / (vec ? 4 : 1)) + (tail_len + (vec ? 3 : 0)) / (vec ? 4 : 1);
+    int64_t nb = (items + 255) / 256;
+    nb = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
+#define PK(U, V)                                                                                                         \
+    hipLaunchKernelGGL((pack_rows_kernel<U, V>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, flat, row_offsets, \
+                       n_rows, D, tail_offset, tail_len, packed)
+    if (unpack) { if (vec) PK(true, true); else PK(true, false); }
+    else { if (vec) PK(false, true); else PK(false, false); }
+#undef PK
+    return (int)hipGetLastError();
+}
+
 extern "C" {
 
 int invpref_abi_version(void) { return INVPREF_ABI_VERSION; }
@@ -1012,6 +1067,18 @@ int invpref_adam_hip(float *param, float *grad, float *exp_avg, float *exp_avg_s
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                        exp_avg_sq, n, a, zero_grad, head);
     return (int)hipGetLastError();
+}
+
+int invpref_pack_rows_hip(const float *flat, const int64_t *row_offsets, int64_t n_rows, int32_t D, int64_t tail_offset,
+                          int64_t tail_len, float *packed, int vec_ok, void *stream) {
+    return pack_rows_launch(false, const_cast<float *>(flat), row_offsets, n_rows, D, tail_offset, tail_len, packed, vec_ok,
+                            stream);
+}
+
+int invpref_unpack_rows_hip(float *flat, const int64_t *row_offsets, int64_t n_rows, int32_t D, int64_t tail_offset,
+                            int64_t tail_len, const float *packed, int vec_ok, void *stream) {
+    return pack_rows_launch(true, flat, row_offsets, n_rows, D, tail_offset, tail_len, const_cast<float *>(packed), vec_ok,
+                            stream);
 }
 
 static int adam_ranges_launch(float *param, float *grad, float *exp_avg, float *exp_avg_sq, const int64_t *offsets,

@@ -112,6 +112,19 @@ def adam_ranges_(param, grad, exp_avg, exp_avg_sq, offsets, lengths, step: int, 
                       float(lr), float(beta1), float(beta2), float(eps), bool(zero_grad), s_state, s_table, int(s_slot))
 
 
+def pack_rows(flat: torch.Tensor, row_offsets: torch.Tensor, D: int, tail_offset: int, tail_len: int, packed: torch.Tensor,
+              vec_ok: bool = True) -> None:
+    """the packed exchange of a row-sharded step: rows `row_offsets` (first float of each, D floats) of the flat gradient,
+    then its tail [tail_offset, tail_offset + tail_len), copied into `packed` for ONE all-reduce."""
+    _o().pack_rows_(flat, row_offsets, int(D), int(tail_offset), int(tail_len), packed, bool(vec_ok))
+
+
+def unpack_rows(flat: torch.Tensor, row_offsets: torch.Tensor, D: int, tail_offset: int, tail_len: int, packed: torch.Tensor,
+                vec_ok: bool = True) -> None:
+    """the reverse copy: the all-reduced rows and tail back into the flat gradient"""
+    _o().unpack_rows_(flat, row_offsets, int(D), int(tail_offset), int(tail_len), packed, bool(vec_ok))
+
+
 def estep(params: Sequence[torch.Tensor], users, items, scores, implicit: bool, old_envs: Optional[torch.Tensor],
           workspace: Workspace, eps_rows: Optional[torch.Tensor] = None, new_envs: Optional[torch.Tensor] = None,
           want_weights: bool = True, perm_index: Optional[torch.Tensor] = None, eps_base=None):

@@ -17,6 +17,7 @@ What replaces what in the reference:
 ``flush_deferred_``            brings every deferred user row up to date (before anything reads all rows)
 ``adam_dense_``                ``optimizer.zero_grad()`` + ``torch.optim.Adam.step()`` (train.py:41, :155-157)
 ``adam_ranges_``               the same over up to four pieces of the flat buffers (user-sharded ranks)
+``pack_rows_`` / ``unpack_``   the touched rows of the flat gradient into / out of one buffer (row-sharded ranks' exchange)
 ``estep_assign``               ``cluster_a_batch`` / ``cluster`` (train.py:169-202, :235-259), functional
 ``estep_assign_``              ``cluster()`` updating ``envs`` in place + the ``stat_envs()`` that follows (train.py:330)
 ``stat_envs``                  ``stat_envs()`` (train.py:268-280)
@@ -291,6 +292,46 @@ def _adam_dense(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, z
 
 @_fake('adam_dense_')
 def _adam_dense_fake(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, zero_grad):
+    return None
+
+
+# ------------------------------------------------------------------------------------------------ packed exchange
+_define('pack_rows_(Tensor flat, Tensor row_offsets, int D, int tail_offset, int tail_len, Tensor(a!) packed, bool vec_ok) -> ()')
+_define('unpack_rows_(Tensor(a!) flat, Tensor row_offsets, int D, int tail_offset, int tail_len, Tensor packed, bool vec_ok) -> ()')
+
+
+def _pack_check(flat, row_offsets, D, tail_offset, tail_len, packed):
+    _f32(flat, 'flat')
+    _f32(packed, 'packed')
+    if row_offsets.dtype != torch.int64 or not row_offsets.is_contiguous() or row_offsets.device != flat.device:
+        raise InvPrefError('pack_rows: row_offsets must be a contiguous int64 tensor on the device of `flat`')
+    n = row_offsets.numel()
+    if packed.numel() < n * D + tail_len or tail_offset + tail_len > flat.numel():
+        raise InvPrefError('pack_rows: buffer too small')
+    return n
+
+
+@_impl('pack_rows_')
+def _pack_rows(flat, row_offsets, D, tail_offset, tail_len, packed, vec_ok):
+    n = _pack_check(flat, row_offsets, D, tail_offset, tail_len, packed)
+    check(lib().invpref_pack_rows_hip(ptr(flat), ptr(row_offsets), n, int(D), int(tail_offset), int(tail_len), ptr(packed),
+                                      int(bool(vec_ok)), stream_ptr()), 'invpref_pack_rows_hip')
+
+
+@_impl('unpack_rows_')
+def _unpack_rows(flat, row_offsets, D, tail_offset, tail_len, packed, vec_ok):
+    n = _pack_check(flat, row_offsets, D, tail_offset, tail_len, packed)
+    check(lib().invpref_unpack_rows_hip(ptr(flat), ptr(row_offsets), n, int(D), int(tail_offset), int(tail_len), ptr(packed),
+                                        int(bool(vec_ok)), stream_ptr()), 'invpref_unpack_rows_hip')
+
+
+@_fake('pack_rows_')
+def _pack_rows_fake(flat, row_offsets, D, tail_offset, tail_len, packed, vec_ok):
+    return None
+
+
+@_fake('unpack_rows_')
+def _unpack_rows_fake(flat, row_offsets, D, tail_offset, tail_len, packed, vec_ok):
     return None
 
 

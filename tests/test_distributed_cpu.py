@@ -75,8 +75,18 @@ def _oracle_ops(monkey_target):
         for o, n in zip(offsets, lengths):
             adam_(param[o:o + n], grad[o:o + n], m[o:o + n], v[o:o + n], step, lr, zero_grad=zero_grad)
 
+    def pack_rows(flat, row_offsets, D, tail_offset, tail_len, packed, vec_ok=True):
+        idx = (row_offsets[:, None] + torch.arange(D)).reshape(-1)
+        packed[:idx.numel()] = flat[idx]
+        packed[idx.numel():idx.numel() + tail_len] = flat[tail_offset:tail_offset + tail_len]
+
+    def unpack_rows(flat, row_offsets, D, tail_offset, tail_len, packed, vec_ok=True):
+        idx = (row_offsets[:, None] + torch.arange(D)).reshape(-1)
+        flat[idx] = packed[:idx.numel()]
+        flat[tail_offset:tail_offset + tail_len] = packed[idx.numel():idx.numel() + tail_len]
+
     for name, fn in dict(mstep_grad=mstep_grad, adam_=adam_, adam_ranges_=adam_ranges_, estep=estep, stat_envs=stat_envs,
-                         sample_weights=sample_weights).items():
+                         sample_weights=sample_weights, pack_rows=pack_rows, unpack_rows=unpack_rows).items():
         setattr(monkey_target, name, fn)
 
 
@@ -272,13 +282,14 @@ def _yahoo_worker(rank, world, port, out_dir, mode):
         np.savez(os.path.join(out_dir, f'rank{rank}.npz'), param=mgr.state.param.numpy(),
                  offsets=np.array(mgr.state.offsets), losses=np.array([[l[k] for k in LOSS_KEYS] for l in (l1, l2)]),
                  diff=diff, counts=np.array([cnt[e] for e in range(YE)]), envs=mgr.envs.numpy(),
-                 rows=mgr.shard.local_rows().numpy(), ar_floats=mgr.state.n + 8 - mgr._ar_lo)
+                 rows=mgr.shard.local_rows().numpy(), ar_floats=mgr.state.n + 8 - mgr._ar_lo,
+                 packed_floats=np.array(getattr(mgr, 'packed_floats', [0])))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('world,mode', [(4, 'rows'), (8, 'rows'), (8, 'rows-allreduce'), (8, 'users')])
+@pytest.mark.parametrize('world,mode', [(4, 'rows'), (8, 'rows'), (8, 'rows-allreduce'), (8, 'rows-packed'), (8, 'users')])
 def test_yahoo_shaped_epochs_world_4_and_8(tmp_path, world, mode):
     mp.spawn(_yahoo_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
     r = [np.load(tmp_path / f'rank{i}.npz') for i in range(world)]
@@ -287,7 +298,12 @@ def test_yahoo_shaped_epochs_world_4_and_8(tmp_path, world, mode):
         np.testing.assert_array_equal(r[0]['losses'], x['losses'])
         assert int(r[0]['diff']) == int(x['diff'])
     P = 2 * (YU + YI) * YD + 2 * YE * YD + YE
-    if mode.startswith('rows'):
+    if mode == 'rows-packed':
+        # one all-reduce per step over the rows the GLOBAL minibatch touches + the small tables: at this split (8 192
+        # interactions per global minibatch over 15 400 users) well under half of the flat gradient
+        pf = r[0]['packed_floats']
+        assert len(pf) == 31 and 0 < pf.max() < 0.5 * P and pf.min() >= 2 * YE * YD + YE
+    elif mode.startswith('rows'):
         assert int(r[0]['ar_floats']) >= P + 8            # the whole flat gradient + the loss tail, one all-reduce
     else:
         assert int(r[0]['ar_floats']) < 2 * YI * YD + 2 * YE * YD + YE + 8 + 5 * 64   # item side + small tables only

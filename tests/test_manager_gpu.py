@@ -490,6 +490,74 @@ def test_sharded_epochs_graph_vs_eager(monkeypatch, mode):
         np.testing.assert_array_equal(res[0][2][k], res[1][2][k], err_msg=k)
 
 
+def test_packed_exchange_equals_the_whole_all_reduce(monkeypatch):
+    """INVPREF_EXCHANGE=packed (row-sharded ranks all-reduce the rows the GLOBAL minibatch touches + the small tables through
+    one packed buffer, invpref_pack_rows_hip / invpref_unpack_rows_hip) against the all-reduce of the whole flat gradient, on a
+    1-rank RCCL group where the collective adds nothing: the two runs must agree BITWISE -- every row the packed form leaves
+    out is zero -- eagerly and with the exchange captured in the epoch graph."""
+    import torch.distributed as dist
+    z = np.load(os.path.join(G, 'g4_yahoo_like_traj.npz'))
+    U, I, E, D, bs, epochs, seed = [int(x) for x in z['meta']]
+    data = synth.yahoo_like(seed)[:30000]
+    tabs = synth.tables(seed + 7, U, I, E, D, std=0.05)
+    monkeypatch.setenv('INVPREF_FORCE_SHARDED_PATH', '1')
+    monkeypatch.setenv('INVPREF_SHARD', 'rows')
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29537')
+        dist.init_process_group('nccl', rank=0, world_size=1)
+    res = []
+    try:
+        for exchange, eager in (('allreduce', '0'), ('packed', '0'), ('packed', '1')):
+            monkeypatch.setenv('INVPREF_EXCHANGE', exchange)
+            monkeypatch.setenv('INVPREF_NO_COLLECTIVE_GRAPH', eager)
+            model = InvPrefImplicit(U, I, E, D, reg_only_embed=False, reg_env_embed=True)
+            model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+            np.random.seed(seed)
+            mgr = _mgr(ImplicitTrainManager, model, data, z, use_class_re_weight=True, use_recommend_re_weight=True)
+            assert mgr.exchange == exchange
+            if exchange == 'packed':
+                P = mgr.state.n
+                assert len(mgr.packed_floats) == mgr.batch_num and 0 < max(mgr.packed_floats) < P
+            mgr.stat_envs()
+            tr = mgr.train_epochs(3)
+            d = mgr.cluster()
+            tr += mgr.train_epochs(2)
+            assert bool(mgr._graphs) == (eager == '0')
+            res.append((np.array([[e[k] for k in LOSS_KEYS] for e in tr]), d,
+                        {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}))
+    finally:
+        dist.destroy_process_group()
+    for other in res[1:]:
+        np.testing.assert_array_equal(res[0][0], other[0])
+        assert res[0][1] == other[1]
+        for k in O.PARAM_NAMES:
+            np.testing.assert_array_equal(res[0][2][k], other[2][k], err_msg=k)
+
+
+@pytest.mark.parametrize('D', [64, 30, 7])
+def test_pack_rows_round_trip(D):
+    """invpref_pack_rows_hip / invpref_unpack_rows_hip against torch indexing: float4 rows (D = 64), rows that are not whole
+    float4 (30, 7), a tail that is not a multiple of four, an empty row list."""
+    from invpref_kdd_2022_amd import ops
+    g = torch.Generator().manual_seed(D)
+    n_flat, tail_off, tail_len = 5000 * D + 123, 5000 * D, 123
+    flat = torch.randn(n_flat, generator=g).to(DEV)
+    for n_rows in (0, 1, 777):
+        rows = (torch.randperm(5000, generator=g)[:n_rows].sort().values * D).to(DEV)
+        packed = torch.full((n_rows * D + tail_len + 4,), float('nan'), device=DEV)
+        ops.pack_rows(flat, rows, D, tail_off, tail_len, packed, D % 4 == 0)
+        idx = (rows[:, None] + torch.arange(D, device=DEV)).reshape(-1)
+        want = torch.cat([flat[idx], flat[tail_off:tail_off + tail_len]])
+        assert torch.equal(packed[:want.numel()], want) and bool(torch.isnan(packed[want.numel():]).all())
+        back = torch.zeros_like(flat)
+        ops.unpack_rows(back, rows, D, tail_off, tail_len, packed, D % 4 == 0)
+        ref = torch.zeros_like(flat)
+        ref[idx] = flat[idx]
+        ref[tail_off:tail_off + tail_len] = flat[tail_off:tail_off + tail_len]
+        assert torch.equal(back, ref)
+
+
 def test_wide_rows_take_the_unfused_sequence(monkeypatch):
     """factor_num > 128 (64-lane groups): the fused pass is the default at every row length; INVPREF_UNFUSED=1 runs the
     gradient pass + flat Adam sequence (what a sharded rank runs) on one GPU.  Same trajectory either way."""

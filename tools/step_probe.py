@@ -184,6 +184,9 @@ for launch, name in ((0, 'launch 1 (eval)'), (1, 'launch 2 (apply)')):
         print('  job phases (us, median): stage issue %.2f | descriptor %.2f | gathers+sync %.2f | interactions %.2f | slice meet %.2f | '
               'adam+store %.2f | partial slab %.2f' % (tuple(np.median(ph, axis=0)) + (np.median(tail),)))
         if os.environ.get('PROBE_TOP'):
+            print('  job phases (us, p90):    ' + ' | '.join('%.2f' % x for x in np.quantile(ph, .9, axis=0)) +
+                  ' ; slowest tenth of the jobs (median): ' +
+                  ' | '.join('%.2f' % x for x in np.median(ph[(j[:, 6] - j[:, 0]) >= np.quantile(j[:, 6] - j[:, 0], .9)], axis=0)))
             desc = pl['user_desc'] if launch == 0 else pl['item_desc']
             idx = np.flatnonzero((kind == 'job') & live)
             order = idx[np.argsort(-(end[idx] - st[idx, 0]))][:int(os.environ['PROBE_TOP'])]

@@ -585,7 +585,10 @@ __global__ __launch_bounds__(256) void eps_unrank_kernel(const IT *__restrict__ 
 // once (4 bytes each) and look an interaction's row up there -- no unranking launch, no packed rows through memory
 constexpr int kEpsTableMaxE = 7;
 
-template <int NC, bool VEC>
+// NARROW: every big table is under 2^32 bytes (any reference configuration: MIND's are 51 MB), so a row's address is its
+// table's base + one 32-bit offset (id x D in a 32-bit multiply) instead of a 64-bit product per gathered row; the ids
+// arrive as the reference's int64 (LongTensor) either way.
+template <int NC, bool VEC, bool NARROW>
 __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const int64_t *__restrict__ users,
                                                            const int64_t *__restrict__ items,
                                                            const float *__restrict__ scores, int64_t N, uint32_t flags,
@@ -649,10 +652,18 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
         const int64_t u = users[s], v = items[s];
         const float y = scores[s];
         float4 pu[NC], qi[NC], pa[NC], qa[NC];
-        load_row<NC, VEC>(t.Pu, u, t.D, l16, pu);
-        load_row<NC, VEC>(t.Qi, v, t.D, l16, qi);
-        load_row<NC, VEC>(t.Pa, u, t.D, l16, pa);
-        load_row<NC, VEC>(t.Qa, v, t.D, l16, qa);
+        if (NARROW) {
+            const unsigned uo = (unsigned)u * (unsigned)t.D, vo = (unsigned)v * (unsigned)t.D;
+            load_row<NC, VEC>(t.Pu + uo, 0, t.D, l16, pu);
+            load_row<NC, VEC>(t.Qi + vo, 0, t.D, l16, qi);
+            load_row<NC, VEC>(t.Pa + uo, 0, t.D, l16, pa);
+            load_row<NC, VEC>(t.Qa + vo, 0, t.D, l16, qa);
+        } else {
+            load_row<NC, VEC>(t.Pu, u, t.D, l16, pu);
+            load_row<NC, VEC>(t.Qi, v, t.D, l16, qi);
+            load_row<NC, VEC>(t.Pa, u, t.D, l16, pa);
+            load_row<NC, VEC>(t.Qa, v, t.D, l16, qa);
+        }
         const float p = dot2<NC>(pu, qi);
         const float sp = implicit ? c_sigmoid(p) : p;
         // One environment per LANE: q_e is a group-uniform value after the row reduction and lane e keeps it; the
@@ -1213,12 +1224,15 @@ static int estep_launch(const InvPrefTables *tables, const int64_t *users, const
         else
             hipLaunchKernelGGL(eps_unrank_kernel<int64_t>, dim3((unsigned)ub), dim3(256), 0, st, (const int64_t *)perm_index, N, t.E, fac, eps_packed);
     }
-#define ECALL(NCV, VECV)                                                                                          \
-    hipLaunchKernelGGL((estep_assign_kernel<NCV, VECV>), dim3(nb), dim3(kEstepThreads), lds + lds_extra, st, t, users, items, \
+#define ECALL1(NCV, VECV, NARV)                                                                                   \
+    hipLaunchKernelGGL((estep_assign_kernel<NCV, VECV, NARV>), dim3(nb), dim3(kEstepThreads), lds + lds_extra, st, t, users, items, \
                        scores, N, flags, eps_rows, eps_packed, eps_base, eps_index, index_bytes, eps_rows_n, fac, old_envs, \
                        new_envs, slabs)
+#define ECALL(NCV, VECV) do { if (narrow) ECALL1(NCV, VECV, true); else ECALL1(NCV, VECV, false); } while (0)
+    const bool narrow = (uint64_t)std::max(t.U, t.I) * (uint64_t)t.D * 4u < (1ull << 32);
     if (!vec) { ECALL(4, false); } else if (nc == 1) { ECALL(1, true); } else if (nc == 2) { ECALL(2, true); } else { ECALL(4, true); }
 #undef ECALL
+#undef ECALL1
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return (int)err;
     int64_t nb2 = (N + 255) / 256;

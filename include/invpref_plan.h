@@ -26,6 +26,8 @@ typedef struct InvPrefPlanParams {
     int32_t push;                     /* item side in push form: no inline interactions, push_slot produced */
     int32_t user_lo, user_hi;         /* untouched user rows outside [user_lo, user_hi) are not streamed; (0, user_num) = all */
     int32_t fill_cap;                 /* launch-1 residency the stream split fills (0: plain split) */
+    int32_t snake_user;               /* > 0: launch 1's rounds of a class heaviest first, every other row of this many reversed
+                                       * (tasks j, j + 32 .. of an XCD share a CU: heavy rounds meet light ones) */
     double stream_split;              /* share of a class's untouched rows streamed by launch 1 */
 } InvPrefPlanParams;
 

@@ -183,8 +183,24 @@ void side_rounds(const Side &s, int64_t n, const int32_t *list, int stride, int 
 
 // the rounds of ONE class (into arrays of their own), padded to a multiple of pad_to rounds with idle rounds
 void class_rounds(const Side &s, int64_t n, const int32_t *list, int stride, int w, int ng, int per_slice, int pad_to, int inl_max,
-                  const std::vector<int32_t> &class_rows, std::vector<int32_t> &d, std::vector<int32_t> &it) {
+                  const std::vector<int32_t> &class_rows, std::vector<int32_t> &d, std::vector<int32_t> &it, int snake) {
     side_rounds(s, n, list, stride, w, ng, per_slice, pad_to, inl_max, class_rows, d, it);
+    if (snake > 0 && it.size() > 1) {
+        // co-residency order (plan.py: _side_rounds): heaviest rounds first, every other row of `snake` rounds reversed
+        const size_t nr = it.size(), slot = (size_t)ng * 8;
+        std::vector<int32_t> perm(nr);
+        for (size_t i = 0; i < nr; i++) perm[i] = (int32_t)i;
+        std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return it[(size_t)a] > it[(size_t)b]; });
+        for (size_t r = 1; r * (size_t)snake < nr; r += 2)
+            std::reverse(perm.begin() + (ptrdiff_t)(r * snake), perm.begin() + (ptrdiff_t)std::min(nr, (r + 1) * (size_t)snake));
+        std::vector<int32_t> d2(d.size()), it2(nr);
+        for (size_t i = 0; i < nr; i++) {
+            std::memcpy(d2.data() + i * slot, d.data() + (size_t)perm[i] * slot, slot * 4);
+            it2[i] = it[(size_t)perm[i]];
+        }
+        d.swap(d2);
+        it.swap(it2);
+    }
     const int64_t have = (int64_t)it.size();
     const int64_t pad = ((-have) % pad_to + pad_to) % pad_to;
     for (int64_t p = 0; p < pad; p++) {
@@ -258,10 +274,10 @@ InvPrefHostPlan *build(const int64_t *users, const int64_t *items, const float *
     parallel_for(2 * ncls, nt, [&](int q) {
         const int c = q >> 1;
         if ((q & 1) == 0)
-            class_rounds(us, n, ul, 4, 3, ng, p.per_slice, p.rounds_per_task, 2, urows[(size_t)c], cd[(size_t)q], cit[(size_t)q]);
+            class_rounds(us, n, ul, 4, 3, ng, p.per_slice, p.rounds_per_task, 2, urows[(size_t)c], cd[(size_t)q], cit[(size_t)q], p.snake_user);
         else
             class_rounds(is, n, il, 2, 2, ng, p.item_per_slice, p.item_rounds_per_task, p.push ? 0 : 3, irows[(size_t)c],
-                         cd[(size_t)q], cit[(size_t)q]);
+                         cd[(size_t)q], cit[(size_t)q], 0);
     });
     lap("rounds of the classes");
     int32_t cls[8][8];

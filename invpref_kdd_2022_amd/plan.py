@@ -46,6 +46,7 @@ ARRAYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list'
 OPTIONAL_ARRAYS = ('push_slot',)   # may be absent (plan[k] is None; meta offset -1; NULL in the struct)
 
 N_CLASSES = 8          # XCDs of an MI355X: blocks b and b + 8 of a launch share one (round-robin placement)
+CUS_PER_XCD = 32       # ... and inside an XCD tasks j, j + 32, j + 64 of a class share a CU (tools/probes/cu_map.hip)
 CLASS_SHIFT = 6        # rows are dealt to the classes in blocks of 64
 
 
@@ -70,7 +71,7 @@ def row_class(rows: np.ndarray, n_classes: int) -> np.ndarray:
     return (np.asarray(rows) >> CLASS_SHIFT) % n_classes
 
 
-def _side_rounds(own, cols, n_rows: int, ng: int, per_slice: int, pad_to: int, inline: int, skip):
+def _side_rounds(own, cols, n_rows: int, ng: int, per_slice: int, pad_to: int, inline: int, skip, snake: int = 0):
     """(desc [n_rounds, ng, 8] int32, iters [n_rounds]) for one side.  own: the side's row of every interaction in the
     side's sorted order; cols: the int32 columns of the sorted list (user side: partner, position, label bits; item
     side: partner, position) -- `inline` interactions of a slice travel inside the descriptor, longer slices as a range
@@ -121,6 +122,16 @@ def _side_rounds(own, cols, n_rows: int, ng: int, per_slice: int, pad_to: int, i
             iters.append(it)
         g >>= 1
     d, it = np.concatenate(descs), np.concatenate(iters)
+    if snake and len(it) > 1:
+        # Which rounds share a CU: the dispatcher deals the workgroups of a launch to the CUs breadth-first, so tasks j, j + 32,
+        # j + 64 ... of one XCD class run on the SAME CU while the launch fits one residency (tools/probes/cu_map.hip) and
+        # compete for its SIMDs.  Heaviest rounds first, then every other row of `snake` (= the CUs of an XCD) reversed:
+        # the heaviest round shares its CU with the lightest of the next row (measured at the MovieLens shape: launch 1 ends
+        # at 40 us instead of 46, the step takes 63.7 us instead of 66.0).
+        perm = np.argsort(-it, kind='stable')
+        for r in range(1, -(-len(perm) // snake), 2):
+            perm[r * snake:(r + 1) * snake] = perm[r * snake:(r + 1) * snake][::-1].copy()
+        d, it = d[perm], it[perm]
     pad = (-len(d)) % pad_to
     if pad:
         idle = np.zeros((pad, ng, 8), np.int32)
@@ -159,7 +170,7 @@ class PlanParamsStruct(C.Structure):
     _fields_ = [('lanes_per_group', C.c_int32), ('per_slice', C.c_int32), ('item_per_slice', C.c_int32),
                 ('rounds_per_task', C.c_int32), ('item_rounds_per_task', C.c_int32), ('n_classes', C.c_int32),
                 ('rows_per_stream_task', C.c_int32), ('push', C.c_int32), ('user_lo', C.c_int32), ('user_hi', C.c_int32),
-                ('fill_cap', C.c_int32), ('stream_split', C.c_double)]
+                ('fill_cap', C.c_int32), ('snake_user', C.c_int32), ('stream_split', C.c_double)]
 
 
 _NATIVE = None
@@ -192,7 +203,7 @@ def _native_lib():
 def _params_struct(r: dict) -> PlanParamsStruct:
     return PlanParamsStruct(r['lanes'], r['per_slice'], r['item_per_slice'], r['rounds_per_task'], r['item_rounds_per_task'],
                             r['n_classes'], r['rows_per_stream_task'], int(r['push']), r['user_lo'], r['user_hi'], r['fill_cap'],
-                            r['stream_split'])
+                            r['snake_user'], r['stream_split'])
 
 
 class _NativePlan:
@@ -425,12 +436,15 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         bias = float(os.environ.get('INVPREF_PLAN_EVAL_COST', '3.0'))
         s1 = (12.0 * ti - 12.0 * tu - bias * n + 12.0 * n_stream) / 24.0
         stream_split = min(1.0, max(0.0, s1 / n_stream)) if n_stream else 0.0
+    # wide-row instances, one round per task: launch 1's rounds in co-residency order (_side_rounds: snake)
+    snake_user = int(os.environ.get('INVPREF_PLAN_SNAKE', str(CUS_PER_XCD if (not small and rounds_per_task == 1) else 0)))
     # ---- every parameter is resolved: the arrays themselves come from the native builder (csrc/invpref_plan.cpp, the same
     # arrays byte for byte: tests/test_plan_native.py) unless INVPREF_PLAN_NATIVE=0 or `_resolve_only`
     resolved = dict(lanes=lanes, per_slice=int(per_slice), item_per_slice=int(item_per_slice),
                     rounds_per_task=int(rounds_per_task), item_rounds_per_task=int(item_rounds_per_task),
                     n_classes=int(n_classes), rows_per_stream_task=int(rows_per_stream_task),
                     rows_per_stream_task2=int(rows_per_stream_task2), stream_split=float(stream_split), fill_cap=int(fill_cap),
+                    snake_user=int(snake_user),
                     push=bool(push), user_lo=0 if user_range is None else int(user_range[0]),
                     user_hi=int(user_num) if user_range is None else int(user_range[1]), factor_num=factor_num, n=n)
     if _resolve_only:
@@ -450,7 +464,7 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     defer_tail = np.zeros((8, 2), np.int32)
     for c in range(n_classes):
         d, it = _side_rounds(users[pu], ucols, user_num, ng, per_slice, rounds_per_task, 2,
-                             skip=(ucnt == 0) | (ucls != c))
+                             skip=(ucnt == 0) | (ucls != c), snake=snake_user)
         du_parts.append(d)
         it_parts.append(it)
         d, _ = _side_rounds(items[pi], icols, item_num, ng, item_per_slice, item_rounds_per_task, 0 if push else 3,

@@ -186,3 +186,26 @@ def test_slice_length_of_mid_sized_launches_follows_the_makespan_estimate():
     assert all(est[ps] > 1.02 * min(est.values()) for ps in est if ps < p['per_slice'])
     d = synth.yahoo_like()[:8192]
     assert planlib.build_row_plan(d[:, 0], d[:, 1], d[:, 2], 15400, 1000, env_num=4)['per_slice'] == 2
+
+
+def test_launch_1_rounds_are_in_co_residency_order_for_wide_rows():
+    """rows of more than 64 floats (or more than 4 environments), one round per task: every XCD class's rounds come heaviest
+    first in rows of 32 (the CUs of an XCD), every other row reversed -- tasks j and j + 32 of a class share a CU, so the
+    heaviest round meets the lightest of the next row.  The Yahoo-class instance keeps the plain order."""
+    from invpref_kdd_2022_amd import synth
+    d = synth.interactions(3, 6040, 3706, 65536, implicit=True)
+    pl = planlib.build_row_plan(d[:, 0], d[:, 1], d[:, 2], 6040, 3706, factor_num=128, env_num=8)
+    assert pl['user_rounds_per_task'] == 1
+    it, cls = np.asarray(pl['user_round_iters']), np.asarray(pl['cls'])
+    for c in range(pl['n_classes']):
+        its = it[cls[c, 0]:cls[c, 0] + cls[c, 1]]
+        assert len(its) > 40
+        rows = [its[r:r + 32] for r in range(0, len(its), 32)]
+        assert all(np.diff(rows[0]) <= 0) and all(np.diff(rows[1]) >= 0)
+        assert rows[0].min() >= rows[1].max()
+    plain = planlib.build_row_plan(d[:, 0], d[:, 1], d[:, 2], 6040, 3706, factor_num=128, env_num=8, native=False)
+    for k in ('user_desc', 'user_round_iters', 'item_desc'):
+        assert np.array_equal(np.asarray(pl[k]), np.asarray(plain[k])), k
+    y = synth.yahoo_like()[:8192]
+    py = planlib.build_row_plan(y[:, 0], y[:, 1], y[:, 2], 15400, 1000, factor_num=64, env_num=4, _resolve_only=True)
+    assert py['snake_user'] == 0

@@ -90,7 +90,7 @@ def test_plan_header_symbols_are_exported():
     L = C.CDLL(build.INGEST_LIB)
     for n in names:
         assert hasattr(L, n), n
-    assert C.sizeof(planlib.PlanParamsStruct) == 11 * 4 + 4 + 8   # 11 int32, padding, one double
+    assert C.sizeof(planlib.PlanParamsStruct) == 12 * 4 + 8   # 12 int32, one double
 
 
 def test_row_counts_match_bincount_and_reject_bad_ids():

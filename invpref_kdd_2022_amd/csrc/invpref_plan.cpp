@@ -173,6 +173,10 @@ void side_rounds(const Side &s, int64_t n, const int32_t *list, int stride, int 
                         if (inl && m > q)
                             for (int cc = 0; cc < w; cc++) d[2 + q * w + cc] = list[(size_t)jq * stride + cc];
                     }
+                    // (a list slice's leading interactions ride in the descriptor's spare words: plan.py)
+                    if (!inl && inl_max > 0)
+                        for (int q = 0; q < (8 - 4) / w && q < m; q++)
+                            for (int cc = 0; cc < w; cc++) d[4 + q * w + cc] = list[(size_t)(j0 + q) * stride + cc];
                 }
                 int32_t &it = iters[ibase + (size_t)rnd];
                 it = std::max(it, (int32_t)m);

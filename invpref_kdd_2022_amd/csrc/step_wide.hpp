@@ -41,6 +41,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef WIDE_STEP_FENCE_MASK
 #define WIDE_STEP_FENCE_MASK 0   // what may cross the fences between two lock-step iterations (0x8: the MFMA block)
 #endif
+#ifndef WIDE_FIRST_FROM_DESC
+#define WIDE_FIRST_FROM_DESC 0   // 1: a slice's first gather from the descriptor's registers instead of through list_at (measured: no gain)
+#endif
 #ifndef WIDE_PUSH_DEPTH
 #define WIDE_PUSH_DEPTH 4   // (measured at the MovieLens shape: 66.7 -> 66.0 us against 2)
 #endif
@@ -97,8 +100,24 @@ struct WGeo {
         }                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     } while (0)
+// (inside eval_wide: the same stamps through a context handed in by the caller; tags 10 ..)
+struct WTraceCtx { unsigned long long *buf; int *n; bool on; };
+#define ETRACE(tag)                                                                                           \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (tc.on && *tc.n < 120) {                                                                           \
+            tc.buf[100000 + *tc.n] = ((unsigned long long)(tag) << 56) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffffull); \
+            (*tc.n)++;                                                                                        \
+        }                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
+#define ETRACE_PARAM , WTraceCtx tc
+#define ETRACE_ARG , WTraceCtx{a.stamps, &wtrace_n, a.stamps && blockIdx.x == 40 && threadIdx.x == 0}
 #else
 #define WTRACE(tag) do { } while (0)
+#define ETRACE(tag) do { } while (0)
+#define ETRACE_PARAM
+#define ETRACE_ARG
 #endif
 
 // VEC in this file = FULL rows: factor_num == DP (64 / 128 / 256) and 16-byte aligned tables.  A full row is loaded with
@@ -152,7 +171,7 @@ template <int LG, int NC, int EMAX>
 __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], const float4 (&qi)[NC],
                                           const float4 (&pa)[NC], const float4 (&qa)[NC], const float4 (&ev)[NC],
                                           const float *sW, const float *sb, float *gzs, int E, int e, float y, float cw_rec,
-                                          float cw_cls, const StepScalars &k, bool implicit, bool pure, int lg, bool has) {
+                                          float cw_cls, const StepScalars &k, bool implicit, bool pure, int lg, bool has ETRACE_PARAM) {
     // `has` = false (an empty slot of a lock-step iteration): the arithmetic runs on the slot's stale -- finite -- rows
     // and every gradient scalar is forced to zero, so that everything downstream contributes nothing; no branch.
     constexpr int DP = 4 * LG * NC;
@@ -165,6 +184,7 @@ __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], 
     }
     const float p = group_sum<LG>(ps);
     const float q = group_sum<LG>(qs);
+    ETRACE(10);
     if (implicit) {
         const float sp = f_sigmoid(p), sq = f_sigmoid(q), sv = sp * sq;
         o.li = f_bce(sp, y);
@@ -182,6 +202,7 @@ __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], 
         o.g_q = d_env;
     }
     if (!has) o.g_p = o.g_q = o.li = o.le = 0.f;
+    ETRACE(11);
     o.lcls = 0.f;
     o.gz_lane = 0.f;
 #pragma unroll
@@ -204,6 +225,7 @@ __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], 
         part[c] = s;
     }
     if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(WIDE_FENCE_MASK);
+    ETRACE(12);
     const float zred = group_sum_above<LG, EMAX>(class_butterfly<EMAX>(part, lg), lg);
     const float zmine = lg < E ? zred + sb[lg & (EMAX - 1)] : -__builtin_inff();
     const float mxl = group_max<LG>(zmine);
@@ -214,8 +236,10 @@ __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], 
     // every lane needs every gz_c for the backward: through the group's LDS words (in-order LDS operations of one wave)
     if (lg < EMAX) gzs[lg] = gzl;
     if (lg == e) gzs[EMAX + 1] = -f_log(ez * rsel);   // (lane e holds the picked class: its loss term)
+    ETRACE(13);
     WAVE_LDS_FENCE();
     o.lcls = has ? gzs[EMAX + 1] : 0.f;
+    ETRACE(14);
 #pragma unroll
     for (int c4 = 0; c4 < EMAX; c4 += 4) {
         if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(WIDE_FENCE_MASK);
@@ -306,7 +330,8 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
     const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
 
     STAMP(0);
-    int4 d = a.desc[(r0 * NG + grp) * 2];   // (the inline interactions of the descriptor's second half are read back from memory)
+    // both halves of the descriptor: row | meta | list range or inline interactions | a list slice's leading interaction
+    int4 d = a.desc[(r0 * NG + grp) * 2], d2 = a.desc[(r0 * NG + grp) * 2 + 1];
     STAMP(1);
 
     constexpr bool SH = Shared<EMAX, EVL2>::value;   // one accumulator set for both products
@@ -328,7 +353,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
 #endif
 
     for (int r = r0; r < r0 + nr; r++) {
-        const int4 dd = d;
+        const int4 dd = d, dd2 = d2;
         const int row = dd.x, meta = dd.y;
         const bool active = row >= 0, leader = meta & 1;
         const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
@@ -344,6 +369,9 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
         const int lo = dd.z, hi1 = max(dd.w - 1, dd.z);
         const int *dwords = reinterpret_cast<const int *>(a.desc + (r * NG + grp) * 2);
         auto list_at = [&](int sidx) {
+#ifdef WIDE_DIAG_NOLIST   // (what-if build: no list round trip in front of the gathers -- ids made up from the slice bounds)
+            return USample{(lo + sidx) & 1023, min(lo + sidx, hi1), 0.f};
+#endif
             const int *src = mode == 7 ? reinterpret_cast<const int *>(a.ulist + min(lo + sidx, hi1)) : dwords + 2 + 3 * min(sidx, 1);
             return USample{src[0], src[1], __builtin_bit_cast(float, src[2])};
         };
@@ -379,6 +407,10 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             if (rw_rec || rw_cls) q.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + pso * 4u);
             if (push) q.cs = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.push_slot) + pso * 4u);
         };
+        // the slice's FIRST interaction is in the descriptor's registers either way (inline form: words 2 .. 4, list form:
+        // words 4 .. 6), so its gather leaves as soon as the descriptor is here -- not one list round trip later
+        const USample first = mode == 7 ? USample{dd2.x, dd2.y, __builtin_bit_cast(float, dd2.z)}
+                                        : USample{dd.z, dd.w, __builtin_bit_cast(float, dd2.x)};
 #pragma unroll
         for (int j = 0; j < UE; j++) {
 #pragma unroll
@@ -386,7 +418,8 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             sl[j].ps = sl[j].e = sl[j].cs = 0;
             sl[j].y = 0.f;
             sl[j].w = 1.f;
-            gather(sl[j], list_at(j));
+            if (WIDE_FIRST_FROM_DESC && j == 0) gather(sl[j], first);
+            else gather(sl[j], list_at(j));
         }
 #pragma unroll
         for (int j = 0; j < UE; j++) idn[j] = list_at(UE + j);
@@ -419,7 +452,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
 #endif
             WEval<NC> o;
             eval_wide<LG, NC, EMAX>(o, oi, q.qi, oe, q.qa, ev, sW, sb, gzs, t.E, e, q.y, w_rec * k.invB, w_cls * k.invB, k,
-                                    implicit, pure, lg, has);
+                                    implicit, pure, lg, has ETRACE_ARG);
 #ifdef WIDE_DIAG_TRACE
             { float probe = o.gx[0].x + o.g_p + o.lcls; asm volatile("" :: "v"(probe)); }
             WTRACE(3);
@@ -496,7 +529,10 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             }
         }
         if (r == r0) STAMP(4);
-        if (r + 1 < r0 + nr) d = a.desc[((r + 1) * NG + grp) * 2];
+        if (r + 1 < r0 + nr) {
+            d = a.desc[((r + 1) * NG + grp) * 2];
+            d2 = a.desc[((r + 1) * NG + grp) * 2 + 1];
+        }
         const float cnt = (float)(meta >> 9);
         if (active && leader) {   // regulariser reports: the user's rows count once per interaction
             float s2 = 0.f, s1 = 0.f;

@@ -116,6 +116,14 @@ def _side_rounds(own, cols, n_rows: int, ng: int, per_slice: int, pad_to: int, i
                         on = inl & (m > q)
                         for c in range(w):
                             slot[:, 2 + q * w + c] = np.where(on, cols[c][jq], slot[:, 2 + q * w + c])
+                    # a list slice also carries its LEADING interactions in the descriptor's spare words (4 ..: one on the
+                    # user side, two on the item side): their gathers start when the descriptor arrives, one round trip
+                    # before the list's entries are there
+                    for q in range((8 - 4) // w if inline > 0 else 0):
+                        jq = np.minimum(j0 + q, len(own) - 1)
+                        on = ~inl & (m > q)
+                        for c in range(w):
+                            slot[:, 4 + q * w + c] = np.where(on, cols[c][jq], slot[:, 4 + q * w + c])
                 d[rnd, first + k] = slot
                 np.maximum.at(it, rnd, m.astype(np.int32))
             descs.append(d)

@@ -1,0 +1,18 @@
+#!/bin/bash
+# tools/hot_diag.sh -- what-if: the wide kernels with every partner-row gather hitting the same 16 rows (-DWIDE_DIAG_HOT):
+# what launch 1 costs without gather latency.  Rebuilds the library ON THE BOX (the in-tree one is untouched elsewhere).
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+shapes=${SHAPES:-"50000x51283x16x256x262144 400000x100000x16x256x1048576 400000x100000x8x128x1048576 6040x3706x8x128x65536"}
+probe() {
+  for s in $shapes; do
+    echo "== $1 $s"
+    PROBE_SHAPE=$s timeout 300 python tools/step_probe.py 2>&1 | grep "us per step"
+    PROBE_STAMPS=1 PROBE_STEPS=3 PROBE_SHAPE=$s timeout 300 python tools/step_probe.py 2>&1 | grep "launch 1\|launch 2\|job phases" | cut -c1-220
+  done
+}
+probe default > gpurun_out/hot_diag.log 2>&1
+DIAG=${DIAG:--DWIDE_DIAG_HOT}
+INVPREF_HIPCC_EXTRA="$DIAG" python -c "from invpref_kdd_2022_amd import build; build.build(force=True)" > /dev/null 2>&1
+probe hot >> gpurun_out/hot_diag.log 2>&1
+cat gpurun_out/hot_diag.log

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """tools/wide_trace.py -- with a -DWIDE_DIAG_TRACE build (INVPREF_LIB): shader-clock stamps of the first steps of one wave
 of a wide launch-1 task (workgroup 40): where a lock-step iteration spends its time.
-tags: 1 step entry | 2 slot rows + env row arrived | 3 evaluation done | 4 stores / updates issued | 5 MFMAs issued | 6 refill issued"""
+tags: 1 step entry | 2 slot rows + env row arrived | (inside the evaluation: 10 row sums | 11 loss chains | 12 class dot
+products | 13 butterfly + softmax, gz written | 14 gz read back) | 3 evaluation done | 4 stores / updates issued | 5 MFMAs issued |
+6 refill issued"""
 import os
 import sys
 
@@ -34,10 +36,12 @@ for _ in range(3):
                         losses, 5, 0.005, ws)
 torch.cuda.synchronize()
 raw = stamps.cpu().numpy()[100000:100120]
+skip = int(os.environ.get('TRACE_SKIP', '0'))
 raw = raw[raw != 0]
 tag, t = (raw >> 56) & 0xff, raw & ((1 << 56) - 1)
 t = t - t[0]
-names = {1: 'entry', 2: 'rows arrived', 3: 'evaluated', 4: 'updates/stores', 5: 'mfma issued', 6: 'refill issued'}
+names = {1: 'entry', 2: 'rows arrived', 3: 'evaluated (gx done)', 4: 'updates/stores', 5: 'mfma issued', 6: 'refill issued',
+         10: '  row sums', 11: '  loss chains', 12: '  class dots', 13: '  softmax, gz out', 14: '  gz back'}
 prev = 0
 for k, (g, x) in enumerate(zip(tag, t)):
     print('%3d %-16s t=%8d clk  +%6d' % (k, names.get(int(g), str(g)), x, x - prev))

@@ -247,6 +247,12 @@ struct StepArgs {
         }                                                                         \
     } while (0)
 
+// (which round of a task the per-round stamps 2 .. 5 describe: 0 = its first -- table staging included --, diagnostic builds
+//  pass -DSTAMP_ROUND_OFFSET=k for a steady-state round)
+#ifndef STAMP_ROUND_OFFSET
+#define STAMP_ROUND_OFFSET 0
+#endif
+#define STAMP_ROUND (STAMP_ROUND_OFFSET < nr ? STAMP_ROUND_OFFSET : nr - 1)
 #ifndef STEP_SLOT_ALIAS
 #define STEP_SLOT_ALIAS 1
 #endif
@@ -508,7 +514,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
         const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
         const int nsmp = active ? (mode == 7 ? dd.w - dd.z : mode) : 0;
         const int iters = G::REG ? nsmp : a.round_iters[r];
-        if (r == r0) STAMP(2);
+        if (r == r0 + STAMP_ROUND) STAMP(2);
         // sample sidx of the slice: inline in the descriptor (up to two) or one 16-byte load from the sorted list.
         // FULL instances fetch it with ONE unconditional load from a selected address (list index clamped into the slice;
         // the inline form read back from the descriptor's own words, 3 ints per interaction from word 2 on): every gather of
@@ -785,7 +791,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 if (FULL || s + 2 * UE + j < nsmp) idn[j] = sample_at(s + 2 * UE + j);
             }
         }
-        if (r == r0) STAMP(4);
+        if (r == r0 + STAMP_ROUND) STAMP(4);
         // (requested here, behind the interaction loop's register peak: it flies under the slice meet and the row finish)
         if (r + 1 < r0 + nr) { d = a.desc[((r + 1) * NG + grp) * 2]; d1 = a.desc[((r + 1) * NG + grp) * 2 + 1]; }
         const float cnt = (float)(meta >> 9);
@@ -904,7 +910,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             }
             if (!last) __syncthreads();  // the slots are rewritten by the next round
         }
-        if (r == r0) STAMP(5);
+        if (r == r0 + STAMP_ROUND) STAMP(5);
         // ---- the leader finishes the row
         if (active && leader) {
             if (cnt != 0.f) {
@@ -985,7 +991,7 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
         const bool active = row >= 0, leader = meta & 1;
         const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
         const int nsmp = active ? (mode == 7 ? dd.w - dd.z : mode) : 0;
-        if (r == r0) STAMP(2);
+        if (r == r0 + STAMP_ROUND) STAMP(2);
         float4 oi = f4zero(), oe = f4zero(), gi = f4zero(), ge = f4zero();
         {   // (an idle slot reads row 0 rather than branching around the loads)
             const int rowc = active ? row : 0;
@@ -1064,7 +1070,7 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
                 if (s + 2 * U + j < nsmp) idn[j] = ids_at(s + 2 * U + j);
             }
         }
-        if (r == r0) STAMP(4);
+        if (r == r0 + STAMP_ROUND) STAMP(4);
         if (slices > 1) {
             float *mine = slots + grp * 2 * DP;
             *reinterpret_cast<float4 *>(mine + lg * 4) = gi;
@@ -1080,7 +1086,7 @@ __device__ __forceinline__ void item_task(const DevTables &t, const StepArgs &a,
             }
             if (r + 1 < r0 + nr) __syncthreads();
         }
-        if (r == r0) STAMP(5);
+        if (r == r0 + STAMP_ROUND) STAMP(5);
         if (active && leader) {
             const float cnt = (float)(meta >> 9);
             if (cnt != 0.f) {
@@ -1144,7 +1150,7 @@ __device__ __forceinline__ void item_task_push(const DevTables &t, const StepArg
         const bool active = row >= 0, leader = meta & 1;
         const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
         const int nsmp = (active && mode == 7) ? dd.w - dd.z : 0;
-        if (r == r0) STAMP(2);
+        if (r == r0 + STAMP_ROUND) STAMP(2);
         float4 oi, oe = f4zero(), gi = f4zero(), ge = f4zero();
         {
             const int rowc = active ? row : 0;
@@ -1174,7 +1180,7 @@ __device__ __forceinline__ void item_task_push(const DevTables &t, const StepArg
                         (__attribute__((address_space(3))) void *)(mv_wave + tn * 64), 16, 0, 0);
             }
         }
-        if (r == r0) STAMP(3);
+        if (r == r0 + STAMP_ROUND) STAMP(3);
         for (int s0 = 0; s0 < nsmp; s0 += PCH) {
 #pragma unroll
             for (int j = 0; j < PCH; j++) {
@@ -1184,7 +1190,7 @@ __device__ __forceinline__ void item_task_push(const DevTables &t, const StepArg
             }
             if (s0 + PCH < nsmp) fetch(s0 + PCH);
         }
-        if (r == r0) STAMP(4);
+        if (r == r0 + STAMP_ROUND) STAMP(4);
         if (slices > 1) {
             float *mine = slots + grp * 2 * DP;
             *reinterpret_cast<float4 *>(mine + lg * 4) = gi;
@@ -1200,7 +1206,7 @@ __device__ __forceinline__ void item_task_push(const DevTables &t, const StepArg
             }
             if (r + 1 < r0 + nr) __syncthreads();
         }
-        if (r == r0) STAMP(5);
+        if (r == r0 + STAMP_ROUND) STAMP(5);
         if (active && leader) {
             const float cnt = (float)(meta >> 9);
             if (cnt != 0.f) {

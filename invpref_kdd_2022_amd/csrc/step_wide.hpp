@@ -359,7 +359,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
         const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
         const int nsmp = active ? (mode == 7 ? dd.w - dd.z : mode) : 0;
         const int iters = a.round_iters[r];   // the round's longest slice: the loop (and its MFMAs) is workgroup-uniform
-        if (r == r0) STAMP(2);
+        if (r == r0 + STAMP_ROUND) STAMP(2);
         // The slice's interactions come from the sorted list (mode 7) or, up to two of them, from the descriptor itself.
         // Every load of the loop below is UNCONDITIONAL -- list indices are clamped into the slice, so a finished slice
         // re-reads its last interaction (cache hits) and an idle slot reads entry 0 -- because a load under a divergent
@@ -430,8 +430,8 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             stage_small(sW, t.W, t.E, t.D, EMAX, DP);
             if (threadIdx.x < 16) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
             __syncthreads();
-            STAMP(3);
         }
+        if (r == r0 + STAMP_ROUND) STAMP(3);
 
         auto step = [&](const Slot &q, bool has) {
             // branch-free: an empty slot (the round's longest slice sets the trip count) evaluates its stale rows with
@@ -528,7 +528,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
                 WTRACE(6);
             }
         }
-        if (r == r0) STAMP(4);
+        if (r == r0 + STAMP_ROUND) STAMP(4);
         if (r + 1 < r0 + nr) {
             d = a.desc[((r + 1) * NG + grp) * 2];
             d2 = a.desc[((r + 1) * NG + grp) * 2 + 1];
@@ -579,7 +579,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             }
             __syncthreads();  // the slots are rewritten by the next round
         }
-        if (r == r0) STAMP(5);
+        if (r == r0 + STAMP_ROUND) STAMP(5);
         // ---- the leader finishes the row
         if (active && leader) {
             if (cnt != 0.f) {
@@ -698,7 +698,7 @@ __device__ __forceinline__ void item_task_wide(const DevTables &t, const StepArg
             for (int g = 0; g < 64 / LG; g++) mx = max(mx, __builtin_amdgcn_readlane(nsmp, g * LG));
             iters = mx;
         }
-        if (r == r0) STAMP(2);
+        if (r == r0 + STAMP_ROUND) STAMP(2);
         // (the job's own rows are needed when the row is finished -- and Qa[v] by embed_env's product, EVL2: they are
         //  requested there, not held across the loop)
         float4 oi[NC], oe[NC], gi[NC], ge[NC];
@@ -783,8 +783,8 @@ __device__ __forceinline__ void item_task_wide(const DevTables &t, const StepArg
             stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
             stage_small(sW, t.W, t.E, t.D, EMAX, DP);
             __syncthreads();
-            STAMP(3);
         }
+        if (r == r0 + STAMP_ROUND) STAMP(3);
         for (int s = 0; s < iters; s += U) {
 #pragma unroll
             for (int j = 0; j < U; j++) {
@@ -793,7 +793,7 @@ __device__ __forceinline__ void item_task_wide(const DevTables &t, const StepArg
                 idn[j] = ids_at(s + 2 * U + j);
             }
         }
-        if (r == r0) STAMP(4);
+        if (r == r0 + STAMP_ROUND) STAMP(4);
         if (slices > 1) {
             float *mine = slots + grp * 2 * DP;
 #pragma unroll
@@ -815,7 +815,7 @@ __device__ __forceinline__ void item_task_wide(const DevTables &t, const StepArg
             }
             if (r + 1 < r0 + nr) __syncthreads();
         }
-        if (r == r0) STAMP(5);
+        if (r == r0 + STAMP_ROUND) STAMP(5);
         if (active && leader) {
             load_row<LG, NC, VEC>(oi, t.Qi, row, t.D, lg);
             if (!EVL2 && !pure) load_row<LG, NC, VEC>(oe, t.Qa, row, t.D, lg);
@@ -882,7 +882,7 @@ __device__ __forceinline__ void item_task_push_wide(const DevTables &t, const St
         const bool active = row >= 0, leader = meta & 1;
         const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
         const int nsmp = (active && mode == 7) ? dd.w - dd.z : 0;
-        if (r == r0) STAMP(2);
+        if (r == r0 + STAMP_ROUND) STAMP(2);
         float4 oi[NC], oe[NC], gi[NC], ge[NC];
 #pragma unroll
         for (int j = 0; j < NC; j++) oi[j] = oe[j] = gi[j] = ge[j] = f4zero();
@@ -906,7 +906,7 @@ __device__ __forceinline__ void item_task_push_wide(const DevTables &t, const St
             }
         };
         fetch(0);
-        if (r == r0) STAMP(3);
+        if (r == r0 + STAMP_ROUND) STAMP(3);
         for (int s0 = 0; s0 < nsmp; s0 += PCH) {
 #pragma unroll
             for (int q = 0; q < PCH; q++) {
@@ -919,7 +919,7 @@ __device__ __forceinline__ void item_task_push_wide(const DevTables &t, const St
             }
             if (s0 + PCH < nsmp) fetch(s0 + PCH);
         }
-        if (r == r0) STAMP(4);
+        if (r == r0 + STAMP_ROUND) STAMP(4);
         if (slices > 1) {
             float *mine = slots + grp * 2 * DP;
 #pragma unroll
@@ -941,7 +941,7 @@ __device__ __forceinline__ void item_task_push_wide(const DevTables &t, const St
             }
             if (r + 1 < r0 + nr) __syncthreads();
         }
-        if (r == r0) STAMP(5);
+        if (r == r0 + STAMP_ROUND) STAMP(5);
         if (active && leader) {
             const float cnt = (float)(meta >> 9);
             if (cnt != 0.f) {

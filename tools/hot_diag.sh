@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/hot_diag.sh -- what-if: the wide kernels with every partner-row gather hitting the same 16 rows (-DWIDE_DIAG_HOT):
+# tools/hot_diag.sh -- what-if / diagnostic builds (DIAG="-D...", SHAPES=..., SKIP_DEFAULT=1): the wide kernels with every partner-row gather hitting the same 16 rows (-DWIDE_DIAG_HOT):
 # what launch 1 costs without gather latency.  Rebuilds the library ON THE BOX (the in-tree one is untouched elsewhere).
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
@@ -11,8 +11,9 @@ probe() {
     PROBE_STAMPS=1 PROBE_STEPS=3 PROBE_SHAPE=$s timeout 300 python tools/step_probe.py 2>&1 | grep "launch 1\|launch 2\|job phases" | cut -c1-220
   done
 }
-probe default > gpurun_out/hot_diag.log 2>&1
+[ -z "$SKIP_DEFAULT" ] && probe default > gpurun_out/hot_diag.log 2>&1
 DIAG=${DIAG:--DWIDE_DIAG_HOT}
+[ -n "$SKIP_DEFAULT" ] && : > gpurun_out/hot_diag.log
 INVPREF_HIPCC_EXTRA="$DIAG" python -c "from invpref_kdd_2022_amd import build; build.build(force=True)" > /dev/null 2>&1
 probe hot >> gpurun_out/hot_diag.log 2>&1
 cat gpurun_out/hot_diag.log

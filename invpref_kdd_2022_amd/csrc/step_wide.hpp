@@ -153,6 +153,18 @@ __device__ __forceinline__ void store_row(float *__restrict__ base, int row, int
         }
     }
 }
+// regulariser reports: x^2 + z^2 into a, y^2 + w^2 into b (two independent fma chains: packed pairs); sum of magnitudes as
+// one add chain (the |x| is a source modifier of the add)
+__device__ __forceinline__ void sq_acc(float &a, float &b, const float4 &v) {
+    a = fmaf(v.x, v.x, a);
+    b = fmaf(v.y, v.y, b);
+    a = fmaf(v.z, v.z, a);
+    b = fmaf(v.w, v.w, b);
+}
+__device__ __forceinline__ float abs_acc(float s, const float4 &v) {
+    return (((s + fabsf(v.x)) + fabsf(v.y)) + fabsf(v.z)) + fabsf(v.w);
+}
+
 template <int LG, int NC>
 __device__ __forceinline__ void lds_row(float4 (&r)[NC], const float *tab, int e, int lg) {
     constexpr int DP = 4 * LG * NC;
@@ -177,10 +189,11 @@ __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], 
     constexpr int DP = 4 * LG * NC;
     float ps = 0.f, qs = 0.f;
 #pragma unroll
-    for (int j = 0; j < NC; j++) {
+    for (int j = 0; j < NC; j++) {   // (the first term starts the sum: no 0 + x instruction)
         o.x[j] = f4mul(pu[j], qi[j]);
-        ps += (o.x[j].x + o.x[j].y) + (o.x[j].z + o.x[j].w);
-        qs += dot4(f4mul(pa[j], qa[j]), ev[j]);
+        const float pj = (o.x[j].x + o.x[j].y) + (o.x[j].z + o.x[j].w), qj = dot4(f4mul(pa[j], qa[j]), ev[j]);
+        ps = j ? ps + pj : pj;
+        qs = j ? qs + qj : qj;
     }
     const float p = group_sum<LG>(ps);
     const float q = group_sum<LG>(qs);
@@ -203,12 +216,17 @@ __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], 
     }
     if (!has) o.g_p = o.g_q = o.li = o.le = 0.f;
     ETRACE(11);
-    o.lcls = 0.f;
-    o.gz_lane = 0.f;
+    if (pure) {   // PureMF: no classifier (the zeros are written on THIS path only: no register moves on the other)
+        o.lcls = 0.f;
+        o.gz_lane = 0.f;
+#pragma unroll
+        for (int j = 0; j < NC; j++) o.gx[j] = f4zero();
+        return;
+    }
+#ifdef WIDE_DIAG_NOCLS
+    o.lcls = o.gz_lane = 0.f;
 #pragma unroll
     for (int j = 0; j < NC; j++) o.gx[j] = f4zero();
-    if (pure) return;   // PureMF: no classifier
-#ifdef WIDE_DIAG_NOCLS
     return;
 #endif
     // all EMAX class dot products per lane (rows c >= E are staged as zeros), then ONE reduce-scatter butterfly: lane l of
@@ -221,7 +239,10 @@ __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], 
         if (WIDE_FENCE && NC > 1 && (c & 3) == 0) __builtin_amdgcn_sched_barrier(WIDE_FENCE_MASK);
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < NC; j++) s += dot4(o.x[j], *reinterpret_cast<const float4 *>(sW + c * DP + 4 * (lg + LG * j)));
+        for (int j = 0; j < NC; j++) {
+            const float dj = dot4(o.x[j], *reinterpret_cast<const float4 *>(sW + c * DP + 4 * (lg + LG * j)));
+            s = j ? s + dj : dj;
+        }
         part[c] = s;
     }
     if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(WIDE_FENCE_MASK);
@@ -247,6 +268,7 @@ __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], 
 #pragma unroll
         for (int j = 0; j < NC; j++) {
             const float *wr = sW + c4 * DP + 4 * (lg + LG * j);
+            if (c4 == 0) o.gx[j] = f4zero();
             f4fma(o.gx[j], g4.x, *reinterpret_cast<const float4 *>(wr));
             f4fma(o.gx[j], g4.y, *reinterpret_cast<const float4 *>(wr + DP));
             f4fma(o.gx[j], g4.z, *reinterpret_cast<const float4 *>(wr + 2 * DP));
@@ -457,7 +479,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             { float probe = o.gx[0].x + o.g_p + o.lcls; asm volatile("" :: "v"(probe)); }
             WTRACE(3);
 #endif
-            float s2 = 0.f, s1 = 0.f;
+            float s2 = 0.f, s1 = 0.f, s2a = 0.f, s2b = 0.f;
             // (an empty slot stores to the spare row / record behind the minibatch's: the loop's stores are unconditional too)
             float *cr = a.records + (unsigned)(has ? q.cs : a.n_rec) * (unsigned)(2 * DP);
             float4 boo[EVL2 ? 1 : NC];
@@ -482,9 +504,11 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
                     if (reg_env && has) f4add(oo, reg_term(ev[j], 2.f * k.r2, 2.f * k.r1));
                     boo[j] = oo;
                 }
-                // regulariser REPORTS over the item rows of the interaction (env rows weigh double)
-                s2 += f4sq(q.qi[j]) + f4sq(q.qa[j]);
-                s1 += f4abs(q.qi[j]) + f4abs(q.qa[j]);
+                // regulariser REPORTS over the item rows of the interaction (env rows weigh double): two fma chains for the
+                // squares (packed pairs), one add chain for the magnitudes
+                sq_acc(s2a, s2b, q.qi[j]);
+                sq_acc(s2a, s2b, q.qa[j]);
+                s1 = abs_acc(abs_acc(s1, q.qi[j]), q.qa[j]);
                 if (reg_env) { s2 += 2.f * f4sq(ev[j]); s1 += 2.f * f4abs(ev[j]); }
             }
             if (!push) {
@@ -499,7 +523,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
                     rec_g[LG + wi] = pure ? 0.f : gzs[LG - 4 + wi];
                 }
             }
-            accL2 += has ? s2 : 0.f;
+            accL2 += has ? s2 + (s2a + s2b) : 0.f;
             accL1 += has ? s1 : 0.f;
             if (lg == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; accLc += o.lcls * w_cls; }
             // A operands: class (lane & 15) of this interaction; rows on 32 lanes read it back from the group's words

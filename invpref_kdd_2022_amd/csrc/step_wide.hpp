@@ -176,13 +176,28 @@ __device__ __forceinline__ void lds_row(float4 (&r)[NC], const float *tab, int e
 // hardware exp / log / rcp).  One class per lane: lane c of the group (c < E <= 16) ends up with class c's logit.
 template <int NC>
 struct WEval {
-    float g_p, g_q, li, le, lcls, gz_lane;
+    float g_p, g_q, li, le, lcls, gz_lane, gz_all;
     float4 x[NC], gx[NC];   // x = Pu*Qi ; gx = sum_c gz_c W_c
 };
+template <int LG, int NC, int EMAX, int C>
+__device__ __forceinline__ void gx_classes(float4 (&gx)[NC], float gzl, const float *sW, int lg) {
+    if constexpr (C < EMAX) {
+        constexpr int DP = 4 * LG * NC;
+        if (WIDE_FENCE && NC > 1 && (C & 3) == 0) __builtin_amdgcn_sched_barrier(WIDE_FENCE_MASK);
+        const float g = dpp_move<0x150 + C>(gzl);   // row_share:C
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+            const float4 w = *reinterpret_cast<const float4 *>(sW + C * DP + 4 * (lg + LG * j));
+            if (C == 0) gx[j] = f4zero();
+            f4fma(gx[j], g, w);
+        }
+        gx_classes<LG, NC, EMAX, C + 1>(gx, gzl, sW, lg);
+    }
+}
 template <int LG, int NC, int EMAX>
 __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], const float4 (&qi)[NC],
                                           const float4 (&pa)[NC], const float4 (&qa)[NC], const float4 (&ev)[NC],
-                                          const float *sW, const float *sb, float *gzs, int E, int e, float y, float cw_rec,
+                                          const float *sW, float bias_l, float *gzs, bool wr_gzs, int E, int e, float y, float cw_rec,
                                           float cw_cls, const StepScalars &k, bool implicit, bool pure, int lg, bool has ETRACE_PARAM) {
     // `has` = false (an empty slot of a lock-step iteration): the arithmetic runs on the slot's stale -- finite -- rows
     // and every gradient scalar is forced to zero, so that everything downstream contributes nothing; no branch.
@@ -218,13 +233,13 @@ __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], 
     ETRACE(11);
     if (pure) {   // PureMF: no classifier (the zeros are written on THIS path only: no register moves on the other)
         o.lcls = 0.f;
-        o.gz_lane = 0.f;
+        o.gz_lane = o.gz_all = 0.f;
 #pragma unroll
         for (int j = 0; j < NC; j++) o.gx[j] = f4zero();
         return;
     }
 #ifdef WIDE_DIAG_NOCLS
-    o.lcls = o.gz_lane = 0.f;
+    o.lcls = o.gz_lane = o.gz_all = 0.f;
 #pragma unroll
     for (int j = 0; j < NC; j++) o.gx[j] = f4zero();
     return;
@@ -248,33 +263,26 @@ __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], 
     if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(WIDE_FENCE_MASK);
     ETRACE(12);
     const float zred = group_sum_above<LG, EMAX>(class_butterfly<EMAX>(part, lg), lg);
-    const float zmine = lg < E ? zred + sb[lg & (EMAX - 1)] : -__builtin_inff();
+    const float zmine = lg < E ? zred + bias_l : -__builtin_inff();
     const float mxl = group_max<LG>(zmine);
     const float ez = lg < E ? f_exp(zmine - mxl) : 0.f;
     const float rsel = f_rcp(group_sum<LG>(ez));
     const float gzl = (lg < E && has) ? k.cc * cw_cls * (ez * rsel - (lg == e ? 1.f : 0.f)) : 0.f;
     o.gz_lane = gzl;
-    // every lane needs every gz_c for the backward: through the group's LDS words (in-order LDS operations of one wave)
-    if (lg < EMAX) gzs[lg] = gzl;
-    if (lg == e) gzs[EMAX + 1] = -f_log(ez * rsel);   // (lane e holds the picked class: its loss term)
+    // (rows on 32 lanes: the group's second 16-lane row gets the first one's values -- its own are zeros -- so that every
+    //  lane of the wave holds gz of class lane & 15)
+    const float gz_all = LG >= 32 ? xor16_sum(gzl) : gzl;
+    o.gz_all = gz_all;
+    // the picked class's loss term stays on ITS lane (the task's loss sums run over every lane)
+    o.lcls = (lg == e && has) ? -f_log(ez * rsel) : 0.f;
+    // the group's LDS words keep a copy of gz for whoever reads it by class later (pull records, the A operand of rows on 32
+    // lanes); the backward below takes it from the lanes themselves
+    if (wr_gzs && lg < EMAX) gzs[lg] = gzl;
     ETRACE(13);
-    WAVE_LDS_FENCE();
-    o.lcls = has ? gzs[EMAX + 1] : 0.f;
     ETRACE(14);
-#pragma unroll
-    for (int c4 = 0; c4 < EMAX; c4 += 4) {
-        if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(WIDE_FENCE_MASK);
-        const float4 g4 = *reinterpret_cast<const float4 *>(gzs + c4);
-#pragma unroll
-        for (int j = 0; j < NC; j++) {
-            const float *wr = sW + c4 * DP + 4 * (lg + LG * j);
-            if (c4 == 0) o.gx[j] = f4zero();
-            f4fma(o.gx[j], g4.x, *reinterpret_cast<const float4 *>(wr));
-            f4fma(o.gx[j], g4.y, *reinterpret_cast<const float4 *>(wr + DP));
-            f4fma(o.gx[j], g4.z, *reinterpret_cast<const float4 *>(wr + 2 * DP));
-            f4fma(o.gx[j], g4.w, *reinterpret_cast<const float4 *>(wr + 3 * DP));
-        }
-    }
+    // gx = sum_c gz_c W_c, classes in order; gz_c = lane c of the lane's own 16-lane row (DPP row_share: no LDS round trip
+    // between the softmax and the backward)
+    gx_classes<LG, NC, EMAX, 0>(o.gx, gz_all, sW, lg);
 }
 
 // acc[tile][component] += A (x) B over the wave's lane quarters: tile (j, h) covers the float4 columns
@@ -367,6 +375,8 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
 #pragma unroll
         for (int c = 0; c < 4; c++) accE[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dBacc = 0.f;   // lane c of every group: sum of gz_c
+    float bias_l = 0.f;
+    const bool wr_gzs = !push;   // (the pull record and nothing else reads gz back from the group's LDS words)
     float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
     int it_total = 0;    // parity of the gz words
     float *slab = a.slabs + (int64_t)slab_index * G::SLAB;
@@ -452,6 +462,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             stage_small(sW, t.W, t.E, t.D, EMAX, DP);
             if (threadIdx.x < 16) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
             __syncthreads();
+            bias_l = sb[lg & (EMAX - 1)];   // the lane's class bias, once: an LDS read per interaction sat on the softmax chain
         }
         if (r == r0 + STAMP_ROUND) STAMP(3);
 
@@ -473,7 +484,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             WTRACE(2);
 #endif
             WEval<NC> o;
-            eval_wide<LG, NC, EMAX>(o, oi, q.qi, oe, q.qa, ev, sW, sb, gzs, t.E, e, q.y, w_rec * k.invB, w_cls * k.invB, k,
+            eval_wide<LG, NC, EMAX>(o, oi, q.qi, oe, q.qa, ev, sW, bias_l, gzs, wr_gzs, t.E, e, q.y, w_rec * k.invB, w_cls * k.invB, k,
                                     implicit, pure, lg, has ETRACE_ARG);
 #ifdef WIDE_DIAG_TRACE
             { float probe = o.gx[0].x + o.g_p + o.lcls; asm volatile("" :: "v"(probe)); }
@@ -515,6 +526,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
                 // pull form: the record {g_p, g_q, env, 0, gz[EMAX]} the item side consumes -- one word per lane, every lane
                 // (lanes beyond the record repeat its last word), so that the store is one unconditional wave instruction
                 float *rec_g = a.records + (unsigned)(has ? q.ps : a.n_rec) * (unsigned)RS;
+                WAVE_LDS_FENCE();   // (gz of this interaction was written by the evaluation above: in-order LDS operations of one wave)
                 const float gzw = pure ? 0.f : gzs[min(max(lg - 4, 0), EMAX - 1)];
                 const float val = lg >= 4 ? gzw : (lg == 0 ? o.g_p : (lg == 1 ? o.g_q : (lg == 2 ? __builtin_bit_cast(float, e) : 0.f)));
                 rec_g[min(lg, RS - 1)] = val;
@@ -525,10 +537,11 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             }
             accL2 += has ? s2 + (s2a + s2b) : 0.f;
             accL1 += has ? s1 : 0.f;
-            if (lg == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; accLc += o.lcls * w_cls; }
+            if (lg == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; }
+            accLc += o.lcls * w_cls;   // (nonzero on the picked class's lane only)
             // A operands: class (lane & 15) of this interaction; rows on 32 lanes read it back from the group's words
             const int lc = lane & 15;
-            const float a_gz = LG == 16 ? o.gz_lane : ((lc < EMAX && !pure) ? gzs[lc] : 0.f);
+            const float a_gz = LG == 16 ? o.gz_lane : (lc < EMAX ? o.gz_all : 0.f);   // (every lane holds gz of class lane & 15)
             if (lg < 16) dBacc += o.gz_lane;
             WTRACE(4);
             if (WIDE_FENCE && WIDE_MFMA_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);

@@ -134,6 +134,17 @@ __device__ __forceinline__ void f4add(float4 &acc, float4 a) { acc.x += a.x; acc
 __device__ __forceinline__ float4 f4scale(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
 __device__ __forceinline__ float f4sq(float4 a) { return a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
 __device__ __forceinline__ float f4abs(float4 a) { return fabsf(a.x) + fabsf(a.y) + fabsf(a.z) + fabsf(a.w); }
+// regulariser reports: x^2 + z^2 into a, y^2 + w^2 into b (two independent fma chains); sum of magnitudes as one add chain
+// (the |x| is a source modifier of the add)
+__device__ __forceinline__ void sq_acc(float &a, float &b, const float4 &v) {
+    a = fmaf(v.x, v.x, a);
+    b = fmaf(v.y, v.y, b);
+    a = fmaf(v.z, v.z, a);
+    b = fmaf(v.w, v.w, b);
+}
+__device__ __forceinline__ float abs_acc(float s, const float4 &v) {
+    return (((s + fabsf(v.x)) + fabsf(v.y)) + fabsf(v.z)) + fabsf(v.w);
+}
 __device__ __forceinline__ float4 reg_term(float4 p, float r2, float r1) {   // r2 p + r1 sign(p)
     return make_float4(r2 * p.x + r1 * c_sign(p.x), r2 * p.y + r1 * c_sign(p.y), r2 * p.z + r1 * c_sign(p.z),
                        r2 * p.w + r1 * c_sign(p.w));
@@ -758,7 +769,11 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
 #endif
                 }
                 // regulariser REPORTS over the item rows of the interaction (env rows weigh double: 1/(BD) vs 1/(2BD))
-                float s2 = f4sq(q.qi) + f4sq(q.qa), s1 = f4abs(q.qi) + f4abs(q.qa);
+                // (two fma chains for the squares, one |x| add chain for the magnitudes: 16 instructions instead of 28)
+                float s2a = 0.f, s2b = 0.f;
+                sq_acc(s2a, s2b, q.qi);
+                sq_acc(s2a, s2b, q.qa);
+                float s2 = s2a + s2b, s1 = abs_acc(abs_acc(0.f, q.qi), q.qa);
                 if (reg_env) { s2 += 2.f * f4sq(ev); s1 += 2.f * f4abs(ev); }
                 accL2 += s2;
                 accL1 += s1;

@@ -153,18 +153,6 @@ __device__ __forceinline__ void store_row(float *__restrict__ base, int row, int
         }
     }
 }
-// regulariser reports: x^2 + z^2 into a, y^2 + w^2 into b (two independent fma chains: packed pairs); sum of magnitudes as
-// one add chain (the |x| is a source modifier of the add)
-__device__ __forceinline__ void sq_acc(float &a, float &b, const float4 &v) {
-    a = fmaf(v.x, v.x, a);
-    b = fmaf(v.y, v.y, b);
-    a = fmaf(v.z, v.z, a);
-    b = fmaf(v.w, v.w, b);
-}
-__device__ __forceinline__ float abs_acc(float s, const float4 &v) {
-    return (((s + fabsf(v.x)) + fabsf(v.y)) + fabsf(v.z)) + fabsf(v.w);
-}
-
 template <int LG, int NC>
 __device__ __forceinline__ void lds_row(float4 (&r)[NC], const float *tab, int e, int lg) {
     constexpr int DP = 4 * LG * NC;

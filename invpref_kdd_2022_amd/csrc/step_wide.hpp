@@ -185,7 +185,7 @@ __device__ __forceinline__ void gx_classes(float4 (&gx)[NC], float gzl, const fl
 template <int LG, int NC, int EMAX>
 __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], const float4 (&qi)[NC],
                                           const float4 (&pa)[NC], const float4 (&qa)[NC], const float4 (&ev)[NC],
-                                          const float *sW, float bias_l, float *gzs, bool wr_gzs, int E, int e, float y, float cw_rec,
+                                          const float *sW, const float *sb, float bias_l, float *gzs, bool wr_gzs, int E, int e, float y, float cw_rec,
                                           float cw_cls, const StepScalars &k, bool implicit, bool pure, int lg, bool has ETRACE_PARAM) {
     // `has` = false (an empty slot of a lock-step iteration): the arithmetic runs on the slot's stale -- finite -- rows
     // and every gradient scalar is forced to zero, so that everything downstream contributes nothing; no branch.
@@ -251,26 +251,46 @@ __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], 
     if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(WIDE_FENCE_MASK);
     ETRACE(12);
     const float zred = group_sum_above<LG, EMAX>(class_butterfly<EMAX>(part, lg), lg);
-    const float zmine = lg < E ? zred + bias_l : -__builtin_inff();
+    // (16-lane rows: the lane's class bias sits in a register; 32-lane rows have none to spare and read it from LDS)
+    const float zmine = lg < E ? zred + (LG == 16 ? bias_l : sb[lg & (EMAX - 1)]) : -__builtin_inff();
     const float mxl = group_max<LG>(zmine);
     const float ez = lg < E ? f_exp(zmine - mxl) : 0.f;
     const float rsel = f_rcp(group_sum<LG>(ez));
     const float gzl = (lg < E && has) ? k.cc * cw_cls * (ez * rsel - (lg == e ? 1.f : 0.f)) : 0.f;
     o.gz_lane = gzl;
-    // (rows on 32 lanes: the group's second 16-lane row gets the first one's values -- its own are zeros -- so that every
-    //  lane of the wave holds gz of class lane & 15)
-    const float gz_all = LG >= 32 ? xor16_sum(gzl) : gzl;
-    o.gz_all = gz_all;
     // the picked class's loss term stays on ITS lane (the task's loss sums run over every lane)
     o.lcls = (lg == e && has) ? -f_log(ez * rsel) : 0.f;
-    // the group's LDS words keep a copy of gz for whoever reads it by class later (pull records, the A operand of rows on 32
-    // lanes); the backward below takes it from the lanes themselves
-    if (wr_gzs && lg < EMAX) gzs[lg] = gzl;
-    ETRACE(13);
-    ETRACE(14);
-    // gx = sum_c gz_c W_c, classes in order; gz_c = lane c of the lane's own 16-lane row (DPP row_share: no LDS round trip
-    // between the softmax and the backward)
-    gx_classes<LG, NC, EMAX, 0>(o.gx, gz_all, sW, lg);
+    if constexpr (LG == 16) {
+        // gx = sum_c gz_c W_c, classes in order; gz_c = lane c of the lane's own 16-lane row (DPP row_share: no LDS round
+        // trip between the softmax and the backward).  The group's LDS words keep a copy of gz only for the pull record.
+        o.gz_all = gzl;
+        if (wr_gzs && lg < EMAX) gzs[lg] = gzl;
+        ETRACE(13);
+        ETRACE(14);
+        gx_classes<LG, NC, EMAX, 0>(o.gx, gzl, sW, lg);
+    } else {
+        // rows on 32 lanes sit at the register limit (every live value more is a spill per round): gz goes through the
+        // group's LDS words -- in-order LDS operations of one wave -- to the backward, the record and the MFMA A operand
+        if (lg < EMAX) gzs[lg] = gzl;
+        ETRACE(13);
+        WAVE_LDS_FENCE();
+        ETRACE(14);
+        o.gz_all = (lg & 15) < EMAX ? gzs[lg & 15] : 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < EMAX; c4 += 4) {
+            if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(WIDE_FENCE_MASK);
+            const float4 g4 = *reinterpret_cast<const float4 *>(gzs + c4);
+#pragma unroll
+            for (int j = 0; j < NC; j++) {
+                const float *wr = sW + c4 * DP + 4 * (lg + LG * j);
+                if (c4 == 0) o.gx[j] = f4zero();
+                f4fma(o.gx[j], g4.x, *reinterpret_cast<const float4 *>(wr));
+                f4fma(o.gx[j], g4.y, *reinterpret_cast<const float4 *>(wr + DP));
+                f4fma(o.gx[j], g4.z, *reinterpret_cast<const float4 *>(wr + 2 * DP));
+                f4fma(o.gx[j], g4.w, *reinterpret_cast<const float4 *>(wr + 3 * DP));
+            }
+        }
+    }
 }
 
 // acc[tile][component] += A (x) B over the wave's lane quarters: tile (j, h) covers the float4 columns
@@ -450,7 +470,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             stage_small(sW, t.W, t.E, t.D, EMAX, DP);
             if (threadIdx.x < 16) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
             __syncthreads();
-            bias_l = sb[lg & (EMAX - 1)];   // the lane's class bias, once: an LDS read per interaction sat on the softmax chain
+            if (LG == 16) bias_l = sb[lg & (EMAX - 1)];   // the lane's class bias, once: an LDS read per interaction sat on the softmax chain
         }
         if (r == r0 + STAMP_ROUND) STAMP(3);
 
@@ -472,7 +492,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             WTRACE(2);
 #endif
             WEval<NC> o;
-            eval_wide<LG, NC, EMAX>(o, oi, q.qi, oe, q.qa, ev, sW, bias_l, gzs, wr_gzs, t.E, e, q.y, w_rec * k.invB, w_cls * k.invB, k,
+            eval_wide<LG, NC, EMAX>(o, oi, q.qi, oe, q.qa, ev, sW, sb, bias_l, gzs, wr_gzs, t.E, e, q.y, w_rec * k.invB, w_cls * k.invB, k,
                                     implicit, pure, lg, has ETRACE_ARG);
 #ifdef WIDE_DIAG_TRACE
             { float probe = o.gx[0].x + o.g_p + o.lcls; asm volatile("" :: "v"(probe)); }

@@ -14,7 +14,7 @@ INGEST_LIB = os.path.join(PKG, 'libinvpref_ingest.so')   # host-only data ingest
 INGEST_SRC = os.path.join(CSRC, 'invpref_ingest.cpp')
 PLAN_SRC = os.path.join(CSRC, 'invpref_plan.cpp')        # host-only row-plan builder (include/invpref_plan.h), same library
 SOURCES = ['invpref_kernels.hip', 'invpref_step.hip', 'invpref_eval.hip']
-HEADERS = ['canon_math.hpp', 'kernel_common.hpp', os.path.join('..', '..', 'include', 'invpref_hip.h')]
+HEADERS = ['canon_math.hpp', 'kernel_common.hpp', 'step_wide.hpp', os.path.join('..', '..', 'include', 'invpref_hip.h')]
 # -ffp-contract=off: every fma of the canonical arithmetic is written explicitly
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-ffp-contract=off',
          '-fno-fast-math', '-Wall', '-Wno-unused-function']
@@ -32,6 +32,8 @@ def needs_build() -> bool:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    # (every header next to the sources counts, listed or not: a stale library is worse than a spare rebuild)
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hpp', '.h'))]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -42,7 +42,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define WIDE_STEP_FENCE_MASK 0   // what may cross the fences between two lock-step iterations (0x8: the MFMA block)
 #endif
 #ifndef WIDE_FIRST_FROM_DESC
-#define WIDE_FIRST_FROM_DESC 0   // 1: a slice's first gather from the descriptor's registers instead of through list_at (measured: no gain)
+#define WIDE_FIRST_FROM_DESC 1   // 16-lane rows: a slice's first gather from the descriptor's registers instead of through list_at (32-lane rows have no registers for the descriptor's second half: +3-4 %)
 #endif
 #ifndef WIDE_PUSH_DEPTH
 #define WIDE_PUSH_DEPTH 4   // (measured at the MovieLens shape: 66.7 -> 66.0 us against 2)
@@ -458,7 +458,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             sl[j].ps = sl[j].e = sl[j].cs = 0;
             sl[j].y = 0.f;
             sl[j].w = 1.f;
-            if (WIDE_FIRST_FROM_DESC && j == 0) gather(sl[j], first);
+            if (WIDE_FIRST_FROM_DESC && LG == 16 && j == 0) gather(sl[j], first);
             else gather(sl[j], list_at(j));
         }
 #pragma unroll

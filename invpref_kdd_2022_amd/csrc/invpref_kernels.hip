@@ -1229,7 +1229,9 @@ static int estep_launch(const InvPrefTables *tables, const int64_t *users, const
                        scores, N, flags, eps_rows, eps_packed, eps_base, eps_index, index_bytes, eps_rows_n, fac, old_envs, \
                        new_envs, slabs)
 #define ECALL(NCV, VECV) do { if (narrow) ECALL1(NCV, VECV, true); else ECALL1(NCV, VECV, false); } while (0)
-    const bool narrow = (uint64_t)std::max(t.U, t.I) * (uint64_t)t.D * 4u < (1ull << 32);
+    // (INVPREF_ESTEP_OFFSETS64=1: the 64-bit form regardless -- the only way a test reaches it short of a 4 GB table)
+    static const bool force64 = std::getenv("INVPREF_ESTEP_OFFSETS64") != nullptr && std::getenv("INVPREF_ESTEP_OFFSETS64")[0] == '1';
+    const bool narrow = !force64 && (uint64_t)std::max(t.U, t.I) * (uint64_t)t.D * 4u < (1ull << 32);
     if (!vec) { ECALL(4, false); } else if (nc == 1) { ECALL(1, true); } else if (nc == 2) { ECALL(2, true); } else { ECALL(4, true); }
 #undef ECALL
 #undef ECALL1

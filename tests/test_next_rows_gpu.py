@@ -243,3 +243,38 @@ def test_estep_unranks_the_permutation_rows_on_the_device(E):
     # the tie-break really decided rows: without it everything ties at environment 0
     plain = ops.estep(P, dev(u), dev(v), dev(y), True, old, ws)[0].cpu().numpy()
     assert (plain == 0).all() and (a[0].cpu().numpy() != 0).any()
+
+
+def test_estep_row_offsets_32_and_64_bit_agree():
+    """estep_assign_kernel addresses rows with 32-bit offsets whenever every table is under 4 GB and with 64-bit products
+    otherwise; INVPREF_ESTEP_OFFSETS64=1 (read once per process: a child process here) forces the second form -- the same
+    assignments, counts and weights bit for bit, at a row length that takes the float4 path and one that does not."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, torch, sys\n"
+        "from invpref_kdd_2022_amd import ops, synth\n"
+        "dev = torch.device('cuda:0')\n"
+        "out = []\n"
+        "for D, E in ((64, 4), (30, 3), (256, 16)):\n"
+        "    U, I, N = 700, 300, 30000\n"
+        "    rs = np.random.RandomState(D)\n"
+        "    tabs = synth.tables(D + 1, U, I, E, D, std=0.3)\n"
+        "    P = [torch.from_numpy(tabs[k]).to(dev) for k in ops.PARAM_NAMES]\n"
+        "    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)\n"
+        "    r = ops.estep(P, t(rs.randint(0, U, N)), t(rs.randint(0, I, N)), t(rs.randint(0, 2, N).astype(np.float32)), True,\n"
+        "                  t(rs.randint(0, E, N).astype(np.int64)), ops.Workspace(dev))\n"
+        "    out += [x.cpu().numpy() for x in r if x is not None]\n"
+        "np.savez(sys.argv[1], *out)\n")
+    import tempfile
+    res = []
+    with tempfile.TemporaryDirectory() as d:
+        for flag in ('0', '1'):
+            path = os.path.join(d, f'r{flag}.npz')
+            env = dict(os.environ, INVPREF_ESTEP_OFFSETS64=flag)
+            subprocess.run([sys.executable, '-c', code, path], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            z = np.load(path)
+            res.append([z[k] for k in z.files])
+    assert len(res[0]) == len(res[1]) >= 12
+    for a, b in zip(*res):
+        np.testing.assert_array_equal(a, b)

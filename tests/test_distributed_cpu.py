@@ -340,7 +340,8 @@ def test_yahoo_shaped_epochs_world_4_and_8(tmp_path, world, mode):
 
 # ---- PureMF managers sharded: the planned gradient pass (HIP-only) is stood in for by the oracle
 def _pure_worker(rank, world, port, out_dir, mode):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), INVPREF_SHARD=mode)
+    mode, _, exchange = mode.partition('-')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), INVPREF_SHARD=mode, INVPREF_EXCHANGE=exchange or 'scatter')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         _oracle_ops(ops)
@@ -376,6 +377,10 @@ def _pure_worker(rank, world, port, out_dir, mode):
         mgr = BasicImplicitTrainManager(model, Stub(), torch.device('cpu'), torch.from_numpy(data), B, 3, 10 ** 9, LR,
                                         0.01, 0.001, rank=rank, world_size=world)
         assert mgr.shard_mode == mode and mgr.users_tensor.shape[0] < N
+        if exchange:
+            assert mgr.exchange == exchange
+        if exchange == 'packed':   # two tables, no small ones: rows only, fewer than the whole flat gradient
+            assert mgr._packed_tail[1] == 0 and 0 < max(mgr.packed_floats) <= (U + I) * D
         (losses, _), _ = mgr.train(silent=True)
         np.savez(os.path.join(out_dir, f'rank{rank}.npz'), pu=model.user_emb.weight.detach().numpy(),
                  qi=model.item_emb.weight.detach().numpy(), losses=np.array([[l[k] for k in l] for l in losses]))
@@ -384,7 +389,7 @@ def _pure_worker(rank, world, port, out_dir, mode):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize('mode', ['users', 'rows'])
+@pytest.mark.parametrize('mode', ['users', 'rows', 'rows-packed'])
 def test_pure_mf_manager_sharded(tmp_path, mode):
     world = 2
     mp.spawn(_pure_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)

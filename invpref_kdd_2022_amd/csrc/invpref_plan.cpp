@@ -73,7 +73,8 @@ bool sort_side(const int64_t *rows, int64_t n, int64_t n_rows, Side &s, int thre
     s.n_rows = n_rows;
     s.cnt.assign((size_t)n_rows, 0);
     s.ptr.assign((size_t)n_rows + 1, 0);
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n >> 16));
+    // (one int32 histogram over the rows per thread: at most 256 MB of them)
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(threads, n >> 16), (int64_t(64) << 20) / std::max<int64_t>(n_rows, 1)));
     const int64_t chunk = T > 1 ? cdiv_i(n, T) : n;
     std::vector<std::vector<int32_t>> at((size_t)T);
     std::atomic<int> invalid{0};
@@ -354,15 +355,20 @@ InvPrefHostPlan *build(const int64_t *users, const int64_t *items, const float *
 
 extern "C" {
 
-InvPrefHostPlan *invpref_plan_build(const int64_t *users, const int64_t *items, const float *scores, int64_t n,
-                                    int64_t user_num, int64_t item_num, const InvPrefPlanParams *params) {
+static InvPrefHostPlan *build_guarded(const int64_t *users, const int64_t *items, const float *scores, int64_t n,
+                                      int64_t user_num, int64_t item_num, const InvPrefPlanParams *params, int threads) {
     if (!params) return nullptr;
     try {
-        const int hw = (int)std::min<unsigned>(kMaxThreads, std::max(1u, std::thread::hardware_concurrency()));
-        return build(users, items, scores, n, user_num, item_num, *params, hw);
+        return build(users, items, scores, n, user_num, item_num, *params, threads);
     } catch (...) {
         return nullptr;
     }
+}
+
+InvPrefHostPlan *invpref_plan_build(const int64_t *users, const int64_t *items, const float *scores, int64_t n,
+                                    int64_t user_num, int64_t item_num, const InvPrefPlanParams *params) {
+    const int hw = (int)std::min<unsigned>(kMaxThreads, std::max(1u, std::thread::hardware_concurrency()));
+    return build_guarded(users, items, scores, n, user_num, item_num, params, hw);
 }
 
 int64_t invpref_plan_array(const InvPrefHostPlan *plan, int32_t which, const int32_t **data) {
@@ -380,7 +386,7 @@ void invpref_plan_free(InvPrefHostPlan *plan) { delete plan; }
 int invpref_plan_row_counts(const int64_t *rows, int64_t n, int64_t n_rows, int64_t *counts) {
     if (n < 0 || n_rows <= 0 || !counts || (n > 0 && !rows)) return -1;
     const int hw = (int)std::min<unsigned>(kMaxThreads, std::max(1u, std::thread::hardware_concurrency()));
-    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(hw, n >> 18));
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(hw, n >> 18), (int64_t(64) << 20) / n_rows));
     const int64_t chunk = cdiv_i(std::max<int64_t>(n, 1), T);
     std::vector<std::vector<int32_t>> h((size_t)T);
     std::atomic<int> invalid{0};
@@ -408,13 +414,16 @@ int invpref_plan_build_many(const int64_t *users, const int64_t *items, const fl
     if (!offsets || !params || !out || count < 0) return -1;
     int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(kMaxThreads, std::max(1u, std::thread::hardware_concurrency()));
     nt = std::max(1, std::min(nt, (int)count));
+    const int hw_all = (int)std::min<unsigned>(kMaxThreads, std::max(1u, std::thread::hardware_concurrency()));
+    const int inner = std::max(1, hw_all / nt);
     std::atomic<int> next{0};
     auto work = [&]() {
         for (;;) {
             const int k = next.fetch_add(1);
             if (k >= count) return;
             const int64_t lo = offsets[k], n = offsets[k + 1] - lo;
-            out[k] = invpref_plan_build(users + lo, items + lo, scores + lo, n, user_num, item_num, params + k);
+            // (a large minibatch spreads over threads of its own: what the pool leaves of the machine, not all of it again)
+            out[k] = build_guarded(users + lo, items + lo, scores + lo, n, user_num, item_num, params + k, inner);
         }
     };
     std::vector<std::thread> th;

@@ -221,9 +221,12 @@ class _NativePlan:
         self.L, self.h = L, h
 
     def __del__(self):
-        if self.h:
-            self.L.invpref_plan_free(self.h)
-            self.h = None
+        try:
+            if self.h:
+                self.L.invpref_plan_free(self.h)
+                self.h = None
+        except Exception:      # (interpreter shutdown: the library may be gone already)
+            pass
 
 
 def _plan_from_handle(L, h, r: dict) -> dict:

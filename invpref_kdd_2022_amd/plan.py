@@ -372,6 +372,10 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         else:
             r16 = rounds_for(ucnt0, 16)
             per_slice = next((ps for ps in (3, 4, 6, 8, 12) if rounds_for(ucnt0, ps) <= 1.05 * r16), 16)
+            # rows with dozens of interactions each (2^24 interactions over 400 000 users: 42 per row): 24 per slice halves
+            # the slices again (measured at that size, D = 64 / 128 / 256: +3 % each over 16; 20, 28 and 32 are behind)
+            if per_slice == 16 and rounds_for(ucnt0, 24) <= 0.75 * r16:
+                per_slice = 24
             if r16 <= 6 * resident and os.environ.get('INVPREF_PLAN_SIMULATE', '1') == '1':
                 # a launch of a few residencies: where its last workgroup ends depends on how the task lengths pack
                 # into the resident slots.  Estimate that for each slice length (list scheduling of the tasks in launch
@@ -408,8 +412,11 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
                                             str(min(32, max(floor, -(-n // (ng * 2 * target)))))))
 
     if rounds_per_task is None:
+        # (at most 8 rounds per task for rows on 16 lanes -- measured on cache-exceeding launches of 2^20 .. 2^24 interactions:
+        #  D = 64 +4 %, D = 128 +2 .. +5 % over 16 -- and 16 for rows on 32 lanes, whose tasks stage 32 KB of tables first: -3 % at 8)
+        cap = 16 if lanes == 32 else 8
         rounds_per_task = int(os.environ.get('INVPREF_PLAN_ROUNDS', '0')) or \
-            min(16, max(1, round(rounds_for(counts('u'), per_slice) / target)))
+            min(cap, max(1, round(rounds_for(counts('u'), per_slice) / target)))
     if item_rounds_per_task is None:
         # (rows of up to 1 KB, pull form: an item task first stages two [E, D] tables of up to 16 KB each, holds only eight
         #  rows and leaves a 16 KB partial slab of embed_env's gradient -- fewer, longer tasks: MIND-shaped steps 898 -> 769 us

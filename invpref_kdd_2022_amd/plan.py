@@ -415,8 +415,11 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         # (at most 8 rounds per task for rows on 16 lanes -- measured on cache-exceeding launches of 2^20 .. 2^24 interactions:
         #  D = 64 +4 %, D = 128 +2 .. +5 % over 16 -- and 16 for rows on 32 lanes, whose tasks stage 32 KB of tables first: -3 % at 8)
         cap = 16 if lanes == 32 else 8
+        # (rows on 32 lanes: about 800 tasks -- not quite two residencies of 512 -- instead of 1 536: measured at MIND's tables
+        #  with minibatches of 32 768 .. 262 144, best at 4 / 6 / 6 / 4-8 rounds per task: +5 % at the rank share of eight GPUs)
+        tgt = target * 800 // TARGET_WORKGROUPS if lanes == 32 else target
         rounds_per_task = int(os.environ.get('INVPREF_PLAN_ROUNDS', '0')) or \
-            min(cap, max(1, round(rounds_for(counts('u'), per_slice) / target)))
+            min(cap, max(1, round(rounds_for(counts('u'), per_slice) / tgt)))
     if item_rounds_per_task is None:
         # (rows of up to 1 KB, pull form: an item task first stages two [E, D] tables of up to 16 KB each, holds only eight
         #  rows and leaves a 16 KB partial slab of embed_env's gradient -- fewer, longer tasks: MIND-shaped steps 898 -> 769 us

@@ -1173,17 +1173,33 @@ __device__ __forceinline__ void item_task_push(const DevTables &t, const StepArg
             if (!pure) oe = row4<VEC, FULL>(t.Qa, rowc, t.D, lg);
         }
         const float *base = a.records + (unsigned)dd.z * (unsigned)(2 * DP) + lg * 4;
-        float4 ci[PCH], ce[PCH];
-        auto fetch = [&](int s0) {   // contribution rows s0 .. s0 + PCH of the slice (clamped: no branch around a load)
+        // Two register sets of H = PCH / 2 pairs each: while one set's rows are added the other's are in flight, and a set is
+        // refilled as soon as it has been added -- a slice of n rows is one round trip + n additions, not n / PCH round trips
+        // (the refill used to sit under a divergent branch: waited for at the join, every batch a round trip of its own).
+        // Rows are added in slice order either way: the sums are bit for bit those of the one-set form.  Refills are taken
+        // while ANY group of the wave still has rows to come (a wave-uniform branch); indices are clamped into the slice.
+        constexpr int H = PCH / 2;
+        static_assert(PCH % 2 == 0, "two register sets");
+        float4 ci[2][H], ce[2][H];
+        auto fetch = [&](int set, int s0) {
 #pragma unroll
-            for (int j = 0; j < PCH; j++) {
+            for (int j = 0; j < H; j++) {
                 const int sj = s0 + j < nsmp ? s0 + j : (nsmp > 0 ? nsmp - 1 : 0);
                 const float *p = base + (unsigned)sj * (unsigned)(2 * DP);
-                ci[j] = *reinterpret_cast<const float4 *>(nsmp > 0 ? p : a.records + lg * 4);
-                if (!pure) ce[j] = *reinterpret_cast<const float4 *>(nsmp > 0 ? p + DP : a.records + DP + lg * 4);
+                ci[set][j] = *reinterpret_cast<const float4 *>(nsmp > 0 ? p : a.records + lg * 4);
+                if (!pure) ce[set][j] = *reinterpret_cast<const float4 *>(nsmp > 0 ? p + DP : a.records + DP + lg * 4);
             }
         };
-        fetch(0);
+        auto add = [&](int set, int s0) {
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                const bool has = s0 + j < nsmp;
+                f4add(gi, has ? ci[set][j] : f4zero());
+                if (!pure) f4add(ge, has ? ce[set][j] : f4zero());
+            }
+        };
+        fetch(0, 0);
+        fetch(1, H);
         if (dma) {   // the row's Adam moments: needed last, sent straight to LDS
             const bool mine = active && leader && lg * 4 < t.D;
 #pragma unroll
@@ -1196,14 +1212,14 @@ __device__ __forceinline__ void item_task_push(const DevTables &t, const StepArg
             }
         }
         if (r == r0 + STAMP_ROUND) STAMP(3);
-        for (int s0 = 0; s0 < nsmp; s0 += PCH) {
+        int n_wave = nsmp;   // the wave's longest slice
 #pragma unroll
-            for (int j = 0; j < PCH; j++) {
-                const bool has = s0 + j < nsmp;
-                f4add(gi, has ? ci[j] : f4zero());
-                if (!pure) f4add(ge, has ? ce[j] : f4zero());
-            }
-            if (s0 + PCH < nsmp) fetch(s0 + PCH);
+        for (int g = 0; g < 64 / LG; g++) n_wave = max(n_wave, __builtin_amdgcn_readlane(nsmp, g * LG));
+        for (int s0 = 0; s0 < n_wave; s0 += PCH) {
+            add(0, s0);
+            if (s0 + PCH < n_wave) fetch(0, s0 + PCH);
+            add(1, s0 + H);
+            if (s0 + PCH + H < n_wave) fetch(1, s0 + PCH + H);
         }
         if (r == r0 + STAMP_ROUND) STAMP(4);
         if (slices > 1) {

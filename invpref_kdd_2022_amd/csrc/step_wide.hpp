@@ -938,32 +938,45 @@ __device__ __forceinline__ void item_task_push_wide(const DevTables &t, const St
             if (!pure) load_row<LG, NC, VEC>(oe, t.Qa, rowc, t.D, lg);
         }
         const float *base = a.records + (unsigned)dd.z * (unsigned)(2 * DP);
-        float4 ci[PCH][NC], ce[PCH][NC];
-        auto fetch = [&](int s0) {   // contribution rows s0 .. s0 + PCH of the slice (clamped: no branch around a load)
+        // two register sets of H = PCH / 2 pairs: one is added while the other is in flight and refilled as soon as it has
+        // been added (see item_task_push in invpref_step.hip); rows are added in slice order: same sums bit for bit
+        constexpr int H = PCH / 2;
+        static_assert(PCH % 2 == 0, "two register sets");
+        float4 ci[2][H][NC], ce[2][H][NC];
+        auto fetch = [&](int set, int s0) {   // (clamped: no branch around a load)
 #pragma unroll
-            for (int q = 0; q < PCH; q++) {
+            for (int q = 0; q < H; q++) {
                 const int sj = s0 + q < nsmp ? s0 + q : (nsmp > 0 ? nsmp - 1 : 0);
                 const float *p = nsmp > 0 ? base + (unsigned)sj * (unsigned)(2 * DP) : a.records;
 #pragma unroll
                 for (int j = 0; j < NC; j++) {
-                    ci[q][j] = *reinterpret_cast<const float4 *>(p + 4 * (lg + LG * j));
-                    if (!pure) ce[q][j] = *reinterpret_cast<const float4 *>(p + DP + 4 * (lg + LG * j));
+                    ci[set][q][j] = *reinterpret_cast<const float4 *>(p + 4 * (lg + LG * j));
+                    if (!pure) ce[set][q][j] = *reinterpret_cast<const float4 *>(p + DP + 4 * (lg + LG * j));
                 }
             }
         };
-        fetch(0);
-        if (r == r0 + STAMP_ROUND) STAMP(3);
-        for (int s0 = 0; s0 < nsmp; s0 += PCH) {
+        auto add = [&](int set, int s0) {
 #pragma unroll
-            for (int q = 0; q < PCH; q++) {
+            for (int q = 0; q < H; q++) {
                 const bool has = s0 + q < nsmp;
 #pragma unroll
                 for (int j = 0; j < NC; j++) {
-                    f4add(gi[j], has ? ci[q][j] : f4zero());
-                    if (!pure) f4add(ge[j], has ? ce[q][j] : f4zero());
+                    f4add(gi[j], has ? ci[set][q][j] : f4zero());
+                    if (!pure) f4add(ge[j], has ? ce[set][q][j] : f4zero());
                 }
             }
-            if (s0 + PCH < nsmp) fetch(s0 + PCH);
+        };
+        fetch(0, 0);
+        fetch(1, H);
+        if (r == r0 + STAMP_ROUND) STAMP(3);
+        int n_wave = nsmp;   // the wave's longest slice: refills are wave-uniform branches
+#pragma unroll
+        for (int g = 0; g < 64 / LG; g++) n_wave = max(n_wave, __builtin_amdgcn_readlane(nsmp, g * LG));
+        for (int s0 = 0; s0 < n_wave; s0 += PCH) {
+            add(0, s0);
+            if (s0 + PCH < n_wave) fetch(0, s0 + PCH);
+            add(1, s0 + H);
+            if (s0 + PCH + H < n_wave) fetch(1, s0 + PCH + H);
         }
         if (r == r0 + STAMP_ROUND) STAMP(4);
         if (slices > 1) {

@@ -610,7 +610,9 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             if (__builtin_amdgcn_ballot_w64(mode == 7) != 0) {
 #pragma unroll
                 for (int j = 0; j < 2 * UE; j++) {
-                    const int4 q = a.ulist[min(s_lo + j, s_hi1)];
+                    // (groups WITHOUT a list ride along in this wave-uniform branch: their words 2 / 3 are an inline
+                    //  interaction's ids, not a list range -- entry 0 for them, or the load runs off a small plan's list)
+                    const int4 q = a.ulist[mode == 7 ? min(s_lo + j, s_hi1) : 0];
                     ls[j] = USample{q.x, q.y, __builtin_bit_cast(float, q.z)};
                 }
             }
@@ -1905,7 +1907,10 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
         if (profile_event && hipEventRecord((hipEvent_t)profile_event, st) != hipSuccess) return INVPREF_EINVAL; \
         hipLaunchKernelGGL((mstep_apply_kernel<LGV, VECV, EMAXV>), dim3(grid2), dim3(kThreads), lds2, st, t, a2, f); \
     } while (0)
-    const bool full = vec && t.D == 64;   // rows of exactly 64 floats: loads with nothing behind them (row4<VEC, FULL>)
+    // rows of exactly 64 floats: loads with nothing behind them (row4<VEC, FULL>); INVPREF_NO_FULL=1 (diagnostics) takes the
+    // element-wise-guarded instances instead
+    static const bool no_full = getenv("INVPREF_NO_FULL") != nullptr && getenv("INVPREF_NO_FULL")[0] == '1';
+    const bool full = vec && t.D == 64 && !no_full;
     if (defer) {
         const size_t lds1d = lds1 + kDeferWin * sizeof(float2);
         if ((rc = ensure_lds(mstep_eval_kernel<16, true, 4, true>, lds1d))) return rc;

@@ -142,7 +142,11 @@ def test_train_loop_end_to_end_with_device_evaluator():
     assert all(sum(c.values()) == len(data) for c in cnts) and len(diffs) == 3
 
 
-@pytest.mark.parametrize('seed', range(int(os.environ.get('INVPREF_FUZZ', '12'))))
+# (223: a 15-interaction plan whose wave holds list slices AND inline ones -- the ids-first gather of the full-row instances
+#  read the list at the inline groups' partner ids, off the end of so small a plan: a GPU memory fault, found by the 300-case
+#  soak of round 4; kept as a case of every run)
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('INVPREF_FUZZ', '12')))) +
+                         [s for s in (223,) if s >= int(os.environ.get('INVPREF_FUZZ', '12'))])
 def test_random_plan_parameters_and_shapes(seed):
     """Randomised sweep: shapes (D aligned and not, E up to 16), duplicate-heavy and sparse minibatches, every plan
     parameter (interactions per slice on either side, rounds per workgroup, stream task size, the share of the streamed

@@ -233,6 +233,62 @@ def test_random_plan_parameters_and_shapes(seed):
             assert err <= 1.5e-4 * scale, (k, seed, float(err), float(scale))   # (fp32 sums of up to 3 000 terms vs the fp64 oracle)
 
 
+@pytest.mark.parametrize('seed', range(int(os.environ.get('INVPREF_FUZZ_MID', '6'))))
+def test_random_mid_size_steps_on_default_plans(seed):
+    """The small-shape sweep above never makes a task of several rounds, a launch of several residencies, 24 interactions per
+    slice or the co-residency order: this one draws mid-size steps (2 000 .. 40 000 table rows, 20 000 .. 120 000 interactions,
+    uniform or Zipf ids, D = 64 / 128 / 256 with E = 4 / 8 / 16) and lets the plan choose EVERYTHING (env_num given), push and
+    pull forms both -- gradient pass against the oracle entry by entry, losses, run-to-run bitwise."""
+    rs = np.random.RandomState(7000 + seed)
+    U, I = int(rs.choice([2000, 6000, 40000])), int(rs.choice([500, 3000, 20000]))
+    D, E = [(64, 4), (128, 8), (256, 16), (64, 3), (128, 5), (256, 12)][int(rs.randint(6))]
+    B = int(rs.choice([20000, 60000, 120000]))
+    zipf = bool(rs.randint(2))
+    data = synth.interactions(9000 + seed, U, I, B, implicit=True, zipf=zipf)
+    u, v, y = data[:, 0], data[:, 1], data[:, 2].astype(np.float32)
+    e = rs.randint(0, E, B)
+    w = rs.uniform(0.1, 1, B).astype(np.float32)
+    tabs = synth.tables(seed + 50, U, I, E, D, std=0.2)
+    rw_rec, rw_cls, roe, ree = (bool(rs.randint(2)) for _ in range(4))
+    coefs = np.array(COEFS[:6], np.float64)
+    og, ol = O.mstep(O.Tables(tabs), u, v, e, y, w, coefs, O.flags_of(True, rw_rec, rw_cls, roe, ree))
+    P, ws = dev(tabs), ops.Workspace(DEV)
+    flags = ops.flags_of(True, rw_rec, rw_cls, roe, ree)
+    for push in (None, not bool(planlib.build_row_plan(u, v, y, U, I, factor_num=D, env_num=E, _resolve_only=True)['push'])):
+        if push and D > 128:
+            continue   # (rows on 32 lanes have no push form)
+        dp = planlib.upload(planlib.build_row_plan(u, v, y, U, I, factor_num=D, env_num=E, push=push), DEV)
+        outs = []
+        for _ in range(2):
+            G = [torch.full_like(p, 7.0) for p in P]
+            losses = torch.zeros(6, device=DEV)
+            ops.mstep_rows_grad(P, G, dp, t64(e), t32(y), t32(w), B, coefs, flags, losses, ws)
+            outs.append(([g.cpu().numpy() for g in G], losses.cpu().numpy()))
+        np.testing.assert_allclose(outs[0][1], ol, rtol=3e-5, atol=1e-7)
+        np.testing.assert_array_equal(outs[0][1], outs[1][1])
+        for k, g, g2, want in zip(ops.PARAM_NAMES, outs[0][0], outs[1][0], og):
+            np.testing.assert_array_equal(g, g2, err_msg=k)        # no float atomics: run-to-run bitwise
+            err, scale = np.abs(g - want.reshape(g.shape)).max(), max(np.abs(want).max(), 1e-4)
+            assert err <= 3e-4 * scale, (k, seed, push, float(err), float(scale))   # (fp32 sums of up to 1e5 terms vs fp64)
+        # the fused pass of the same plan: same losses, run-to-run bitwise, and the parameters of gradient pass + Adam kernel
+        lr, fused = 0.01, []
+        for _ in range(2):
+            P2, M, V = ([torch.zeros_like(p) for p in P] for _ in range(3))
+            losses = torch.zeros(6, device=DEV)
+            ops.mstep_rows_adam(P, P2, M, V, dp, t64(e), t32(y), t32(w), B, coefs, flags, losses, 1, lr, ws)
+            fused.append(([x.cpu().numpy() for x in P2 + M + V], losses.cpu().numpy()))
+        np.testing.assert_allclose(fused[0][1], ol, rtol=3e-5, atol=1e-7)
+        for a, b in zip(fused[0][0], fused[1][0]):
+            np.testing.assert_array_equal(a, b)
+        for i, k in enumerate(ops.PARAM_NAMES):
+            pk = P[i].clone().reshape(-1)
+            gk = torch.from_numpy(outs[0][0][i]).to(DEV).reshape(-1)
+            ops.adam_(pk, gk, torch.zeros_like(pk), torch.zeros_like(pk), 1, lr)
+            got, want = fused[0][0][i].reshape(-1), pk.cpu().numpy()
+            big = np.abs(outs[0][0][i].reshape(-1)) > 2e-6   # (Adam's first step is lr g / (|g| + eps): noise-level entries can flip)
+            assert np.abs(got - want)[big].max(initial=0.0) < 0.03 * lr, (k, seed, push)
+
+
 @pytest.mark.parametrize('E,D', [(5, 20), (8, 64), (6, 128), (3, 64), (16, 64)])
 def test_groups_of_one_wave_naming_the_same_environment(E, D):
     """Regression (round 3): with 5..8 environments the embed_env partial sums of a WAVE share one set of LDS rows and the

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define INVPREF_ABI_VERSION 4
+#define INVPREF_ABI_VERSION 5
 
 /* error codes */
 #define INVPREF_OK 0
@@ -247,6 +247,70 @@ int invpref_mstep_rows_adam_deferred_hip(const InvPrefTables *tables, const InvP
 int invpref_flush_deferred_hip(const InvPrefTables *home, const InvPrefTables *dst, const InvPrefTables *exp_avg,
                                const InvPrefTables *exp_avg_sq, int32_t *last_step, const InvPrefAdamSchedule *sched,
                                void *stream);
+
+/* ---- ONE launch per optimiser step: the evaluating side alternates (round 5).
+ * The step's arithmetic is symmetric in users and items (models.py:307-326) and torch.optim.Adam (train.py:41, :155-157)
+ * updates every row exactly once per step, so launch c of a run can be
+ *     side S = users (c even) or items (c odd); T = the other side
+ *     (i)   S's rows apply step c-1's update: the contribution rows T's jobs pushed for them in launch c-1 (summed in slot
+ *           order, + the regulariser term), Adam with step c-1's scalars -- in registers;
+ *     (ii)  S's jobs evaluate step c's interactions from their side: own rows now at post-(c-1), partner rows of T
+ *           untouched by this launch and at post-(c-1) since T finished its own step c-1 rows in launch c-1;
+ *     (iii) they apply their own step-c gradient on the spot (second Adam, same registers), store p, m, v ONCE, and push
+ *           the interaction's two contribution rows for T (consumed by launch c+1).
+ * The one grid-wide dependency left is the 2.5 KB of small tables (embed_env, classifier): fold workgroups, first in the
+ * grid, sum launch c-1's partial slabs, apply Adam IN PLACE with write-through stores and publish a flag per fold block
+ * (value = the step number); job workgroups do (i) meanwhile and read the tables with cache-bypassing loads once the
+ * flags match.  The six loss terms of step c-1 are produced by that fold (losses6_prev).
+ * A run starts from a state in which every row is up to date (first launch: plan->has_prev = 0) and ends with a FLUSH
+ * launch (plan->has_cur = 0: T's rows apply the last step's update, the last fold).  Only between those two the
+ * parameter tables are in an intermediate state; the tables are updated in place (no second parameter buffer).
+ * Compiled for rows of up to 64 floats and up to four environments (the two-launch form covers the rest).
+ *
+ * An alt plan describes ONE launch: the current minibatch from side S (desc / list / push_slot as user_desc / user_list /
+ * push_slot of InvPrefRowPlan, with S in the role of the users) and the PREVIOUS launch's pushes for S:
+ *   pend[round][slot] = {a, b, count, 0}: this slice's share [a, b) of the row's pending contribution rows (slots of
+ *           the previous minibatch in S-sorted order) and the row's interaction count in the previous minibatch;
+ *   meta bit 31 of every slot of a round: some row of the round has pending rows (the slices then meet once more);
+ *   stream[i] = {row, a, b, count}: rows of S without a job (no interaction now, few or no pending rows). */
+typedef struct InvPrefAltPlan {
+    int32_t side;                 /* 0: the user tables evaluate / are updated; 1: the item tables */
+    int32_t has_prev, has_cur;    /* 0 / 1, see above */
+    int32_t n, n_prev;            /* interactions of the current / previous minibatch */
+    int32_t lanes_per_group;      /* 16 */
+    int32_t n_rounds, rounds_per_task;
+    const int32_t *desc;          /* [n_rounds][NG][8] */
+    const int32_t *pend;          /* [n_rounds][NG][4] */
+    const int32_t *list;          /* [n][4] {partner row, position, label bits, 0} sorted by own row */
+    const int32_t *push_slot;     /* [n] position -> slot in PARTNER-sorted order (where this launch pushes) */
+    int32_t n_stream, rows_per_stream_task;
+    const int32_t *stream;        /* [n_stream][4] */
+    int32_t n_classes;
+    int32_t cls[8][4];            /* per class: first round, rounds, first stream row, stream rows */
+    int32_t n_partials_prev;      /* job tasks (= partial slabs) of the previous launch */
+} InvPrefAltPlan;
+/* workspace of a run: two halves (parity) of {contribution rows for n_cap interactions, partials_cap partial slabs} +
+ * the fold flags.  Needs no initialisation. */
+size_t invpref_alt_workspace_bytes(const InvPrefTables *tables, int32_t n_cap, int32_t partials_cap);
+/* 1 if the shape runs the alternating form (factor_num <= 64, env_num <= 4) */
+int invpref_alt_supported(const InvPrefTables *tables);
+/* One launch.  tables / exp_avg / exp_avg_sq are updated IN PLACE.  envs / sample_weights: the CURRENT minibatch's
+ * slices.  batch_norm / batch_norm_prev: mean() denominators of the current / previous minibatch.  losses6_prev: where
+ * the previous step's six loss terms are ADDED (may be NULL when has_prev == 0).  Per-step scalars: from `sched` (graph
+ * replay; slot = parity of the current step -- of the LAST step for a flush launch; state words 10 / 11 of a slot carry
+ * the previous step's step_size / bc2_sqrt, maintained by these launches and written by the caller for the first slot)
+ * or, sched == NULL, from (step, lr, betas, eps): `step` is the current step (the last one for a flush).
+ * parity: which workspace half this launch writes (the other one holds the previous launch's output); consecutive
+ * launches alternate.  Same flags / coefficient conventions as invpref_mstep_rows_adam_hip. */
+int invpref_mstep_alt_hip(const InvPrefTables *tables, const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
+                          const InvPrefAltPlan *plan, const int64_t *envs, const float *sample_weights,
+                          int64_t batch_norm, int64_t batch_norm_prev, const InvPrefCoefs *coefs, uint32_t flags,
+                          float *losses6_prev, int64_t step, double lr, double beta1, double beta2, double eps,
+                          const InvPrefAdamSchedule *sched, void *workspace, size_t workspace_bytes, int32_t n_cap,
+                          int32_t partials_cap, int32_t parity, void *stream);
+/* device word the job workgroups set when a wait for the fold flags ran out (never in a healthy run): the int32 at this
+ * byte offset of the workspace */
+size_t invpref_alt_error_offset(const InvPrefTables *tables, int32_t n_cap, int32_t partials_cap);
 
 /* The gradient-pass + stand-alone-Adam sequence (multi-GPU: an all-reduce sits between the two; single GPU: rows of
  * more than 128 floats) for HIP-graph replay.  invpref_mstep_rows_grad_sched_hip reads the step's slot (a scheduled

@@ -26,7 +26,8 @@ EXPORTS = [
     'invpref_static_pop_hip', 'invpref_adam_ranges_hip', 'invpref_mstep_rows_grad_sched_hip',
     'invpref_adam_ranges_sched_hip', 'invpref_rows_lanes_per_group', 'invpref_rows_defer_supported',
     'invpref_mstep_rows_adam_deferred_hip', 'invpref_flush_deferred_hip', 'invpref_estep_perm_hip',
-    'invpref_pack_rows_hip', 'invpref_unpack_rows_hip',
+    'invpref_pack_rows_hip', 'invpref_unpack_rows_hip', 'invpref_alt_workspace_bytes', 'invpref_alt_supported',
+    'invpref_mstep_alt_hip', 'invpref_alt_error_offset',
 ]
 
 
@@ -114,7 +115,15 @@ def lib():
         L.invpref_static_pop_workspace_bytes.restype = C.c_size_t
         L.invpref_static_pop_hip.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, C.c_size_t, vp]
         L.invpref_device_name.argtypes = [C.c_char_p, C.c_size_t]
-        if L.invpref_abi_version() != 4:
+        L.invpref_alt_workspace_bytes.restype = C.c_size_t
+        L.invpref_alt_workspace_bytes.argtypes = [C.POINTER(Tables), C.c_int32, C.c_int32]
+        L.invpref_alt_error_offset.restype = C.c_size_t
+        L.invpref_alt_error_offset.argtypes = [C.POINTER(Tables), C.c_int32, C.c_int32]
+        L.invpref_alt_supported.argtypes = [C.POINTER(Tables)]
+        L.invpref_mstep_alt_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), C.POINTER(Tables), vp, vp, vp, i64, i64,
+                                            C.POINTER(Coefs), u32, vp, i64, f64, f64, f64, f64, C.POINTER(AdamSchedule), vp,
+                                            C.c_size_t, C.c_int32, C.c_int32, C.c_int32, vp]
+        if L.invpref_abi_version() != 5:
             raise InvPrefError('libinvpref_hip.so ABI version mismatch')
         _lib = L
     return _lib

@@ -1947,9 +1947,37 @@ AdamScalars adam_scalars(int64_t step, double lr, double beta1, double beta2, do
     return ad;
 }
 
+#include "step_alt.hpp"
+
 }  // namespace
 
 extern "C" {
+
+size_t invpref_alt_workspace_bytes(const InvPrefTables *tables, int32_t n_cap, int32_t partials_cap) {
+    if (!tables || n_cap < 0 || partials_cap < 0) return 0;
+    return alt_flags_offset(n_cap, partials_cap) + 64 * sizeof(int);
+}
+
+size_t invpref_alt_error_offset(const InvPrefTables *tables, int32_t n_cap, int32_t partials_cap) {
+    (void)tables;
+    return alt_flags_offset(n_cap, partials_cap) + 63 * sizeof(int);
+}
+
+int invpref_alt_supported(const InvPrefTables *tables) {
+    if (!tables || tables->factor_num <= 0 || tables->env_num <= 0) return 0;
+    return tables->factor_num <= 64 && tables->env_num <= 4;
+}
+
+int invpref_mstep_alt_hip(const InvPrefTables *tables, const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
+                          const InvPrefAltPlan *plan, const int64_t *envs, const float *sample_weights,
+                          int64_t batch_norm, int64_t batch_norm_prev, const InvPrefCoefs *coefs, uint32_t flags,
+                          float *losses6_prev, int64_t step, double lr, double beta1, double beta2, double eps,
+                          const InvPrefAdamSchedule *sched, void *workspace, size_t workspace_bytes, int32_t n_cap,
+                          int32_t partials_cap, int32_t parity, void *stream) {
+    return launch_alt(tables, exp_avg, exp_avg_sq, plan, envs, sample_weights, batch_norm, batch_norm_prev, coefs, flags,
+                      losses6_prev, step, lr, beta1, beta2, eps, sched, workspace, workspace_bytes, n_cap, partials_cap, parity,
+                      (hipStream_t)stream);
+}
 
 size_t invpref_rows_workspace_bytes(const InvPrefTables *tables, const InvPrefRowPlan *plan) {
     if (check_tables(tables, tables && !tables->embed_user_env_aware) || !plan || plan->n < 0 || plan->n_user_rounds < 0 ||

@@ -1,0 +1,964 @@
+// step_alt.hpp -- ONE launch per optimiser step: the evaluating side alternates (include/invpref_hip.h: InvPrefAltPlan).
+// Included by invpref_step.hip (lane-group helpers, Eval, Geo, EvalLds, fold geometry come from there).
+//
+// Launch c of a run, side S (users for even c, items for odd c), T = the other side:
+//   fold blocks (first in the grid): sum launch c-1's partial slabs, Adam on embed_env / classifier IN PLACE with
+//       write-through stores, the six loss terms of step c-1, one flag per fold block (value = step number);
+//   S's jobs: (i) sum the contribution rows T pushed for the row in launch c-1 (the slices share them and meet in LDS),
+//       Adam with step c-1's scalars in registers; (ii) wait for the fold flags, stage the small tables with
+//       cache-bypassing loads; (iii) evaluate step c's interactions (forward + analytic backward of train.py:108-153,
+//       models.py:307-391 -- symmetric in users and items), push the two contribution rows per interaction for T,
+//       accumulate the E x D / loss partial sums; (iv) second Adam, ONE store of p, m, v;
+//   S's other rows (no interaction in step c): pending rows (if any) + both Adam updates, streamed.
+// T's rows are only read.  Every sum has a fixed order: bitwise reproducible run to run.
+
+// phase stamps of the alt kernels: diagnostic builds only (-DALT_STAMPS; tools/alt_probe.py) -- the stamp pointer and its
+// branches cost scalar registers the hot instance does not have
+#ifdef ALT_STAMPS
+#define ASTAMP(i) STAMP(i)
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
+
+struct AltArgs {
+    float *own_p[2];              // S's parameter tables (invariant, env-aware): updated in place
+    float *own_m[2], *own_v[2];
+    const float *oth_p[2];        // T's tables: read only
+    float *Ev, *W, *b;            // small tables + moments: updated in place by the fold blocks
+    float *mEv, *mW, *mb, *vEv, *vW, *vb;
+    int E, D;
+    const int4 *desc;             // [rounds][NG][2]
+    const int4 *pend;             // [rounds][NG]
+    const int4 *list;             // [n] {partner row, position, label bits, 0}
+    const int *push_slot;         // [n]
+    const int4 *stream;           // [n_stream] {row, a, b, count}
+    int rounds_per_task, rows_per_stream_task, n_cls;
+    int cls[8][4];
+    const int64_t *envs;
+    const float *weights;
+    StepScalars k;                // current step
+    float r2_prev, r1_prev;       // previous step's regulariser scalars
+    uint32_t flags;
+    int mode;                     // bit 0: has_prev, bit 1: has_cur
+    AdamScalars ad_cur, ad_prev;  // eager form; with a schedule: from the slot
+    int gen;                      // eager form: the step number the fold flags carry
+    int *sched_state;
+    int sched_slot;
+    const SchedRow *sched_table;
+    int sched_n;
+    const float *pend_rows;       // [n_prev][2][DP] contribution rows pushed for S by the previous launch
+    float *push_rows;             // [n][2][DP] contribution rows this launch pushes for T
+    const float *slabs_prev;      // [n_partials_prev][SLAB]
+    int n_partials_prev;
+    float *slabs;                 // [job tasks][SLAB]
+    int *fold_flags;              // [64]; word 63: error
+    float l2, l1;
+    double inv_B_prev, inv_BD2_prev;
+    float *losses_prev;
+    int fold_blocks, first_task_block;
+    int stamps_nodrain;
+    unsigned long long *stamps;
+};
+
+__device__ __forceinline__ float ld_sc1(const float *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_sc1(const int *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(float *p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(int *p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#ifndef ALT_POLL_MAX
+#define ALT_POLL_MAX (1 << 17)    // polls before a waiting workgroup gives up (sets the error word): ~30 ms
+#endif
+#ifndef ALT_EARLY_POLL
+#define ALT_EARLY_POLL 0          // (A/B knob: 1 = wave 0 polls the fold flags behind its first load burst -- measured slower:
+                                  //  a poll that comes too early fails and every retry is a loaded round trip: 19.0 vs 16.3 us)
+#endif
+#ifndef ALT_PEND_COND
+#define ALT_PEND_COND 0           // (A/B knob: 1 = the first pending-row loads only for waves that have pending rows -- measured
+                                  //  slower, 17.0 vs 16.1 us per step: the wave-uniform branch needs the ranges before any load)
+#endif
+#ifndef ALT_PEND_DEPTH
+#define ALT_PEND_DEPTH 4          // pending contribution-row pairs in flight per group (two register sets)
+#endif
+
+// Wave 0 of a job workgroup: wait until every fold block has published this step's flag, then read the small tables with
+// cache-bypassing loads (the fold blocks stored them write-through and drained before the flag: MI355X guide, "Valid
+// forms": sc1 stores + sc1 flag / sc1 poll + sc1 loads by the polling wave) and stage them in LDS.  In three pieces so that
+// the two round trips hide: the poll sits behind the wave's first load burst (its wait is the burst's wait), the nine table
+// loads are issued at once and fly under the previous step's update; alt_stage_finish waits for them.
+struct AltStage {
+    float xe0, xe1, xe2, xe3, xw0, xw1, xw2, xw3, xb;
+};
+__device__ __forceinline__ void alt_poll(const AltArgs &a, int gen) {
+    const int lane = threadIdx.x & 63;
+    int polls = 0;
+    for (;;) {
+        const int v = lane < a.fold_blocks ? ld_sc1(a.fold_flags + lane) : gen;
+        if (__builtin_amdgcn_ballot_w64(v != gen) == 0) break;
+        if (++polls > ALT_POLL_MAX) {
+            if (lane == 0) st_sc1(a.fold_flags + 63, 1);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+    asm volatile("" ::: "memory");   // (the table loads stay behind the poll)
+}
+__device__ __forceinline__ void alt_stage_offsets(const AltArgs &a, int lane, unsigned (&o)[4], unsigned &ob, bool (&on)[4], bool &onb) {
+    constexpr int DP = 64;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int idx = lane + 64 * i, e = idx / DP, d = idx - e * DP;
+        on[i] = e < a.E && d < a.D;
+        o[i] = on[i] ? (unsigned)(e * a.D + d) * 4u : 0u;
+    }
+    onb = lane < a.E;
+    ob = onb ? (unsigned)lane * 4u : 0u;
+}
+__device__ __forceinline__ void alt_stage_issue(const AltArgs &a, AltStage &x) {
+    // every load of the 2.5 KB in ONE burst (the compiler would wait for each relaxed atomic load in turn -- a round trip per
+    // load on the step's critical chain); the base pointers stay in scalar registers
+    unsigned o[4], ob;
+    bool on[4], onb;
+    alt_stage_offsets(a, threadIdx.x & 63, o, ob, on, onb);
+    asm volatile(
+        "global_load_dword %0, %9, %14 sc1\n\t"
+        "global_load_dword %1, %10, %14 sc1\n\t"
+        "global_load_dword %2, %11, %14 sc1\n\t"
+        "global_load_dword %3, %12, %14 sc1\n\t"
+        "global_load_dword %4, %9, %15 sc1\n\t"
+        "global_load_dword %5, %10, %15 sc1\n\t"
+        "global_load_dword %6, %11, %15 sc1\n\t"
+        "global_load_dword %7, %12, %15 sc1\n\t"
+        "global_load_dword %8, %13, %16 sc1"
+        : "=&v"(x.xe0), "=&v"(x.xe1), "=&v"(x.xe2), "=&v"(x.xe3), "=&v"(x.xw0), "=&v"(x.xw1), "=&v"(x.xw2), "=&v"(x.xw3), "=&v"(x.xb)
+        : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(ob), "s"(a.Ev), "s"(a.W), "s"(a.b)
+        : "memory");
+}
+__device__ __forceinline__ void alt_stage_finish(const AltArgs &a, AltStage &x, float *sEv, float *sW, float *sb, bool pure) {
+    constexpr int EMAX = 4, DP = 64;
+    const int lane = threadIdx.x & 63;
+    if (pure) {
+#pragma unroll
+        for (int i = 0; i < EMAX * DP / 64; i++) sEv[lane + 64 * i] = sW[lane + 64 * i] = 0.f;
+        if (lane < EMAX) sb[lane] = 0.f;
+        return;
+    }
+    // (the loaded registers pass THROUGH the wait: nothing the compiler schedules can read them before it)
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(x.xe0), "+v"(x.xe1), "+v"(x.xe2), "+v"(x.xe3), "+v"(x.xw0), "+v"(x.xw1), "+v"(x.xw2), "+v"(x.xw3), "+v"(x.xb)
+                 :
+                 : "memory");
+    unsigned o[4], ob;
+    bool on[4], onb;
+    alt_stage_offsets(a, lane, o, ob, on, onb);
+    sEv[lane + 0] = on[0] ? x.xe0 : 0.f; sEv[lane + 64] = on[1] ? x.xe1 : 0.f;
+    sEv[lane + 128] = on[2] ? x.xe2 : 0.f; sEv[lane + 192] = on[3] ? x.xe3 : 0.f;
+    sW[lane + 0] = on[0] ? x.xw0 : 0.f; sW[lane + 64] = on[1] ? x.xw1 : 0.f;
+    sW[lane + 128] = on[2] ? x.xw2 : 0.f; sW[lane + 192] = on[3] ? x.xw3 : 0.f;
+    if (lane < EMAX) sb[lane] = onb ? x.xb : 0.f;
+}
+
+__device__ __forceinline__ void adam4_prev(float4 &p, float4 g, float4 &m, float4 &v, const AdamScalars &ad, float2 prev2) {
+    AdamScalars ap = ad;
+    ap.step_size = prev2.x; ap.bc2_sqrt = prev2.y;
+    adam4(p, g, m, v, ap);
+}
+
+// =====================================================================================
+// rounds of jobs of the evaluating side
+// =====================================================================================
+template <bool VEC, bool FULL, int MODE>
+__device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_index, float *lds,
+                                         const AdamScalars &ad_cur, float2 prev2, const StepScalars &k, int gen) {
+    constexpr int LG = 16, EMAX = 4, UE = 2;
+    using G = Geo<LG, EMAX>;
+    using L = EvalLds<LG, EMAX>;
+    static_assert(L::ALIAS && G::DIRECT && G::REG && STEP_LDS_DW && !STEP_NO_DMA, "alt_task: the default smallest-instance layout");
+    constexpr int NG = G::NG, DP = G::DP;
+    float *sEv = lds + L::sEv, *sW = lds + L::sW, *sb = lds + L::sb;
+    float4 *mv = reinterpret_cast<float4 *>(lds + L::mv);
+    float *red = lds + L::red;
+    const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float4 *mv_wave = mv + wave * 4 * 64;
+    const bool implicit = a.flags & INVPREF_IMPLICIT;
+    const bool rw_rec = a.flags & INVPREF_REWEIGHT_REC, rw_cls = a.flags & INVPREF_REWEIGHT_CLS;
+    const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
+    const bool pure = a.flags & INVPREF_PURE_MF;
+    const bool dense = (a.flags & INVPREF_DENSE_REG) && !(a.flags & INVPREF_REG_ONLY_EMBED) && !pure;
+    constexpr bool has_prev = MODE & 1, has_cur = MODE & 2;
+    const int D = a.D;
+    float *own0 = a.own_p[0], *own1 = a.own_p[1];
+    const float *oth0 = a.oth_p[0], *oth1 = a.oth_p[1];
+
+    ASTAMP(0);
+    int4 d = a.desc[(r0 * NG + grp) * 2], d1 = a.desc[(r0 * NG + grp) * 2 + 1];
+    // (the round's pending ranges travel with its descriptor: one round trip, not two)
+    int4 pd = make_int4(0, 0, 0, 0);
+    if (has_prev) pd = a.pend[r0 * NG + grp];
+    if (has_cur) {
+        constexpr int ZR4 = (2 * EMAX * DP + EMAX) / 4;   // (dEv | dW | db: 516 floats, SLAB = 524: both multiples of 4)
+        static_assert((2 * EMAX * DP + EMAX) % 4 == 0 && G::SLAB % 4 == 0, "16-byte zeroing");
+        for (int i = threadIdx.x; i < G::RED * ZR4; i += kThreads)
+            *reinterpret_cast<float4 *>(red + (i / ZR4) * G::SLAB + (i % ZR4) * 4) = f4zero();
+    }
+    ASTAMP(1);
+    float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
+    float *slab = a.slabs + (int64_t)slab_index * G::SLAB;
+    auto slot_of = [&](int g) {
+        constexpr int GW = 64 / LG;
+        return lds + L::mv + (g / GW) * (4 * 64 * 4) + (g % GW) * 2 * DP;
+    };
+
+    {   // ONE round per task (InvPrefAltPlan.rounds_per_task == 1: no round loop, nothing carried across the interaction loop)
+        constexpr int nr = 1;
+        const int r = r0;
+        const int4 dd = d, dd1 = d1;
+        const int4 pdd = pd;
+        const int row = dd.x, meta = dd.y;
+        const bool active = row >= 0, leader = meta & 1;
+        const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
+        const bool rpend = has_prev && (meta < 0);            // bit 31: some row of the round has pending rows
+        const int cnt_i = (meta >> 9) & 0x3fffff;
+        const int nsmp = (active && has_cur) ? (mode == 7 ? dd.w - dd.z : mode) : 0;
+        if (r == r0 + STAMP_ROUND) ASTAMP(2);
+        const int s_lo = dd.z, s_hi1 = max(dd.w - 1, dd.z);
+        const int *dwords = reinterpret_cast<const int *>(a.desc + (r * NG + grp) * 2);
+        auto sample_at = [&](int sidx) {
+            USample sm;
+            if (FULL) {
+                const int *src = mode == 7 ? reinterpret_cast<const int *>(a.list + min(s_lo + sidx, s_hi1)) : dwords + 2 + 3 * min(sidx, 1);
+                sm.oth = src[0]; sm.ps = src[1]; sm.y = __builtin_bit_cast(float, src[2]);
+            } else if (mode == 7) {
+                const int4 q = a.list[dd.z + sidx];
+                sm.oth = q.x; sm.ps = q.y; sm.y = __builtin_bit_cast(float, q.z);
+            } else if (sidx == 0) { sm.oth = dd.z; sm.ps = dd.w; sm.y = __builtin_bit_cast(float, dd1.x); }
+            else { sm.oth = dd1.y; sm.ps = dd1.z; sm.y = __builtin_bit_cast(float, dd1.w); }
+            return sm;
+        };
+        // ---- everything that depends only on the descriptor goes out together: own rows + moments, the first pending
+        // rows, the first interactions' partner rows
+        const int rowc = active ? row : 0;
+        float4 oi = row4<VEC, FULL>(own0, rowc, D, lg), oe = f4zero();
+        float4 mi = row4<VEC, FULL>(a.own_m[0], rowc, D, lg), vi = row4<VEC, FULL>(a.own_v[0], rowc, D, lg);
+        float4 me = f4zero(), ve = f4zero();
+        if (!pure) {
+            oe = row4<VEC, FULL>(own1, rowc, D, lg);
+            me = row4<VEC, FULL>(a.own_m[1], rowc, D, lg); ve = row4<VEC, FULL>(a.own_v[1], rowc, D, lg);
+        }
+        // pending contribution rows of this slice: contiguous pairs [pa, pb), two register sets
+        constexpr int H = ALT_PEND_DEPTH / 2;
+        const int npend = (active && has_prev) ? pdd.y - pdd.x : 0;
+        const float *pbase = a.pend_rows + (unsigned)(npend > 0 ? pdd.x : 0) * (unsigned)(2 * DP) + lg * 4;
+        float4 ci[2][H], ce[2][H];
+        auto pfetch = [&](int set, int s0) {
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                const int sj = s0 + j < npend ? s0 + j : (npend > 0 ? npend - 1 : 0);
+                const float *p = pbase + (unsigned)sj * (unsigned)(2 * DP);
+                ci[set][j] = *reinterpret_cast<const float4 *>(p);
+                ce[set][j] = pure ? f4zero() : *reinterpret_cast<const float4 *>(p + DP);
+            }
+        };
+        float4 gpi = f4zero(), gpe = f4zero();
+        auto padd = [&](int set, int s0) {
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                const bool has = s0 + j < npend;
+                f4add(gpi, has ? ci[set][j] : f4zero());
+                if (!pure) f4add(gpe, has ? ce[set][j] : f4zero());
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int j = 0; j < H; j++) ci[s][j] = ce[s][j] = f4zero();
+        // (wave-uniform branches: a wave whose slices have nothing pending -- most user-side waves -- adds no loads to the
+        //  launch's first burst, and the second register set only goes out for slices of more than H pairs)
+        int n_wave = 0;
+        if (rpend) {
+            n_wave = npend;
+#pragma unroll
+            for (int g = 0; g < 64 / LG; g++) n_wave = max(n_wave, __builtin_amdgcn_readlane(npend, g * LG));
+#if ALT_PEND_COND
+            if (n_wave > 0) pfetch(0, 0);
+            if (n_wave > H) pfetch(1, H);
+#else
+            pfetch(0, 0);
+            pfetch(1, H);
+#endif
+        }
+
+        struct Slot {
+            float4 qi, qa;
+            USample sm;
+            int e, cs;
+            float w;
+        };
+        Slot sl[UE];
+        USample idn[UE];
+        auto gather = [&](Slot &q, const USample &sm) {
+            q.sm = sm;
+            q.qi = row4<VEC, FULL>(oth0, sm.oth, D, lg);
+            if (FULL) {
+                const unsigned pso = (unsigned)sm.ps;
+                if (!pure) {
+                    q.qa = row4<VEC, FULL>(oth1, sm.oth, D, lg);
+                    q.e = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.envs) + pso * 8u);
+                }
+                if (rw_rec || rw_cls) q.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + pso * 4u);
+                q.cs = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.push_slot) + pso * 4u);
+                return;
+            }
+            if (!pure) {
+                q.qa = row4<VEC, FULL>(oth1, sm.oth, D, lg);
+                q.e = (int)a.envs[sm.ps];
+            }
+            if (rw_rec || rw_cls) q.w = a.weights[sm.ps];
+            q.cs = a.push_slot[sm.ps];
+        };
+#pragma unroll
+        for (int j = 0; j < UE; j++) {
+            sl[j].qi = sl[j].qa = f4zero();
+            sl[j].sm = USample{0, 0, 0.f};
+            sl[j].e = sl[j].cs = 0;
+            sl[j].w = 1.f;
+            idn[j] = USample{0, 0, 0.f};
+        }
+        if (has_cur) {   // (workgroup-uniform)
+            if (FULL) {
+                USample ls[2 * UE];
+#pragma unroll
+                for (int j = 0; j < 2 * UE; j++) ls[j] = USample{0, 0, 0.f};
+                if (__builtin_amdgcn_ballot_w64(mode == 7) != 0) {
+#pragma unroll
+                    for (int j = 0; j < 2 * UE; j++) {
+                        const int4 q = a.list[mode == 7 ? min(s_lo + j, s_hi1) : 0];
+                        ls[j] = USample{q.x, q.y, __builtin_bit_cast(float, q.z)};
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < UE; j++) {
+                    USample sm = ls[j];
+                    if (mode != 7) sm = j == 0 ? USample{dd.z, dd.w, __builtin_bit_cast(float, dd1.x)} : USample{dd1.y, dd1.z, __builtin_bit_cast(float, dd1.w)};
+                    if (mode == 0 || !active) sm = USample{0, 0, 0.f};   // (a job without interactions: entry 0's rows, unused)
+                    gather(sl[j], sm);
+                    idn[j] = ls[UE + j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < UE; j++)
+                    if (j < nsmp) gather(sl[j], sample_at(j));
+#pragma unroll
+                for (int j = 0; j < UE; j++)
+                    if (UE + j < nsmp) idn[j] = sample_at(UE + j);
+            }
+        }
+        // ---- (ii, first half) the small tables of this step: wave 0 polls behind its own burst and requests them
+        AltStage stg;
+        stg.xe0 = stg.xe1 = stg.xe2 = stg.xe3 = stg.xw0 = stg.xw1 = stg.xw2 = stg.xw3 = stg.xb = 0.f;
+#if ALT_EARLY_POLL
+        if (has_cur && wave == 0 && !pure) {
+            if (has_prev) alt_poll(a, gen);
+            alt_stage_issue(a, stg);
+        }
+#endif
+        // ---- (i) the previous step's update of this row
+        if (has_prev) {
+            if (rpend) {
+                for (int s0 = 0; s0 < n_wave; s0 += 2 * H) {
+                    padd(0, s0);
+                    if (s0 + 2 * H < n_wave) pfetch(0, s0 + 2 * H);
+                    padd(1, s0 + H);
+                    if (s0 + 3 * H < n_wave) pfetch(1, s0 + 3 * H);
+                }
+                if (slices > 1) {   // the slices' shares meet: every slice forms the same fixed-order total
+                    float *mine = slot_of(grp);
+                    *reinterpret_cast<float4 *>(mine + lg * 4) = gpi;
+                    *reinterpret_cast<float4 *>(mine + DP + lg * 4) = gpe;
+                    __syncthreads();
+                    const int lead = grp & ~(slices - 1);
+                    gpi = gpe = f4zero();
+#pragma nounroll
+                    for (int s = 0; s < slices; s++) {
+                        const float *os = slot_of(lead + s);
+                        f4add(gpi, *reinterpret_cast<const float4 *>(os + lg * 4));
+                        f4add(gpe, *reinterpret_cast<const float4 *>(os + DP + lg * 4));
+                    }
+                    __syncthreads();   // (the moments are parked over the slots next)
+                }
+            }
+            const float cp = (float)pdd.z;
+            if (cp != 0.f) {
+                f4fma(gpi, cp, reg_term(oi, a.r2_prev, a.r1_prev));
+                f4fma(gpe, cp, reg_term(oe, a.r2_prev, a.r1_prev));
+            }
+            adam4_prev(oi, gpi, mi, vi, ad_cur, prev2);
+            if (!pure) adam4_prev(oe, gpe, me, ve, ad_cur, prev2);
+        }
+        if (r == r0 + STAMP_ROUND) ASTAMP(3);
+        if (!has_cur) {
+            // a flush launch: the row is finished here
+            if (active && leader) {
+                put4<VEC, 0, FULL>(own0, row, D, lg, oi);
+                put4<VEC, 0, FULL>(a.own_m[0], row, D, lg, mi);
+                put4<VEC, 0, FULL>(a.own_v[0], row, D, lg, vi);
+                if (!pure) {
+                    put4<VEC, 0, FULL>(own1, row, D, lg, oe);
+                    put4<VEC, 0, FULL>(a.own_m[1], row, D, lg, me);
+                    put4<VEC, 0, FULL>(a.own_v[1], row, D, lg, ve);
+                }
+            }
+            return;
+        }
+        // the moments are needed again when the row is finished: parked in the lane's own words of the wave's landing area
+        mv_wave[0 * 64 + lane] = mi; mv_wave[1 * 64 + lane] = vi;
+        if (!pure) { mv_wave[2 * 64 + lane] = me; mv_wave[3 * 64 + lane] = ve; }
+        // ---- (ii) the small tables of this step
+        if (r == r0) {
+            if (wave == 0) {
+#if !ALT_EARLY_POLL
+                if (!pure) {
+                    if (has_prev) alt_poll(a, gen);
+                    alt_stage_issue(a, stg);
+                }
+#endif
+                alt_stage_finish(a, stg, sEv, sW, sb, pure);
+            }
+            __syncthreads();
+            ASTAMP(4);
+        }
+        // ---- (iii) one interaction: evaluate, accumulate the own rows' gradients, push the partner's contribution rows
+        float4 gi = f4zero(), ge = f4zero();
+        auto step = [&](const Slot &q, bool has) {
+            const int e = q.e;
+            if (has) {
+                const float w_rec = rw_rec ? q.w : 1.f, w_cls = rw_cls ? q.w : 1.f;
+                const float4 ev = *reinterpret_cast<const float4 *>(sEv + e * DP + lg * 4);
+                Eval<EMAX> o;
+                eval_interaction<LG, EMAX>(o, oi, q.qi, oe, q.qa, ev, sW, sb, nullptr, a.E, e, q.sm.y, w_rec * k.invB,
+                                           w_cls * k.invB, k, implicit, pure, lg);
+                float4 gip;
+                gip.x = o.g_p - k.alpha * o.gx.x; gip.y = o.g_p - k.alpha * o.gx.y;
+                gip.z = o.g_p - k.alpha * o.gx.z; gip.w = o.g_p - k.alpha * o.gx.w;
+                f4add(gi, f4mul(gip, q.qi));
+                f4fma(ge, o.g_q, f4mul(q.qa, ev));
+                float *cr = a.push_rows + (unsigned)q.cs * (unsigned)(2 * DP) + lg * 4;
+                *reinterpret_cast<float4 *>(cr) = f4mul(gip, oi);
+                *reinterpret_cast<float4 *>(cr + DP) = f4scale(o.g_q, f4mul(oe, ev));
+                float4 oo = f4scale(o.g_q, f4mul(oe, q.qa));
+                if (reg_env) f4add(oo, reg_term(ev, 2.f * k.r2, 2.f * k.r1));
+                float *mine = red + grp * G::SLAB;
+#pragma unroll
+                for (int c = 0; c < EMAX; c++) {
+                    float4 *wr = reinterpret_cast<float4 *>(mine + EMAX * DP + c * DP + lg * 4);
+                    float4 cur = *wr;
+                    f4fma(cur, o.gz[c], o.x);
+                    *wr = cur;
+                }
+                if (lg == 0) {
+                    float4 *br = reinterpret_cast<float4 *>(mine + 2 * EMAX * DP);
+                    float4 cur = *br;
+                    cur.x += o.gz[0]; cur.y += o.gz[1]; cur.z += o.gz[2]; cur.w += o.gz[3];
+                    *br = cur;
+                }
+                float4 *erow = reinterpret_cast<float4 *>(mine + e * DP + lg * 4);
+                float4 cur = *erow;
+                f4add(cur, oo);
+                *erow = cur;
+                float s2a = 0.f, s2b = 0.f;
+                sq_acc(s2a, s2b, q.qi);
+                sq_acc(s2a, s2b, q.qa);
+                float s2 = s2a + s2b, s1 = abs_acc(abs_acc(0.f, q.qi), q.qa);
+                if (reg_env) { s2 += 2.f * f4sq(ev); s1 += 2.f * f4abs(ev); }
+                accL2 += s2;
+                accL1 += s1;
+                if (lg == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; accLc += o.lcls * w_cls; }
+            }
+        };
+        for (int s = 0; s < nsmp; s += UE) {
+#pragma unroll
+            for (int j = 0; j < UE; j++) {
+                if (s + j < nsmp) step(sl[j], true);
+                if (FULL || s + UE + j < nsmp) gather(sl[j], idn[j]);
+                if (FULL || s + 2 * UE + j < nsmp) idn[j] = sample_at(s + 2 * UE + j);
+            }
+        }
+        if (r == r0 + STAMP_ROUND) ASTAMP(5);
+        const float cnt = (float)cnt_i;
+        if (active && leader) {
+            accL2 += cnt * (f4sq(oi) + f4sq(oe));
+            accL1 += cnt * (f4abs(oi) + f4abs(oe));
+        }
+        const bool last = r == r0 + nr - 1;
+        if (last) {
+            accLi = row16_sum(accLi); accLe = row16_sum(accLe); accLc = row16_sum(accLc);
+            accL2 = row16_sum(accL2); accL1 = row16_sum(accL1);
+            if (lg == 0) {
+                float *ls = red + grp * G::SLAB + 2 * EMAX * DP + EMAX;
+                ls[0] = accLi; ls[1] = accLe; ls[2] = accLc; ls[3] = accL2; ls[4] = accL1;
+                ls[5] = ls[6] = ls[7] = 0.f;
+            }
+            if (dense && slab_index == 0 && wave == 0) {
+                // report of the classifier regulariser (models.py:211-217; the tables of THIS step's forward, still staged):
+                // ||W||^2 / (D E) + ||b||^2 / E, the same with |.|  -- by the task that owns slab 0, into group 0's loss slots
+                // (group 0 is on this wave: its own stores above come first in program order)
+                const float4 w4 = *reinterpret_cast<const float4 *>(sW + lane * 4);
+                float w2 = f4sq(w4), w1 = f4abs(w4);
+                const float bb = lane < EMAX ? sb[lane] : 0.f;
+                float b2 = bb * bb, b1 = fabsf(bb);
+                w2 = wave_sum_valu(w2); w1 = wave_sum_valu(w1); b2 = wave_sum_valu(b2); b1 = wave_sum_valu(b1);
+                if (lane == 0) {
+                    float *ls = red + 2 * EMAX * DP + EMAX;
+                    ls[5] = w2 / ((float)a.D * (float)a.E) + b2 / (float)a.E;
+                    ls[6] = w1 / ((float)a.D * (float)a.E) + b1 / (float)a.E;
+                }
+            }
+        }
+        // ---- the slices of a row meet (the leader takes the parked moments out first: same wave, program order)
+        if (active && leader) {
+            mi = mv_wave[0 * 64 + lane]; vi = mv_wave[1 * 64 + lane];
+            if (!pure) { me = mv_wave[2 * 64 + lane]; ve = mv_wave[3 * 64 + lane]; }
+        }
+        asm volatile("" ::: "memory");
+        if (slices > 1) {
+            float *mine = slot_of(grp);
+            *reinterpret_cast<float4 *>(mine + lg * 4) = gi;
+            *reinterpret_cast<float4 *>(mine + DP + lg * 4) = ge;
+        }
+        if (slices > 1 || last) __syncthreads();
+        if (last) {
+            for (int i = threadIdx.x; i < G::SLAB; i += kThreads) {
+                float x[G::RED];
+#pragma unroll
+                for (int q = 0; q < G::RED; q++) x[q] = red[q * G::SLAB + i];
+                float sum = x[0];
+#pragma unroll
+                for (int q = 1; q < G::RED; q++) sum += x[q];
+                slab[i] = sum;
+            }
+        }
+        if (slices > 1) {
+            if (active && leader) {
+#pragma nounroll
+                for (int s = 1; s < slices; s++) {
+                    const float *os = slot_of(grp + s);
+                    f4add(gi, *reinterpret_cast<const float4 *>(os + lg * 4));
+                    f4add(ge, *reinterpret_cast<const float4 *>(os + DP + lg * 4));
+                }
+            }
+            if (!last) __syncthreads();
+        }
+        if (r == r0 + STAMP_ROUND) ASTAMP(6);
+        // ---- (iv) the leader finishes the row: this step's update, one store of p, m, v
+        if (active && leader) {
+            if (cnt != 0.f) {
+                f4fma(gi, cnt, reg_term(oi, k.r2, k.r1));
+                f4fma(ge, cnt, reg_term(oe, k.r2, k.r1));
+            }
+            adam4(oi, gi, mi, vi, ad_cur);
+            put4<VEC, STEP_ROW_ST, FULL>(own0, row, D, lg, oi);
+            put4<VEC, STEP_ROW_ST, FULL>(a.own_m[0], row, D, lg, mi);
+            put4<VEC, STEP_ROW_ST, FULL>(a.own_v[0], row, D, lg, vi);
+            if (!pure) {
+                adam4(oe, ge, me, ve, ad_cur);
+                put4<VEC, STEP_ROW_ST, FULL>(own1, row, D, lg, oe);
+                put4<VEC, STEP_ROW_ST, FULL>(a.own_m[1], row, D, lg, me);
+                put4<VEC, STEP_ROW_ST, FULL>(a.own_v[1], row, D, lg, ve);
+            }
+        }
+    }
+    ASTAMP(7);
+}
+
+// =====================================================================================
+// rows of the evaluating side without a job: pending rows (few), then both updates -- streamed, 2 rows per group
+// =====================================================================================
+template <bool VEC, bool FULL, int MODE>
+__device__ __forceinline__ void alt_stream(const AltArgs &a, const int4 *rows, int n, const AdamScalars &ad_cur, float2 prev2) {
+    constexpr int R = 2, LG = 16, NG = kThreads / LG, DP = 64, H = 2;
+    const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG;
+    const bool pure = a.flags & INVPREF_PURE_MF;
+    constexpr bool has_prev = MODE & 1, has_cur = MODE & 2;
+    const int D = a.D;
+    const int iters = (n + R * NG - 1) / (R * NG);
+    for (int it = 0; it < iters; it++) {
+        int4 e[R];
+        bool on[R];
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            const int idx = grp + (it * R + q) * NG;
+            on[q] = idx < n;
+            e[q] = rows[on[q] ? idx : 0];
+        }
+        float4 p[2 * R], m[2 * R], v[2 * R], ci[R][H], ce[R][H];
+        int npend[R];
+#pragma unroll
+        for (int q = 0; q < 2 * R; q++) {
+            p[q] = m[q] = v[q] = f4zero();
+            if (!(pure && (q & 1))) {
+                p[q] = row4<VEC, FULL>(a.own_p[q & 1], e[q >> 1].x, D, lg);
+                m[q] = row4<VEC, FULL>(a.own_m[q & 1], e[q >> 1].x, D, lg);
+                v[q] = row4<VEC, FULL>(a.own_v[q & 1], e[q >> 1].x, D, lg);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            npend[q] = (on[q] && has_prev) ? e[q].z - e[q].y : 0;
+#pragma unroll
+            for (int j = 0; j < H; j++) ci[q][j] = ce[q][j] = f4zero();
+        }
+        int n_wave = 0;
+        if (has_prev) {
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const float *pb = a.pend_rows + (unsigned)(npend[q] > 0 ? e[q].y : 0) * (unsigned)(2 * DP) + lg * 4;
+#pragma unroll
+                for (int j = 0; j < H; j++) {
+                    const int sj = j < npend[q] ? j : (npend[q] > 0 ? npend[q] - 1 : 0);
+                    ci[q][j] = *reinterpret_cast<const float4 *>(pb + (unsigned)sj * (unsigned)(2 * DP));
+                    if (!pure) ce[q][j] = *reinterpret_cast<const float4 *>(pb + (unsigned)sj * (unsigned)(2 * DP) + DP);
+                }
+#pragma unroll
+                for (int g = 0; g < 64 / LG; g++) n_wave = max(n_wave, __builtin_amdgcn_readlane(npend[q], g * LG));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; q++) {
+            float4 gi = f4zero(), ge = f4zero();
+            if (has_prev) {
+#pragma unroll
+                for (int j = 0; j < H; j++) {
+                    f4add(gi, j < npend[q] ? ci[q][j] : f4zero());
+                    if (!pure) f4add(ge, j < npend[q] ? ce[q][j] : f4zero());
+                }
+                // (rows with more pending pairs than the first burst: rare -- the plan turns long ones into jobs)
+                const float *pb = a.pend_rows + (unsigned)(npend[q] > 0 ? e[q].y : 0) * (unsigned)(2 * DP) + lg * 4;
+                for (int s0 = H; s0 < n_wave; s0 += H) {
+                    float4 xi[H], xe[H];
+#pragma unroll
+                    for (int j = 0; j < H; j++) {
+                        const int sj = s0 + j < npend[q] ? s0 + j : (npend[q] > 0 ? npend[q] - 1 : 0);
+                        xi[j] = *reinterpret_cast<const float4 *>(pb + (unsigned)sj * (unsigned)(2 * DP));
+                        xe[j] = pure ? f4zero() : *reinterpret_cast<const float4 *>(pb + (unsigned)sj * (unsigned)(2 * DP) + DP);
+                    }
+#pragma unroll
+                    for (int j = 0; j < H; j++) {
+                        f4add(gi, s0 + j < npend[q] ? xi[j] : f4zero());
+                        if (!pure) f4add(ge, s0 + j < npend[q] ? xe[j] : f4zero());
+                    }
+                }
+                const float cp = (float)e[q].w;
+                if (cp != 0.f) {
+                    f4fma(gi, cp, reg_term(p[2 * q], a.r2_prev, a.r1_prev));
+                    f4fma(ge, cp, reg_term(p[2 * q + 1], a.r2_prev, a.r1_prev));
+                }
+                adam4_prev(p[2 * q], gi, m[2 * q], v[2 * q], ad_cur, prev2);
+                if (!pure) adam4_prev(p[2 * q + 1], ge, m[2 * q + 1], v[2 * q + 1], ad_cur, prev2);
+            }
+            if (has_cur) {
+                adam4(p[2 * q], f4zero(), m[2 * q], v[2 * q], ad_cur);
+                if (!pure) adam4(p[2 * q + 1], f4zero(), m[2 * q + 1], v[2 * q + 1], ad_cur);
+            }
+            if (on[q]) {
+#pragma unroll
+                for (int tb = 0; tb < 2; tb++) {
+                    if (pure && tb) continue;
+                    put4<VEC, STEP_STREAM_ST, FULL>(a.own_p[tb], e[q].x, D, lg, p[2 * q + tb]);
+                    put4<VEC, STEP_STREAM_ST, FULL>(a.own_m[tb], e[q].x, D, lg, m[2 * q + tb]);
+                    put4<VEC, STEP_STREAM_ST, FULL>(a.own_v[tb], e[q].x, D, lg, v[2 * q + tb]);
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================
+// fold block fb: 16 columns of the previous launch's partial slabs -> gradient of embed_env / classifier -> Adam IN PLACE
+// (write-through stores), the six loss outputs of the previous step, the block's flag
+// =====================================================================================
+__device__ __forceinline__ void alt_fold_block(const AltArgs &a, int fb, float *lds, const AdamScalars &ad, int gen) {
+    constexpr int DP = 64, EMAX = 4, SLAB = 2 * EMAX * DP + EMAX + kLossSlots, EDP = EMAX * DP;
+    double *part = reinterpret_cast<double *>(lds);   // [kFoldSubs][kFoldCols] (+ kLossSlots)
+    const int colx = threadIdx.x % kFoldCols, sub = threadIdx.x / kFoldCols;
+    const int idx = fb * kFoldCols + colx;
+    const bool pure = a.flags & INVPREF_PURE_MF;
+    const bool dense = (a.flags & INVPREF_DENSE_REG) && !(a.flags & INVPREF_REG_ONLY_EMBED) && !pure;
+    const bool mine = idx < SLAB;
+    const bool isLoss = idx >= 2 * EDP + EMAX, isB = !isLoss && idx >= 2 * EDP, isW = !isLoss && !isB && idx >= EDP;
+    const int rr = isW ? idx - EDP : idx;
+    const int e = isB ? idx - 2 * EDP : rr / DP, dd = isB ? 0 : rr - e * DP;
+    const bool live = mine && !isLoss && e < a.E && dd < a.D && !pure;
+    const int off = live ? (isB ? e : e * a.D + dd) : 0;
+    float pre_p = 0.f, pre_m = 0.f, pre_v = 0.f;
+    if (sub == 0 && live) {
+        pre_p = (isB ? a.b : (isW ? a.W : a.Ev))[off];
+        pre_m = (isB ? a.mb : (isW ? a.mW : a.mEv))[off];
+        pre_v = (isB ? a.vb : (isW ? a.vW : a.vEv))[off];
+    }
+    const float *col = a.slabs_prev + (mine ? idx : 0);
+    const int np = a.n_partials_prev;
+    double acc = 0.0;
+    constexpr int CH = STEP_FOLD_CH;
+    for (int s0 = sub; s0 < np; s0 += CH * kFoldSubs) {
+        float x[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) x[j] = col[(int64_t)min(s0 + j * kFoldSubs, np - 1) * SLAB];
+#pragma unroll
+        for (int j = 0; j < CH; j++) acc += (s0 + j * kFoldSubs < np) ? (double)x[j] : 0.0;
+    }
+    part[sub * kFoldCols + colx] = acc;
+    __syncthreads();
+    if (sub == 0 && mine) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < kFoldSubs; q++) v += part[q * kFoldCols + colx];
+        if (!isLoss) {
+            if (live) {
+                float gv = (float)v, pv = pre_p;
+                if (isB) {
+                    if (dense) gv += 2.f * a.l2 / (float)a.E * pv + a.l1 / (float)a.E * c_sign(pv);
+                } else if (isW && dense) {
+                    gv += 2.f * a.l2 / ((float)a.D * (float)a.E) * pv + a.l1 / ((float)a.D * (float)a.E) * c_sign(pv);
+                }
+                float mm = pre_m, vv = pre_v;
+                adam1(pv, gv, mm, vv, ad);
+                st_sc1((isB ? a.b : (isW ? a.W : a.Ev)) + off, pv);
+                (isB ? a.mb : (isW ? a.mW : a.mEv))[off] = mm;
+                (isB ? a.vb : (isW ? a.vW : a.vEv))[off] = vv;
+            }
+        } else {
+            double *sl = part + kFoldSubs * kFoldCols;
+            sl[idx - 2 * EDP - EMAX] = v;
+        }
+    }
+    // publish: every storing wave drains its stores, the workgroup meets, one lane stores the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) st_sc1(a.fold_flags + fb, gen);
+    constexpr int loss0 = 2 * EDP + EMAX;
+    if (fb == loss0 / kFoldCols && threadIdx.x == 0 && a.losses_prev) {
+        const double *sl = part + kFoldSubs * kFoldCols;
+        const StepScalars &k = a.k;
+        const double Li = sl[0] * a.inv_B_prev, Le = sl[1] * a.inv_B_prev, Lc = sl[2] * a.inv_B_prev;
+        const double L2 = sl[3] * a.inv_BD2_prev + (dense ? sl[5] : 0.0), L1 = sl[4] * a.inv_BD2_prev + (dense ? sl[6] : 0.0);
+        atomicAdd(a.losses_prev + 0, (float)Li); atomicAdd(a.losses_prev + 1, (float)Le); atomicAdd(a.losses_prev + 2, (float)Lc);
+        atomicAdd(a.losses_prev + 3, (float)L2); atomicAdd(a.losses_prev + 4, (float)L1);
+        atomicAdd(a.losses_prev + 5, (float)((double)k.ca * Li + (double)k.cb * Le + (double)k.cc * Lc + (double)a.l2 * L2 + (double)a.l1 * L1));
+    }
+}
+
+template <bool VEC, bool FULL, int MODE>
+__global__ __launch_bounds__(kThreads, 3) void mstep_alt_kernel(AltArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // (the previous step's Adam scalars differ from this step's in step_size / bc2_sqrt only: two scalars, not a second set)
+    AdamScalars ad_cur = a.ad_cur;
+    float2 prev2 = make_float2(a.ad_prev.step_size, a.ad_prev.bc2_sqrt);
+    StepScalars k = a.k;
+    int gen = a.gen;
+    if (a.sched_state) {
+        const int *cur = a.sched_state + 16 * a.sched_slot;
+        const SchedRow *sr = reinterpret_cast<const SchedRow *>(cur + 2);
+        gen = cur[0];
+        ad_cur = sr->ad;
+        // (a flush launch runs in the slot of the step it finishes: that row IS the "previous" step)
+        prev2 = (MODE & 2) ? make_float2(__builtin_bit_cast(float, cur[10]), __builtin_bit_cast(float, cur[11]))
+                           : make_float2(sr->ad.step_size, sr->ad.bc2_sqrt);
+        const float al = sr->alpha;
+        if (al == al) k.alpha = al;
+    }
+    const int b = (int)blockIdx.x;
+    if (b < a.first_task_block) {
+        if (b < a.fold_blocks) {
+            if (MODE & 1) {
+                ASTAMP(0);
+                { AdamScalars adp = ad_cur; adp.step_size = prev2.x; adp.bc2_sqrt = prev2.y; alt_fold_block(a, b, lds, adp, gen); }
+                ASTAMP(7);
+            }
+        } else if (b == a.fold_blocks) {
+            // the device-side schedule moves on (nobody reads the other slot before the next launch)
+            if (a.sched_state && (MODE & 2) && threadIdx.x == 0) {
+                const int *cur = a.sched_state + 16 * a.sched_slot;
+                int *nxt = a.sched_state + 16 * (a.sched_slot ^ 1);
+                const int next = cur[0] + 1, base = cur[1], idx = next - base;
+                nxt[0] = next;
+                nxt[1] = base;
+                if (idx >= 0 && idx < a.sched_n) *reinterpret_cast<SchedRow *>(nxt + 2) = a.sched_table[idx];
+                nxt[10] = cur[2];   // this step's step_size / bc2_sqrt: the next launch's "previous step"
+                nxt[11] = cur[3];
+            }
+        }
+        return;
+    }
+    const int tb = b - a.first_task_block;
+    const int ncls = a.n_cls;
+    const int c = tb % ncls;
+    int j = tb / ncls;
+    int q[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+        const int on = (c == kk) ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) q[i] += a.cls[kk][i] * on;
+    }
+    const int rpt = a.rounds_per_task, spt = a.rows_per_stream_task;
+    const int tj = (q[1] + rpt - 1) / rpt;
+    if (j < tj) {
+        alt_task<VEC, FULL, MODE>(a, q[0] + j, q[0] + j, lds, ad_cur, prev2, k, gen);
+        return;
+    }
+    j -= tj;
+    if (j * spt < q[3]) {
+        ASTAMP(0);
+        alt_stream<VEC, FULL, MODE>(a, a.stream + q[2] + j * spt, min(spt, q[3] - j * spt), ad_cur, prev2);
+        ASTAMP(7);
+    }
+}
+
+// ---- host side
+inline size_t alt_half_floats(int n_cap, int partials_cap) {
+    const size_t rows = ((size_t)(n_cap > 0 ? n_cap : 0) + 1) * 2 * 64;
+    const size_t slabs = (size_t)(partials_cap > 0 ? partials_cap : 1) * (2 * 4 * 64 + 4 + kLossSlots);
+    return (rows + slabs + 63) & ~(size_t)63;
+}
+inline size_t alt_flags_offset(int n_cap, int partials_cap) { return 2 * alt_half_floats(n_cap, partials_cap) * sizeof(float); }
+
+int launch_alt(const InvPrefTables *tables, const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
+               const InvPrefAltPlan *plan, const int64_t *envs, const float *weights, int64_t batch_norm,
+               int64_t batch_norm_prev, const InvPrefCoefs *coefs, uint32_t flags, float *losses6_prev, int64_t step, double lr,
+               double beta1, double beta2, double eps, const InvPrefAdamSchedule *sched, void *workspace,
+               size_t workspace_bytes, int n_cap, int partials_cap, int parity, hipStream_t st) {
+    const bool pure = flags & INVPREF_PURE_MF;
+    int rc;
+    if ((rc = check_tables(tables, pure)) || (rc = check_tables(exp_avg, pure)) || (rc = check_tables(exp_avg_sq, pure))) return rc;
+    if (!plan || !coefs || !workspace) return INVPREF_EINVAL;
+    if (sched && (!sched->state || !sched->table || sched->n <= 0)) return INVPREF_EINVAL;
+    const int D = (int)tables->factor_num, E = (int)tables->env_num;
+    if (D > 64 || E > 4) return INVPREF_EUNSUPPORTED;
+    const bool has_prev = plan->has_prev != 0, has_cur = plan->has_cur != 0;
+    if (!has_prev && !has_cur) return INVPREF_EINVAL;
+    if (has_cur && (batch_norm <= 0 || (!envs && !pure) || plan->n <= 0)) return INVPREF_EINVAL;
+    if (has_prev && batch_norm_prev <= 0) return INVPREF_EINVAL;
+    if (!sched && step < 1) return INVPREF_EINVAL;
+    if (pure && (flags & (INVPREF_REWEIGHT_CLS | INVPREF_REG_ENV_EMBED))) return INVPREF_EINVAL;
+    if (has_cur && (flags & (INVPREF_REWEIGHT_REC | INVPREF_REWEIGHT_CLS)) && !weights) return INVPREF_EINVAL;
+    if ((uint64_t)(tables->user_num > tables->item_num ? tables->user_num : tables->item_num) * (uint64_t)D * 4ull >= (1ull << 32))
+        return INVPREF_EUNSUPPORTED;
+    if (plan->lanes_per_group != 16 || plan->side < 0 || plan->side > 1 || plan->n < 0 || plan->n_prev < 0 ||
+        plan->n_rounds < 0 || plan->rounds_per_task != 1 || plan->n_rounds % plan->rounds_per_task != 0 ||
+        plan->n_stream < 0 || plan->rows_per_stream_task <= 0 || (plan->n_rounds > 0 && (!plan->desc || !plan->pend)) ||
+        (plan->n > 0 && (!plan->list || !plan->push_slot)) || (plan->n_stream > 0 && !plan->stream) ||
+        plan->n > n_cap || plan->n_prev > n_cap || plan->n_partials_prev < 0 || plan->n_partials_prev > partials_cap ||
+        plan->n_rounds / plan->rounds_per_task > partials_cap || (parity != 0 && parity != 1))
+        return INVPREF_EINVAL;
+    const int ncls = plan->n_classes > 0 ? plan->n_classes : 1;
+    if (ncls > 8) return INVPREF_EINVAL;
+    int per_class = 0;
+    for (int c = 0; c < ncls; c++) {
+        const int32_t *q = plan->cls[c];
+        for (int i = 0; i < 4; i++) if (q[i] < 0) return INVPREF_EINVAL;
+        if (q[0] + q[1] > plan->n_rounds || q[2] + q[3] > plan->n_stream || q[0] % plan->rounds_per_task) return INVPREF_EINVAL;
+        const int tot = (q[1] + plan->rounds_per_task - 1) / plan->rounds_per_task +
+                        (q[3] + plan->rows_per_stream_task - 1) / plan->rows_per_stream_task;
+        per_class = tot > per_class ? tot : per_class;
+    }
+    if (workspace_bytes < alt_flags_offset(n_cap, partials_cap) + 64 * sizeof(int)) return INVPREF_EWORKSPACE;
+    const size_t half = alt_half_floats(n_cap, partials_cap);
+    const size_t rows_floats = ((size_t)n_cap + 1) * 2 * 64;
+    float *ws = (float *)workspace;
+    AltArgs a{};
+    const int s = plan->side;
+    float *P[4] = {tables->embed_user_invariant, tables->embed_item_invariant, tables->embed_user_env_aware, tables->embed_item_env_aware};
+    float *M[4] = {exp_avg->embed_user_invariant, exp_avg->embed_item_invariant, exp_avg->embed_user_env_aware, exp_avg->embed_item_env_aware};
+    float *V[4] = {exp_avg_sq->embed_user_invariant, exp_avg_sq->embed_item_invariant, exp_avg_sq->embed_user_env_aware, exp_avg_sq->embed_item_env_aware};
+    for (int tb = 0; tb < 2; tb++) {
+        a.own_p[tb] = P[2 * tb + s]; a.own_m[tb] = M[2 * tb + s]; a.own_v[tb] = V[2 * tb + s];
+        a.oth_p[tb] = P[2 * tb + (1 - s)];
+    }
+    a.Ev = tables->embed_env; a.W = tables->classifier_weight; a.b = tables->classifier_bias;
+    a.mEv = exp_avg->embed_env; a.mW = exp_avg->classifier_weight; a.mb = exp_avg->classifier_bias;
+    a.vEv = exp_avg_sq->embed_env; a.vW = exp_avg_sq->classifier_weight; a.vb = exp_avg_sq->classifier_bias;
+    a.E = E; a.D = D;
+    a.desc = reinterpret_cast<const int4 *>(plan->desc);
+    a.pend = reinterpret_cast<const int4 *>(plan->pend);
+    a.list = reinterpret_cast<const int4 *>(plan->list);
+    a.push_slot = plan->push_slot;
+    a.stream = reinterpret_cast<const int4 *>(plan->stream);
+    a.rounds_per_task = plan->rounds_per_task; a.rows_per_stream_task = plan->rows_per_stream_task; a.n_cls = ncls;
+    for (int c = 0; c < 8; c++) for (int i = 0; i < 4; i++) a.cls[c][i] = c < ncls ? plan->cls[c][i] : 0;
+    a.envs = envs; a.weights = weights;
+    StepScalars k{};
+    k.ca = coefs->invariant_coe; k.cb = coefs->env_aware_coe; k.cc = coefs->env_coe; k.alpha = coefs->alpha;
+    if (has_cur) {
+        k.invB = 1.0f / (float)batch_norm;
+        k.r2 = coefs->L2_coe / ((float)batch_norm * (float)D);
+        k.r1 = coefs->L1_coe / (2.0f * (float)batch_norm * (float)D);
+    }
+    a.k = k;
+    if (has_prev) {
+        a.r2_prev = coefs->L2_coe / ((float)batch_norm_prev * (float)D);
+        a.r1_prev = coefs->L1_coe / (2.0f * (float)batch_norm_prev * (float)D);
+        a.inv_B_prev = 1.0 / (double)batch_norm_prev;
+        a.inv_BD2_prev = 1.0 / ((double)batch_norm_prev * (double)D * 2.0);
+    }
+    a.flags = flags;
+    a.mode = (has_prev ? 1 : 0) | (has_cur ? 2 : 0);
+    if (!sched) {
+        // has_cur: `step` is the current step, the previous one is step - 1; a flush finishes `step` itself
+        a.ad_cur = adam_scalars(step, lr, beta1, beta2, eps);
+        a.ad_prev = has_cur ? adam_scalars(step > 1 ? step - 1 : 1, lr, beta1, beta2, eps) : a.ad_cur;
+        a.gen = (int)step;
+    } else {
+        a.sched_state = sched->state; a.sched_slot = sched->slot & 1;
+        a.sched_table = reinterpret_cast<const SchedRow *>(sched->table); a.sched_n = sched->n;
+    }
+    float *mine = ws + (size_t)parity * half, *other = ws + (size_t)(1 - parity) * half;
+    a.push_rows = mine; a.slabs = mine + rows_floats;
+    a.pend_rows = other; a.slabs_prev = other + rows_floats;
+    a.n_partials_prev = plan->n_partials_prev;
+    a.fold_flags = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + alt_flags_offset(n_cap, partials_cap));
+    a.l2 = coefs->L2_coe; a.l1 = coefs->L1_coe;
+    a.losses_prev = has_prev ? losses6_prev : nullptr;
+    constexpr int SLAB = 2 * 4 * 64 + 4 + kLossSlots;
+    a.fold_blocks = (SLAB + kFoldCols - 1) / kFoldCols;
+    if (a.fold_blocks > 62) return INVPREF_EUNSUPPORTED;
+    a.first_task_block = (a.fold_blocks + 1 + 7) & ~7;   // (a multiple of the XCD count: task block tb keeps class tb % 8 on XCD b % 8)
+    static const char *stamp_env = getenv("INVPREF_STAMPS");
+    a.stamps = stamp_env ? reinterpret_cast<unsigned long long *>(strtoull(stamp_env, nullptr, 16)) : nullptr;
+    static const bool nodrain = getenv("INVPREF_STAMPS_NODRAIN") != nullptr;
+    a.stamps_nodrain = nodrain;
+    if (!has_prev) {
+        // a run starts: no stale flag of an earlier run may look like this run's step number
+        hipError_t e = hipMemsetAsync(a.fold_flags, 0, 64 * sizeof(int), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    const size_t lds_job = sizeof(float) * EvalLds<16, 4>::total;
+    const size_t lds = lds_job > fold_lds_bytes() ? lds_job : fold_lds_bytes();
+    const int grid = a.first_task_block + per_class * ncls;
+    const bool vec = vec_ok(tables) && vec_ok(exp_avg) && vec_ok(exp_avg_sq);
+    static const bool no_full = getenv("INVPREF_NO_FULL") != nullptr && getenv("INVPREF_NO_FULL")[0] == '1';
+    const bool full = vec && D == 64 && !no_full;
+#define CALL_ALT_M(VECV, FULLV, MODEV)                                                                      \
+    do {                                                                                                    \
+        if ((rc = ensure_lds(mstep_alt_kernel<VECV, FULLV, MODEV>, lds))) return rc;                        \
+        hipLaunchKernelGGL((mstep_alt_kernel<VECV, FULLV, MODEV>), dim3(grid), dim3(kThreads), lds, st, a); \
+    } while (0)
+#define CALL_ALT(VECV, FULLV)                                                   \
+    do {                                                                        \
+        if (a.mode == 3) CALL_ALT_M(VECV, FULLV, 3);                            \
+        else if (a.mode == 2) CALL_ALT_M(VECV, FULLV, 2);                       \
+        else CALL_ALT_M(VECV, FULLV, 1);                                        \
+    } while (0)
+    if (full) CALL_ALT(true, true);
+    else if (vec) CALL_ALT(true, false);
+    else CALL_ALT(false, false);
+#undef CALL_ALT
+#undef CALL_ALT_M
+    return (int)hipGetLastError();
+}

@@ -229,6 +229,49 @@ def mstep_rows_adam(params, new_params, exp_avg, exp_avg_sq, dplan, envs, scores
                                   s_state, s_table, int(s_slot), ws, last_step)
 
 
+class AltWorkspace:
+    """scratch of a run of alternating launches (include/invpref_hip.h: invpref_mstep_alt_hip): two halves of
+    {contribution rows, partial slabs} + the fold flags.  Never reallocated while a captured graph may replay into it."""
+
+    def __init__(self, params, n_cap: int, partials_cap: int, pure: bool = False):
+        t = (_capi.make_pure_tables if pure else make_tables)(params)
+        self.n_cap, self.partials_cap = int(n_cap), int(partials_cap)
+        nbytes = lib().invpref_alt_workspace_bytes(C.byref(t), self.n_cap, self.partials_cap)
+        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=params[0].device)
+        self.err_off = lib().invpref_alt_error_offset(C.byref(t), self.n_cap, self.partials_cap)
+
+    def error(self) -> int:
+        """1 if a job workgroup ever gave up waiting for the fold flags (host sync)"""
+        return int(self.buf[self.err_off:self.err_off + 4].view(torch.int32).item())
+
+
+def alt_supported(params) -> bool:
+    t = (_capi.make_pure_tables if len(params) == 2 else make_tables)(params)
+    return bool(lib().invpref_alt_supported(C.byref(t)))
+
+
+def mstep_alt(params, exp_avg, exp_avg_sq, aplan, envs, sample_weights, batch_norm: int, batch_norm_prev: int, coefs,
+              flags: int, losses6_prev, step: int, lr: float, aws: AltWorkspace, parity: int, beta1: float = 0.9,
+              beta2: float = 0.999, eps: float = 1e-8, pure: bool = False, sched=None) -> None:
+    """ONE launch of the alternating form (include/invpref_hip.h: invpref_mstep_alt_hip): the plan's side applies the
+    previous step's pending update, evaluates the current minibatch, applies its own update and pushes for the other side.
+    params / moments are updated in place.  sched = (state, table, slot) as for mstep_rows_adam."""
+    if pure:
+        flags |= _capi.PURE_MF
+    _gpu(*params, envs, sample_weights, losses6_prev)
+    mk = _capi.make_pure_tables if pure else make_tables
+    t, tm, tv = mk(params), mk(exp_avg), mk(exp_avg_sq)
+    cf = _capi.Coefs(*[float(c) for c in coefs[:6]])
+    sc = None
+    if sched is not None:
+        sc = C.byref(_capi.AdamSchedule(sched[0].data_ptr(), sched[1].data_ptr(), int(sched[1].shape[0]), int(sched[2])))
+    check(lib().invpref_mstep_alt_hip(
+        C.byref(t), C.byref(tm), C.byref(tv), C.byref(aplan.struct), ptr(envs), ptr(sample_weights), int(batch_norm),
+        int(batch_norm_prev), C.byref(cf), int(flags), ptr(losses6_prev), int(step), float(lr), float(beta1), float(beta2),
+        float(eps), sc, ptr(aws.buf), aws.buf.numel(), aws.n_cap, aws.partials_cap, int(parity), stream_ptr()),
+        'invpref_mstep_alt_hip')
+
+
 def defer_supported(params, dplan) -> bool:
     """may this plan run with deferred dense Adam on its untouched user rows? (push form, smallest kernel instance)"""
     t = (_capi.make_pure_tables if len(params) == 2 else make_tables)(params)

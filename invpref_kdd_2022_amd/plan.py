@@ -631,3 +631,204 @@ def _meta_of(st: RowPlanStruct, offs: dict) -> list:
         else:
             meta.append(v)
     return meta
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Alt plans: ONE launch per optimiser step, the evaluating side alternates (include/invpref_hip.h: InvPrefAltPlan,
+# csrc/step_alt.hpp).  A plan describes one launch: the CURRENT minibatch seen from side S (S's rows own the jobs, the
+# other side's rows are the partners) + the contribution rows the PREVIOUS launch pushed for S's rows.
+class AltPlanStruct(C.Structure):
+    """struct InvPrefAltPlan"""
+    _fields_ = [('side', C.c_int32), ('has_prev', C.c_int32), ('has_cur', C.c_int32), ('n', C.c_int32), ('n_prev', C.c_int32),
+                ('lanes_per_group', C.c_int32), ('n_rounds', C.c_int32), ('rounds_per_task', C.c_int32),
+                ('desc', C.c_void_p), ('pend', C.c_void_p), ('list', C.c_void_p), ('push_slot', C.c_void_p),
+                ('n_stream', C.c_int32), ('rows_per_stream_task', C.c_int32), ('stream', C.c_void_p),
+                ('n_classes', C.c_int32), ('cls', C.c_int32 * 32), ('n_partials_prev', C.c_int32)]
+
+
+ALT_ARRAYS = ('desc', 'pend', 'list', 'push_slot', 'stream')
+ALT_PEND_JOB_MIN = 9       # rows WITHOUT a current interaction and at least this many pending rows get a (sliced) job
+ALT_PEND_PER_SLICE = 4
+
+
+def alt_supported(factor_num: int, env_num: int) -> bool:
+    return factor_num <= 64 and env_num <= 4
+
+
+def build_alt_plan(cur, prev, side: int, user_num: int, item_num: int, factor_num: int = 64, per_slice: int | None = None,
+                   rounds_per_task: int = 1, n_classes: int | None = None, rows_per_stream_task: int | None = None,
+                   n_partials_prev: int = 0) -> dict:
+    """cur: (users, items, scores) of the minibatch this launch evaluates, or None (a flush launch); prev: (users, items)
+    of the minibatch the previous launch evaluated (from the OTHER side), or None (first launch of a run); side: 0 = the
+    user tables evaluate / are updated, 1 = the item tables.  n_partials_prev: job tasks of the previous launch (its
+    plan's 'n_tasks')."""
+    lanes = 16
+    ng = THREADS // lanes
+    own_num = user_num if side == 0 else item_num
+    if per_slice is None:
+        per_slice = int(os.environ.get('INVPREF_ALT_PER_SLICE_I' if side else 'INVPREF_ALT_PER_SLICE_U', '2'))
+    if n_classes is None:
+        n_classes = int(os.environ.get('INVPREF_PLAN_CLASSES', str(N_CLASSES)))
+    n_classes = max(1, min(8, n_classes))
+    if rows_per_stream_task is None:
+        rows_per_stream_task = int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', str(stream_rows_default(factor_num))))
+    has_cur, has_prev = cur is not None, prev is not None
+    if has_cur:
+        u, i, y = (np.asarray(cur[0], np.int64), np.asarray(cur[1], np.int64), np.asarray(cur[2], np.float32))
+        own, oth = (u, i) if side == 0 else (i, u)
+        n = len(own)
+        po = np.argsort(own, kind='stable')
+        cols = (oth[po].astype(np.int32), po.astype(np.int32), y.view(np.int32)[po])
+        own_sorted = own[po]
+        cnt = np.bincount(own, minlength=own_num).astype(np.int64)
+        push_slot = np.argsort(np.argsort(oth, kind='stable'), kind='stable').astype(np.int32)
+        lst = np.stack([cols[0], cols[1], cols[2], np.zeros(n, np.int32)], axis=1).reshape(-1)
+    else:
+        n = 0
+        cols, own_sorted = (np.zeros(0, np.int32),) * 3, np.zeros(0, np.int64)
+        cnt = np.zeros(own_num, np.int64)
+        push_slot, lst = np.zeros(0, np.int32), np.zeros(0, np.int32)
+    if has_prev:
+        ownp = np.asarray(prev[0] if side == 0 else prev[1], np.int64)
+        n_prev = len(ownp)
+        cntp = np.bincount(ownp, minlength=own_num).astype(np.int64)
+    else:
+        n_prev = 0
+        cntp = np.zeros(own_num, np.int64)
+    if n and max(cnt.max(), cntp.max()) >= MAX_ROW_COUNT:
+        raise ValueError('a row with too many interactions in one minibatch overflows the job descriptor')
+    ptrp = np.concatenate([[0], np.cumsum(cntp)])
+    pjob = (cnt == 0) & (cntp >= ALT_PEND_JOB_MIN)          # pending-only rows worth slicing
+    rcls = row_class(np.arange(own_num), n_classes)
+    d_parts, p_parts, s_parts = [], [], []
+    cls = np.zeros((8, 4), np.int32)
+    ownp_sorted = np.sort(ownp, kind='stable') if has_prev else np.zeros(0, np.int64)
+    for c in range(n_classes):
+        parts = []
+        if has_cur:
+            d, _ = _side_rounds(own_sorted, cols, own_num, ng, per_slice, 1, 2, skip=(cnt == 0) | (rcls != c))
+            parts.append(d)
+        if pjob.any():
+            # jobs without interactions: slices over the pending rows (mode 7 ranges of the previous S-sorted order)
+            d, _ = _side_rounds(ownp_sorted, (), own_num, ng, ALT_PEND_PER_SLICE, 1, 0, skip=~pjob | (rcls != c))
+            parts.append(d)
+        d = np.concatenate(parts) if parts else np.zeros((0, ng, 8), np.int32)
+        d = d[(d[:, :, 0] >= 0).any(axis=1)] if len(d) else d            # (drop the padding rounds of the parts)
+        pend = np.zeros((len(d), ng, 4), np.int32)
+        if len(d):
+            row = d[:, :, 0].astype(np.int64)
+            act = row >= 0
+            rowc = np.where(act, row, 0)
+            g = (d[:, :, 1] >> 1) & 31
+            k = np.arange(ng)[None, :] % np.maximum(g, 1)
+            cp = np.where(act, cntp[rowc], 0)
+            ln = -(-cp // np.maximum(g, 1))
+            a0 = ptrp[rowc] + np.minimum(k * ln, cp)
+            b0 = ptrp[rowc] + np.minimum((k + 1) * ln, cp)
+            pend_only = act & (cnt[rowc] == 0)
+            pend[:, :, 0] = np.where(act, a0, 0)
+            pend[:, :, 1] = np.where(act, b0, 0)
+            pend[:, :, 2] = cp
+            # pending-only jobs: no interactions (mode 0, count 0), leader / slices bits kept
+            meta = d[:, :, 1]
+            meta = np.where(pend_only, meta & 0x3f, meta)
+            d[:, :, 1] = meta
+            d[:, :, 2:] = np.where(pend_only[:, :, None], 0, d[:, :, 2:])
+            has = (cp > 0).any(axis=1)
+            d[:, :, 1] |= np.where(has, np.int32(-2 ** 31), np.int32(0))[:, None]
+        pad = (-len(d)) % rounds_per_task
+        if pad:
+            idle = np.zeros((pad, ng, 8), np.int32)
+            idle[:, :, 0] = -1
+            idle[:, :, 1] = 1 << 1
+            d = np.concatenate([d, idle])
+            pend = np.concatenate([pend, np.zeros((pad, ng, 4), np.int32)])
+        d_parts.append(d)
+        p_parts.append(pend)
+        rows = np.flatnonzero((cnt == 0) & ~pjob & (rcls == c))
+        s = np.stack([rows, ptrp[rows], ptrp[rows + 1], cntp[rows]], axis=1).astype(np.int32)
+        s_parts.append(s)
+    rb = sb = 0
+    for c in range(n_classes):
+        cls[c] = rb, len(d_parts[c]), sb, len(s_parts[c])
+        rb += len(d_parts[c])
+        sb += len(s_parts[c])
+    desc = np.concatenate(d_parts)
+    return dict(side=side, has_prev=int(has_prev), has_cur=int(has_cur), n=n, n_prev=n_prev, lanes_per_group=lanes,
+                rounds_per_task=rounds_per_task, desc=desc, pend=np.concatenate(p_parts), list=lst, push_slot=push_slot,
+                stream=np.concatenate(s_parts).reshape(-1), n_stream=sb, rows_per_stream_task=rows_per_stream_task,
+                n_classes=n_classes, cls=cls, n_partials_prev=int(n_partials_prev),
+                n_tasks=(len(desc) // rounds_per_task if has_cur else 0), per_slice=per_slice)
+
+
+def alt_workgroups(plan: dict) -> int:
+    ncls, cls = int(plan['n_classes']), np.asarray(plan['cls'])
+    rpt, spt = plan['rounds_per_task'], plan['rows_per_stream_task']
+    return ncls * max(-(-int(cls[c, 1]) // rpt) + -(-int(cls[c, 3]) // spt) for c in range(ncls))
+
+
+@dataclass
+class DeviceAltPlan:
+    struct: AltPlanStruct
+    buf: torch.Tensor
+    n_tasks: int
+    n: int
+    side: int
+    has_prev: int
+    has_cur: int
+    meta: torch.Tensor = None   # CPU int64: the struct's fields in order, pointers as int32 offsets into buf (-1: NULL)
+
+
+def alt_struct_from_meta(buf: torch.Tensor, meta: torch.Tensor) -> AltPlanStruct:
+    if buf.dtype != torch.int32 or not buf.is_contiguous() or meta.dtype != torch.int64 or meta.is_cuda:
+        raise ValueError('alt plan: int32 device buffer + CPU int64 meta tensor expected')
+    vals = meta.tolist()
+    base, nb = buf.data_ptr(), buf.numel()
+    args, i = [], 0
+    for name, ty in AltPlanStruct._fields_:
+        if name == 'cls':
+            args.append((C.c_int32 * 32)(*vals[i:i + 32]))
+            i += 32
+            continue
+        v = vals[i]
+        i += 1
+        if ty is C.c_void_p:
+            if v < 0:
+                v = None
+            elif v > nb:
+                raise ValueError('alt plan: array offset outside the buffer')
+            else:
+                v = base + 4 * v
+        args.append(v)
+    if i != len(vals):
+        raise ValueError('alt plan: meta length')
+    return AltPlanStruct(*args)
+
+
+def upload_alt(plan: dict, device) -> DeviceAltPlan:
+    parts, offs, off = [], {}, 0
+    for k in ALT_ARRAYS:
+        a = np.ascontiguousarray(plan[k], np.int32).reshape(-1)
+        if len(a) == 0:
+            offs[k] = -1
+            continue
+        parts.append((off, a))
+        offs[k] = off
+        off += len(a) + (-len(a)) % 4
+    host = np.zeros(off + 4, np.int32)
+    for o, a in parts:
+        host[o:o + len(a)] = a
+    buf = torch.from_numpy(host).to(device)
+    meta = []
+    for name, ty in AltPlanStruct._fields_:
+        if name == 'cls':
+            meta.extend(np.asarray(plan['cls'], np.int32).reshape(-1).tolist())
+        elif ty is C.c_void_p:
+            meta.append(offs[name])
+        elif name == 'n_rounds':
+            meta.append(len(plan['desc']))
+        else:
+            meta.append(int(plan[name]))
+    meta = torch.tensor(meta, dtype=torch.int64)
+    return DeviceAltPlan(alt_struct_from_meta(buf, meta), buf, plan['n_tasks'], plan['n'], plan['side'], plan['has_prev'],
+                         plan['has_cur'], meta)

@@ -168,6 +168,7 @@ class _BasicTrainManager(_InvPrefTrainManager):
         self._estep_graphs = {}
         self._grad_stale = False
         self._sched, self._sched_synced = None, False
+        self._alt = None
 
     def _coefs(self, alpha):
         return (1., 0., 0., 2. * self.L2_coe, 2. * self.L1_coe, 0.)

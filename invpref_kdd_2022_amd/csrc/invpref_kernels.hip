@@ -200,15 +200,13 @@ __global__ __launch_bounds__(512) void mstep_atomic_kernel(DevTables t, DevGrads
                 mx = z[c] > mx ? z[c] : mx;
             }
         }
-        float se = 0.f, ze = 0.f;
+        float se = 0.f, zr = 0.f;
 #pragma unroll
         for (int c = 0; c < EMAX; c++) {
-            if (c < t.E) { z[c] = c_exp(z[c] - mx) ; se += z[c]; }
+            if (c < t.E) { const float dz = z[c] - mx; zr = (c == e) ? dz : zr; z[c] = c_exp(dz); se += z[c]; }
         }
-        // z[c] now holds exp(z-mx); log-prob of the true env: log(ex_e/se)
-#pragma unroll
-        for (int c = 0; c < EMAX; c++) ze = (c == e) ? z[c] : ze;
-        const float lcls = UPSTREAM ? 0.f : -c_log(ze / se);
+        // z[c] now holds exp(z-mx); NLL of log_softmax as the reference forms it (models.py:206-209): finite for finite logits
+        const float lcls = UPSTREAM ? 0.f : c_log(se) - zr;
         const float rse = 1.f / se;
         float usum = 0.f;  // sum_c d_out[c]  (log_softmax backward: dz = d_out - softmax * sum d_out)
         if (UPSTREAM && up.d_out) {

@@ -364,13 +364,19 @@ __device__ __forceinline__ void eval_interaction(Eval<EMAX> &o, float4 pu, float
             z[c] = c < E ? zc : -__builtin_inff();
             mx = z[c] > mx ? z[c] : mx;
         }
-        float se = 0.f, ze = 0.f;
+        // NLL of log_softmax as the reference forms it (models.py:206-209, train.py:42-44): log(sum exp(z - max)) - (z_e - max).
+        // Finite for any finite logits -- log(exp(z_e - max) / sum) is +inf once that exponential underflows, which embeddings
+        // grown to a few units reach (seen after 2 000 steps of the Yahoo-shaped run: tools/alt_soak.py)
+        float se = 0.f, zr = 0.f;
 #pragma unroll
-        for (int c = 0; c < (EMAX <= 4 ? EMAX : 1); c++) { z[c] = f_exp(z[c] - mx); se += z[c]; }   // exp(-inf) = 0
-#pragma unroll
-        for (int c = 0; c < (EMAX <= 4 ? EMAX : 1); c++) ze = (c == e) ? z[c] : ze;
+        for (int c = 0; c < (EMAX <= 4 ? EMAX : 1); c++) {
+            const float dz = z[c] - mx;
+            zr = (c == e) ? dz : zr;
+            z[c] = f_exp(dz);   // exp(-inf) = 0
+            se += z[c];
+        }
         const float rse = f_rcp(se);
-        o.lcls = -f_log(ze * rse);
+        o.lcls = f_log(se) - zr;
 #pragma unroll
         for (int c = 0; c < (EMAX <= 4 ? EMAX : 1); c++) {
             o.gz[c] = c < E ? k.cc * cw_cls * (z[c] * rse - (c == e ? 1.f : 0.f)) : 0.f;

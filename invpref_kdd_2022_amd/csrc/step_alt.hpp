@@ -775,6 +775,12 @@ __global__ __launch_bounds__(kThreads, 3) void mstep_alt_kernel(AltArgs a) {
     }
     const int b = (int)blockIdx.x;
     if (b < a.first_task_block) {
+        if (!(MODE & 1) && b == 0 && threadIdx.x < 64) {
+            // a run starts (no fold in this launch, nobody polls): every flag word back to zero, so that no stale flag of an
+            // earlier run can look like one of this run's step numbers.  (In the kernel, not a hipMemsetAsync in front of
+            // it: a captured memset node replayed garbage into these words on ROCm 7.0.2 -- tools/alt_soak.py)
+            a.fold_flags[threadIdx.x] = 0;
+        }
         if (b < a.fold_blocks) {
             if (MODE & 1) {
                 ASTAMP(0);
@@ -933,11 +939,6 @@ int launch_alt(const InvPrefTables *tables, const InvPrefTables *exp_avg, const 
     a.stamps = stamp_env ? reinterpret_cast<unsigned long long *>(strtoull(stamp_env, nullptr, 16)) : nullptr;
     static const bool nodrain = getenv("INVPREF_STAMPS_NODRAIN") != nullptr;
     a.stamps_nodrain = nodrain;
-    if (!has_prev) {
-        // a run starts: no stale flag of an earlier run may look like this run's step number
-        hipError_t e = hipMemsetAsync(a.fold_flags, 0, 64 * sizeof(int), st);
-        if (e != hipSuccess) return (int)e;
-    }
     const size_t lds_job = sizeof(float) * EvalLds<16, 4>::total;
     const size_t lds = lds_job > fold_lds_bytes() ? lds_job : fold_lds_bytes();
     const int grid = a.first_task_block + per_class * ncls;

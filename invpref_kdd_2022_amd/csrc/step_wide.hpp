@@ -259,7 +259,9 @@ __device__ __forceinline__ void eval_wide(WEval<NC> &o, const float4 (&pu)[NC], 
     const float gzl = (lg < E && has) ? k.cc * cw_cls * (ez * rsel - (lg == e ? 1.f : 0.f)) : 0.f;
     o.gz_lane = gzl;
     // the picked class's loss term stays on ITS lane (the task's loss sums run over every lane)
-    o.lcls = (lg == e && has) ? -f_log(ez * rsel) : 0.f;
+    // (the reference's log_softmax form, models.py:206-209: finite for any finite logits)
+    // (log(sum) = -log(1 / sum): the reciprocal is at hand, no register for the sum itself)
+    o.lcls = (lg == e && has) ? -f_log(rsel) - (zmine - mxl) : 0.f;
     if constexpr (LG == 16) {
         // gx = sum_c gz_c W_c, classes in order; gz_c = lane c of the lane's own 16-lane row (DPP row_share: no LDS round
         // trip between the softmax and the backward).  The group's LDS words keep a copy of gz only for the pull record.

@@ -259,17 +259,11 @@ def mstep_alt(params, exp_avg, exp_avg_sq, aplan, envs, sample_weights, batch_no
     if pure:
         flags |= _capi.PURE_MF
     _gpu(*params, envs, sample_weights, losses6_prev)
-    mk = _capi.make_pure_tables if pure else make_tables
-    t, tm, tv = mk(params), mk(exp_avg), mk(exp_avg_sq)
-    cf = _capi.Coefs(*[float(c) for c in coefs[:6]])
-    sc = None
-    if sched is not None:
-        sc = C.byref(_capi.AdamSchedule(sched[0].data_ptr(), sched[1].data_ptr(), int(sched[1].shape[0]), int(sched[2])))
-    check(lib().invpref_mstep_alt_hip(
-        C.byref(t), C.byref(tm), C.byref(tv), C.byref(aplan.struct), ptr(envs), ptr(sample_weights), int(batch_norm),
-        int(batch_norm_prev), C.byref(cf), int(flags), ptr(losses6_prev), int(step), float(lr), float(beta1), float(beta2),
-        float(eps), sc, ptr(aws.buf), aws.buf.numel(), aws.n_cap, aws.partials_cap, int(parity), stream_ptr()),
-        'invpref_mstep_alt_hip')
+    s_state, s_table, s_slot = sched if sched is not None else (None, None, 0)
+    _o().train_step_alt_(list(params), list(exp_avg), list(exp_avg_sq), aplan.buf, aplan.meta, envs, sample_weights,
+                         int(batch_norm), int(batch_norm_prev), [float(c) for c in coefs[:6]], int(flags), losses6_prev,
+                         int(step), float(lr), float(beta1), float(beta2), float(eps), s_state, s_table, int(s_slot), aws.buf,
+                         aws.n_cap, aws.partials_cap, int(parity))
 
 
 def defer_supported(params, dplan) -> bool:

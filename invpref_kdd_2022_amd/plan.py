@@ -805,6 +805,15 @@ def alt_struct_from_meta(buf: torch.Tensor, meta: torch.Tensor) -> AltPlanStruct
     return AltPlanStruct(*args)
 
 
+def alt_with_partials(dp: DeviceAltPlan, n_partials_prev: int) -> DeviceAltPlan:
+    """the same plan behind a launch that left another number of partial slabs (the arrays are shared)"""
+    if int(dp.meta[-1]) == int(n_partials_prev):
+        return dp
+    meta = dp.meta.clone()
+    meta[-1] = int(n_partials_prev)
+    return DeviceAltPlan(alt_struct_from_meta(dp.buf, meta), dp.buf, dp.n_tasks, dp.n, dp.side, dp.has_prev, dp.has_cur, meta)
+
+
 def upload_alt(plan: dict, device) -> DeviceAltPlan:
     parts, offs, off = [], {}, 0
     for k in ALT_ARRAYS:

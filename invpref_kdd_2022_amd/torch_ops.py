@@ -15,6 +15,8 @@ What replaces what in the reference:
 ``train_step_planned_adam_``   the same + ``optimizer.step()`` in one pass (train.py:94-157 entire); with ``last_step``:
                                dense Adam on untouched user rows deferred and replayed exactly (train.py:41, :155-157)
 ``flush_deferred_``            brings every deferred user row up to date (before anything reads all rows)
+``train_step_alt_``            ONE launch of the alternating form: a whole ``train_a_batch`` step per launch, the evaluating
+                               side (users / items) alternating; tables and moments in place (train.py:94-157, :41)
 ``adam_dense_``                ``optimizer.zero_grad()`` + ``torch.optim.Adam.step()`` (train.py:41, :155-157)
 ``adam_ranges_``               the same over up to four pieces of the flat buffers (user-sharded ranks)
 ``pack_rows_`` / ``unpack_``   the touched rows of the flat gradient into / out of one buffer (row-sharded ranks' exchange)
@@ -243,6 +245,39 @@ def _planned_adam(tables, new_tables, exp_avg, exp_avg_sq, plan_buf, plan_meta, 
 def _planned_adam_fake(tables, new_tables, exp_avg, exp_avg_sq, plan_buf, plan_meta, envs, scores, sample_weights,
                        batch_norm, coefs, flags, losses6, step, lr, beta1, beta2, eps, sched_state, sched_table,
                        sched_slot, workspace, last_step=None):
+    return None
+
+
+_define('train_step_alt_(Tensor(a!)[] tables, Tensor(b!)[] exp_avg, Tensor(c!)[] exp_avg_sq, Tensor plan_buf, Tensor plan_meta, '
+        'Tensor? envs, Tensor? sample_weights, int batch_norm, int batch_norm_prev, float[] coefs, int flags, '
+        'Tensor(d!)? losses6_prev, int step, float lr, float beta1, float beta2, float eps, Tensor(e!)? sched_state, '
+        'Tensor? sched_table, int sched_slot, Tensor(f!) workspace, int n_cap, int partials_cap, int parity) -> ()')
+
+
+@_impl('train_step_alt_')
+def _step_alt(tables, exp_avg, exp_avg_sq, plan_buf, plan_meta, envs, sample_weights, batch_norm, batch_norm_prev, coefs,
+              flags, losses6_prev, step, lr, beta1, beta2, eps, sched_state, sched_table, sched_slot, workspace, n_cap,
+              partials_cap, parity):
+    # include/invpref_hip.h: invpref_mstep_alt_hip.  The plan (plan.DeviceAltPlan) travels like a row plan: its int32 device
+    # buffer and a CPU int64 meta tensor
+    from .plan import alt_struct_from_meta
+    t, tm, tv = _tables(tables), _tables(exp_avg), _tables(exp_avg_sq)
+    _f32(sample_weights, 'sample_weights'); _f32(losses6_prev, 'losses6_prev')
+    cf = _coefs(coefs)
+    ps = alt_struct_from_meta(plan_buf, plan_meta)
+    pe = ptr(None if envs is None else _ids(envs, 'envs'))
+    sc = None if sched_state is None else C.byref(_sched_struct(sched_state, sched_table, sched_slot))
+    check(lib().invpref_mstep_alt_hip(C.byref(t), C.byref(tm), C.byref(tv), C.byref(ps), pe, ptr(sample_weights),
+                                      int(batch_norm), int(batch_norm_prev), C.byref(cf), int(flags), ptr(losses6_prev),
+                                      int(step), float(lr), float(beta1), float(beta2), float(eps), sc, ptr(workspace),
+                                      workspace.numel(), int(n_cap), int(partials_cap), int(parity), stream_ptr()),
+          'invpref_mstep_alt_hip')
+
+
+@_fake('train_step_alt_')
+def _step_alt_fake(tables, exp_avg, exp_avg_sq, plan_buf, plan_meta, envs, sample_weights, batch_norm, batch_norm_prev, coefs,
+                   flags, losses6_prev, step, lr, beta1, beta2, eps, sched_state, sched_table, sched_slot, workspace, n_cap,
+                   partials_cap, parity):
     return None
 
 

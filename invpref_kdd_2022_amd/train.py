@@ -213,6 +213,7 @@ class _InvPrefTrainManager:
         self._grad_stale = False
         self._sched = None
         self._sched_synced = False
+        self._alt = None
 
     def _setup_ranges(self, model):
         """What one optimiser step exchanges and updates on this rank: `_ar_lo` = first float of the flat
@@ -457,12 +458,100 @@ class _InvPrefTrainManager:
             self._last_step = torch.zeros(self.model.user_num, dtype=torch.int32, device=self.device)
             self._last_step_valid = None
         self._defer_home = None
+        self._alt_setup()
         if self.use_plan and self.users_tensor.is_cuda:
             # every plan shares ONE scratch (records + partial slabs; nothing carries over between steps): size it for
             # the largest BEFORE any graph capture bakes its address in
             t = self._make_tables(st.p_views)
             self.workspace.get_zeroed(max(L.invpref_rows_workspace_bytes(C.byref(t), C.byref(dp.struct))
                                           for dp in self._plans))
+
+    # ---- the alternating form: ONE launch per optimiser step (include/invpref_hip.h: invpref_mstep_alt_hip; csrc/step_alt.hpp).
+    # Inside a run of whole epochs launch i evaluates minibatch i % batch_num from the users' side (even i) or the items'
+    # (odd i): the side applies the previous step's pending update to its rows, evaluates, applies its own update and
+    # pushes contribution rows for the other side; a flush launch ends the run.  Nothing outside a run ever sees the
+    # intermediate state; parameters and moments are updated in place (no buffer swap).
+    def _alt_setup(self):
+        st = self.state
+        self._alt = None
+        # (eagerly issued epochs run the same launches as captured ones: graph replay == eager launches, bit for bit;
+        #  INVPREF_ALT_EAGER=0 keeps eagerly issued epochs on the two-launch form)
+        self._alt_eager = os.environ.get('INVPREF_ALT_EAGER', '1') == '1'
+        if not (self.use_plan and self._plans and self.users_tensor.is_cuda and self._fused_seq() and not self._defer
+                and os.environ.get('INVPREF_ALT', '1') == '1' and ops.alt_supported(st.p_views)):
+            return
+        n_cap = max(b[1] for b in self._raw_batches)
+        host = getattr(self, '_alt_host', None)
+        if host is None:
+            host = self._alt_host = (self.users_tensor.cpu().numpy(), self.items_tensor.cpu().numpy(),
+                                     self.scores_tensor.cpu().numpy().astype(np.float32))
+        self._alt = dict(plans={}, host_plans={}, n_cap=n_cap, partials_cap=n_cap // 4 + n_cap // 8 + 128, ws=None,
+                         build_s=0.0)
+
+    def _alt_batch(self, k: int):
+        lo, n = self._raw_batches[k][0], self._raw_batches[k][1]
+        u, v, y = self._alt_host
+        return u[lo:lo + n], v[lo:lo + n], y[lo:lo + n]
+
+    def _alt_plan(self, k_prev, k, side: int, partials_prev: int):
+        """device plan of the launch that evaluates minibatch k (None: a flush) from `side` after a launch that evaluated
+        minibatch k_prev (None: first launch of a run) and left `partials_prev` partial slabs"""
+        A = self._alt
+        key = (k_prev, k, side)
+        dp = A['plans'].get(key)
+        if dp is None:
+            t0 = time.perf_counter()
+            hp = planlib.build_alt_plan(None if k is None else self._alt_batch(k),
+                                        None if k_prev is None else self._alt_batch(k_prev)[:2], side, self.model.user_num,
+                                        self.model.item_num, factor_num=self.model.factor_num)
+            if hp['n_tasks'] > A['partials_cap']:
+                raise _capi.InvPrefError('alt plan: more job tasks than the workspace was sized for')
+            dp = A['plans'][key] = planlib.upload_alt(hp, self.device)
+            A['build_s'] += time.perf_counter() - t0
+        if A['ws'] is None:
+            A['ws'] = ops.AltWorkspace(self.state.p_views, A['n_cap'], A['partials_cap'], pure=self._pure)
+        return planlib.alt_with_partials(dp, partials_prev)
+
+    def _alt_prepare(self, n: int):
+        """builds (and uploads) every plan a run of n epochs needs and its workspace -- BEFORE a graph capture starts: host
+        to device copies and allocations are not capturable"""
+        bn, total = self.batch_num, n * self.batch_num
+        k_prev, tasks_prev = None, 0
+        for i in range(min(total, 2 * bn + 1)):      # (the plan sequence is periodic after the first launch)
+            dp = self._alt_plan(k_prev, i % bn, i & 1, tasks_prev)
+            k_prev, tasks_prev = i % bn, dp.n_tasks
+        self._alt_plan((total - 1) % bn, None, total & 1, 0)
+
+    def _issue_epochs_alt(self, sched: bool, n: int):
+        st, A, bn = self.state, self._alt, self.batch_num
+        total = n * bn
+        k_prev, tasks_prev, alpha = None, 0, self.alpha
+        for i in range(total):
+            j, k = divmod(i, bn)
+            self._loss_slot = j
+            dp = self._alt_plan(k_prev, k, i & 1, tasks_prev)
+            lo, nloc, bnorm, bu, bi, by, be, bw = self._raw_batches[k]
+            alpha = self._alpha_for(k)
+            st.step += 1
+            sc = (self._sched['state'], self._sched['table'], st.step & 1) if sched else None
+            lp = self._epoch_losses[(i - 1) // bn, (i - 1) % bn] if i else None
+            ops.mstep_alt(st.p_views, st.m_views, st.v_views, dp, be, bw, bnorm,
+                          self._raw_batches[k_prev][2] if k_prev is not None else bnorm, self._coefs(alpha), self._flags, lp,
+                          st.step, self.lr, A['ws'], i & 1, pure=self._pure, sched=sc)
+            k_prev, tasks_prev = k, dp.n_tasks
+        # the flush: the other side's rows take the last step's update, the last fold (in the LAST step's schedule slot)
+        dp = self._alt_plan(k_prev, None, total & 1, tasks_prev)
+        sc = (self._sched['state'], self._sched['table'], st.step & 1) if sched else None
+        bnorm = self._raw_batches[k_prev][2]
+        ops.mstep_alt(st.p_views, st.m_views, st.v_views, dp, None, None, bnorm, bnorm, self._coefs(alpha), self._flags,
+                      self._epoch_losses[(total - 1) // bn, (total - 1) % bn], st.step, self.lr, A['ws'], total & 1,
+                      pure=self._pure, sched=sc)
+        self._loss_slot = 0
+
+    def alt_error(self) -> int:
+        """1 if a workgroup of an alternating launch ever gave up waiting for the fold flags (host sync; never in a healthy run)"""
+        A = getattr(self, '_alt', None)
+        return 0 if not A or A['ws'] is None else A['ws'].error()
 
     def _raw_step(self, k: int, alpha: float, stream=None, mid_event=None, sched=False):
         st = self.state
@@ -567,6 +656,9 @@ class _InvPrefTrainManager:
     def _issue_epochs(self, stream, sched: bool, n: int):
         self._epoch_losses[:n].zero_()
         st = self.state
+        if getattr(self, '_alt', None) is not None and (sched or self._alt_eager):
+            self._issue_epochs_alt(sched, n)
+            return
         defer = bool(sched and getattr(self, '_defer', False))
         self._defer_home = list(st.p_views) if defer else None
         try:
@@ -654,7 +746,7 @@ class _InvPrefTrainManager:
             if getattr(self, '_defer', False):
                 self._last_step_valid = st.step + steps
             st.step += steps
-            if steps % 2 and fused_seq:
+            if steps % 2 and fused_seq and self._alt is None:   # (the alternating form updates in place)
                 st.swap()
             if self.world_size > 1:
                 all_reduce_sum_(self._epoch_losses[:n], self.process_group)   # per-rank loss partials -> totals
@@ -711,6 +803,8 @@ class _InvPrefTrainManager:
         key = self._graph_key(n)
         g = self._graphs.get(key)
         if g is None:
+            if self._alt is not None:
+                self._alt_prepare(n)
             step0, views0 = st.step, st.p_views
             g = torch.cuda.CUDAGraph()
             try:
@@ -736,7 +830,7 @@ class _InvPrefTrainManager:
             step0 = self.state.step
             for _ in range(2):  # a fused step swaps the buffers and flips the schedule slot: both move together
                 self._graph_for(n)
-                if self._fused_seq():
+                if self._fused_seq() and self._alt is None:   # (the alternating form: in place, only the slot parity moves)
                     self.state.swap()
                 self.state.step += 1
             self.state.step = step0

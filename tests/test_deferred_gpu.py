@@ -23,6 +23,7 @@ class StubEvaluator:
 
 def _manager(monkeypatch, defer: bool, U, I, E, D, N, B, alpha, seed=11):
     monkeypatch.setenv('INVPREF_DEFER', '1' if defer else '0')
+    monkeypatch.setenv('INVPREF_ALT', '0')   # (the dense TWO-LAUNCH form is what the deferred form must equal bit for bit)
     data = synth.interactions(seed, U, I, N, implicit=True, zipf=True)
     tabs = synth.tables(seed + 7, U, I, E, D)
     model = InvPrefImplicit(U, I, E, D, reg_only_embed=True, reg_env_embed=False)

@@ -37,7 +37,8 @@ y = torch.from_numpy(data[:N, 2].astype(np.float32)).to(dev)
 e = torch.from_numpy(np.random.RandomState(3).randint(0, E, N).astype(np.int64)).to(dev)
 w = torch.from_numpy(np.random.RandomState(4).rand(N).astype(np.float32)).to(dev)
 coefs = (3.35, 9.99, 9.06, 3.13, 0.49, float(os.environ.get('PROBE_ALPHA', '1.9')))
-flags = ops.flags_of(True, True, True, False, True)
+fl = [x == '1' for x in os.environ.get('PROBE_FLAGS', '1,1,1,0,1').split(',')]   # implicit, rw_rec, rw_cls, reg_only_embed, reg_env_embed
+flags = ops.flags_of(*fl)
 FIRST, LR = 5, 0.005
 Pn = sum(p.numel() for p in P0)
 nbytes = B * (32 + 16 * D) + 24 * Pn

@@ -861,7 +861,7 @@ int launch_alt(const InvPrefTables *tables, const InvPrefTables *exp_avg, const 
         plan->n_stream < 0 || plan->rows_per_stream_task <= 0 || (plan->n_rounds > 0 && (!plan->desc || !plan->pend)) ||
         (plan->n > 0 && (!plan->list || !plan->push_slot)) || (plan->n_stream > 0 && !plan->stream) ||
         plan->n > n_cap || plan->n_prev > n_cap || plan->n_partials_prev < 0 || plan->n_partials_prev > partials_cap ||
-        plan->n_rounds / plan->rounds_per_task > partials_cap || (parity != 0 && parity != 1))
+        (has_cur && plan->n_rounds > partials_cap) || (parity != 0 && parity != 1))   // (a flush launch writes no slabs)
         return INVPREF_EINVAL;
     const int ncls = plan->n_classes > 0 ? plan->n_classes : 1;
     if (ncls > 8) return INVPREF_EINVAL;

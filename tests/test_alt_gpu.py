@@ -1,0 +1,207 @@
+"""GPU: the alternating one-launch-per-step form (include/invpref_hip.h: invpref_mstep_alt_hip; csrc/step_alt.hpp) against
+the two-launch planned form -- itself held to the oracle and the reference's goldens by tests/test_hip_parity.py,
+test_edge_cases_gpu.py and test_manager_gpu.py -- on the same minibatches: k steps through both (train.py:94-157 each),
+parameters, both Adam moments and the six loss terms of every step; run-to-run bitwise; the workspace's bounds.
+
+Tolerances: both forms compute the same sums in different orders (an item-side launch walks a user row's contributions in
+slot order, a user-side launch in list order), so they agree to float rounding: parameters and moments 2e-5 of the table's
+largest entry after 5 steps (measured <= 3e-6), loss terms 2e-5 relative (measured <= 2e-7).  The runs start from NON-ZERO
+Adam moments: with zero moments the first update is lr * g / (|g| + eps), which turns a rounding difference in an
+all-but-cancelled gradient entry into a full step (tests/test_edge_cases_gpu.py masks those entries instead)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from invpref_kdd_2022_amd import _capi, ops, plan as planlib, synth
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+COEFS = (2.05, 8.63, 5.1, 7.73, 0.0015, 1.74)
+FIRST, LR = 5, 0.01
+
+
+def _state(seed, U, I, E, D, pure):
+    tabs = synth.tables(seed, U, I, E, D, std=0.2)
+    names = ops.PARAM_NAMES[:2] if pure else ops.PARAM_NAMES
+    rs = np.random.RandomState(seed + 1)
+    P = [torch.from_numpy(np.ascontiguousarray(tabs[k], np.float32)).to(DEV) for k in names]
+    M = [torch.from_numpy((1e-3 * rs.standard_normal(p.shape)).astype(np.float32)).to(DEV) for p in P]
+    V = [torch.from_numpy((1e-5 * rs.random_sample(p.shape) + 1e-8).astype(np.float32)).to(DEV) for p in P]
+    return P, M, V
+
+
+def _clone(x):
+    return [[t.clone() for t in part] for part in x]
+
+
+def run_both(seed, U, I, E, D, sizes, implicit=True, pure=False, fl=(True, True, False, True), alt_kw=None, reps=1,
+             zipf=True, guard=False):
+    """sizes: minibatch lengths of consecutive steps.  Returns (two-launch result, [alt results]) as lists of numpy arrays:
+    parameters + exp_avg + exp_avg_sq + [losses (k, 6)]."""
+    k, N = len(sizes), int(sum(sizes))
+    rs = np.random.RandomState(seed)
+    data = synth.interactions(seed, U, I, N, implicit=implicit, zipf=zipf)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    y = torch.from_numpy(data[:, 2].astype(np.float32)).to(DEV)
+    e = None if pure else torch.from_numpy(rs.randint(0, E, N).astype(np.int64)).to(DEV)
+    w = None if pure else torch.from_numpy(rs.uniform(0.1, 1, N).astype(np.float32)).to(DEV)
+    coefs = (1., 0., 0., 0.6, 0.1, 0.) if pure else COEFS
+    flags = (ops.flags_of(implicit, False, False, True, False, dense_reg=False) if pure
+             else ops.flags_of(implicit, *fl))
+    S0 = _state(seed, U, I, E, D, pure)
+
+    def mb(c):
+        sl = slice(int(offs[c]), int(offs[c + 1]))
+        return data[sl, 0], data[sl, 1], data[sl, 2].astype(np.float32)
+
+    def sl(t, c):
+        return None if t is None else t[int(offs[c]):int(offs[c + 1])]
+
+    # ---- two launches per step
+    P, M, V = _clone(S0)
+    P2 = [p.clone() for p in P]
+    ws = ops.Workspace(DEV)
+    losses = torch.zeros(k, 6, device=DEV)
+    a, b = P, P2
+    for c in range(k):
+        dp = planlib.upload(planlib.build_row_plan(*mb(c), U, I, factor_num=D, env_num=E), DEV)
+        ops.mstep_rows_adam(a, b, M, V, dp, sl(e, c), sl(y, c), sl(w, c), sizes[c], coefs, flags, losses[c], FIRST + c, LR, ws,
+                            pure=pure)
+        a, b = b, a
+    want = [t.cpu().numpy() for t in a + M + V] + [losses.cpu().numpy()]
+    # ---- one launch per step, the evaluating side alternating, then the flush
+    kw = dict(alt_kw or {})
+    apl = []
+    for c in range(k):
+        apl.append(planlib.build_alt_plan(mb(c), None if c == 0 else mb(c - 1)[:2], c % 2, U, I, factor_num=D,
+                                          n_partials_prev=apl[-1]['n_tasks'] if c else 0, **kw))
+    apl.append(planlib.build_alt_plan(None, mb(k - 1)[:2], k % 2, U, I, factor_num=D, n_partials_prev=apl[-1]['n_tasks'], **kw))
+    dps = [planlib.upload_alt(p, DEV) for p in apl]
+    got = []
+    for _ in range(reps):
+        P, M, V = _clone(S0)
+        aws = ops.AltWorkspace(P, max(sizes), max(p['n_tasks'] for p in apl) + 1, pure=pure)
+        if guard:   # the workspace inside a larger poisoned buffer: nothing outside [0, nbytes) may change
+            nbytes, pad = aws.buf.numel(), 4096
+            big = torch.full((nbytes + 2 * pad,), 0xA5, dtype=torch.uint8, device=DEV)
+            big[pad:pad + nbytes].zero_()
+            aws.buf = big[pad:pad + nbytes]
+        losses = torch.zeros(k, 6, device=DEV)
+        for c in range(k):
+            ops.mstep_alt(P, M, V, dps[c], sl(e, c), sl(w, c), sizes[c], sizes[c - 1] if c else sizes[c], coefs, flags,
+                          losses[c - 1] if c else None, FIRST + c, LR, aws, c & 1, pure=pure)
+        ops.mstep_alt(P, M, V, dps[k], None, None, sizes[k - 1], sizes[k - 1], coefs, flags, losses[k - 1], FIRST + k - 1, LR,
+                      aws, k & 1, pure=pure)
+        torch.cuda.synchronize()
+        assert aws.error() == 0
+        if guard:
+            assert bool((big[:pad] == 0xA5).all()) and bool((big[pad + nbytes:] == 0xA5).all())
+        got.append([t.cpu().numpy() for t in P + M + V] + [losses.cpu().numpy()])
+    return want, got
+
+
+def check(want, got, tol=2e-5):
+    for i, (a, b) in enumerate(zip(want[:-1], got[:-1])):
+        assert np.isfinite(b).all()
+        scale = max(float(np.abs(a).max()), 1e-30)
+        assert float(np.abs(a - b).max()) <= tol * scale, (i, float(np.abs(a - b).max()), scale)
+    np.testing.assert_allclose(got[-1], want[-1], rtol=tol, atol=1e-7)
+
+
+@pytest.mark.parametrize('U,I,E,D,sizes', [
+    (300, 40, 4, 64, [700, 700, 700, 700, 333]),        # full rows (the FULL instance); a ragged last minibatch
+    (300, 40, 3, 40, [700, 650, 700, 100, 700, 9]),     # the reference drivers' factor_num 40: vector loads, guarded
+    (120, 30, 2, 30, [500, 500, 500, 77]),              # Coat's factor_num 30: element-wise instances
+    (50, 7, 1, 7, [100, 100, 100]),
+    (40, 200, 4, 64, [900, 900, 900, 900]),             # more items than users
+    (3, 2, 4, 64, [40, 1, 40, 17]),                     # a handful of rows, every one hot
+    (1, 1, 1, 4, [1, 1, 1]),
+])
+@pytest.mark.parametrize('implicit', [True, False])
+def test_alternating_steps_equal_two_launch_steps(U, I, E, D, sizes, implicit):
+    want, got = run_both(11 + U + D, U, I, E, D, sizes, implicit=implicit, reps=2)
+    check(want, got[0])
+    for a, b in zip(got[0], got[1]):                     # every sum in a fixed order: run-to-run bitwise
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize('fl', [(False, False, True, False), (True, False, False, False), (False, True, False, True),
+                                (True, True, True, True)])
+def test_alternating_steps_flag_sets(fl):
+    # (re-weighting of the recommendation / class losses, reg_only_embed, reg_env_embed: train.py:120-142, models.py:369-391)
+    want, got = run_both(5, 500, 60, 4, 64, [2000, 2000, 2000, 2000, 1234], fl=fl)
+    check(want, got[0])
+
+
+@pytest.mark.parametrize('D', [64, 20])
+def test_alternating_steps_pure_mf(D):
+    # the PureMF baselines (baseline_models.py:12-69 under Basic*TrainManager) on the same kernels, INVPREF_PURE_MF
+    want, got = run_both(9, 400, 90, 1, D, [1500, 1500, 1500, 600], pure=True)
+    check(want, got[0])
+
+
+def test_alternating_steps_yahoo_shape_and_workspace_bounds():
+    d = synth.YAHOO_SHAPE
+    want, got = run_both(17373331, d['user_num'], d['item_num'], 4, 64, [8192] * 6 + [4394], reps=2, guard=True)
+    check(want, got[0])
+    for a, b in zip(got[0], got[1]):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize('seed', range(int(os.environ.get('INVPREF_FUZZ_ALT', '32'))))
+def test_alternating_steps_random_shapes_and_plans(seed):
+    """Randomised sweep, tiny plans weighted up: shapes (rows aligned and not), duplicate-heavy and sparse minibatches of
+    1 .. 3 000 interactions, slice lengths, class counts, flag sets, InvPref and PureMF."""
+    rs = np.random.RandomState(4000 + seed)
+    U, I = int(rs.choice([1, 3, 17, 60, 300, 2000])), int(rs.choice([1, 2, 9, 40, 150]))
+    E, D = int(rs.choice([1, 2, 3, 4])), int(rs.choice([1, 4, 8, 20, 30, 40, 63, 64]))
+    k = int(rs.randint(2, 6))
+    sizes = [int(rs.choice([1, 2, 15, 16, 17, 100, 700, 3000])) for _ in range(k)]
+    pure = bool(rs.randint(4) == 0)
+    if pure:
+        E = 1
+    fl = tuple(bool(rs.randint(2)) for _ in range(4))
+    kw = dict(per_slice=int(rs.choice([1, 2, 3, 8])), n_classes=int(rs.choice([1, 3, 8])),
+              rows_per_stream_task=int(rs.choice([1, 16, 32, 64, 200])))
+    want, got = run_both(100 + seed, U, I, E, D, sizes, implicit=bool(rs.randint(2)), pure=pure, fl=fl, alt_kw=kw,
+                         zipf=bool(rs.randint(2)), guard=bool(seed % 4 == 0))
+    check(want, got[0], tol=5e-5)
+
+
+def test_plan_parameters_change_nothing_but_the_order_of_sums():
+    base = None
+    for kw in (dict(), dict(per_slice=1), dict(per_slice=5, n_classes=1), dict(rows_per_stream_task=7, n_classes=3)):
+        want, got = run_both(3, 700, 120, 4, 64, [3000, 3000, 3000, 2000], alt_kw=kw)
+        check(want, got[0])
+        if base is not None:
+            check(base, got[0])
+        base = got[0]
+
+
+def test_argument_validation():
+    P, M, V = _state(1, 30, 10, 4, 64, False)
+    d = synth.interactions(1, 30, 10, 100, implicit=True)
+    cur = (d[:, 0], d[:, 1], d[:, 2].astype(np.float32))
+    dp = planlib.upload_alt(planlib.build_alt_plan(cur, None, 0, 30, 10), DEV)
+    aws = ops.AltWorkspace(P, 100, dp.n_tasks + 1)
+    e = torch.zeros(100, dtype=torch.int64, device=DEV)
+    w = torch.ones(100, device=DEV)
+    flags = ops.flags_of(True, True, True, False, True)
+    with pytest.raises(_capi.InvPrefError):   # parity is 0 or 1
+        ops.mstep_alt(P, M, V, dp, e, w, 100, 100, COEFS, flags, None, 1, LR, aws, 2)
+    with pytest.raises(_capi.InvPrefError):   # a step number is needed without a schedule
+        ops.mstep_alt(P, M, V, dp, e, w, 100, 100, COEFS, flags, None, 0, LR, aws, 0)
+    with pytest.raises(_capi.InvPrefError):   # re-weighting without weights
+        ops.mstep_alt(P, M, V, dp, e, None, 100, 100, COEFS, flags, None, 1, LR, aws, 0)
+    small = ops.AltWorkspace(P, 50, dp.n_tasks + 1)
+    with pytest.raises(_capi.InvPrefError):   # a minibatch larger than the workspace was sized for
+        ops.mstep_alt(P, M, V, dp, e, w, 100, 100, COEFS, flags, None, 1, LR, small, 0)
+    wide = [torch.zeros(30, 128, device=DEV), torch.zeros(10, 128, device=DEV), torch.zeros(30, 128, device=DEV),
+            torch.zeros(10, 128, device=DEV), torch.zeros(4, 128, device=DEV), torch.zeros(4, 128, device=DEV),
+            torch.zeros(4, device=DEV)]
+    assert not ops.alt_supported(wide) and ops.alt_supported(P)
+    cpu = [p.cpu() for p in P]
+    with pytest.raises(Exception):            # CPU tensors: no fallback
+        ops.mstep_alt(cpu, M, V, dp, e, w, 100, 100, COEFS, flags, None, 1, LR, aws, 0)

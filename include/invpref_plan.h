@@ -51,6 +51,28 @@ int invpref_plan_build_many(const int64_t *users, const int64_t *items, const fl
                             int32_t count, int64_t user_num, int64_t item_num, const InvPrefPlanParams *params,
                             InvPrefHostPlan **out, int32_t n_threads);
 
+/* ---- alt plans (include/invpref_hip.h: InvPrefAltPlan; plan.py: build_alt_plan is the numpy reference implementation the
+ * arrays equal byte for byte, tests/test_plan_native.py).  One launch of the alternating form: the CURRENT minibatch
+ * (cur_* arrays, n interactions; n = 0: a flush launch) seen from `side` (0: users own the jobs, 1: items) and the PREVIOUS
+ * minibatch (prev_*, n_prev interactions; n_prev = 0 with prev_users == NULL: first launch of a run).
+ * which: 0 desc [rounds][16][8] | 1 pend [rounds][16][4] | 2 list [n][4] | 3 push_slot [n] | 4 stream [n_stream][4] |
+ *        5 cls [8][4]. */
+typedef struct InvPrefAltPlanParams {
+    int32_t side, per_slice, n_classes;
+    int32_t pend_job_min;             /* rows without a current interaction and at least this many pending rows get a job */
+    int32_t pend_per_slice;
+} InvPrefAltPlanParams;
+InvPrefHostPlan *invpref_alt_plan_build(const int64_t *cur_users, const int64_t *cur_items, const float *cur_scores, int64_t n,
+                                        const int64_t *prev_users, const int64_t *prev_items, int64_t n_prev,
+                                        int64_t user_num, int64_t item_num, const InvPrefAltPlanParams *params);
+/* `count` alt plans over the same interaction arrays: plan k evaluates interactions [cur_lo[k], cur_lo[k] + cur_n[k]) (cur_n
+ * 0: a flush) after a launch that evaluated [prev_lo[k], prev_lo[k] + prev_n[k]) (prev_n[k] < 0: none), from side[k]; the
+ * other parameters are shared.  out[k] receives the handle.  n_threads <= 0: one per hardware thread (at most 32). */
+int invpref_alt_plan_build_many(const int64_t *users, const int64_t *items, const float *scores, const int64_t *cur_lo,
+                                const int64_t *cur_n, const int64_t *prev_lo, const int64_t *prev_n, const int32_t *side,
+                                int32_t count, int64_t user_num, int64_t item_num, const InvPrefAltPlanParams *params,
+                                InvPrefHostPlan **out, int32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

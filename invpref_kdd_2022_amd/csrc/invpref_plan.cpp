@@ -16,7 +16,7 @@
 #include <vector>
 
 struct InvPrefHostPlan {
-    std::vector<int32_t> arr[9];
+    std::vector<int32_t> arr[9];   // (alt plans use 0 .. 5)
     // the big arrays (lists, descriptors, push slots) live in UNINITIALISED storage: every element is written exactly once by
     // the builder, and zero-filling 0.5 GB first costs as much as the sort itself
     std::unique_ptr<int32_t[]> big[9];
@@ -351,9 +351,142 @@ InvPrefHostPlan *build(const int64_t *users, const int64_t *items, const float *
     return hp;
 }
 
+// ---- alt plans (plan.py: build_alt_plan, the same arrays byte for byte)
+InvPrefHostPlan *build_alt(const int64_t *cu, const int64_t *ci, const float *cy, int64_t n, const int64_t *pu, const int64_t *pi,
+                           int64_t n_prev, int64_t U, int64_t I, const InvPrefAltPlanParams &p) {
+    const bool has_cur = n > 0, has_prev = pu != nullptr && n_prev >= 0;
+    if (U <= 0 || I <= 0 || n < 0 || (p.side != 0 && p.side != 1) || p.per_slice < 1 || p.n_classes < 1 || p.n_classes > 8 ||
+        p.pend_job_min < 1 || p.pend_per_slice < 1 || (has_cur && (!cu || !ci || !cy)) || (has_prev && (!pu || !pi)))
+        return nullptr;
+    constexpr int ng = 16;
+    const int ncls = p.n_classes;
+    const int64_t own_num = p.side == 0 ? U : I, oth_num = p.side == 0 ? I : U;
+    const int64_t *own = p.side == 0 ? cu : ci, *oth = p.side == 0 ? ci : cu, *ownp = p.side == 0 ? pu : pi;
+    InvPrefHostPlan *hp = new InvPrefHostPlan();
+    std::vector<int32_t> &lst = hp->arr[2], &ps = hp->arr[3];
+    Side S, T, Sp;
+    lst.assign((size_t)n * 4, 0);
+    ps.assign((size_t)n, 0);
+    bool ok = sort_side(own, n, own_num, S, 1, [&](int64_t i, int64_t j) {
+        int32_t *d = lst.data() + (size_t)j * 4;
+        d[0] = (int32_t)oth[i];
+        d[1] = (int32_t)i;
+        std::memcpy(d + 2, cy + i, 4);
+    });
+    ok = ok && sort_side(oth, n, oth_num, T, 1, [&](int64_t i, int64_t j) { ps[(size_t)i] = (int32_t)j; });
+    ok = ok && sort_side(ownp, has_prev ? n_prev : 0, own_num, Sp, 1, [&](int64_t, int64_t) {});
+    if (!ok) {
+        delete hp;
+        return nullptr;
+    }
+    std::vector<int32_t> &desc = hp->arr[0], &pend = hp->arr[1], &stream = hp->arr[4];
+    int32_t cls[8][4];
+    std::memset(cls, 0, sizeof(cls));
+    int32_t rb = 0;
+    std::vector<std::vector<int32_t>> srows((size_t)ncls);
+    for (int c = 0; c < ncls; c++) {
+        std::vector<int32_t> arows, jrows;
+        for (int64_t r = 0; r < own_num; r++) {
+            if ((r >> kClassShift) % ncls != c) continue;
+            if (S.cnt[(size_t)r] > 0) arows.push_back((int32_t)r);
+            else if (Sp.cnt[(size_t)r] >= p.pend_job_min) jrows.push_back((int32_t)r);
+            else srows[(size_t)c].push_back((int32_t)r);
+        }
+        std::vector<int32_t> d, it;
+        if (has_cur) side_rounds(S, n, lst.data(), 4, 3, ng, p.per_slice, 1, 2, arows, d, it);
+        const size_t n_a = d.size() / ((size_t)ng * 8);
+        if (!jrows.empty()) side_rounds(Sp, 0, nullptr, 0, 0, ng, p.pend_per_slice, 1, 0, jrows, d, it);
+        const size_t nr = d.size() / ((size_t)ng * 8);
+        const size_t pbase = pend.size();
+        pend.resize(pbase + nr * ng * 4, 0);
+        for (size_t r = 0; r < nr; r++) {
+            bool any = false;
+            for (int sl = 0; sl < ng; sl++) {
+                int32_t *dd = d.data() + (r * ng + sl) * 8, *pp = pend.data() + pbase + (r * ng + sl) * 4;
+                const int64_t row = dd[0];
+                if (row < 0) continue;
+                const int g = (dd[1] >> 1) & 31, k = sl % (g > 0 ? g : 1);
+                const int64_t cp = Sp.cnt[(size_t)row], p0 = Sp.ptr[(size_t)row];
+                const int64_t ln = cdiv(cp, g > 0 ? g : 1);
+                pp[0] = (int32_t)(p0 + std::min<int64_t>(k * ln, cp));
+                pp[1] = (int32_t)(p0 + std::min<int64_t>((k + 1) * ln, cp));
+                pp[2] = (int32_t)cp;
+                any = any || cp > 0;
+                if (r >= n_a) {   // a pending-only job: no interactions (mode 0, count 0), leader / slices bits kept
+                    dd[1] &= 0x3f;
+                    for (int q = 2; q < 8; q++) dd[q] = 0;
+                }
+            }
+            if (any)
+                for (int sl = 0; sl < ng; sl++) d[(r * ng + sl) * 8 + 1] |= (int32_t)0x80000000u;
+        }
+        desc.insert(desc.end(), d.begin(), d.end());
+        cls[c][0] = rb;
+        cls[c][1] = (int32_t)nr;
+        rb += (int32_t)nr;
+    }
+    int32_t sb = 0;
+    for (int c = 0; c < ncls; c++) {
+        cls[c][2] = sb;
+        cls[c][3] = (int32_t)srows[(size_t)c].size();
+        sb += cls[c][3];
+        for (int32_t r : srows[(size_t)c]) {
+            const int32_t e[4] = {r, (int32_t)Sp.ptr[(size_t)r], (int32_t)Sp.ptr[(size_t)r + 1], (int32_t)Sp.cnt[(size_t)r]};
+            stream.insert(stream.end(), e, e + 4);
+        }
+    }
+    hp->arr[5].assign(&cls[0][0], &cls[0][0] + 32);
+    return hp;
+}
+
 }  // namespace
 
 extern "C" {
+
+static InvPrefHostPlan *build_alt_guarded(const int64_t *cu, const int64_t *ci, const float *cy, int64_t n, const int64_t *pu,
+                                          const int64_t *pi, int64_t n_prev, int64_t U, int64_t I, const InvPrefAltPlanParams *p) {
+    if (!p) return nullptr;
+    try {
+        return build_alt(cu, ci, cy, n, pu, pi, n_prev, U, I, *p);
+    } catch (...) {
+        return nullptr;
+    }
+}
+
+InvPrefHostPlan *invpref_alt_plan_build(const int64_t *cur_users, const int64_t *cur_items, const float *cur_scores, int64_t n,
+                                        const int64_t *prev_users, const int64_t *prev_items, int64_t n_prev,
+                                        int64_t user_num, int64_t item_num, const InvPrefAltPlanParams *params) {
+    return build_alt_guarded(cur_users, cur_items, cur_scores, n, prev_users, prev_items, n_prev, user_num, item_num, params);
+}
+
+int invpref_alt_plan_build_many(const int64_t *users, const int64_t *items, const float *scores, const int64_t *cur_lo,
+                                const int64_t *cur_n, const int64_t *prev_lo, const int64_t *prev_n, const int32_t *side,
+                                int32_t count, int64_t user_num, int64_t item_num, const InvPrefAltPlanParams *params,
+                                InvPrefHostPlan **out, int32_t n_threads) {
+    if (!users || !items || !scores || !cur_lo || !cur_n || !prev_lo || !prev_n || !side || !params || !out || count < 0) return -1;
+    int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(kMaxThreads, std::max(1u, std::thread::hardware_concurrency()));
+    nt = std::max(1, std::min(nt, (int)count));
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int k = next.fetch_add(1);
+            if (k >= count) return;
+            InvPrefAltPlanParams p = *params;
+            p.side = side[k];
+            const bool hp = prev_n[k] >= 0;
+            out[k] = build_alt_guarded(users + cur_lo[k], items + cur_lo[k], scores + cur_lo[k], cur_n[k],
+                                       hp ? users + prev_lo[k] : nullptr, hp ? items + prev_lo[k] : nullptr, hp ? prev_n[k] : 0,
+                                       user_num, item_num, &p);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    for (int k = 0; k < count; k++)
+        if (!out[k]) return -2;
+    return 0;
+}
 
 static InvPrefHostPlan *build_guarded(const int64_t *users, const int64_t *items, const float *scores, int64_t n,
                                       int64_t user_num, int64_t item_num, const InvPrefPlanParams *params, int threads) {

@@ -181,6 +181,12 @@ class PlanParamsStruct(C.Structure):
                 ('fill_cap', C.c_int32), ('snake_user', C.c_int32), ('stream_split', C.c_double)]
 
 
+class AltPlanParamsStruct(C.Structure):
+    """struct InvPrefAltPlanParams (include/invpref_plan.h)"""
+    _fields_ = [('side', C.c_int32), ('per_slice', C.c_int32), ('n_classes', C.c_int32), ('pend_job_min', C.c_int32),
+                ('pend_per_slice', C.c_int32)]
+
+
 _NATIVE = None
 _NATIVE_ARRAYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list', 'stream_rows', 'push_slot', 'cls',
                   'defer_tail')
@@ -202,6 +208,12 @@ def _native_lib():
             L.invpref_plan_row_counts.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
             L.invpref_plan_build_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                                   C.c_int64, C.POINTER(PlanParamsStruct), C.POINTER(C.c_void_p), C.c_int32]
+            L.invpref_alt_plan_build.restype = C.c_void_p
+            L.invpref_alt_plan_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                                 C.c_int64, C.c_int64, C.POINTER(AltPlanParamsStruct)]
+            L.invpref_alt_plan_build_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64,
+                                                      C.POINTER(AltPlanParamsStruct), C.POINTER(C.c_void_p), C.c_int32]
             _NATIVE = L
         except (OSError, AttributeError):
             _NATIVE = False
@@ -657,7 +669,7 @@ def alt_supported(factor_num: int, env_num: int) -> bool:
 
 def build_alt_plan(cur, prev, side: int, user_num: int, item_num: int, factor_num: int = 64, per_slice: int | None = None,
                    rounds_per_task: int = 1, n_classes: int | None = None, rows_per_stream_task: int | None = None,
-                   n_partials_prev: int = 0) -> dict:
+                   n_partials_prev: int = 0, native: bool | None = None) -> dict:
     """cur: (users, items, scores) of the minibatch this launch evaluates, or None (a flush launch); prev: (users, items)
     of the minibatch the previous launch evaluated (from the OTHER side), or None (first launch of a run); side: 0 = the
     user tables evaluate / are updated, 1 = the item tables.  n_partials_prev: job tasks of the previous launch (its
@@ -673,6 +685,22 @@ def build_alt_plan(cur, prev, side: int, user_num: int, item_num: int, factor_nu
     if rows_per_stream_task is None:
         rows_per_stream_task = int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', str(stream_rows_default(factor_num))))
     has_cur, has_prev = cur is not None, prev is not None
+    if native is None:
+        native = os.environ.get('INVPREF_PLAN_NATIVE', '1') != '0'
+    if native and _native_lib() is not None and rounds_per_task == 1:
+        L = _native_lib()
+        z64 = np.zeros(0, np.int64)
+        cu, ci = (np.ascontiguousarray(cur[0], np.int64), np.ascontiguousarray(cur[1], np.int64)) if has_cur else (z64, z64)
+        cy = np.ascontiguousarray(cur[2], np.float32) if has_cur else np.zeros(0, np.float32)
+        pu, pi = (np.ascontiguousarray(prev[0], np.int64), np.ascontiguousarray(prev[1], np.int64)) if has_prev else (z64, z64)
+        ps = AltPlanParamsStruct(side, per_slice, n_classes, ALT_PEND_JOB_MIN, ALT_PEND_PER_SLICE)
+        h = L.invpref_alt_plan_build(cu.ctypes.data, ci.ctypes.data, cy.ctypes.data, len(cu),
+                                     pu.ctypes.data if has_prev else None, pi.ctypes.data if has_prev else None, len(pu),
+                                     user_num, item_num, C.byref(ps))
+        if not h:
+            raise ValueError('native alt plan builder: invalid arguments (row ids out of range?)')
+        return _alt_from_handle(L, h, side, has_prev, has_cur, len(cu), len(pu), per_slice, n_classes, rows_per_stream_task,
+                                n_partials_prev)
     if has_cur:
         u, i, y = (np.asarray(cur[0], np.int64), np.asarray(cur[1], np.int64), np.asarray(cur[2], np.float32))
         own, oth = (u, i) if side == 0 else (i, u)
@@ -759,6 +787,68 @@ def build_alt_plan(cur, prev, side: int, user_num: int, item_num: int, factor_nu
                 stream=np.concatenate(s_parts).reshape(-1), n_stream=sb, rows_per_stream_task=rows_per_stream_task,
                 n_classes=n_classes, cls=cls, n_partials_prev=int(n_partials_prev),
                 n_tasks=(len(desc) // rounds_per_task if has_cur else 0), per_slice=per_slice)
+
+
+def _alt_from_handle(L, h, side, has_prev, has_cur, n, n_prev, per_slice, n_classes, rows_per_stream_task, n_partials_prev) -> dict:
+    out = []
+    try:
+        for which in range(6):
+            ptr = C.POINTER(C.c_int32)()
+            ln = L.invpref_plan_array(h, which, C.byref(ptr))
+            out.append(np.ctypeslib.as_array(ptr, shape=(ln,)).copy() if ln > 0 else np.zeros(0, np.int32))
+    finally:
+        L.invpref_plan_free(h)
+    desc, pend, lst, push_slot, stream, cls = out
+    desc = desc.reshape(-1, 16, 8)
+    return dict(side=side, has_prev=int(has_prev), has_cur=int(has_cur), n=int(n), n_prev=int(n_prev), lanes_per_group=16,
+                rounds_per_task=1, desc=desc, pend=pend.reshape(-1, 16, 4), list=lst, push_slot=push_slot, stream=stream,
+                n_stream=len(stream) // 4, rows_per_stream_task=rows_per_stream_task, n_classes=n_classes,
+                cls=cls.reshape(8, 4).copy(), n_partials_prev=int(n_partials_prev), n_tasks=(len(desc) if has_cur else 0),
+                per_slice=per_slice)
+
+
+def build_alt_plans(users: np.ndarray, items: np.ndarray, scores: np.ndarray, specs, user_num: int, item_num: int,
+                    factor_num: int = 64, per_slice_u: int | None = None, per_slice_i: int | None = None,
+                    n_classes: int | None = None, rows_per_stream_task: int | None = None, threads: int = 0) -> list:
+    """Many alt plans over the same interaction arrays in one native call (a thread pool): specs = [(cur, prev, side)] with
+    cur / prev = (lo, n) ranges of the arrays or None.  Falls back to build_alt_plan per spec without the library."""
+    users, items = np.ascontiguousarray(users, np.int64), np.ascontiguousarray(items, np.int64)
+    scores = np.ascontiguousarray(scores, np.float32)
+    if per_slice_u is None:
+        per_slice_u = int(os.environ.get('INVPREF_ALT_PER_SLICE_U', '2'))
+    if per_slice_i is None:
+        per_slice_i = int(os.environ.get('INVPREF_ALT_PER_SLICE_I', '2'))
+    if n_classes is None:
+        n_classes = int(os.environ.get('INVPREF_PLAN_CLASSES', str(N_CLASSES)))
+    n_classes = max(1, min(8, n_classes))
+    if rows_per_stream_task is None:
+        rows_per_stream_task = int(os.environ.get('INVPREF_PLAN_STREAM_ROWS', str(stream_rows_default(factor_num))))
+
+    def rng(r):
+        return None if r is None else (users[r[0]:r[0] + r[1]], items[r[0]:r[0] + r[1]], scores[r[0]:r[0] + r[1]])
+    L = _native_lib()
+    if L is None or os.environ.get('INVPREF_PLAN_NATIVE', '1') == '0' or per_slice_u != per_slice_i:
+        return [build_alt_plan(rng(c), None if pv is None else rng(pv)[:2], side, user_num, item_num, factor_num=factor_num,
+                               per_slice=per_slice_i if side else per_slice_u, n_classes=n_classes,
+                               rows_per_stream_task=rows_per_stream_task) for c, pv, side in specs]
+    k = len(specs)
+    cur_lo = np.array([0 if c is None else c[0] for c, _, _ in specs], np.int64)
+    cur_n = np.array([0 if c is None else c[1] for c, _, _ in specs], np.int64)
+    prev_lo = np.array([0 if pv is None else pv[0] for _, pv, _ in specs], np.int64)
+    prev_n = np.array([-1 if pv is None else pv[1] for _, pv, _ in specs], np.int64)
+    sides = np.array([sd for _, _, sd in specs], np.int32)
+    ps = AltPlanParamsStruct(0, per_slice_u, n_classes, ALT_PEND_JOB_MIN, ALT_PEND_PER_SLICE)
+    handles = (C.c_void_p * k)()
+    rc = L.invpref_alt_plan_build_many(users.ctypes.data, items.ctypes.data, scores.ctypes.data, cur_lo.ctypes.data,
+                                       cur_n.ctypes.data, prev_lo.ctypes.data, prev_n.ctypes.data, sides.ctypes.data, k,
+                                       user_num, item_num, C.byref(ps), handles, int(threads))
+    if rc != 0:
+        for h in handles:
+            if h:
+                L.invpref_plan_free(h)
+        raise ValueError('native alt plan builder: invalid arguments (row ids out of range?)')
+    return [_alt_from_handle(L, handles[j], specs[j][2], specs[j][1] is not None, specs[j][0] is not None, int(cur_n[j]),
+                             max(0, int(prev_n[j])), per_slice_u, n_classes, rows_per_stream_task, 0) for j in range(k)]
 
 
 def alt_workgroups(plan: dict) -> int:

@@ -488,43 +488,41 @@ class _InvPrefTrainManager:
         self._alt = dict(plans={}, host_plans={}, n_cap=n_cap, partials_cap=n_cap // 4 + n_cap // 8 + 128, ws=None,
                          build_s=0.0)
 
-    def _alt_batch(self, k: int):
-        lo, n = self._raw_batches[k][0], self._raw_batches[k][1]
-        u, v, y = self._alt_host
-        return u[lo:lo + n], v[lo:lo + n], y[lo:lo + n]
+    def _alt_keys(self, n: int):
+        """(k_prev, k, side) of every launch of a run of n epochs, the flush (k = None) last"""
+        bn, total = self.batch_num, n * self.batch_num
+        keys = [(None, 0, 0)] + [((i - 1) % bn, i % bn, i & 1) for i in range(1, min(total, 2 * bn + 1))]
+        return keys + [((total - 1) % bn, None, total & 1)]     # (the plan sequence is periodic after the first launch)
+
+    def _alt_prepare(self, n: int):
+        """builds (natively, one call: csrc/invpref_plan.cpp) and uploads every plan a run of n epochs needs, and the run's
+        workspace -- BEFORE a graph capture starts: host-to-device copies and allocations are not capturable"""
+        A = self._alt
+        need = [key for key in dict.fromkeys(self._alt_keys(n)) if key not in A['plans']]
+        if need:
+            t0 = time.perf_counter()
+            u, v, y = self._alt_host
+            rng = lambda k: None if k is None else (self._raw_batches[k][0], self._raw_batches[k][1])   # noqa: E731
+            hps = planlib.build_alt_plans(u, v, y, [(rng(k), rng(kp), side) for kp, k, side in need], self.model.user_num,
+                                          self.model.item_num, factor_num=self.model.factor_num)
+            for key, hp in zip(need, hps):
+                if hp['n_tasks'] > A['partials_cap']:
+                    raise _capi.InvPrefError('alt plan: more job tasks than the workspace was sized for')
+                A['plans'][key] = planlib.upload_alt(hp, self.device)
+            A['build_s'] += time.perf_counter() - t0
+        if A['ws'] is None:
+            A['ws'] = ops.AltWorkspace(self.state.p_views, A['n_cap'], A['partials_cap'], pure=self._pure)
 
     def _alt_plan(self, k_prev, k, side: int, partials_prev: int):
         """device plan of the launch that evaluates minibatch k (None: a flush) from `side` after a launch that evaluated
         minibatch k_prev (None: first launch of a run) and left `partials_prev` partial slabs"""
-        A = self._alt
-        key = (k_prev, k, side)
-        dp = A['plans'].get(key)
-        if dp is None:
-            t0 = time.perf_counter()
-            hp = planlib.build_alt_plan(None if k is None else self._alt_batch(k),
-                                        None if k_prev is None else self._alt_batch(k_prev)[:2], side, self.model.user_num,
-                                        self.model.item_num, factor_num=self.model.factor_num)
-            if hp['n_tasks'] > A['partials_cap']:
-                raise _capi.InvPrefError('alt plan: more job tasks than the workspace was sized for')
-            dp = A['plans'][key] = planlib.upload_alt(hp, self.device)
-            A['build_s'] += time.perf_counter() - t0
-        if A['ws'] is None:
-            A['ws'] = ops.AltWorkspace(self.state.p_views, A['n_cap'], A['partials_cap'], pure=self._pure)
-        return planlib.alt_with_partials(dp, partials_prev)
-
-    def _alt_prepare(self, n: int):
-        """builds (and uploads) every plan a run of n epochs needs and its workspace -- BEFORE a graph capture starts: host
-        to device copies and allocations are not capturable"""
-        bn, total = self.batch_num, n * self.batch_num
-        k_prev, tasks_prev = None, 0
-        for i in range(min(total, 2 * bn + 1)):      # (the plan sequence is periodic after the first launch)
-            dp = self._alt_plan(k_prev, i % bn, i & 1, tasks_prev)
-            k_prev, tasks_prev = i % bn, dp.n_tasks
-        self._alt_plan((total - 1) % bn, None, total & 1, 0)
+        return planlib.alt_with_partials(self._alt['plans'][(k_prev, k, side)], partials_prev)
 
     def _issue_epochs_alt(self, sched: bool, n: int):
         st, A, bn = self.state, self._alt, self.batch_num
         total = n * bn
+        if not torch.cuda.is_current_stream_capturing():
+            self._alt_prepare(n)
         k_prev, tasks_prev, alpha = None, 0, self.alpha
         for i in range(total):
             j, k = divmod(i, bn)

@@ -45,6 +45,13 @@ def test_struct_layouts_match_header():
     fields = re.sub(r'\[\d+\]', '', fields)
     names = re.findall(r'[\*\s,](\w+)\s*(?=[,;])', fields)
     assert names == [f[0] for f in planlib.RowPlanStruct._fields_]
+    # InvPrefAltPlan: 8 int32, 4 ptr, 2 int32, 1 ptr, int32, int32[8][4], int32 (+ padding to 8)
+    assert C.sizeof(planlib.AltPlanStruct) == 8 * 4 + 4 * 8 + 8 + 8 + 4 + 32 * 4 + 4
+    fields = re.search(r'typedef struct InvPrefAltPlan \{(.*?)\} InvPrefAltPlan;', HEADER, re.S).group(1)
+    fields = re.sub(r'/\*.*?\*/', '', fields, flags=re.S)
+    fields = re.sub(r'\[\d+\]', '', fields)
+    names = re.findall(r'[\*\s,](\w+)\s*(?=[,;])', fields)
+    assert names == [f[0] for f in planlib.AltPlanStruct._fields_]
 
 
 def test_argument_validation_without_a_device(lib):
@@ -58,6 +65,20 @@ def test_argument_validation_without_a_device(lib):
     assert lib.invpref_adam_schedule_fill(buf, 1, 2, 0.01, 0.9, 0.999, 1e-8) == 0
     assert abs(buf[0] - 0.01 / (1 - 0.9)) < 1e-6 and abs(buf[8] - 0.01 / (1 - 0.81)) < 1e-6
     assert buf[6] != buf[6] and buf[14] != buf[14] and buf[7] == 0.0
+    # the alternating form: bad arguments come back as codes before anything touches a device
+    L = _capi.lib()
+    t = _capi.Tables(10, 10, 4, 64, 1, 1, 1, 1, 1, 1, 1)
+    cf = _capi.Coefs(1, 1, 1, 0, 0, 0)
+    assert L.invpref_mstep_alt_hip(C.byref(t), C.byref(t), C.byref(t), None, None, None, 8, 8, C.byref(cf), 1, None, 1, 0.01,
+                                   0.9, 0.999, 1e-8, None, None, 0, 8, 8, 0, None) == -1
+    ap = planlib.AltPlanStruct(side=0, has_prev=0, has_cur=1, n=4, n_prev=0, lanes_per_group=16, n_rounds=0, rounds_per_task=2)
+    assert L.invpref_mstep_alt_hip(C.byref(t), C.byref(t), C.byref(t), C.byref(ap), 1, None, 8, 8, C.byref(cf), 1, None, 1, 0.01,
+                                   0.9, 0.999, 1e-8, None, 1, 1 << 20, 8, 8, 0, None) == -1     # rounds_per_task must be 1
+    wide = _capi.Tables(10, 10, 8, 128, 1, 1, 1, 1, 1, 1, 1)
+    assert L.invpref_alt_supported(C.byref(wide)) == 0 and L.invpref_alt_supported(C.byref(t)) == 1
+    assert L.invpref_mstep_alt_hip(C.byref(wide), C.byref(wide), C.byref(wide), C.byref(ap), 1, None, 8, 8, C.byref(cf), 1, None,
+                                   1, 0.01, 0.9, 0.999, 1e-8, None, 1, 1 << 20, 8, 8, 0, None) == -2   # EUNSUPPORTED
+    assert L.invpref_alt_workspace_bytes(C.byref(t), 8, 8) > L.invpref_alt_error_offset(C.byref(t), 8, 8) > 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -127,3 +127,42 @@ def test_big_minibatch_on_threads_is_byte_identical():
     with pytest.raises(ValueError):
         users[5] = U
         planlib.build_row_plan(users, items, scores, U, I, native=True)
+
+
+# ---- alt plans (one launch per optimiser step): the native builder against plan.build_alt_plan's numpy implementation
+def _alt_same(a, b):
+    for k in ('desc', 'pend', 'list', 'push_slot', 'stream', 'cls'):
+        x, y = np.asarray(a[k]).reshape(-1), np.asarray(b[k]).reshape(-1)
+        assert x.dtype == np.int32 and x.shape == y.shape and (x == y).all(), k
+    for k in ('n', 'n_prev', 'has_cur', 'has_prev', 'n_stream', 'n_tasks', 'side', 'n_classes', 'rows_per_stream_task'):
+        assert a[k] == b[k], k
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_native_alt_plans_equal_numpy_alt_plans(seed):
+    rs = np.random.RandomState(seed)
+    U, I = int(rs.choice([1, 40, 300, 5000])), int(rs.choice([1, 25, 900]))
+    n, n_prev = int(rs.choice([1, 17, 900, 8192])), int(rs.choice([1, 33, 700, 8192]))
+    cur = synth.interactions(seed, U, I, n, implicit=True, zipf=bool(seed & 1))
+    prev = synth.interactions(50 + seed, U, I, n_prev, implicit=True, zipf=bool(seed & 2))
+    c3 = (cur[:, 0], cur[:, 1], cur[:, 2].astype(np.float32))
+    kw = dict(per_slice=int(rs.choice([1, 2, 3, 8])), n_classes=int(rs.choice([1, 3, 8])),
+              rows_per_stream_task=int(rs.choice([1, 32, 100])))
+    for side in (0, 1):
+        for c, p in ((c3, None), (c3, (prev[:, 0], prev[:, 1])), (None, (prev[:, 0], prev[:, 1]))):
+            _alt_same(planlib.build_alt_plan(c, p, side, U, I, native=True, **kw),
+                      planlib.build_alt_plan(c, p, side, U, I, native=False, **kw))
+
+
+def test_native_alt_plans_many_at_once_and_bad_ids():
+    d = synth.yahoo_like()[:40000]
+    y = d[:, 2].astype(np.float32)
+    B = 8192
+    specs = [((0, B), None, 0), ((B, B), (0, B), 1), ((2 * B, B), (B, B), 0), ((4 * B, 40000 - 4 * B), (3 * B, B), 1),
+             (None, (4 * B, 40000 - 4 * B), 0)]
+    pls = planlib.build_alt_plans(d[:, 0], d[:, 1], y, specs, 15400, 1000)
+    for (c, p, side), got in zip(specs, pls):
+        sl = lambda r: None if r is None else (d[r[0]:r[0] + r[1], 0], d[r[0]:r[0] + r[1], 1], y[r[0]:r[0] + r[1]])  # noqa: E731
+        _alt_same(got, planlib.build_alt_plan(sl(c), None if p is None else sl(p)[:2], side, 15400, 1000, native=False))
+    with pytest.raises(ValueError):
+        planlib.build_alt_plan((np.array([5]), np.array([0]), np.ones(1, np.float32)), None, 0, 5, 3, native=True)   # user 5 of 5

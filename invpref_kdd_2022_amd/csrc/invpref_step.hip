@@ -320,12 +320,17 @@ struct Eval {
     float gz_lane;                    // E > 4: lane lg of the group holds class lg (0 beyond E)
     float4 x, gx;                     // x = Pu*Qi ; gx = sum_c gz_c W_c
 };
-template <int LG, int EMAX>
+// KIND -1: implicit / PureMF decided at run time (workgroup-uniform branches); 0 / 1: explicit / implicit InvPref fixed at
+// compile time -- the body is then ONE basic block, so that two calls in a row can be interleaved by the scheduler (the
+// paired evaluation of csrc/step_alt.hpp)
+template <int LG, int EMAX, int KIND = -1>
 __device__ __forceinline__ void eval_interaction(Eval<EMAX> &o, float4 pu, float4 qi, float4 pa, float4 qa, float4 ev,
                                                  const float *sW, const float *sb, float *gzs, int E, int e, float y,
-                                                 float cw_rec, float cw_cls, const StepScalars &k, bool implicit,
-                                                 bool pure, int lg) {
+                                                 float cw_rec, float cw_cls, const StepScalars &k, bool implicit_rt,
+                                                 bool pure_rt, int lg) {
     constexpr int DP = 4 * LG;
+    const bool implicit = KIND < 0 ? implicit_rt : (KIND == 1);
+    const bool pure = KIND < 0 ? pure_rt : false;
     o.x = f4mul(pu, qi);
     const float p = group_sum<LG>((o.x.x + o.x.y) + (o.x.z + o.x.w));
     const float q = group_sum<LG>(dot4(f4mul(pa, qa), ev));

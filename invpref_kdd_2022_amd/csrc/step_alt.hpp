@@ -80,6 +80,9 @@ __device__ __forceinline__ void st_sc1(int *p, int v) {
 #define ALT_EARLY_POLL 0          // (A/B knob: 1 = wave 0 polls the fold flags behind its first load burst -- measured slower:
                                   //  a poll that comes too early fails and every retry is a loaded round trip: 19.0 vs 16.3 us)
 #endif
+#ifndef ALT_STREAM_DELAY
+#define ALT_STREAM_DELAY 0        // s_sleep units of 64 clocks in front of a stream task (evaluating launches)
+#endif
 #ifndef ALT_PEND_COND
 #define ALT_PEND_COND 0           // (A/B knob: 1 = the first pending-row loads only for waves that have pending rows -- measured
                                   //  slower, 17.0 vs 16.1 us per step: the wave-uniform branch needs the ranges before any load)
@@ -385,11 +388,24 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
                     __syncthreads();
                     const int lead = grp & ~(slices - 1);
                     gpi = gpe = f4zero();
+                    if (VEC && slices >= 4) {   // (batches of four slices: the LDS reads of a batch in flight together)
 #pragma nounroll
-                    for (int s = 0; s < slices; s++) {
-                        const float *os = slot_of(lead + s);
-                        f4add(gpi, *reinterpret_cast<const float4 *>(os + lg * 4));
-                        f4add(gpe, *reinterpret_cast<const float4 *>(os + DP + lg * 4));
+                        for (int s = 0; s < slices; s += 4) {
+                            float4 xi[4], xe[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                xi[j] = *reinterpret_cast<const float4 *>(slot_of(lead + s + j) + lg * 4);
+                                xe[j] = *reinterpret_cast<const float4 *>(slot_of(lead + s + j) + DP + lg * 4);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; j++) { f4add(gpi, xi[j]); f4add(gpe, xe[j]); }
+                        }
+                    } else {   // (two slices; the element-wise instances, short of registers, one slice at a time)
+#pragma nounroll
+                        for (int s = 0; s < slices; s++) {
+                            f4add(gpi, *reinterpret_cast<const float4 *>(slot_of(lead + s) + lg * 4));
+                            f4add(gpe, *reinterpret_cast<const float4 *>(slot_of(lead + s) + DP + lg * 4));
+                        }
                     }
                     __syncthreads();   // (the moments are parked over the slots next)
                 }
@@ -482,6 +498,9 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
                 if (lg == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; accLc += o.lcls * w_cls; }
             }
         };
+        // (Tried in round 5: the slice's interactions evaluated two at a time in one basic block at two workgroups per CU, so
+        //  that both chains interleave -- item-side launches 17.4 us against 16.7: one wave's evaluation is bound by vector
+        //  instruction ISSUE, ~340 VALU instructions per interaction, not by dependent latencies; nothing to interleave)
         for (int s = 0; s < nsmp; s += UE) {
 #pragma unroll
             for (int j = 0; j < UE; j++) {
@@ -546,11 +565,35 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
         }
         if (slices > 1) {
             if (active && leader) {
+                // (slices is a power of two: the other slices' partials in batches of up to four -- eight LDS reads in flight,
+                //  then the adds in slice order; one read + add at a time made a 16-slice meet 2 us of LDS latencies)
+                if (VEC && slices >= 4) {
+                    f4add(gi, *reinterpret_cast<const float4 *>(slot_of(grp + 1) + lg * 4));
+                    f4add(ge, *reinterpret_cast<const float4 *>(slot_of(grp + 1) + DP + lg * 4));
+                    float4 xi[4], xe[4];
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        xi[j] = *reinterpret_cast<const float4 *>(slot_of(grp + 2 + j) + lg * 4);
+                        xe[j] = *reinterpret_cast<const float4 *>(slot_of(grp + 2 + j) + DP + lg * 4);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; j++) { f4add(gi, xi[j]); f4add(ge, xe[j]); }
 #pragma nounroll
-                for (int s = 1; s < slices; s++) {
-                    const float *os = slot_of(grp + s);
-                    f4add(gi, *reinterpret_cast<const float4 *>(os + lg * 4));
-                    f4add(ge, *reinterpret_cast<const float4 *>(os + DP + lg * 4));
+                    for (int s = 4; s < slices; s += 4) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            xi[j] = *reinterpret_cast<const float4 *>(slot_of(grp + s + j) + lg * 4);
+                            xe[j] = *reinterpret_cast<const float4 *>(slot_of(grp + s + j) + DP + lg * 4);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { f4add(gi, xi[j]); f4add(ge, xe[j]); }
+                    }
+                } else {
+#pragma nounroll
+                    for (int s = 1; s < slices; s++) {
+                        f4add(gi, *reinterpret_cast<const float4 *>(slot_of(grp + s) + lg * 4));
+                        f4add(ge, *reinterpret_cast<const float4 *>(slot_of(grp + s) + DP + lg * 4));
+                    }
                 }
             }
             if (!last) __syncthreads();
@@ -822,6 +865,9 @@ __global__ __launch_bounds__(kThreads, 3) void mstep_alt_kernel(AltArgs a) {
     j -= tj;
     if (j * spt < q[3]) {
         ASTAMP(0);
+        // (started a little late: the rows without a job are off the launch's critical chain, and their load burst would
+        //  queue in front of the jobs' first gathers and the fold blocks' slab reads -- as in the two-launch form)
+        if (MODE & 2) stream_delay<ALT_STREAM_DELAY>();
         alt_stream<VEC, FULL, MODE>(a, a.stream + q[2] + j * spt, min(spt, q[3] - j * spt), ad_cur, prev2);
         ASTAMP(7);
     }

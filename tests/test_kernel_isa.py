@@ -40,10 +40,10 @@ def test_full_row_instances_have_no_scratch_traffic(kernels):
     # the latency-tuned Yahoo instance keeps three workgroups per CU: at most 168 registers
     assert ks['mstep_eval_kernel<16, true, 4, false, true>']['vgpr'] <= 168
     # the alternating one-launch-per-step kernels (csrc/step_alt.hpp): every instance free of scratch, three per CU
-    alt = [k for name, k in ks.items() if name.startswith('mstep_alt_kernel')]
+    alt = {name: k for name, k in ks.items() if name.startswith('mstep_alt_kernel')}
     assert len(alt) == 9
-    for k in alt:
-        assert k['scratch_ops'] == 0 and k['scratch'] == 0 and k['vgpr'] <= 168 and k['mfma'] == 0, k
+    for name, k in alt.items():
+        assert k['scratch_ops'] == 0 and k['scratch'] == 0 and k['mfma'] == 0 and k['vgpr'] <= 168, (name, k)
 
 
 def test_wide_instances_run_their_outer_products_on_mfma(kernels):

@@ -249,3 +249,16 @@ for rep in range(2):
                 print('  job phases (us, median): zero red %.2f | descriptor %.2f | pending + Adam(prev) %.2f | flag wait + stage %.2f | '
                       'interactions %.2f | slice meet %.2f | Adam + store %.2f' % tuple(np.median(ph, axis=0)))
                 print('  job phases (us, p90)   : ' + ' | '.join('%.2f' % x for x in np.quantile(ph, .9, axis=0)))
+                idx = np.flatnonzero((kind == 'job') & live)
+                order = idx[np.argsort(-(end[idx] - st[idx, 0]))][:int(os.environ.get('PROBE_TOP', '8'))]
+                for bk in order:
+                    cc, jj = (bk - 40) % ncls, (bk - 40) // ncls
+                    rnd = int(cls[cc, 0]) + jj
+                    meta = pl['desc'][rnd, :, 1]
+                    act = pl['desc'][rnd, :, 0] >= 0
+                    cnts = ((meta >> 9) & 0x3fffff)[act]
+                    pend_n = (pl['pend'][rnd, :, 1] - pl['pend'][rnd, :, 0])[act]
+                    print('    wg %4d start %.2f life %5.2f end %5.2f phases %s | round %d: slices %d, row counts %s, pending per slice max %d' % (
+                        bk, (st[bk, 0] - t0) / 100, (end[bk] - st[bk, 0]) / 100, (end[bk] - t0) / 100,
+                        ' '.join('%.2f' % x for x in np.diff(st[bk].astype(np.float64)) / 100), rnd, (meta[0] >> 1) & 31,
+                        sorted(set(cnts.tolist()), reverse=True)[:4], int(pend_n.max(initial=0))))

@@ -278,6 +278,8 @@ typedef struct InvPrefAltPlan {
     int32_t has_prev, has_cur;    /* 0 / 1, see above */
     int32_t n, n_prev;            /* interactions of the current / previous minibatch */
     int32_t lanes_per_group;      /* 16 */
+    int32_t slots_per_round;      /* NG: 16 (workgroups of 256 threads) or 32 (512 threads: up to 32 slices per row; a slice
+                                   * count of 32 is stored as 0 in the descriptor's 5-bit field) */
     int32_t n_rounds, rounds_per_task;
     const int32_t *desc;          /* [n_rounds][NG][8] */
     const int32_t *pend;          /* [n_rounds][NG][4] */

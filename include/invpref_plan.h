@@ -55,12 +55,13 @@ int invpref_plan_build_many(const int64_t *users, const int64_t *items, const fl
  * arrays equal byte for byte, tests/test_plan_native.py).  One launch of the alternating form: the CURRENT minibatch
  * (cur_* arrays, n interactions; n = 0: a flush launch) seen from `side` (0: users own the jobs, 1: items) and the PREVIOUS
  * minibatch (prev_*, n_prev interactions; n_prev = 0 with prev_users == NULL: first launch of a run).
- * which: 0 desc [rounds][16][8] | 1 pend [rounds][16][4] | 2 list [n][4] | 3 push_slot [n] | 4 stream [n_stream][4] |
+ * which: 0 desc [rounds][slots][8] | 1 pend [rounds][slots][4] | 2 list [n][4] | 3 push_slot [n] | 4 stream [n_stream][4] |
  *        5 cls [8][4]. */
 typedef struct InvPrefAltPlanParams {
     int32_t side, per_slice, n_classes;
     int32_t pend_job_min;             /* rows without a current interaction and at least this many pending rows get a job */
     int32_t pend_per_slice;
+    int32_t slots;                    /* group slots per round: 16 or 32 (InvPrefAltPlan.slots_per_round) */
 } InvPrefAltPlanParams;
 InvPrefHostPlan *invpref_alt_plan_build(const int64_t *cur_users, const int64_t *cur_items, const float *cur_scores, int64_t n,
                                         const int64_t *prev_users, const int64_t *prev_items, int64_t n_prev,

@@ -152,7 +152,7 @@ void side_rounds(const Side &s, int64_t n, const int32_t *list, int stride, int 
             for (int sl = 0; sl < ng; sl++) {
                 int32_t *d = desc.data() + base + ((size_t)rr * ng + sl) * slot_w;
                 d[0] = -1;
-                d[1] = g << 1;   // idle slots still tell the round's slice count (sync decision)
+                d[1] = (g & 31) << 1;   // idle slots still tell the round's slice count (sync decision); 32 slices: 0
             }
         for (size_t i = 0; i < rows.size(); i++) {
             const int64_t row = rows[i], rnd = (int64_t)i / per_round, first = ((int64_t)i % per_round) * g;
@@ -161,7 +161,7 @@ void side_rounds(const Side &s, int64_t n, const int32_t *list, int stride, int 
             for (int k = 0; k < g; k++) {
                 const int64_t j0 = std::min(p0 + k * sl, p1), j1 = std::min(j0 + sl, p1), m = j1 - j0;
                 const int64_t mode = m <= inl_max ? m : kModeList;
-                const int64_t meta = (k == 0 ? 1 : 0) | ((int64_t)g << 1) | (mode << 6) | (c << 9);
+                const int64_t meta = (k == 0 ? 1 : 0) | ((int64_t)(g & 31) << 1) | (mode << 6) | (c << 9);
                 int32_t *d = desc.data() + base + ((size_t)rnd * ng + (size_t)(first + k)) * slot_w;
                 d[0] = (int32_t)row;
                 d[1] = (int32_t)meta;
@@ -356,9 +356,9 @@ InvPrefHostPlan *build_alt(const int64_t *cu, const int64_t *ci, const float *cy
                            int64_t n_prev, int64_t U, int64_t I, const InvPrefAltPlanParams &p) {
     const bool has_cur = n > 0, has_prev = pu != nullptr && n_prev >= 0;
     if (U <= 0 || I <= 0 || n < 0 || (p.side != 0 && p.side != 1) || p.per_slice < 1 || p.n_classes < 1 || p.n_classes > 8 ||
-        p.pend_job_min < 1 || p.pend_per_slice < 1 || (has_cur && (!cu || !ci || !cy)) || (has_prev && (!pu || !pi)))
+        p.pend_job_min < 1 || p.pend_per_slice < 1 || (p.slots != 16 && p.slots != 32) || (has_cur && (!cu || !ci || !cy)) || (has_prev && (!pu || !pi)))
         return nullptr;
-    constexpr int ng = 16;
+    const int ng = p.slots;
     const int ncls = p.n_classes;
     const int64_t own_num = p.side == 0 ? U : I, oth_num = p.side == 0 ? I : U;
     const int64_t *own = p.side == 0 ? cu : ci, *oth = p.side == 0 ? ci : cu, *ownp = p.side == 0 ? pu : pi;
@@ -405,9 +405,9 @@ InvPrefHostPlan *build_alt(const int64_t *cu, const int64_t *ci, const float *cy
                 int32_t *dd = d.data() + (r * ng + sl) * 8, *pp = pend.data() + pbase + (r * ng + sl) * 4;
                 const int64_t row = dd[0];
                 if (row < 0) continue;
-                const int g = (dd[1] >> 1) & 31, k = sl % (g > 0 ? g : 1);
+                const int gf = (dd[1] >> 1) & 31, g = gf ? gf : 32, k = sl % g;   // (32 slices are stored as 0)
                 const int64_t cp = Sp.cnt[(size_t)row], p0 = Sp.ptr[(size_t)row];
-                const int64_t ln = cdiv(cp, g > 0 ? g : 1);
+                const int64_t ln = cdiv(cp, g);
                 pp[0] = (int32_t)(p0 + std::min<int64_t>(k * ln, cp));
                 pp[1] = (int32_t)(p0 + std::min<int64_t>((k + 1) * ln, cp));
                 pp[2] = (int32_t)cp;

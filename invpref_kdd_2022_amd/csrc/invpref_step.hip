@@ -1966,7 +1966,7 @@ extern "C" {
 
 size_t invpref_alt_workspace_bytes(const InvPrefTables *tables, int32_t n_cap, int32_t partials_cap) {
     if (!tables || n_cap < 0 || partials_cap < 0) return 0;
-    return alt_flags_offset(n_cap, partials_cap) + 64 * sizeof(int);
+    return alt_flags_offset(n_cap, partials_cap) + kAltTailBytes;
 }
 
 size_t invpref_alt_error_offset(const InvPrefTables *tables, int32_t n_cap, int32_t partials_cap) {

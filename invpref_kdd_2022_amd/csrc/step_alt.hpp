@@ -52,6 +52,7 @@ struct AltArgs {
     int n_partials_prev;
     float *slabs;                 // [job tasks][SLAB]
     int *fold_flags;              // [64]; word 63: error
+    unsigned long long *pub;      // [2 * EMAX * DP + EMAX] granules {value, step}: the small tables as the fold blocks publish them
     float l2, l1;
     double inv_B_prev, inv_BD2_prev;
     float *losses_prev;
@@ -76,10 +77,6 @@ __device__ __forceinline__ void st_sc1(int *p, int v) {
 #ifndef ALT_POLL_MAX
 #define ALT_POLL_MAX (1 << 17)    // polls before a waiting workgroup gives up (sets the error word): ~30 ms
 #endif
-#ifndef ALT_EARLY_POLL
-#define ALT_EARLY_POLL 0          // (A/B knob: 1 = wave 0 polls the fold flags behind its first load burst -- measured slower:
-                                  //  a poll that comes too early fails and every retry is a loaded round trip: 19.0 vs 16.3 us)
-#endif
 #ifndef ALT_STREAM_DELAY
 #define ALT_STREAM_DELAY 0        // s_sleep units of 64 clocks in front of a stream task (evaluating launches)
 #endif
@@ -87,86 +84,120 @@ __device__ __forceinline__ void st_sc1(int *p, int v) {
 #define ALT_PEND_COND 0           // (A/B knob: 1 = the first pending-row loads only for waves that have pending rows -- measured
                                   //  slower, 17.0 vs 16.1 us per step: the wave-uniform branch needs the ranges before any load)
 #endif
+#ifndef ALT_EARLY_STAGE
+#define ALT_EARLY_STAGE 0         // (A/B knob: 1 = the small tables' granules requested in front of the previous step's update;
+                                  //  18 registers across that phase: needs ALT_PEND_DEPTH 2 to stay free of scratch)
+#endif
 #ifndef ALT_PEND_DEPTH
 #define ALT_PEND_DEPTH 4          // pending contribution-row pairs in flight per group (two register sets)
 #endif
 
-// Wave 0 of a job workgroup: wait until every fold block has published this step's flag, then read the small tables with
-// cache-bypassing loads (the fold blocks stored them write-through and drained before the flag: MI355X guide, "Valid
-// forms": sc1 stores + sc1 flag / sc1 poll + sc1 loads by the polling wave) and stage them in LDS.  In three pieces so that
-// the two round trips hide: the poll sits behind the wave's first load burst (its wait is the burst's wait), the nine table
-// loads are issued at once and fly under the previous step's update; alt_stage_finish waits for them.
+// The small tables travel from the fold blocks to the job workgroups of the SAME launch as data-tagged granules: the fold
+// thread that finishes an entry stores {value, step number} as ONE 8-byte write-through store, wave 0 of a job workgroup
+// loads its nine granules in one burst with cache-bypassing loads and accepts them when every tag carries this step's
+// number -- one round trip once the fold is through (a separate flag costs two: poll, then loads), no ordering needed
+// between the stores (MI355X guide, inter-workgroup visibility: R2 granules, observed untorn for naturally aligned 8-byte
+// sc1 stores on gfx950).  Entries outside the tables (classes >= env_num, columns >= factor_num) are never published and
+// never waited for.  A run's first launch (no fold) zeroes the tags, so a stale granule of an earlier run cannot carry
+// one of this run's step numbers.
 struct AltStage {
-    float xe0, xe1, xe2, xe3, xw0, xw1, xw2, xw3, xb;
+    unsigned long long g[9];
 };
-__device__ __forceinline__ void alt_poll(const AltArgs &a, int gen) {
-    const int lane = threadIdx.x & 63;
-    int polls = 0;
-    for (;;) {
-        const int v = lane < a.fold_blocks ? ld_sc1(a.fold_flags + lane) : gen;
-        if (__builtin_amdgcn_ballot_w64(v != gen) == 0) break;
-        if (++polls > ALT_POLL_MAX) {
-            if (lane == 0) st_sc1(a.fold_flags + 63, 1);
-            break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-    }
-    asm volatile("" ::: "memory");   // (the table loads stay behind the poll)
-}
-__device__ __forceinline__ void alt_stage_offsets(const AltArgs &a, int lane, unsigned (&o)[4], unsigned &ob, bool (&on)[4], bool &onb) {
+__device__ __forceinline__ void alt_stage_lanes(const AltArgs &a, int lane, bool (&on)[4], bool &onb) {
     constexpr int DP = 64;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int idx = lane + 64 * i, e = idx / DP, d = idx - e * DP;
         on[i] = e < a.E && d < a.D;
-        o[i] = on[i] ? (unsigned)(e * a.D + d) * 4u : 0u;
     }
     onb = lane < a.E;
-    ob = onb ? (unsigned)lane * 4u : 0u;
 }
+#define ALT_GRANULE_LOADS                                                                                                     \
+    "global_load_dwordx2 %0, %9, %11 sc1\n\t"                                                                              \
+    "global_load_dwordx2 %1, %9, %11 offset:512 sc1\n\t"                                                                   \
+    "global_load_dwordx2 %2, %9, %11 offset:1024 sc1\n\t"                                                                  \
+    "global_load_dwordx2 %3, %9, %11 offset:1536 sc1\n\t"                                                                  \
+    "global_load_dwordx2 %4, %9, %11 offset:2048 sc1\n\t"                                                                  \
+    "global_load_dwordx2 %5, %9, %11 offset:2560 sc1\n\t"                                                                  \
+    "global_load_dwordx2 %6, %9, %11 offset:3072 sc1\n\t"                                                                  \
+    "global_load_dwordx2 %7, %9, %11 offset:3584 sc1\n\t"                                                                  \
+    "global_load_dwordx2 %8, %10, %11 sc1"
+// all nine loads in ONE burst, the base pointer in scalar registers; no wait: they fly under the previous step's update
 __device__ __forceinline__ void alt_stage_issue(const AltArgs &a, AltStage &x) {
-    // every load of the 2.5 KB in ONE burst (the compiler would wait for each relaxed atomic load in turn -- a round trip per
-    // load on the step's critical chain); the base pointers stay in scalar registers
-    unsigned o[4], ob;
-    bool on[4], onb;
-    alt_stage_offsets(a, threadIdx.x & 63, o, ob, on, onb);
-    asm volatile(
-        "global_load_dword %0, %9, %14 sc1\n\t"
-        "global_load_dword %1, %10, %14 sc1\n\t"
-        "global_load_dword %2, %11, %14 sc1\n\t"
-        "global_load_dword %3, %12, %14 sc1\n\t"
-        "global_load_dword %4, %9, %15 sc1\n\t"
-        "global_load_dword %5, %10, %15 sc1\n\t"
-        "global_load_dword %6, %11, %15 sc1\n\t"
-        "global_load_dword %7, %12, %15 sc1\n\t"
-        "global_load_dword %8, %13, %16 sc1"
-        : "=&v"(x.xe0), "=&v"(x.xe1), "=&v"(x.xe2), "=&v"(x.xe3), "=&v"(x.xw0), "=&v"(x.xw1), "=&v"(x.xw2), "=&v"(x.xw3), "=&v"(x.xb)
-        : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(ob), "s"(a.Ev), "s"(a.W), "s"(a.b)
-        : "memory");
-}
-__device__ __forceinline__ void alt_stage_finish(const AltArgs &a, AltStage &x, float *sEv, float *sW, float *sb, bool pure) {
-    constexpr int EMAX = 4, DP = 64;
+    constexpr int EDP = 4 * 64;
     const int lane = threadIdx.x & 63;
-    if (pure) {
-#pragma unroll
-        for (int i = 0; i < EMAX * DP / 64; i++) sEv[lane + 64 * i] = sW[lane + 64 * i] = 0.f;
-        if (lane < EMAX) sb[lane] = 0.f;
-        return;
-    }
+    const unsigned o0 = (unsigned)lane * 8u, ob = (unsigned)(2 * EDP + (lane < a.E ? lane : 0)) * 8u;
+    asm volatile(ALT_GRANULE_LOADS
+                 : "=&v"(x.g[0]), "=&v"(x.g[1]), "=&v"(x.g[2]), "=&v"(x.g[3]), "=&v"(x.g[4]), "=&v"(x.g[5]), "=&v"(x.g[6]),
+                   "=&v"(x.g[7]), "=&v"(x.g[8])
+                 : "v"(o0), "v"(ob), "s"(a.pub)
+                 : "memory");
+}
+__device__ __forceinline__ void alt_stage_finish(const AltArgs &a, AltStage &x, int gen, float *sEv, float *sW, float *sb) {
+    constexpr int EMAX = 4, EDP = 4 * 64;
+    const int lane = threadIdx.x & 63;
+    bool on[4], onb;
+    alt_stage_lanes(a, lane, on, onb);
+    const unsigned o0 = (unsigned)lane * 8u, ob = (unsigned)(2 * EDP + (onb ? lane : 0)) * 8u;
     // (the loaded registers pass THROUGH the wait: nothing the compiler schedules can read them before it)
     asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(x.xe0), "+v"(x.xe1), "+v"(x.xe2), "+v"(x.xe3), "+v"(x.xw0), "+v"(x.xw1), "+v"(x.xw2), "+v"(x.xw3), "+v"(x.xb)
+                 : "+v"(x.g[0]), "+v"(x.g[1]), "+v"(x.g[2]), "+v"(x.g[3]), "+v"(x.g[4]), "+v"(x.g[5]), "+v"(x.g[6]), "+v"(x.g[7]),
+                   "+v"(x.g[8])
                  :
                  : "memory");
-    unsigned o[4], ob;
-    bool on[4], onb;
-    alt_stage_offsets(a, lane, o, ob, on, onb);
-    sEv[lane + 0] = on[0] ? x.xe0 : 0.f; sEv[lane + 64] = on[1] ? x.xe1 : 0.f;
-    sEv[lane + 128] = on[2] ? x.xe2 : 0.f; sEv[lane + 192] = on[3] ? x.xe3 : 0.f;
-    sW[lane + 0] = on[0] ? x.xw0 : 0.f; sW[lane + 64] = on[1] ? x.xw1 : 0.f;
-    sW[lane + 128] = on[2] ? x.xw2 : 0.f; sW[lane + 192] = on[3] ? x.xw3 : 0.f;
-    if (lane < EMAX) sb[lane] = onb ? x.xb : 0.f;
+    int polls = 0;
+    for (;;) {
+        bool ok = !onb || (int)(x.g[8] >> 32) == gen;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            ok = ok && (!on[i] || ((int)(x.g[i] >> 32) == gen && (int)(x.g[4 + i] >> 32) == gen));
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+        if (++polls > ALT_POLL_MAX) {
+            if (lane == 0) st_sc1(a.fold_flags + 63, 1);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+        asm volatile(ALT_GRANULE_LOADS "\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(x.g[0]), "=&v"(x.g[1]), "=&v"(x.g[2]), "=&v"(x.g[3]), "=&v"(x.g[4]), "=&v"(x.g[5]), "=&v"(x.g[6]),
+                       "=&v"(x.g[7]), "=&v"(x.g[8])
+                     : "v"(o0), "v"(ob), "s"(a.pub)
+                     : "memory");
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        sEv[lane + 64 * i] = on[i] ? __builtin_bit_cast(float, (unsigned)x.g[i]) : 0.f;
+        sW[lane + 64 * i] = on[i] ? __builtin_bit_cast(float, (unsigned)x.g[4 + i]) : 0.f;
+    }
+    if (lane < EMAX) sb[lane] = onb ? __builtin_bit_cast(float, (unsigned)x.g[8]) : 0.f;
 }
+// a run's first launch: the tables are final in memory (the previous run's flush launch ended before this one began)
+__device__ __forceinline__ void alt_stage_plain(const AltArgs &a, float *sEv, float *sW, float *sb, bool pure) {
+    constexpr int EMAX = 4, DP = 64;
+    const int lane = threadIdx.x & 63;
+    bool on[4], onb;
+    alt_stage_lanes(a, lane, on, onb);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int idx = lane + 64 * i, e = idx / DP, d = idx - e * DP;
+        const bool o = on[i] && !pure;
+        sEv[idx] = o ? a.Ev[e * a.D + d] : 0.f;
+        sW[idx] = o ? a.W[e * a.D + d] : 0.f;
+    }
+    if (lane < EMAX) sb[lane] = (onb && !pure) ? a.b[lane] : 0.f;
+}
+
+// geometry of a job workgroup of THREADS threads: THREADS / 16 group slots (16 or 32: a hot row's interactions spread over up
+// to 32 slices -- the evaluation is bound by vector-instruction issue, ~340 instructions per interaction, so a slice's
+// length is what a hot row costs), one partial slab row per group, a 4 KB landing / slot area per wave
+template <int THREADS>
+struct AltGeo {
+    static constexpr int NG = THREADS / 16, WAVES = THREADS / 64, DP = 64, EMAX = 4;
+    static constexpr int SLAB = 2 * EMAX * DP + EMAX + kLossSlots;
+    static constexpr int sEv = 0, sW = sEv + EMAX * DP, sb = sW + EMAX * DP;
+    static constexpr int mv = sb + EMAX;                      // [WAVES][4][64] float4
+    static constexpr int red = mv + WAVES * 4 * 64 * 4;       // [NG][SLAB]
+    static constexpr int total = red + NG * SLAB;
+};
 
 __device__ __forceinline__ void adam4_prev(float4 &p, float4 g, float4 &m, float4 &v, const AdamScalars &ad, float2 prev2) {
     AdamScalars ap = ad;
@@ -177,13 +208,13 @@ __device__ __forceinline__ void adam4_prev(float4 &p, float4 g, float4 &m, float
 // =====================================================================================
 // rounds of jobs of the evaluating side
 // =====================================================================================
-template <bool VEC, bool FULL, int MODE>
+template <bool VEC, bool FULL, int MODE, int THREADS>
 __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_index, float *lds,
                                          const AdamScalars &ad_cur, float2 prev2, const StepScalars &k, int gen) {
     constexpr int LG = 16, EMAX = 4, UE = 2;
-    using G = Geo<LG, EMAX>;
-    using L = EvalLds<LG, EMAX>;
-    static_assert(L::ALIAS && G::DIRECT && G::REG && STEP_LDS_DW && !STEP_NO_DMA, "alt_task: the default smallest-instance layout");
+    using G = AltGeo<THREADS>;
+    using L = AltGeo<THREADS>;
+    static_assert(STEP_LDS_DW && !STEP_NO_DMA && EvalLds<16, 4>::total == AltGeo<256>::total, "alt_task: the default smallest-instance layout");
     constexpr int NG = G::NG, DP = G::DP;
     float *sEv = lds + L::sEv, *sW = lds + L::sW, *sb = lds + L::sb;
     float4 *mv = reinterpret_cast<float4 *>(lds + L::mv);
@@ -208,7 +239,7 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
     if (has_cur) {
         constexpr int ZR4 = (2 * EMAX * DP + EMAX) / 4;   // (dEv | dW | db: 516 floats, SLAB = 524: both multiples of 4)
         static_assert((2 * EMAX * DP + EMAX) % 4 == 0 && G::SLAB % 4 == 0, "16-byte zeroing");
-        for (int i = threadIdx.x; i < G::RED * ZR4; i += kThreads)
+        for (int i = threadIdx.x; i < NG * ZR4; i += THREADS)
             *reinterpret_cast<float4 *>(red + (i / ZR4) * G::SLAB + (i % ZR4) * 4) = f4zero();
     }
     ASTAMP(1);
@@ -226,7 +257,8 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
         const int4 pdd = pd;
         const int row = dd.x, meta = dd.y;
         const bool active = row >= 0, leader = meta & 1;
-        const int slices = (meta >> 1) & 31, mode = (meta >> 6) & 7;
+        const int slices_f = (meta >> 1) & 31, mode = (meta >> 6) & 7;
+        const int slices = slices_f ? slices_f : 32;   // (32 slices, rounds of 32 slots: the field holds 0)
         const bool rpend = has_prev && (meta < 0);            // bit 31: some row of the round has pending rows
         const int cnt_i = (meta >> 9) & 0x3fffff;
         const int nsmp = (active && has_cur) ? (mode == 7 ? dd.w - dd.z : mode) : 0;
@@ -363,12 +395,15 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
                     if (UE + j < nsmp) idn[j] = sample_at(UE + j);
             }
         }
-        // ---- (ii, first half) the small tables of this step: wave 0 polls behind its own burst and requests them
+        // ---- (ii, first half) this step's small tables are requested as soon as this wave's first burst is in -- by then the
+        // fold blocks have usually published them (they end ~5 us into a launch, the burst arrives ~6 us in) -- and fly under
+        // the previous step's update; a request that comes too early is repeated at the point of use
         AltStage stg;
-        stg.xe0 = stg.xe1 = stg.xe2 = stg.xe3 = stg.xw0 = stg.xw1 = stg.xw2 = stg.xw3 = stg.xb = 0.f;
-#if ALT_EARLY_POLL
-        if (has_cur && wave == 0 && !pure) {
-            if (has_prev) alt_poll(a, gen);
+#pragma unroll
+        for (int i = 0; i < 9; i++) stg.g[i] = 0ull;
+#if ALT_EARLY_STAGE
+        if (has_cur && has_prev && !pure && wave == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             alt_stage_issue(a, stg);
         }
 #endif
@@ -387,20 +422,41 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
                     *reinterpret_cast<float4 *>(mine + DP + lg * 4) = gpe;
                     __syncthreads();
                     const int lead = grp & ~(slices - 1);
-                    gpi = gpe = f4zero();
-                    if (VEC && slices >= 4) {   // (batches of four slices: the LDS reads of a batch in flight together)
+                    if (VEC && slices >= 8) {
+                        // a hot row (8 .. 32 slices): the LEADER sums the shares -- eight slices' LDS reads in flight at a
+                        // time -- and hands the total back through its own slot (every slice reading every share is
+                        // slices^2 reads: a third of a 32-slice workgroup's LDS time)
+                        if (active && leader) {
+                            gpi = gpe = f4zero();
 #pragma nounroll
-                        for (int s = 0; s < slices; s += 4) {
-                            float4 xi[4], xe[4];
+                            for (int s = 0; s < slices; s += 8) {
+                                float4 xi[8], xe[8];
 #pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                xi[j] = *reinterpret_cast<const float4 *>(slot_of(lead + s + j) + lg * 4);
-                                xe[j] = *reinterpret_cast<const float4 *>(slot_of(lead + s + j) + DP + lg * 4);
+                                for (int j = 0; j < 8; j++) {
+                                    xi[j] = *reinterpret_cast<const float4 *>(slot_of(lead + s + j) + lg * 4);
+                                    xe[j] = *reinterpret_cast<const float4 *>(slot_of(lead + s + j) + DP + lg * 4);
+                                }
+#pragma unroll
+                                for (int j = 0; j < 8; j++) { f4add(gpi, xi[j]); f4add(gpe, xe[j]); }
                             }
-#pragma unroll
-                            for (int j = 0; j < 4; j++) { f4add(gpi, xi[j]); f4add(gpe, xe[j]); }
+                            *reinterpret_cast<float4 *>(mine + lg * 4) = gpi;
+                            *reinterpret_cast<float4 *>(mine + DP + lg * 4) = gpe;
                         }
+                        __syncthreads();
+                        gpi = *reinterpret_cast<const float4 *>(slot_of(lead) + lg * 4);
+                        gpe = *reinterpret_cast<const float4 *>(slot_of(lead) + DP + lg * 4);
+                    } else if (VEC && slices == 4) {   // (the four slices' LDS reads in flight together)
+                        float4 xi[4], xe[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            xi[j] = *reinterpret_cast<const float4 *>(slot_of(lead + j) + lg * 4);
+                            xe[j] = *reinterpret_cast<const float4 *>(slot_of(lead + j) + DP + lg * 4);
+                        }
+                        gpi = gpe = f4zero();
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { f4add(gpi, xi[j]); f4add(gpe, xe[j]); }
                     } else {   // (two slices; the element-wise instances, short of registers, one slice at a time)
+                        gpi = gpe = f4zero();
 #pragma nounroll
                         for (int s = 0; s < slices; s++) {
                             f4add(gpi, *reinterpret_cast<const float4 *>(slot_of(lead + s) + lg * 4));
@@ -439,13 +495,11 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
         // ---- (ii) the small tables of this step
         if (r == r0) {
             if (wave == 0) {
-#if !ALT_EARLY_POLL
-                if (!pure) {
-                    if (has_prev) alt_poll(a, gen);
-                    alt_stage_issue(a, stg);
-                }
+#if !ALT_EARLY_STAGE
+                if (has_prev && !pure) alt_stage_issue(a, stg);
 #endif
-                alt_stage_finish(a, stg, sEv, sW, sb, pure);
+                if (has_prev && !pure) alt_stage_finish(a, stg, gen, sEv, sW, sb);
+                else alt_stage_plain(a, sEv, sW, sb, pure);
             }
             __syncthreads();
             ASTAMP(4);
@@ -553,41 +607,54 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
         }
         if (slices > 1 || last) __syncthreads();
         if (last) {
-            for (int i = threadIdx.x; i < G::SLAB; i += kThreads) {
-                float x[G::RED];
+            // (the groups' rows summed in group order, four columns per thread: 16-byte LDS reads, eight rows in flight)
+            static_assert(G::SLAB % 4 == 0 && G::SLAB / 4 <= THREADS && NG % 8 == 0, "slab sum: one float4 column set per thread");
+            if ((int)threadIdx.x < G::SLAB / 4) {
+                const float *col = red + threadIdx.x * 4;
+                float4 sum = *reinterpret_cast<const float4 *>(col);
 #pragma unroll
-                for (int q = 0; q < G::RED; q++) x[q] = red[q * G::SLAB + i];
-                float sum = x[0];
+                for (int q0 = 0; q0 < NG; q0 += 8) {
+                    float4 x[8];
 #pragma unroll
-                for (int q = 1; q < G::RED; q++) sum += x[q];
-                slab[i] = sum;
+                    for (int j = 0; j < 8; j++) x[j] = *reinterpret_cast<const float4 *>(col + (q0 + j) * G::SLAB);
+#pragma unroll
+                    for (int j = (q0 == 0 ? 1 : 0); j < 8; j++) f4add(sum, x[j]);
+                }
+                *reinterpret_cast<float4 *>(slab + threadIdx.x * 4) = sum;
             }
         }
         if (slices > 1) {
             if (active && leader) {
                 // (slices is a power of two: the other slices' partials in batches of up to four -- eight LDS reads in flight,
                 //  then the adds in slice order; one read + add at a time made a 16-slice meet 2 us of LDS latencies)
-                if (VEC && slices >= 4) {
-                    f4add(gi, *reinterpret_cast<const float4 *>(slot_of(grp + 1) + lg * 4));
-                    f4add(ge, *reinterpret_cast<const float4 *>(slot_of(grp + 1) + DP + lg * 4));
-                    float4 xi[4], xe[4];
+                if (VEC && slices >= 8) {
+                    float4 xi[8], xe[8];
 #pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        xi[j] = *reinterpret_cast<const float4 *>(slot_of(grp + 2 + j) + lg * 4);
-                        xe[j] = *reinterpret_cast<const float4 *>(slot_of(grp + 2 + j) + DP + lg * 4);
+                    for (int j = 1; j < 8; j++) {
+                        xi[j] = *reinterpret_cast<const float4 *>(slot_of(grp + j) + lg * 4);
+                        xe[j] = *reinterpret_cast<const float4 *>(slot_of(grp + j) + DP + lg * 4);
                     }
 #pragma unroll
-                    for (int j = 0; j < 2; j++) { f4add(gi, xi[j]); f4add(ge, xe[j]); }
+                    for (int j = 1; j < 8; j++) { f4add(gi, xi[j]); f4add(ge, xe[j]); }
 #pragma nounroll
-                    for (int s = 4; s < slices; s += 4) {
+                    for (int s = 8; s < slices; s += 8) {
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
+                        for (int j = 0; j < 8; j++) {
                             xi[j] = *reinterpret_cast<const float4 *>(slot_of(grp + s + j) + lg * 4);
                             xe[j] = *reinterpret_cast<const float4 *>(slot_of(grp + s + j) + DP + lg * 4);
                         }
 #pragma unroll
-                        for (int j = 0; j < 4; j++) { f4add(gi, xi[j]); f4add(ge, xe[j]); }
+                        for (int j = 0; j < 8; j++) { f4add(gi, xi[j]); f4add(ge, xe[j]); }
                     }
+                } else if (VEC && slices == 4) {
+                    float4 xi[4], xe[4];
+#pragma unroll
+                    for (int j = 1; j < 4; j++) {
+                        xi[j] = *reinterpret_cast<const float4 *>(slot_of(grp + j) + lg * 4);
+                        xe[j] = *reinterpret_cast<const float4 *>(slot_of(grp + j) + DP + lg * 4);
+                    }
+#pragma unroll
+                    for (int j = 1; j < 4; j++) { f4add(gi, xi[j]); f4add(ge, xe[j]); }
                 } else {
 #pragma nounroll
                     for (int s = 1; s < slices; s++) {
@@ -623,9 +690,9 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
 // =====================================================================================
 // rows of the evaluating side without a job: pending rows (few), then both updates -- streamed, 2 rows per group
 // =====================================================================================
-template <bool VEC, bool FULL, int MODE>
+template <bool VEC, bool FULL, int MODE, int THREADS>
 __device__ __forceinline__ void alt_stream(const AltArgs &a, const int4 *rows, int n, const AdamScalars &ad_cur, float2 prev2) {
-    constexpr int R = 2, LG = 16, NG = kThreads / LG, DP = 64, H = 2;
+    constexpr int R = 2, LG = 16, NG = THREADS / LG, DP = 64, H = 2;
     const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG;
     const bool pure = a.flags & INVPREF_PURE_MF;
     constexpr bool has_prev = MODE & 1, has_cur = MODE & 2;
@@ -726,7 +793,9 @@ __device__ __forceinline__ void alt_stream(const AltArgs &a, const int4 *rows, i
 // fold block fb: 16 columns of the previous launch's partial slabs -> gradient of embed_env / classifier -> Adam IN PLACE
 // (write-through stores), the six loss outputs of the previous step, the block's flag
 // =====================================================================================
+template <int THREADS>
 __device__ __forceinline__ void alt_fold_block(const AltArgs &a, int fb, float *lds, const AdamScalars &ad, int gen) {
+    constexpr int kFoldSubs = THREADS / kFoldCols;   // (shadows the 256-thread constant: more sub-rows, fewer loads per thread)
     constexpr int DP = 64, EMAX = 4, SLAB = 2 * EMAX * DP + EMAX + kLossSlots, EDP = EMAX * DP;
     double *part = reinterpret_cast<double *>(lds);   // [kFoldSubs][kFoldCols] (+ kLossSlots)
     const int colx = threadIdx.x % kFoldCols, sub = threadIdx.x / kFoldCols;
@@ -772,7 +841,9 @@ __device__ __forceinline__ void alt_fold_block(const AltArgs &a, int fb, float *
                 }
                 float mm = pre_m, vv = pre_v;
                 adam1(pv, gv, mm, vv, ad);
-                st_sc1((isB ? a.b : (isW ? a.W : a.Ev)) + off, pv);
+                (isB ? a.b : (isW ? a.W : a.Ev))[off] = pv;          // (the next launch's fold reads it: plain)
+                __hip_atomic_store(a.pub + idx, ((unsigned long long)(unsigned)gen << 32) | (unsigned long long)__builtin_bit_cast(unsigned, pv),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // {value, step}: one 8-byte write-through store
                 (isB ? a.mb : (isW ? a.mW : a.mEv))[off] = mm;
                 (isB ? a.vb : (isW ? a.vW : a.vEv))[off] = vv;
             }
@@ -781,10 +852,7 @@ __device__ __forceinline__ void alt_fold_block(const AltArgs &a, int fb, float *
             sl[idx - 2 * EDP - EMAX] = v;
         }
     }
-    // publish: every storing wave drains its stores, the workgroup meets, one lane stores the flag
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) st_sc1(a.fold_flags + fb, gen);
+    __syncthreads();   // (the loss columns meet in LDS)
     constexpr int loss0 = 2 * EDP + EMAX;
     if (fb == loss0 / kFoldCols && threadIdx.x == 0 && a.losses_prev) {
         const double *sl = part + kFoldSubs * kFoldCols;
@@ -797,8 +865,8 @@ __device__ __forceinline__ void alt_fold_block(const AltArgs &a, int fb, float *
     }
 }
 
-template <bool VEC, bool FULL, int MODE>
-__global__ __launch_bounds__(kThreads, 3) void mstep_alt_kernel(AltArgs a) {
+template <bool VEC, bool FULL, int MODE, int THREADS = 256>
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) void mstep_alt_kernel(AltArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // (the previous step's Adam scalars differ from this step's in step_size / bc2_sqrt only: two scalars, not a second set)
     AdamScalars ad_cur = a.ad_cur;
@@ -824,10 +892,14 @@ __global__ __launch_bounds__(kThreads, 3) void mstep_alt_kernel(AltArgs a) {
             // it: a captured memset node replayed garbage into these words on ROCm 7.0.2 -- tools/alt_soak.py)
             a.fold_flags[threadIdx.x] = 0;
         }
+        if (!(MODE & 1) && b == 0) {
+            constexpr int NPUB = 2 * 4 * 64 + 4;
+            for (int i = threadIdx.x; i < NPUB; i += THREADS) a.pub[i] = 0ull;
+        }
         if (b < a.fold_blocks) {
             if (MODE & 1) {
                 ASTAMP(0);
-                { AdamScalars adp = ad_cur; adp.step_size = prev2.x; adp.bc2_sqrt = prev2.y; alt_fold_block(a, b, lds, adp, gen); }
+                { AdamScalars adp = ad_cur; adp.step_size = prev2.x; adp.bc2_sqrt = prev2.y; alt_fold_block<THREADS>(a, b, lds, adp, gen); }
                 ASTAMP(7);
             }
         } else if (b == a.fold_blocks) {
@@ -859,7 +931,7 @@ __global__ __launch_bounds__(kThreads, 3) void mstep_alt_kernel(AltArgs a) {
     const int rpt = a.rounds_per_task, spt = a.rows_per_stream_task;
     const int tj = (q[1] + rpt - 1) / rpt;
     if (j < tj) {
-        alt_task<VEC, FULL, MODE>(a, q[0] + j, q[0] + j, lds, ad_cur, prev2, k, gen);
+        alt_task<VEC, FULL, MODE, THREADS>(a, q[0] + j, q[0] + j, lds, ad_cur, prev2, k, gen);
         return;
     }
     j -= tj;
@@ -868,7 +940,7 @@ __global__ __launch_bounds__(kThreads, 3) void mstep_alt_kernel(AltArgs a) {
         // (started a little late: the rows without a job are off the launch's critical chain, and their load burst would
         //  queue in front of the jobs' first gathers and the fold blocks' slab reads -- as in the two-launch form)
         if (MODE & 2) stream_delay<ALT_STREAM_DELAY>();
-        alt_stream<VEC, FULL, MODE>(a, a.stream + q[2] + j * spt, min(spt, q[3] - j * spt), ad_cur, prev2);
+        alt_stream<VEC, FULL, MODE, THREADS>(a, a.stream + q[2] + j * spt, min(spt, q[3] - j * spt), ad_cur, prev2);
         ASTAMP(7);
     }
 }
@@ -879,6 +951,7 @@ inline size_t alt_half_floats(int n_cap, int partials_cap) {
     const size_t slabs = (size_t)(partials_cap > 0 ? partials_cap : 1) * (2 * 4 * 64 + 4 + kLossSlots);
     return (rows + slabs + 63) & ~(size_t)63;
 }
+constexpr size_t kAltTailBytes = 64 * sizeof(int) + ((2 * 4 * 64 + 4) * 8 + 255) / 256 * 256;   // fold flags | published granules
 inline size_t alt_flags_offset(int n_cap, int partials_cap) { return 2 * alt_half_floats(n_cap, partials_cap) * sizeof(float); }
 
 int launch_alt(const InvPrefTables *tables, const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
@@ -902,7 +975,7 @@ int launch_alt(const InvPrefTables *tables, const InvPrefTables *exp_avg, const 
     if (has_cur && (flags & (INVPREF_REWEIGHT_REC | INVPREF_REWEIGHT_CLS)) && !weights) return INVPREF_EINVAL;
     if ((uint64_t)(tables->user_num > tables->item_num ? tables->user_num : tables->item_num) * (uint64_t)D * 4ull >= (1ull << 32))
         return INVPREF_EUNSUPPORTED;
-    if (plan->lanes_per_group != 16 || plan->side < 0 || plan->side > 1 || plan->n < 0 || plan->n_prev < 0 ||
+    if (plan->lanes_per_group != 16 || (plan->slots_per_round != 16 && plan->slots_per_round != 32) || plan->side < 0 || plan->side > 1 || plan->n < 0 || plan->n_prev < 0 ||
         plan->n_rounds < 0 || plan->rounds_per_task != 1 || plan->n_rounds % plan->rounds_per_task != 0 ||
         plan->n_stream < 0 || plan->rows_per_stream_task <= 0 || (plan->n_rounds > 0 && (!plan->desc || !plan->pend)) ||
         (plan->n > 0 && (!plan->list || !plan->push_slot)) || (plan->n_stream > 0 && !plan->stream) ||
@@ -920,7 +993,7 @@ int launch_alt(const InvPrefTables *tables, const InvPrefTables *exp_avg, const 
                         (q[3] + plan->rows_per_stream_task - 1) / plan->rows_per_stream_task;
         per_class = tot > per_class ? tot : per_class;
     }
-    if (workspace_bytes < alt_flags_offset(n_cap, partials_cap) + 64 * sizeof(int)) return INVPREF_EWORKSPACE;
+    if (workspace_bytes < alt_flags_offset(n_cap, partials_cap) + kAltTailBytes) return INVPREF_EWORKSPACE;
     const size_t half = alt_half_floats(n_cap, partials_cap);
     const size_t rows_floats = ((size_t)n_cap + 1) * 2 * 64;
     float *ws = (float *)workspace;
@@ -975,6 +1048,7 @@ int launch_alt(const InvPrefTables *tables, const InvPrefTables *exp_avg, const 
     a.pend_rows = other; a.slabs_prev = other + rows_floats;
     a.n_partials_prev = plan->n_partials_prev;
     a.fold_flags = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + alt_flags_offset(n_cap, partials_cap));
+    a.pub = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(workspace) + alt_flags_offset(n_cap, partials_cap) + 64 * sizeof(int));
     a.l2 = coefs->L2_coe; a.l1 = coefs->L1_coe;
     a.losses_prev = has_prev ? losses6_prev : nullptr;
     constexpr int SLAB = 2 * 4 * 64 + 4 + kLossSlots;
@@ -985,27 +1059,34 @@ int launch_alt(const InvPrefTables *tables, const InvPrefTables *exp_avg, const 
     a.stamps = stamp_env ? reinterpret_cast<unsigned long long *>(strtoull(stamp_env, nullptr, 16)) : nullptr;
     static const bool nodrain = getenv("INVPREF_STAMPS_NODRAIN") != nullptr;
     a.stamps_nodrain = nodrain;
-    const size_t lds_job = sizeof(float) * EvalLds<16, 4>::total;
-    const size_t lds = lds_job > fold_lds_bytes() ? lds_job : fold_lds_bytes();
+    const int slots = plan->slots_per_round;
+    const size_t lds_job = sizeof(float) * (slots == 32 ? AltGeo<512>::total : AltGeo<256>::total);
+    const size_t lds_fold = ((size_t)(slots * 16 / kFoldCols) * kFoldCols + kLossSlots) * sizeof(double);
+    const size_t lds = lds_job > lds_fold ? lds_job : lds_fold;
     const int grid = a.first_task_block + per_class * ncls;
     const bool vec = vec_ok(tables) && vec_ok(exp_avg) && vec_ok(exp_avg_sq);
     static const bool no_full = getenv("INVPREF_NO_FULL") != nullptr && getenv("INVPREF_NO_FULL")[0] == '1';
     const bool full = vec && D == 64 && !no_full;
-#define CALL_ALT_M(VECV, FULLV, MODEV)                                                                      \
-    do {                                                                                                    \
-        if ((rc = ensure_lds(mstep_alt_kernel<VECV, FULLV, MODEV>, lds))) return rc;                        \
-        hipLaunchKernelGGL((mstep_alt_kernel<VECV, FULLV, MODEV>), dim3(grid), dim3(kThreads), lds, st, a); \
+#define CALL_ALT_M(VECV, FULLV, MODEV, THR)                                                                      \
+    do {                                                                                                         \
+        if ((rc = ensure_lds(mstep_alt_kernel<VECV, FULLV, MODEV, THR>, lds))) return rc;                        \
+        hipLaunchKernelGGL((mstep_alt_kernel<VECV, FULLV, MODEV, THR>), dim3(grid), dim3(THR), lds, st, a);      \
     } while (0)
-#define CALL_ALT(VECV, FULLV)                                                   \
-    do {                                                                        \
-        if (a.mode == 3) CALL_ALT_M(VECV, FULLV, 3);                            \
-        else if (a.mode == 2) CALL_ALT_M(VECV, FULLV, 2);                       \
-        else CALL_ALT_M(VECV, FULLV, 1);                                        \
+#define CALL_ALT_T(VECV, FULLV, THR)                                                 \
+    do {                                                                             \
+        if (a.mode == 3) CALL_ALT_M(VECV, FULLV, 3, THR);                            \
+        else if (a.mode == 2) CALL_ALT_M(VECV, FULLV, 2, THR);                       \
+        else CALL_ALT_M(VECV, FULLV, 1, THR);                                        \
+    } while (0)
+#define CALL_ALT(VECV, FULLV)                                                        \
+    do {                                                                             \
+        if (slots == 32) CALL_ALT_T(VECV, FULLV, 512); else CALL_ALT_T(VECV, FULLV, 256); \
     } while (0)
     if (full) CALL_ALT(true, true);
     else if (vec) CALL_ALT(true, false);
     else CALL_ALT(false, false);
 #undef CALL_ALT
+#undef CALL_ALT_T
 #undef CALL_ALT_M
     return (int)hipGetLastError();
 }

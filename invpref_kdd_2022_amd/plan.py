@@ -95,7 +95,7 @@ def _side_rounds(own, cols, n_rows: int, ng: int, per_slice: int, pad_to: int, i
             n_rounds = -(-len(rows) // per_round)
             d = np.zeros((n_rounds, ng, 8), np.int32)
             d[:, :, 0] = -1
-            d[:, :, 1] = g << 1            # idle slots still tell the round's slice count (sync decision)
+            d[:, :, 1] = (g & 31) << 1     # idle slots still tell the round's slice count (sync decision); 32 slices: 0
             it = np.zeros(n_rounds, np.int32)
             i = np.arange(len(rows))
             rnd, first = i // per_round, (i % per_round) * g
@@ -104,7 +104,7 @@ def _side_rounds(own, cols, n_rows: int, ng: int, per_slice: int, pad_to: int, i
                 j1 = np.minimum(j0 + sl_len[rows], ptr[rows + 1])
                 m = j1 - j0
                 mode = np.where(m <= inline, m, MODE_LIST)
-                meta = (1 if k == 0 else 0) | (g << 1) | (mode << 6) | (cnt[rows] << 9)
+                meta = (1 if k == 0 else 0) | ((g & 31) << 1) | (mode << 6) | (cnt[rows] << 9)
                 slot = d[rnd, first + k]
                 slot[:, 0], slot[:, 1] = rows, meta
                 if len(own):
@@ -184,7 +184,7 @@ class PlanParamsStruct(C.Structure):
 class AltPlanParamsStruct(C.Structure):
     """struct InvPrefAltPlanParams (include/invpref_plan.h)"""
     _fields_ = [('side', C.c_int32), ('per_slice', C.c_int32), ('n_classes', C.c_int32), ('pend_job_min', C.c_int32),
-                ('pend_per_slice', C.c_int32)]
+                ('pend_per_slice', C.c_int32), ('slots', C.c_int32)]
 
 
 _NATIVE = None
@@ -652,8 +652,8 @@ def _meta_of(st: RowPlanStruct, offs: dict) -> list:
 class AltPlanStruct(C.Structure):
     """struct InvPrefAltPlan"""
     _fields_ = [('side', C.c_int32), ('has_prev', C.c_int32), ('has_cur', C.c_int32), ('n', C.c_int32), ('n_prev', C.c_int32),
-                ('lanes_per_group', C.c_int32), ('n_rounds', C.c_int32), ('rounds_per_task', C.c_int32),
-                ('desc', C.c_void_p), ('pend', C.c_void_p), ('list', C.c_void_p), ('push_slot', C.c_void_p),
+                ('lanes_per_group', C.c_int32), ('slots_per_round', C.c_int32), ('n_rounds', C.c_int32),
+                ('rounds_per_task', C.c_int32), ('desc', C.c_void_p), ('pend', C.c_void_p), ('list', C.c_void_p), ('push_slot', C.c_void_p),
                 ('n_stream', C.c_int32), ('rows_per_stream_task', C.c_int32), ('stream', C.c_void_p),
                 ('n_classes', C.c_int32), ('cls', C.c_int32 * 32), ('n_partials_prev', C.c_int32)]
 
@@ -669,13 +669,15 @@ def alt_supported(factor_num: int, env_num: int) -> bool:
 
 def build_alt_plan(cur, prev, side: int, user_num: int, item_num: int, factor_num: int = 64, per_slice: int | None = None,
                    rounds_per_task: int = 1, n_classes: int | None = None, rows_per_stream_task: int | None = None,
-                   n_partials_prev: int = 0, native: bool | None = None) -> dict:
+                   n_partials_prev: int = 0, native: bool | None = None, slots: int = 16) -> dict:
     """cur: (users, items, scores) of the minibatch this launch evaluates, or None (a flush launch); prev: (users, items)
     of the minibatch the previous launch evaluated (from the OTHER side), or None (first launch of a run); side: 0 = the
     user tables evaluate / are updated, 1 = the item tables.  n_partials_prev: job tasks of the previous launch (its
     plan's 'n_tasks')."""
     lanes = 16
-    ng = THREADS // lanes
+    if slots not in (16, 32):
+        raise ValueError('slots per round: 16 (workgroups of 256 threads) or 32 (512 threads)')
+    ng = slots
     own_num = user_num if side == 0 else item_num
     if per_slice is None:
         per_slice = int(os.environ.get('INVPREF_ALT_PER_SLICE_I' if side else 'INVPREF_ALT_PER_SLICE_U', '2'))
@@ -693,14 +695,14 @@ def build_alt_plan(cur, prev, side: int, user_num: int, item_num: int, factor_nu
         cu, ci = (np.ascontiguousarray(cur[0], np.int64), np.ascontiguousarray(cur[1], np.int64)) if has_cur else (z64, z64)
         cy = np.ascontiguousarray(cur[2], np.float32) if has_cur else np.zeros(0, np.float32)
         pu, pi = (np.ascontiguousarray(prev[0], np.int64), np.ascontiguousarray(prev[1], np.int64)) if has_prev else (z64, z64)
-        ps = AltPlanParamsStruct(side, per_slice, n_classes, ALT_PEND_JOB_MIN, ALT_PEND_PER_SLICE)
+        ps = AltPlanParamsStruct(side, per_slice, n_classes, ALT_PEND_JOB_MIN, ALT_PEND_PER_SLICE, slots)
         h = L.invpref_alt_plan_build(cu.ctypes.data, ci.ctypes.data, cy.ctypes.data, len(cu),
                                      pu.ctypes.data if has_prev else None, pi.ctypes.data if has_prev else None, len(pu),
                                      user_num, item_num, C.byref(ps))
         if not h:
             raise ValueError('native alt plan builder: invalid arguments (row ids out of range?)')
         return _alt_from_handle(L, h, side, has_prev, has_cur, len(cu), len(pu), per_slice, n_classes, rows_per_stream_task,
-                                n_partials_prev)
+                                n_partials_prev, slots)
     if has_cur:
         u, i, y = (np.asarray(cur[0], np.int64), np.asarray(cur[1], np.int64), np.asarray(cur[2], np.float32))
         own, oth = (u, i) if side == 0 else (i, u)
@@ -748,6 +750,7 @@ def build_alt_plan(cur, prev, side: int, user_num: int, item_num: int, factor_nu
             act = row >= 0
             rowc = np.where(act, row, 0)
             g = (d[:, :, 1] >> 1) & 31
+            g = np.where(g == 0, 32, g)            # (32 slices are stored as 0)
             k = np.arange(ng)[None, :] % np.maximum(g, 1)
             cp = np.where(act, cntp[rowc], 0)
             ln = -(-cp // np.maximum(g, 1))
@@ -783,13 +786,14 @@ def build_alt_plan(cur, prev, side: int, user_num: int, item_num: int, factor_nu
         sb += len(s_parts[c])
     desc = np.concatenate(d_parts)
     return dict(side=side, has_prev=int(has_prev), has_cur=int(has_cur), n=n, n_prev=n_prev, lanes_per_group=lanes,
-                rounds_per_task=rounds_per_task, desc=desc, pend=np.concatenate(p_parts), list=lst, push_slot=push_slot,
+                slots_per_round=ng, rounds_per_task=rounds_per_task, desc=desc, pend=np.concatenate(p_parts), list=lst, push_slot=push_slot,
                 stream=np.concatenate(s_parts).reshape(-1), n_stream=sb, rows_per_stream_task=rows_per_stream_task,
                 n_classes=n_classes, cls=cls, n_partials_prev=int(n_partials_prev),
                 n_tasks=(len(desc) // rounds_per_task if has_cur else 0), per_slice=per_slice)
 
 
-def _alt_from_handle(L, h, side, has_prev, has_cur, n, n_prev, per_slice, n_classes, rows_per_stream_task, n_partials_prev) -> dict:
+def _alt_from_handle(L, h, side, has_prev, has_cur, n, n_prev, per_slice, n_classes, rows_per_stream_task, n_partials_prev,
+                     slots=16) -> dict:
     out = []
     try:
         for which in range(6):
@@ -799,17 +803,37 @@ def _alt_from_handle(L, h, side, has_prev, has_cur, n, n_prev, per_slice, n_clas
     finally:
         L.invpref_plan_free(h)
     desc, pend, lst, push_slot, stream, cls = out
-    desc = desc.reshape(-1, 16, 8)
+    desc = desc.reshape(-1, slots, 8)
     return dict(side=side, has_prev=int(has_prev), has_cur=int(has_cur), n=int(n), n_prev=int(n_prev), lanes_per_group=16,
-                rounds_per_task=1, desc=desc, pend=pend.reshape(-1, 16, 4), list=lst, push_slot=push_slot, stream=stream,
+                slots_per_round=slots, rounds_per_task=1, desc=desc, pend=pend.reshape(-1, slots, 4), list=lst, push_slot=push_slot, stream=stream,
                 n_stream=len(stream) // 4, rows_per_stream_task=rows_per_stream_task, n_classes=n_classes,
                 cls=cls.reshape(8, 4).copy(), n_partials_prev=int(n_partials_prev), n_tasks=(len(desc) if has_cur else 0),
                 per_slice=per_slice)
 
 
+def alt_slots_for(own_rows: np.ndarray, n_rows: int, per_slice: int, n_classes: int = N_CLASSES) -> int:
+    """Group slots per round for a side's evaluating launches: 32 (workgroups of 512 threads, one per CU: a hot row's
+    interactions spread over up to 32 slices) while such a launch still fits ONE residency of the 256 CUs, else 16 (256
+    threads, three per CU).  own_rows: the side's row of every interaction of a representative minibatch."""
+    forced = os.environ.get('INVPREF_ALT_SLOTS')
+    if forced in ('16', '32'):
+        return int(forced)
+    cnt = np.bincount(np.asarray(own_rows, np.int64), minlength=n_rows)
+    c = cnt[cnt > 0]
+    if len(c) == 0:
+        return 16
+    need = np.maximum(1, -(-c // per_slice))
+    slices = np.minimum(32, 1 << np.ceil(np.log2(need)).astype(np.int64))
+    rounds = sum(-(-int((slices == g).sum()) // (32 // g)) for g in (1, 2, 4, 8, 16, 32))
+    # (per class the round lists are rounded up: allow one round per class and slice count in use)
+    rounds += n_classes * len(np.unique(slices)) // 2
+    return 32 if rounds + 48 <= 256 else 16
+
+
 def build_alt_plans(users: np.ndarray, items: np.ndarray, scores: np.ndarray, specs, user_num: int, item_num: int,
                     factor_num: int = 64, per_slice_u: int | None = None, per_slice_i: int | None = None,
-                    n_classes: int | None = None, rows_per_stream_task: int | None = None, threads: int = 0) -> list:
+                    n_classes: int | None = None, rows_per_stream_task: int | None = None, threads: int = 0,
+                    slots_u: int = 16, slots_i: int = 16) -> list:
     """Many alt plans over the same interaction arrays in one native call (a thread pool): specs = [(cur, prev, side)] with
     cur / prev = (lo, n) ranges of the arrays or None.  Falls back to build_alt_plan per spec without the library."""
     users, items = np.ascontiguousarray(users, np.int64), np.ascontiguousarray(items, np.int64)
@@ -827,17 +851,18 @@ def build_alt_plans(users: np.ndarray, items: np.ndarray, scores: np.ndarray, sp
     def rng(r):
         return None if r is None else (users[r[0]:r[0] + r[1]], items[r[0]:r[0] + r[1]], scores[r[0]:r[0] + r[1]])
     L = _native_lib()
-    if L is None or os.environ.get('INVPREF_PLAN_NATIVE', '1') == '0' or per_slice_u != per_slice_i:
+    if L is None or os.environ.get('INVPREF_PLAN_NATIVE', '1') == '0' or per_slice_u != per_slice_i or slots_u != slots_i:
         return [build_alt_plan(rng(c), None if pv is None else rng(pv)[:2], side, user_num, item_num, factor_num=factor_num,
                                per_slice=per_slice_i if side else per_slice_u, n_classes=n_classes,
-                               rows_per_stream_task=rows_per_stream_task) for c, pv, side in specs]
+                               rows_per_stream_task=rows_per_stream_task, slots=slots_i if side else slots_u)
+                for c, pv, side in specs]
     k = len(specs)
     cur_lo = np.array([0 if c is None else c[0] for c, _, _ in specs], np.int64)
     cur_n = np.array([0 if c is None else c[1] for c, _, _ in specs], np.int64)
     prev_lo = np.array([0 if pv is None else pv[0] for _, pv, _ in specs], np.int64)
     prev_n = np.array([-1 if pv is None else pv[1] for _, pv, _ in specs], np.int64)
     sides = np.array([sd for _, _, sd in specs], np.int32)
-    ps = AltPlanParamsStruct(0, per_slice_u, n_classes, ALT_PEND_JOB_MIN, ALT_PEND_PER_SLICE)
+    ps = AltPlanParamsStruct(0, per_slice_u, n_classes, ALT_PEND_JOB_MIN, ALT_PEND_PER_SLICE, slots_u)
     handles = (C.c_void_p * k)()
     rc = L.invpref_alt_plan_build_many(users.ctypes.data, items.ctypes.data, scores.ctypes.data, cur_lo.ctypes.data,
                                        cur_n.ctypes.data, prev_lo.ctypes.data, prev_n.ctypes.data, sides.ctypes.data, k,
@@ -848,7 +873,7 @@ def build_alt_plans(users: np.ndarray, items: np.ndarray, scores: np.ndarray, sp
                 L.invpref_plan_free(h)
         raise ValueError('native alt plan builder: invalid arguments (row ids out of range?)')
     return [_alt_from_handle(L, handles[j], specs[j][2], specs[j][1] is not None, specs[j][0] is not None, int(cur_n[j]),
-                             max(0, int(prev_n[j])), per_slice_u, n_classes, rows_per_stream_task, 0) for j in range(k)]
+                             max(0, int(prev_n[j])), per_slice_u, n_classes, rows_per_stream_task, 0, slots_u) for j in range(k)]
 
 
 def alt_workgroups(plan: dict) -> int:

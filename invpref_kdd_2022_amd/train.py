@@ -503,8 +503,14 @@ class _InvPrefTrainManager:
             t0 = time.perf_counter()
             u, v, y = self._alt_host
             rng = lambda k: None if k is None else (self._raw_batches[k][0], self._raw_batches[k][1])   # noqa: E731
+            if 'slots' not in A:   # group slots per round of either side's launches, from the first minibatch
+                lo, n0 = self._raw_batches[0][0], self._raw_batches[0][1]
+                ps = (int(os.environ.get('INVPREF_ALT_PER_SLICE_U', '2')), int(os.environ.get('INVPREF_ALT_PER_SLICE_I', '2')))
+                A['slots'] = (planlib.alt_slots_for(u[lo:lo + n0], self.model.user_num, ps[0]),
+                              planlib.alt_slots_for(v[lo:lo + n0], self.model.item_num, ps[1]))
             hps = planlib.build_alt_plans(u, v, y, [(rng(k), rng(kp), side) for kp, k, side in need], self.model.user_num,
-                                          self.model.item_num, factor_num=self.model.factor_num)
+                                          self.model.item_num, factor_num=self.model.factor_num, slots_u=A['slots'][0],
+                                          slots_i=A['slots'][1])
             for key, hp in zip(need, hps):
                 if hp['n_tasks'] > A['partials_cap']:
                     raise _capi.InvPrefError('alt plan: more job tasks than the workspace was sized for')

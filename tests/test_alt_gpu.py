@@ -120,8 +120,10 @@ def check(want, got, tol=2e-5):
     (1, 1, 1, 4, [1, 1, 1]),
 ])
 @pytest.mark.parametrize('implicit', [True, False])
-def test_alternating_steps_equal_two_launch_steps(U, I, E, D, sizes, implicit):
-    want, got = run_both(11 + U + D, U, I, E, D, sizes, implicit=implicit, reps=2)
+@pytest.mark.parametrize('slots', [16, 32])
+def test_alternating_steps_equal_two_launch_steps(U, I, E, D, sizes, implicit, slots):
+    # slots: group slots per round = workgroups of 256 / 512 threads (up to 16 / 32 slices per row)
+    want, got = run_both(11 + U + D, U, I, E, D, sizes, implicit=implicit, reps=2, alt_kw=dict(slots=slots))
     check(want, got[0])
     for a, b in zip(got[0], got[1]):                     # every sum in a fixed order: run-to-run bitwise
         np.testing.assert_array_equal(a, b)
@@ -144,7 +146,8 @@ def test_alternating_steps_pure_mf(D):
 
 def test_alternating_steps_yahoo_shape_and_workspace_bounds():
     d = synth.YAHOO_SHAPE
-    want, got = run_both(17373331, d['user_num'], d['item_num'], 4, 64, [8192] * 6 + [4394], reps=2, guard=True)
+    want, got = run_both(17373331, d['user_num'], d['item_num'], 4, 64, [8192] * 6 + [4394], reps=2, guard=True,
+                         alt_kw=dict(slots=32))
     check(want, got[0])
     for a, b in zip(got[0], got[1]):
         np.testing.assert_array_equal(a, b)
@@ -164,7 +167,7 @@ def test_alternating_steps_random_shapes_and_plans(seed):
         E = 1
     fl = tuple(bool(rs.randint(2)) for _ in range(4))
     kw = dict(per_slice=int(rs.choice([1, 2, 3, 8])), n_classes=int(rs.choice([1, 3, 8])),
-              rows_per_stream_task=int(rs.choice([1, 16, 32, 64, 200])))
+              rows_per_stream_task=int(rs.choice([1, 16, 32, 64, 200])), slots=int(rs.choice([16, 32])))
     want, got = run_both(100 + seed, U, I, E, D, sizes, implicit=bool(rs.randint(2)), pure=pure, fl=fl, alt_kw=kw,
                          zipf=bool(rs.randint(2)), guard=bool(seed % 4 == 0))
     check(want, got[0], tol=5e-5)
@@ -172,7 +175,8 @@ def test_alternating_steps_random_shapes_and_plans(seed):
 
 def test_plan_parameters_change_nothing_but_the_order_of_sums():
     base = None
-    for kw in (dict(), dict(per_slice=1), dict(per_slice=5, n_classes=1), dict(rows_per_stream_task=7, n_classes=3)):
+    for kw in (dict(), dict(per_slice=1), dict(per_slice=5, n_classes=1), dict(rows_per_stream_task=7, n_classes=3),
+               dict(slots=32), dict(slots=32, per_slice=1, n_classes=1)):
         want, got = run_both(3, 700, 120, 4, 64, [3000, 3000, 3000, 2000], alt_kw=kw)
         check(want, got[0])
         if base is not None:

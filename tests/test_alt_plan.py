@@ -5,11 +5,12 @@ import pytest
 
 from invpref_kdd_2022_amd import plan as planlib, synth
 
-NG = 16
 
 
 def check_alt(cur, prev, side, U, I, **kw):
     p = planlib.build_alt_plan(cur, prev, side, U, I, **kw)
+    NG = p['slots_per_round']
+    assert NG == kw.get('slots', 16)
     own_num = U if side == 0 else I
     has_cur, has_prev = cur is not None, prev is not None
     assert p['has_cur'] == int(has_cur) and p['has_prev'] == int(has_prev) and p['side'] == side
@@ -46,13 +47,13 @@ def check_alt(cur, prev, side, U, I, **kw):
     seen_pos, job_rows, pend_cover = [], [], np.zeros(int(ptrp[-1]), np.int64)
     for r in range(len(desc)):
         meta0 = desc[r, 0, 1]
-        slices = (meta0 >> 1) & 31
+        slices = ((meta0 >> 1) & 31) or 32            # (32 slices are stored as 0)
         assert slices >= 1 and (slices & (slices - 1)) == 0
         flag = bool(meta0 < 0)
         any_pend = False
         for s in range(NG):
             row, meta = int(desc[r, s, 0]), int(desc[r, s, 1])
-            assert ((meta >> 1) & 31) == slices and bool(meta < 0) == flag   # round-uniform: the barriers depend on them
+            assert (((meta >> 1) & 31) or 32) == slices and bool(meta < 0) == flag   # round-uniform: the barriers depend on them
             if row < 0:
                 assert (pend[r, s] == 0).all()
                 continue
@@ -115,6 +116,7 @@ def test_alt_plan_yahoo_shape(side):
     d = synth.yahoo_like()
     mb = lambda k: (d[k * B:(k + 1) * B, 0], d[k * B:(k + 1) * B, 1], d[k * B:(k + 1) * B, 2].astype(np.float32))  # noqa: E731
     check_alt(mb(1), None, side, U, I)
+    check_alt(mb(1), mb(0)[:2], side, U, I, slots=32)
     p = check_alt(mb(1), mb(0)[:2], side, U, I, n_partials_prev=7)
     assert p['n_partials_prev'] == 7
     check_alt(None, mb(1)[:2], side, U, I)
@@ -131,7 +133,7 @@ def test_alt_plan_random_small(seed):
     n, n_prev = int(rs.randint(1, 700)), int(rs.randint(1, 700))
     cur, prev = _mb(seed, n, U, I, zipf=bool(seed & 1)), _mb(100 + seed, n_prev, U, I, zipf=bool(seed & 2))
     for side in (0, 1):
-        kw = dict(per_slice=int(rs.randint(1, 5)), n_classes=int(rs.choice([1, 2, 8])))
+        kw = dict(per_slice=int(rs.randint(1, 5)), n_classes=int(rs.choice([1, 2, 8])), slots=int(rs.choice([16, 32])))
         check_alt(cur, None, side, U, I, **kw)
         check_alt(cur, prev[:2], side, U, I, **kw)
         check_alt(None, prev[:2], side, U, I, **kw)

@@ -45,8 +45,8 @@ def test_struct_layouts_match_header():
     fields = re.sub(r'\[\d+\]', '', fields)
     names = re.findall(r'[\*\s,](\w+)\s*(?=[,;])', fields)
     assert names == [f[0] for f in planlib.RowPlanStruct._fields_]
-    # InvPrefAltPlan: 8 int32, 4 ptr, 2 int32, 1 ptr, int32, int32[8][4], int32 (+ padding to 8)
-    assert C.sizeof(planlib.AltPlanStruct) == 8 * 4 + 4 * 8 + 8 + 8 + 4 + 32 * 4 + 4
+    # InvPrefAltPlan: 9 int32 (+ 4 padding), 4 ptr, 2 int32, 1 ptr, int32, int32[8][4], int32 (+ padding to 8)
+    assert C.sizeof(planlib.AltPlanStruct) == 9 * 4 + 4 + 4 * 8 + 8 + 8 + 4 + 32 * 4 + 4
     fields = re.search(r'typedef struct InvPrefAltPlan \{(.*?)\} InvPrefAltPlan;', HEADER, re.S).group(1)
     fields = re.sub(r'/\*.*?\*/', '', fields, flags=re.S)
     fields = re.sub(r'\[\d+\]', '', fields)
@@ -71,7 +71,8 @@ def test_argument_validation_without_a_device(lib):
     cf = _capi.Coefs(1, 1, 1, 0, 0, 0)
     assert L.invpref_mstep_alt_hip(C.byref(t), C.byref(t), C.byref(t), None, None, None, 8, 8, C.byref(cf), 1, None, 1, 0.01,
                                    0.9, 0.999, 1e-8, None, None, 0, 8, 8, 0, None) == -1
-    ap = planlib.AltPlanStruct(side=0, has_prev=0, has_cur=1, n=4, n_prev=0, lanes_per_group=16, n_rounds=0, rounds_per_task=2)
+    ap = planlib.AltPlanStruct(side=0, has_prev=0, has_cur=1, n=4, n_prev=0, lanes_per_group=16, slots_per_round=16, n_rounds=0,
+                               rounds_per_task=2)
     assert L.invpref_mstep_alt_hip(C.byref(t), C.byref(t), C.byref(t), C.byref(ap), 1, None, 8, 8, C.byref(cf), 1, None, 1, 0.01,
                                    0.9, 0.999, 1e-8, None, 1, 1 << 20, 8, 8, 0, None) == -1     # rounds_per_task must be 1
     wide = _capi.Tables(10, 10, 8, 128, 1, 1, 1, 1, 1, 1, 1)

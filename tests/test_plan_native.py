@@ -147,7 +147,7 @@ def test_native_alt_plans_equal_numpy_alt_plans(seed):
     prev = synth.interactions(50 + seed, U, I, n_prev, implicit=True, zipf=bool(seed & 2))
     c3 = (cur[:, 0], cur[:, 1], cur[:, 2].astype(np.float32))
     kw = dict(per_slice=int(rs.choice([1, 2, 3, 8])), n_classes=int(rs.choice([1, 3, 8])),
-              rows_per_stream_task=int(rs.choice([1, 32, 100])))
+              rows_per_stream_task=int(rs.choice([1, 32, 100])), slots=int(rs.choice([16, 32])))
     for side in (0, 1):
         for c, p in ((c3, None), (c3, (prev[:, 0], prev[:, 1])), (None, (prev[:, 0], prev[:, 1]))):
             _alt_same(planlib.build_alt_plan(c, p, side, U, I, native=True, **kw),

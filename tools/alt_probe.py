@@ -65,11 +65,16 @@ def run_two(P, P2, M, V, losses):
 
 
 # ---- the alternating form: launch c evaluates minibatch c from side c % 2; a flush ends the run
+SLOTS = (planlib.alt_slots_for(mb(0)[0], U, 2), planlib.alt_slots_for(mb(0)[1], I, 2))
+if os.environ.get('PROBE_SLOTS'):
+    SLOTS = tuple(int(x) for x in os.environ['PROBE_SLOTS'].split(','))
 apl = []
 for c in range(nb):
     prev = None if c == 0 else mb(c - 1)[:2]
-    apl.append(planlib.build_alt_plan(mb(c), prev, c % 2, U, I, factor_num=D, n_partials_prev=apl[-1]['n_tasks'] if c else 0))
-apl.append(planlib.build_alt_plan(None, mb(nb - 1)[:2], nb % 2, U, I, factor_num=D, n_partials_prev=apl[-1]['n_tasks']))
+    apl.append(planlib.build_alt_plan(mb(c), prev, c % 2, U, I, factor_num=D, n_partials_prev=apl[-1]['n_tasks'] if c else 0,
+                                      slots=SLOTS[c % 2]))
+apl.append(planlib.build_alt_plan(None, mb(nb - 1)[:2], nb % 2, U, I, factor_num=D, n_partials_prev=apl[-1]['n_tasks'],
+                                  slots=SLOTS[nb % 2]))
 aplans = [planlib.upload_alt(p, dev) for p in apl]
 aws = ops.AltWorkspace(P0, B, max(p['n_tasks'] for p in apl) + 1)
 
@@ -86,7 +91,7 @@ def fresh():
     return [p.clone() for p in P0], [torch.zeros_like(p) for p in P0], [torch.zeros_like(p) for p in P0]
 
 
-print(f'shape U={U} I={I} E={E} D={D} B={B}, {nb} steps; alt workgroups: ' +
+print(f'shape U={U} I={I} E={E} D={D} B={B}, {nb} steps; slots per round (users, items) {SLOTS}; alt workgroups: ' +
       ' '.join(f'{"UI"[p["side"]]}{planlib.alt_workgroups(p) + 40}' for p in apl[:4]) + ' ... flush ' +
       f'{planlib.alt_workgroups(apl[-1]) + 40}; two-launch {planlib.launch_workgroups(pls[0], 0)} + {planlib.launch_workgroups(pls[0], 1)}')
 
@@ -225,7 +230,7 @@ for rep in range(2):
             wg = planlib.alt_workgroups(pl) + 40
             st = raw[:wg]
             kind = np.full(wg, 'pad', dtype=object)
-            kind[:33] = 'fold'
+            kind[:33] = "fold"
             for bk in range(40, wg):
                 cc, j = (bk - 40) % ncls, (bk - 40) // ncls
                 tj = int(cls[cc, 1])

@@ -108,6 +108,63 @@ def rocprof_avg_ms(kernel_names):
     return tot if len(seen) == len(kernel_names) else None
 
 
+def alt_profile_figures():
+    """The alternating form in the committed profile (profiles/rNN): every steady-state launch of mstep_alt_kernel is ONE
+    optimiser step, so the per-step figures are launch-weighted means over its instances (256- and 512-thread workgroups =
+    user-side and item-side launches).  Returns (avg launch ms from `rocprofv3 --kernel-trace --stats`, L2<->fabric bytes
+    per launch from the separate --pmc FETCH_SIZE / WRITE_SIZE passes, stamp)."""
+    import csv
+    import glob
+    dirs = sorted(d for d in glob.glob(os.path.join(ROOT, 'profiles', 'r*')) if os.path.exists(os.path.join(d, 'alt_pmc_fetch_summary.csv')))
+    if not dirs:
+        return None, None, None
+    src = dirs[-1]
+    steady = lambda name: 'mstep_alt_kernel' in name and ', 3,' in name     # noqa: E731  (MODE 3: previous + current step)
+    ms = None
+    f = os.path.join(src, 'rocprofv3_kernel_stats_bench_graph.csv')
+    if os.path.exists(f):
+        rows = [r for r in csv.DictReader(open(f)) if steady(r['Name'])]
+        calls = sum(int(r['Calls']) for r in rows)
+        if calls:
+            ms = sum(float(r['TotalDurationNs']) for r in rows) / calls * 1e-6
+    tot = 0.0
+    for cname, scale in (('FETCH_SIZE', 2048.0), ('WRITE_SIZE', 1024.0)):   # KiB; gfx950 counts 128-byte reads as 64
+        rows = [r for r in csv.DictReader(open(os.path.join(src, f'alt_pmc_{cname.split("_")[0].lower()}_summary.csv')))
+                if steady(r['kernel']) and r['counter'] == cname]
+        n = sum(int(r['launches']) for r in rows)
+        if not n:
+            return ms, None, None
+        tot += sum(float(r['mean_value']) * int(r['launches']) for r in rows) / n * scale
+    stamp = {'profile': os.path.relpath(src, ROOT)}
+    try:
+        stamp.update(json.load(open(os.path.join(src, 'STAMP.json'))))
+    except (OSError, ValueError):
+        pass
+    return ms, tot, stamp
+
+
+def large_profile_figures():
+    """roofline_large's traffic: L2<->fabric bytes and the rocprofv3 duration of the fused step's launches at 2^24
+    interactions, D = 64 (profiles/rNN/large24_*), or (None, None, None)."""
+    import csv
+    import glob
+    dirs = sorted(d for d in glob.glob(os.path.join(ROOT, 'profiles', 'r*')) if os.path.exists(os.path.join(d, 'large24_pmc_summary.csv')))
+    if not dirs:
+        return None, None, None
+    tot, dur = 0.0, None
+    rows = list(csv.DictReader(open(os.path.join(dirs[-1], 'large24_pmc_summary.csv'))))
+    for cname, scale in (('FETCH_SIZE', 2048.0), ('WRITE_SIZE', 1024.0)):
+        sel = [r for r in rows if r['counter'] == cname and 'D64' in r['kernel'] and 'mstep_' in r['kernel']]
+        if not sel:
+            return None, None, None
+        tot += sum(float(r['mean_value']) for r in sel) * scale        # (both launches of the step)
+    f = os.path.join(dirs[-1], 'large24_kernel_durations.csv')
+    if os.path.exists(f):
+        sel = [r for r in csv.DictReader(open(f)) if 'D64' in r['shape'] and 'mstep_' in r['kernel']]
+        dur = sum(float(r['mean_us']) for r in sel) * 1e-3 if sel else None
+    return tot, dur, os.path.relpath(dirs[-1], ROOT)
+
+
 def cpu_baseline():
     """The oracle's all-core (OpenMP) loops on the same Yahoo-shaped workload on this box's host cores: M-step
     (gradient + dense Adam) epochs and the E-step, all cores and one core, min of N (SURVEY.md §8(d);
@@ -304,7 +361,17 @@ def device_step_times(mgr, world):
     mgr.cluster(sync=False); mgr.stat_envs(sync=False)
     e1.record()
     torch.cuda.synchronize()
-    return ms_step, e0.elapsed_time(e1)
+    ms_eager = e0.elapsed_time(e1)     # (an eagerly issued cluster(): the host's permutation draws sit inside)
+    # the E-step as the timed loop runs it: one replay of the captured graph (device time, HIP events around each replay)
+    ms_replay = None
+    if world == 1 and mgr.graphs_enabled() and not mgr._pure:
+        g, _, _ = mgr._estep_graph(mgr.cluster_use_random_sort)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
+        for i, (a, b) in enumerate(evs):
+            a.record(); g.replay(); b.record()
+        torch.cuda.synchronize()
+        ms_replay = sorted(a.elapsed_time(b) for a, b in evs[2:])[5]
+    return ms_step, ms_eager, ms_replay
 
 
 def eager_kernel_times(mgr):
@@ -450,7 +517,12 @@ def roofline_large(dev):
     head = dict(res['D64_E4'])
     head['sweep'] = {k: {kk: v[kk] for kk in keep} for k, v in res.items()}
     head['sweep_r03_sizes'] = small
-    head['traffic'] = None
+    # L2 <-> fabric bytes of the D = 64 launch pair at THIS size, from the committed profile (separate PMC passes) with its
+    # rocprofv3 duration beside it
+    tr, dur, src = large_profile_figures()
+    head['traffic'] = tr
+    head['traffic_profile'] = src
+    head['rocprofv3_ms_per_step'] = dur
     return head
 
 
@@ -645,10 +717,15 @@ def main():
     dt, steps, warm_steps, graphs = timed_run(mgr, world, args.steps, args.warmup)
     inter = steps * B_PER_GPU * world
     value = inter / dt
-    ms_step_dev, ms_estep = device_step_times(mgr, world)
+    ms_step_dev, ms_estep_eager, ms_estep_replay = device_step_times(mgr, world)
     n_local = mgr.users_tensor.shape[0]
+    ms_estep = ms_estep_replay if ms_estep_replay else ms_estep_eager
     detail = {'mstep_interactions_per_s_per_gpu': B_PER_GPU / (ms_step_dev * 1e-3),
+              # the E-step rate from ONE REPLAY of the captured E-step (what the timed loop runs); the eagerly issued cluster()
+              # -- the host's numpy permutation draws inside the interval -- beside it
               'estep_interactions_per_s_per_gpu': n_local / (ms_estep * 1e-3), 'estep_ms': ms_estep,
+              'estep_timing': 'graph replay' if ms_estep_replay else 'eager cluster()',
+              'estep_eager_ms': ms_estep_eager, 'estep_eager_interactions_per_s_per_gpu': n_local / (ms_estep_eager * 1e-3),
               'timed_seconds': dt}
     detail.update(eager_kernel_times(mgr))
 
@@ -658,10 +735,17 @@ def main():
     # 4 row reads, 4 gradient-row adds) + Adam 32P (28 B/param + 4 B zeroing).  The fused owner pass never
     # stores the gradient, so it is priced at what it must move: B*(32+16D) + 24P (p,m,v read; p',m',v' written).
     bytes_survey = B_PER_GPU * (32 + 32 * D) + 32 * P
+    alt = fused and getattr(mgr, '_alt', None) is not None     # ONE launch per step, the evaluating side alternating
     if fused:
         nbytes = B_PER_GPU * (32 + 16 * D) + 24 * P
         kname, knames = 'mstep_eval_kernel', ['mstep_eval_kernel', 'mstep_apply_kernel']
         what = 'the whole optimiser step: mstep_eval_kernel (user jobs: evaluation, records, fused Adam) + mstep_apply_kernel (item jobs, fold, fused Adam)'
+        if alt:
+            kname, knames = 'mstep_alt_kernel', ['mstep_alt_kernel']
+            what = ('the whole optimiser step = ONE launch of mstep_alt_kernel (csrc/step_alt.hpp): the evaluating side -- users '
+                    'on even steps, items on odd ones -- applies the previous step\'s pending update to its rows, evaluates, '
+                    'applies its own update and pushes contribution rows for the other side; fold blocks at the head of the '
+                    'launch finish the small tables of the previous step')
     else:
         nbytes = bytes_survey
         kname = 'mstep_eval_kernel' if mgr.use_plan else 'mstep_atomic_kernel'
@@ -676,25 +760,42 @@ def main():
         untouched = sum(int(x) for dp in mgr._plans for x in dp.struct.defer_tail) / len(mgr._plans)
     nbytes_touched = nbytes - 24 * 2 * D * untouched
     traffic, traffic_stamp = pmc_traffic_bytes(knames) if world == 1 else (None, None)
+    rocprof_ms = rocprof_avg_ms(knames) if world == 1 else None      # (the committed profiles are 1-GPU runs)
+    if alt:
+        rocprof_ms, traffic, traffic_stamp = alt_profile_figures()
     roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_profile': traffic_stamp,
-                'traffic_unit': 'bytes/step, both launches (rocprofv3 PMC, FETCH_SIZE x 2 + WRITE_SIZE)', 'kernel': what,
+                'traffic_unit': 'bytes/step (rocprofv3 PMC, FETCH_SIZE x 2 + WRITE_SIZE, separate passes)', 'kernel': what,
                 'avg_launch_ms': ms_step_dev, 'algorithmic_bytes_per_launch': nbytes,
+                'yardstick_note': 'algorithmic_bytes_per_launch is the UNCHANGED yardstick of rounds 3-4, B(32 + 16 D) + 24 P: '
+                                  'ids / labels / weights + 4 row reads per interaction, p, m, v read and written once per step',
                 'timing': 'HIP events on the launch stream around replays of whole-epoch graphs, per step '
                           '(kernel boundaries included)' if graphs else 'HIP events on the launch stream around '
                           'whole eagerly issued epochs, per step',
                 'cache_resident': True,
-                'cache_note': 'all five flat buffers (42 MB) sit in the 256 MiB Infinity Cache at this size: the 8 TB/s '
+                'cache_note': 'all flat buffers (34 MB) sit in the 256 MiB Infinity Cache at this size: the 8 TB/s '
                               'HBM peak is the yardstick north_star names, not the level that serves the bytes; '
                               'roofline_large is the cache-exceeding launch',
-                'rocprofv3_avg_launch_ms': rocprof_avg_ms(knames) if world == 1 else None,   # (the committed profiles are 1-GPU runs)
-                'rocprofv3_note': 'sum of the average durations of the kernels of one step in the committed profile of this command',
+                'rocprofv3_avg_launch_ms': rocprof_ms,
+                'rocprofv3_note': 'launch-weighted mean duration of the step\'s kernel(s) in the committed profile of this command',
                 'GBs_at_survey_unfused_pricing': bytes_survey / (ms_step_dev * 1e-3) / 1e9,
                 'touched_rows_model': {'bytes_per_launch': nbytes_touched, 'untouched_user_rows_per_step': untouched,
                                        'achieved': nbytes_touched / (ms_step_dev * 1e-3) / 1e9,
                                        'frac': nbytes_touched / (ms_step_dev * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                        'note': 'untouched user rows not counted (what deferred Adam would move); the run '
                                                'itself is the dense form'}}
+    if alt:
+        # the second byte model: what the ALTERNATING form itself has to move per step -- per interaction ids /
+        # labels / weights, 2 partner rows gathered, 2 contribution rows written and read back; the big tables' p, m, v read
+        # and written once per TWO steps; the small tables every step -- so that the gain cannot hide in the denominator
+        p_small = 2 * E * D + E
+        alt_bytes = B_PER_GPU * (32 + 24 * D) + 12 * (P - p_small) + 24 * p_small
+        roofline['alt_byte_model'] = {'bytes_per_launch': alt_bytes, 'achieved': alt_bytes / (ms_step_dev * 1e-3) / 1e9,
+                                      'frac': alt_bytes / (ms_step_dev * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      'note': 'B(32 + 24 D) + 12 P_big + 24 P_small: the alternating form streams a side\'s rows '
+                                              'once per two steps and passes the other side\'s gradient through contribution rows'}
+        roofline['alt'] = {'plans': len(mgr._alt['plans']), 'plan_build_s': mgr._alt['build_s'],
+                           'slots_per_round_users_items': list(mgr._alt.get('slots', ())), 'fold_flag_timeouts': mgr.alt_error()}
     out = {
         'metric': 'training interactions/sec, Yahoo-implicit InvPref', 'value': value, 'unit': 'interactions/s',
         'n_gpus': world, 'steps': steps, 'steps_requested': args.steps, 'warmup': warm_steps,
@@ -745,6 +846,12 @@ def main():
         torch.cuda.empty_cache()
         out['roofline_large'] = roofline_large(dev)
         out['detail']['configs'] = other_configs(dev)
+        # the other configurations INSIDE the record the driver keeps (parsed.roofline): whole-step fractions of 8 TB/s
+        rl = out['roofline_large']
+        out['roofline']['configs'] = {k: {'frac': v['frac'], 'ms_per_step': v['ms_per_step']} for k, v in out['detail']['configs'].items()}
+        out['roofline']['configs'].update({f'large_2p24_{k}': {'frac': v['frac'], 'ms_per_step': v['ms_per_step']}
+                                           for k, v in rl['sweep'].items()})
+        out['roofline']['configs']['large_2p24_traffic_D64_E4'] = rl.get('traffic')
         out['detail']['evaluation'] = eval_timing(dev)
         est = estep_random_sort_timing(dev)
         out['detail']['estep_random_sort_ms'] = est['estep_random_sort_ms']

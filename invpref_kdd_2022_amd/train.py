@@ -373,6 +373,7 @@ class _InvPrefTrainManager:
     # row plans of caller-supplied minibatches, keyed by the identity of the tensors they were built from: (data_ptr,
     # length, _version) of users / items / scores -- a slice of a resident tensor that nobody has written to keeps all three
     _BATCH_PLAN_CACHE_MAX = 4096
+    _BATCH_PLAN_CACHE_MAX_FOREIGN = 128
 
     def _cached_batch_plan(self, users, items, scores):
         if not (self.use_plan and self.world_size == 1 and not self._unfused and not self._force_sharded_path
@@ -380,14 +381,31 @@ class _InvPrefTrainManager:
                 and os.environ.get('INVPREF_NO_BATCH_PLAN_CACHE', '0') != '1'):
             return None
         key = tuple(x for t in (users, items, scores) for x in (t.data_ptr(), t.numel(), t._version, t.dtype))
+        # The identity of a tensor (address, length, version counter) names its CONTENT only while the memory is the
+        # manager's own: a slice of the resident interaction arrays (what the reference's loop hands over, train.py:204-233)
+        # cannot be freed and reallocated behind the manager's back.  Any other tensor -- a freshly allocated batch comes
+        # back from the caching allocator at the same address with version 0 -- is keyed by an order-sensitive checksum of its
+        # ids and scores as well (three small kernels and a read-back per step), is planned at its SECOND sighting only,
+        # and shares a small cache.
+        resident = all(any(t.untyped_storage().data_ptr() == r.untyped_storage().data_ptr()
+                           for r in (self.users_tensor, self.items_tensor, self.scores_tensor)) for t in (users, items, scores))
+        if not resident:
+            n = users.numel()
+            pos = getattr(self, '_batch_pos', None)
+            if pos is None or pos.numel() < n:
+                pos = self._batch_pos = torch.arange(max(n, 1 << 16), dtype=torch.int64, device=users.device) * 2654435761 + 1
+            mix = users.to(torch.int64) * 40503 + items.to(torch.int64) * 1000003 + \
+                scores.float().contiguous().view(torch.int32).to(torch.int64)
+            # (the content IS the key: addresses and version counters of foreign tensors say nothing)
+            key = ('foreign', n, users.dtype, items.dtype, int((mix * pos[:n]).sum().item()))
         hit = self._batch_plans.get(key)
         if hit is None:
-            if len(self._batch_plans) >= self._BATCH_PLAN_CACHE_MAX:
+            if len(self._batch_plans) >= (self._BATCH_PLAN_CACHE_MAX if resident else self._BATCH_PLAN_CACHE_MAX_FOREIGN):
                 self._batch_plans.clear()
             # first sighting: with the native builder a plan costs about a millisecond (and the ids' trip to the host), so it
             # is made at once -- INVPREF_BATCH_PLAN_AT=2 waits for the second sighting (a caller that never repeats a
             # minibatch pays nothing for plans it would not reuse) and runs the first one plan-free
-            if os.environ.get('INVPREF_BATCH_PLAN_AT', '1') != '1' or planlib._native_lib() is None:
+            if os.environ.get('INVPREF_BATCH_PLAN_AT', '1') != '1' or planlib._native_lib() is None or not resident:
                 self._batch_plans[key] = 1
                 return None
             hit = 1

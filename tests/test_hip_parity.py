@@ -14,6 +14,11 @@ import torch
 from invpref_kdd_2022_amd import ops, synth
 from oracle import oracle as O
 
+# g5 (MIND shape, one step against the reference's recorded gradients): embed_env's gradient -- per environment a sum over
+# ~16 000 interactions in fp32 against the reference's fp32 autograd -- is the one entry above 2e-5 of the table's largest:
+# measured 1.45e-4 (INVPREF_TOL_REPORT=1 prints every table's error; the classifier's is 8e-8), bound = 2 x that.
+TOL_G5_EMBED_ENV = 3e-4
+
 pytestmark = pytest.mark.gpu
 
 G = os.path.join(os.path.dirname(__file__), 'golden')
@@ -274,7 +279,9 @@ def test_rows_path_mind_shape_g5():
             ref, got = z['grows_' + k], g[z['irows']]
         else:
             ref, got = z['g_' + k], g
-        tol = 2e-5 if 'embed_' in k and 'env.' not in k else 3e-4
+        tol = TOL_G5_EMBED_ENV if 'embed_env.' in k else 2e-5
+        if os.environ.get('INVPREF_TOL_REPORT'):
+            print(f'TOL g5 {k}: measured {np.abs(got - ref).max() / np.abs(ref).max():.3e} (bound {tol:.1e})')
         assert np.abs(got - ref).max() < tol * np.abs(ref).max() + 1e-9, k
 
 

@@ -3,6 +3,8 @@
 MovieLens at full size (g14: 6 040 x 3 706, E=8, D=128, minibatch 65 536, scheduled alpha, graph replay).
 Tolerances: tests/large_traj_fixture.py (1e-5 on the data-loss terms; report terms bounded by the reference's own
 measured error / thread spread); E-step: bit-exact vs the oracle on the same tables, near-tie rule vs the reference."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -11,6 +13,10 @@ from invpref_kdd_2022_amd.models import InvPrefImplicit
 from invpref_kdd_2022_amd.train import ImplicitTrainManager
 from large_traj_fixture import check_losses, exact_reg_terms, load
 from oracle import oracle as O
+
+# share of the rows an E-step may assign differently from the reference after the recorded trajectory (every such row has a
+# relative distance gap < 2e-5, checked on a sample): 2 x the measured share (INVPREF_TOL_REPORT=1 prints it)
+MAX_MISMATCH_SHARE = {'g13': 3e-5, 'g14': 6.5e-3}     # measured: 8 of 786 432 rows = 1.0e-5; 3 240 of 1 048 576 = 3.1e-3
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda:0')
@@ -61,7 +67,9 @@ def test_manager_vs_reference_large_trajectory(case):
     if len(mm):
         assert ((dist[mm, ref[sel][mm]] - dist[mm, on[mm]]) / dist[mm, on[mm]]).max() < 2e-5
     total_mm = int((got != ref).sum())
-    assert total_mm < 0.01 * n and abs(diff - int(z['diff_num'])) <= total_mm
+    if os.environ.get('INVPREF_TOL_REPORT'):
+        print(f'TOL large trajectory {case}: rows assigned differently from the reference {total_mm} of {n} = {total_mm / n:.2e}')
+    assert total_mm < MAX_MISMATCH_SHARE[case] * n and abs(diff - int(z['diff_num'])) <= total_mm
     assert np.abs(np.array([cnt[e] for e in range(E)]) - z['counts']).sum() <= 2 * total_mm
     lr = float(cf[6])
     for k in O.PARAM_NAMES:

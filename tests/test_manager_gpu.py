@@ -132,6 +132,48 @@ def test_reference_loop_through_train_a_batch_is_planned_from_its_second_epoch(m
     assert mgr.planned_batch_steps == before + (plan_at == '1')   # (a new minibatch: planned anew, or plan-free once)
 
 
+def test_freshly_allocated_batches_never_run_a_stale_plan():
+    """a caller that hands train_a_batch freshly allocated tensors (a shuffled index_select per step) gets the
+    same ADDRESS back from the caching allocator with version 0 for a DIFFERENT minibatch.  Such tensors are keyed by an
+    order-sensitive checksum of their content as well and planned at their second sighting: every step must equal the step a
+    plan-free manager takes on the same batch (train.py:94-167)."""
+    z = np.load(os.path.join(G, 'g4_yahoo_like_traj.npz'))
+    U, I, E, D, bs, epochs, seed = [int(x) for x in z['meta']]
+    data = synth.yahoo_like(seed)[:20000]
+    tabs = synth.tables(seed + 7, U, I, E, D, std=0.05)
+    runs = []
+    for no_cache in ('0', '1'):
+        os.environ['INVPREF_NO_BATCH_PLAN_CACHE'] = no_cache
+        try:
+            model = InvPrefImplicit(U, I, E, D, reg_only_embed=True, reg_env_embed=False)
+            model.load_state_dict({k: torch.from_numpy(tabs[k]) for k in O.PARAM_NAMES})
+            np.random.seed(seed)
+            mgr = _mgr(ImplicitTrainManager, model, data, z, use_class_re_weight=True, use_recommend_re_weight=False)
+            mgr.stat_envs()
+            rs = np.random.RandomState(5)
+            perms = [torch.from_numpy(rs.permutation(4096)).to(DEV) for _ in range(3)]
+            seq = [0, 1, 0, 2, 1, 0, 0, 2]      # repeats: the second sighting of a permutation is planned
+            trace, addrs = [], set()
+            for j in seq:
+                idx = perms[j]
+                bu, bi = mgr.users_tensor.index_select(0, idx), mgr.items_tensor.index_select(0, idx)   # fresh allocations
+                by, be, bw = mgr.scores_tensor.index_select(0, idx), mgr.envs.index_select(0, idx), mgr.sample_weights.index_select(0, idx)
+                addrs.add(bu.data_ptr())
+                d = mgr.train_a_batch(bu, bi, by, be, bw, mgr.alpha)
+                trace.append([d[k] for k in LOSS_KEYS])
+                del bu, bi, by, be, bw
+            runs.append((np.array(trace), mgr.planned_batch_steps, len(addrs),
+                         {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}))
+        finally:
+            os.environ.pop('INVPREF_NO_BATCH_PLAN_CACHE', None)
+    (tr_c, planned_c, n_addr, sd_c), (tr_n, planned_n, _, sd_n) = runs
+    assert planned_n == 0 and planned_c == 5          # sightings 2.. of permutations 0 (x3), 1 and 2
+    assert n_addr < len(set([0, 1, 2])) + 2           # (the allocator did hand the same addresses back)
+    np.testing.assert_allclose(tr_c, tr_n, rtol=2e-5)
+    for k in O.PARAM_NAMES:
+        _assert_same_run(np.abs(sd_c[k] - sd_n[k]), float(z['coefs'][6]), k)
+
+
 def test_g12_train_control_flow_matches_reference():
     """train()'s outer loop (train.py:282-342): which epochs evaluate (evaluate_interval, test_begin_epoch), which cluster
     (cluster_interval inside [begin_cluster_epoch, stop_cluster_epoch), diff_num 0 recorded outside) -- the lists the

@@ -577,7 +577,8 @@ template <typename IT>
 __global__ __launch_bounds__(256) void eps_unrank_kernel(const IT *__restrict__ idx, int64_t N, int E, Factorials fac,
                                                          unsigned long long *__restrict__ packed) {
     for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < N; s += (int64_t)gridDim.x * blockDim.x)
-        packed[s] = unrank_packed((unsigned long long)idx[s], E, fac);
+        // (an index outside [0, E!) -- the reference's np.random.randint cannot draw one -- is clamped, not followed past the table)
+        packed[s] = unrank_packed(min((unsigned long long)idx[s], fac.f[E] - 1ull), E, fac);
 }
 // up to seven environments (7! = 5 040 rows): the E-step's workgroups unrank EVERY row of the permutation table into LDS
 // once (4 bytes each) and look an interaction's row up there -- no unranking launch, no packed rows through memory
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
         // the tie-break vector is element (packed >> 4 l16) & 15 of it (eps_unrank_kernel)
         if (eps_packed && l16 < t.E) dist = dist + sbase[(eps_packed[s] >> (4 * l16)) & 15ull];
         if (eps_index && l16 < t.E)   // (E <= 7: the row looked up in the workgroup's LDS table)
-            dist = dist + sbase[(stab[sidx[s - s_begin]] >> (4 * l16)) & 15u];
+            dist = dist + sbase[(stab[min(sidx[s - s_begin], (unsigned)(eps_rows_n - 1))] >> (4 * l16)) & 15u];   // (clamped: see eps_unrank_kernel)
         // argmin with the lowest index among equal minima (torch.argmin; the sequential `dist < best` scan)
         // A NaN distance wins, the first one if there are several (torch.argmin's LessOrNan; only reachable with
         // NaN parameters) -- row16_min ignores NaNs, so the lowest NaN lane is found separately.
@@ -1204,12 +1205,17 @@ static int estep_launch(const InvPrefTables *tables, const int64_t *users, const
         if ((index_bytes == 1 && t.E > 5) || (index_bytes == 4 && t.E > 12)) return INVPREF_EINVAL;
         for (int k = 0; k < t.E; k++) eps_base.v[k] = eps_base_host[k];
     }
-    if (perm_index && t.E <= kEpsTableMaxE && index_bytes != 8) {
+    // the LDS-table form (up to seven environments) while the table and the workgroup's chunk of indices fit 64 KB of LDS;
+    // beyond that (about 2e7 interactions per call) the unrank-first form below takes over (it used to be an error)
+    bool table_form = perm_index && t.E <= kEpsTableMaxE && index_bytes != 8;
+    if (table_form) {
+        const int64_t rpb = kEstepThreads / kRow, chunk = ((N + nb - 1) / nb + rpb - 1) / rpb * rpb;
+        lds_extra = sizeof(unsigned) * ((size_t)fac.f[t.E] + (size_t)chunk);
+        if (lds + lds_extra > 64 * 1024) { table_form = false; lds_extra = 0; }
+    }
+    if (table_form) {
         eps_index = perm_index;
         eps_rows_n = (int)fac.f[t.E];
-        const int64_t rpb = kEstepThreads / kRow, chunk = ((N + nb - 1) / nb + rpb - 1) / rpb * rpb;
-        lds_extra = sizeof(unsigned) * ((size_t)eps_rows_n + (size_t)chunk);
-        if (lds + lds_extra > 64 * 1024) return INVPREF_EUNSUPPORTED;   // (2^24 interactions and more: use the packed form)
     } else if (perm_index) {
         eps_packed = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(workspace) +
                                                            sizeof(int) * (size_t)(t.E + 1) * kEstepMaxBlocks);

@@ -11,7 +11,9 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -51,18 +53,35 @@ void parallel_for(int count, int threads, F fn) {
         for (int i = 0; i < count; i++) fn(i);
         return;
     }
+    // (an exception on a worker thread -- std::bad_alloc of a histogram or of a 0.7 GB list -- would end the process in
+    //  std::terminate; so would unwinding past joinable threads: every worker catches, every thread is joined, and the first
+    //  failure is rethrown on the calling thread, where the C entry points turn it into a NULL handle)
     std::atomic<int> next{0};
+    std::atomic<bool> failed{false};
+    std::exception_ptr first;
+    std::mutex mu;
     auto work = [&]() {
         for (;;) {
             const int i = next.fetch_add(1);
-            if (i >= count) return;
-            fn(i);
+            if (i >= count || failed.load()) return;
+            try {
+                fn(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!first) first = std::current_exception();
+                failed.store(true);
+                return;
+            }
         }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < threads; t++) th.emplace_back(work);
+    try {
+        for (int t = 1; t < threads; t++) th.emplace_back(work);
+    } catch (...) {   // (no more threads to be had: the ones that started and this one do the work)
+    }
     work();
     for (auto &t : th) t.join();
+    if (first) std::rethrow_exception(first);
 }
 
 // Stable counting sort of the minibatch by row, on `threads` threads: emit(i, j) is called once per interaction i with its
@@ -476,11 +495,14 @@ int invpref_alt_plan_build_many(const int64_t *users, const int64_t *items, cons
             const bool hp = prev_n[k] >= 0;
             out[k] = build_alt_guarded(users + cur_lo[k], items + cur_lo[k], scores + cur_lo[k], cur_n[k],
                                        hp ? users + prev_lo[k] : nullptr, hp ? items + prev_lo[k] : nullptr, hp ? prev_n[k] : 0,
-                                       user_num, item_num, &p);
+                                       user_num, item_num, &p);   // (catches)
         }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    try {
+        for (int t = 1; t < nt; t++) th.emplace_back(work);
+    } catch (...) {
+    }
     work();
     for (auto &t : th) t.join();
     for (int k = 0; k < count; k++)
@@ -556,11 +578,14 @@ int invpref_plan_build_many(const int64_t *users, const int64_t *items, const fl
             if (k >= count) return;
             const int64_t lo = offsets[k], n = offsets[k + 1] - lo;
             // (a large minibatch spreads over threads of its own: what the pool leaves of the machine, not all of it again)
-            out[k] = build_guarded(users + lo, items + lo, scores + lo, n, user_num, item_num, params + k, inner);
+            out[k] = build_guarded(users + lo, items + lo, scores + lo, n, user_num, item_num, params + k, inner);   // (catches)
         }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    try {
+        for (int t = 1; t < nt; t++) th.emplace_back(work);
+    } catch (...) {
+    }
     work();
     for (auto &t : th) t.join();
     for (int k = 0; k < count; k++)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/hot_diag.sh -- what-if / diagnostic builds (DIAG="-D...", SHAPES=..., SKIP_DEFAULT=1): the wide kernels with every partner-row gather hitting the same 16 rows (-DWIDE_DIAG_HOT):
-# what launch 1 costs without gather latency.  Rebuilds the library ON THE BOX (the in-tree one is untouched elsewhere).
+# what launch 1 costs without gather latency.  Builds the variant ON THE BOX under invpref_kdd_2022_amd/variants/ (INVPREF_LIB selects it; the in-tree library is never replaced).
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 shapes=${SHAPES:-"50000x51283x16x256x262144 400000x100000x16x256x1048576 400000x100000x8x128x1048576 6040x3706x8x128x65536"}
@@ -14,6 +14,7 @@ probe() {
 [ -z "$SKIP_DEFAULT" ] && probe default > gpurun_out/hot_diag.log 2>&1
 DIAG=${DIAG:--DWIDE_DIAG_HOT}
 [ -n "$SKIP_DEFAULT" ] && : > gpurun_out/hot_diag.log
-INVPREF_HIPCC_EXTRA="$DIAG" python -c "from invpref_kdd_2022_amd import build; build.build(force=True)" > /dev/null 2>&1
-probe hot >> gpurun_out/hot_diag.log 2>&1
+# (a numerically WRONG what-if kernel: built to a path of its own and selected through INVPREF_LIB, never over the in-tree library)
+bash tools/build_variant.sh hot_diag $DIAG > /dev/null 2>&1
+INVPREF_LIB=$PWD/invpref_kdd_2022_amd/variants/hot_diag.so probe hot >> gpurun_out/hot_diag.log 2>&1
 cat gpurun_out/hot_diag.log

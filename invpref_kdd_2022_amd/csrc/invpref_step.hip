@@ -1664,6 +1664,7 @@ __global__ __launch_bounds__(kThreads) void flush_deferred_kernel(FlushArgs f) {
 }
 
 #include "step_wide.hpp"
+#include "step_wide_mm.hpp"
 
 // The row layout and the kernel family of a shape.  Rows of up to 64 floats with up to four environments (Yahoo, Coat,
 // the PureMF baselines) run the latency-tuned kernels above (16 lanes x 1 float4); everything else the wide ones
@@ -1878,10 +1879,17 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     // partial slabs), launch 3 = the fold blocks alone
 #define CALL_W(LGV, NCV, VECV, EMAXV, EV2)                                                                        \
     do {                                                                                                          \
-        if ((rc = ensure_lds(mstep_eval_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>, lds1))) return rc;             \
         if ((rc = ensure_lds(mstep_apply_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>, lds2))) return rc;            \
-        if (wg1 > 0)                                                                                              \
-            hipLaunchKernelGGL((mstep_eval_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>), dim3(wg1), dim3(kThreads), lds1, st, t, a1); \
+        if (VECV && use_mm) {   /* full rows: the classifier as products over the workgroup's interactions (step_wide_mm.hpp) */ \
+            const size_t ldsm = sizeof(float) * MGeo<LGV, NCV, EMAXV, EV2>::total;                                \
+            if ((rc = ensure_lds(mstep_eval_mm_kernel<LGV, NCV, EMAXV, EV2>, ldsm))) return rc;                  \
+            if (wg1 > 0)                                                                                          \
+                hipLaunchKernelGGL((mstep_eval_mm_kernel<LGV, NCV, EMAXV, EV2>), dim3(wg1), dim3(kThreads), ldsm, st, t, a1); \
+        } else {                                                                                                  \
+            if ((rc = ensure_lds(mstep_eval_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>, lds1))) return rc;         \
+            if (wg1 > 0)                                                                                          \
+                hipLaunchKernelGGL((mstep_eval_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>), dim3(wg1), dim3(kThreads), lds1, st, t, a1); \
+        }                                                                                                         \
         if (profile_event && hipEventRecord((hipEvent_t)profile_event, st) != hipSuccess) return INVPREF_EINVAL; \
         if (!EV2) {                                                                                               \
             hipLaunchKernelGGL((mstep_apply_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>), dim3(grid2), dim3(kThreads), lds2, st, t, a2, f); \
@@ -1897,6 +1905,12 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     do {                                                                                           \
         if (emax == 8) CALL_W(LGV, NCV, VECV, 8, EV2); else CALL_W(LGV, NCV, VECV, 16, EV2);       \
     } while (0)
+    // INVPREF_WIDE_MM=0 (diagnostics / A-B): the per-interaction classifier of step_wide.hpp for full rows too
+    // (default: rows on 32 lanes -- D = 256: launch 1 14.4 vs 18.1 ms at 2^24 interactions; rows on 16 lanes measured level
+    //  or slower, profiles/r05/EXPERIMENTS.md; INVPREF_WIDE_MM=1 takes the form for every full-row wide instance)
+    static const char *mm_env = getenv("INVPREF_WIDE_MM");
+    const bool mm_want = mm_env ? mm_env[0] == '1' : shp.lg == 32;
+    const bool use_mm = mm_want && !pure && t.b != nullptr && (reinterpret_cast<uintptr_t>(t.W) & 15u) == 0;
     if (shp.wide && !defer) {
         // (the wide kernels' vector form is for FULL rows only -- factor_num 64 / 128 / 256: no clamps or selects behind a
         //  load; any other row length takes their element-wise form)

@@ -788,6 +788,7 @@ __device__ __forceinline__ void item_task_wide(const DevTables &t, const StepArg
                 for (int j = 0; j < NC; j++) {
                     float4 gx = f4zero();
                     if (!pure) {
+#ifndef WIDE_DIAG_L2_NOGX   // (what-if build: launch 2 without the classifier's backward)
 #pragma unroll
                         for (int c4 = 0; c4 < EMAX / 4; c4++) {
                             if (WIDE_FENCE && NC > 1) __builtin_amdgcn_sched_barrier(0);
@@ -797,6 +798,7 @@ __device__ __forceinline__ void item_task_wide(const DevTables &t, const StepArg
                             f4fma(gx, in.gz[c4].z, *reinterpret_cast<const float4 *>(wr + 2 * DP));
                             f4fma(gx, in.gz[c4].w, *reinterpret_cast<const float4 *>(wr + 3 * DP));
                         }
+#endif
                         const float4 ev = *reinterpret_cast<const float4 *>(sEv + e * DP + 4 * (lg + LG * j));
                         f4fma(ge[j], g_q, f4mul(in.pa[j], ev));
                         if (EVL2) {
@@ -812,7 +814,9 @@ __device__ __forceinline__ void item_task_wide(const DevTables &t, const StepArg
                 }
                 a_one = (lane & 15) == e ? 1.f : 0.f;
             }
+#ifndef WIDE_DIAG_L2_NOMFMA   // (what-if build: launch 2 without embed_env's outer product)
             if constexpr (EVL2) outer_mfma<LG, NC>(accE, a_one, boo, lane);
+#endif
         };
         In nx[U];
         int2 idn[U];
@@ -1036,9 +1040,9 @@ __device__ __forceinline__ void item_task_push_wide(const DevTables &t, const St
 
 // untouched rows: the dense-Adam step with a zero gradient (stream_task for rows of NC float4 per lane, one row of both
 // tables per group in flight)
-template <int LG, int NC, bool VEC>
+template <int LG, int NC, bool VEC, int THREADS = kThreads>
 __device__ __forceinline__ void stream_task_wide(const DevTables &t, const StepArgs &a, const int *rows, int n) {
-    constexpr int NG = kThreads / LG;
+    constexpr int NG = THREADS / LG;
     const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG;
     const AdamScalars ad = a.sched_state ? sched_slot_ptr(a.sched_state, a.sched_slot)->ad : a.ad;
     const bool pure = a.flags & INVPREF_PURE_MF;

@@ -300,17 +300,19 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
             MM_BARRIER();
             // ---- S2: partial logits of the iteration's interactions over the wave's columns
             {
-                f32x4 z = bias4;
+                // (two accumulator chains: a product does not wait for the one in front of it)
+                f32x4 z = bias4, z1 = {0.f, 0.f, 0.f, 0.f};
                 const float *xr = sX + (n16 & (NG - 1)) * XS + base_w + 4 * kq;
 #pragma unroll
                 for (int qd = 0; qd < T; qd++) {
                     const float4 xb = *reinterpret_cast<const float4 *>(xr + 16 * qd);
                     z = mfma4(wA[qd].x, xb.x, z);
-                    z = mfma4(wA[qd].y, xb.y, z);
+                    z1 = mfma4(wA[qd].y, xb.y, z1);
                     z = mfma4(wA[qd].z, xb.z, z);
-                    z = mfma4(wA[qd].w, xb.w, z);
+                    z1 = mfma4(wA[qd].w, xb.w, z1);
                 }
-                *reinterpret_cast<float4 *>(sP + (wave * 16 + n16) * PS + 4 * kq) = make_float4(z[0], z[1], z[2], z[3]);
+                *reinterpret_cast<float4 *>(sP + (wave * 16 + n16) * PS + 4 * kq) =
+                    make_float4(z[0] + z1[0], z[1] + z1[1], z[2] + z1[2], z[3] + z1[3]);
             }
             MM_BARRIER();
             // ---- S3: softmax of every interaction in every wave (lane (n16, kq): classes 4 kq .. 4 kq + 3 of interaction n16)
@@ -362,16 +364,6 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
                 for (int r4 = 0; r4 < 4; r4++)
 #pragma unroll
                     for (int tt = 0; tt < T; tt++) g[tt] = mfma4(gz[r4], wB[tt][r4], g[tt]);
-#pragma unroll
-                for (int r4 = 0; r4 < 4; r4++) {
-                    const int m = 4 * kq + r4;   // accumulator row = interaction
-                    if (m < NG) {
-                        float v[T];
-#pragma unroll
-                        for (int tt = 0; tt < T; tt++) v[tt] = g[tt][r4];
-                        st_t<T>(sG + m * XS + base_w + T * n16, v);
-                    }
-                }
                 WAVE_LDS_FENCE();
                 // dW[class][cols_w] += gz^T X, dEv[env][cols_w] += onehot(env)^T O: k runs over the interactions 4 kk + kq
 #pragma unroll
@@ -392,6 +384,17 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
                             if constexpr (SH) accW[tt] = mfma4(ae, ob[tt], accW[tt]);
                             else accE[tt] = mfma4(ae, ob[tt], accE[tt]);
                         }
+                    }
+                }
+                // (gx leaves last: the products above are all issued before the first of them is waited for)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) {
+                    const int m = 4 * kq + r4;   // accumulator row = interaction
+                    if (m < NG) {
+                        float v[T];
+#pragma unroll
+                        for (int tt = 0; tt < T; tt++) v[tt] = g[tt][r4];
+                        st_t<T>(sG + m * XS + base_w + T * n16, v);
                     }
                 }
             }

@@ -546,6 +546,7 @@ __global__ __launch_bounds__(256) void adam_ranges_kernel(float *__restrict__ p,
 // distances.  Here only the drawn INDEX travels to the device (1, 4 or 8 bytes per interaction); one lane per
 // interaction unranks it -- factorial-base digits, then the d-th element still available, position by position -- into
 // sixteen 4-bit element numbers, which the E-step's lanes turn into their tie-break term.
+constexpr int kEpsTableMaxE = 7;
 struct EpsBase { float v[INVPREF_MAX_ENVS]; };
 struct Factorials { unsigned long long f[INVPREF_MAX_ENVS]; };   // f[k] = k!
 __device__ __forceinline__ unsigned long long unrank_packed(unsigned long long r, int E, const Factorials &fac) {
@@ -573,6 +574,35 @@ __device__ __forceinline__ unsigned long long unrank_packed(unsigned long long r
     }
     return out;
 }
+// the same row for the LDS table of the E-step's workgroups (E <= 7, r < 5 040): 32-bit arithmetic, the factorial-base digits
+// from the low end (c_k = r % (k + 1), r /= k + 1: divisions by compile-time constants) instead of 64-bit divisions by run-time
+// factorials -- the table is rebuilt by every workgroup in front of its first pass, and 24 lanes running ~3 000 instructions each
+// were 5 us of every workgroup's life (round 5)
+__device__ __forceinline__ unsigned unrank_packed_small(unsigned r, int E) {
+    unsigned c[8];
+    c[0] = 0;
+#pragma unroll
+    for (int k = 1; k < 8; k++) { c[k] = r % (unsigned)(k + 1); r /= (unsigned)(k + 1); }
+    unsigned avail = (1u << E) - 1u, out = 0;
+#pragma unroll
+    for (int pos = 0; pos < kEpsTableMaxE; pos++) {
+        if (pos < E) {
+            unsigned d = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) d = (k == E - 1 - pos) ? c[k] : d;
+            unsigned seen = 0, pick = 0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const bool on = (avail >> b) & 1u;
+                pick = (on && seen == d) ? (unsigned)b : pick;
+                seen += on ? 1u : 0u;
+            }
+            avail &= ~(1u << pick);
+            out |= pick << (4 * pos);
+        }
+    }
+    return out;
+}
 template <typename IT>
 __global__ __launch_bounds__(256) void eps_unrank_kernel(const IT *__restrict__ idx, int64_t N, int E, Factorials fac,
                                                          unsigned long long *__restrict__ packed) {
@@ -582,8 +612,6 @@ __global__ __launch_bounds__(256) void eps_unrank_kernel(const IT *__restrict__ 
 }
 // up to seven environments (7! = 5 040 rows): the E-step's workgroups unrank EVERY row of the permutation table into LDS
 // once (4 bytes each) and look an interaction's row up there -- no unranking launch, no packed rows through memory
-constexpr int kEpsTableMaxE = 7;
-
 // NARROW: every big table is under 2^32 bytes (any reference configuration: MIND's are 51 MB), so a row's address is its
 // table's base + one 32-bit offset (id x D in a 32-bit multiply) instead of a 64-bit product per gathered row; the ids
 // arrive as the reference's int64 (LongTensor) either way.
@@ -621,7 +649,7 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
     const int64_t s_begin = blockIdx.x * chunk, s_end = min(N, s_begin + chunk);
     unsigned *sidx = stab + eps_rows_n;   // [chunk] the block's permutation rows (E <= 7)
     if (eps_index) {
-        for (int i = threadIdx.x; i < eps_rows_n; i += blockDim.x) stab[i] = (unsigned)unrank_packed((unsigned long long)i, t.E, fac);
+        for (int i = threadIdx.x; i < eps_rows_n; i += blockDim.x) stab[i] = unrank_packed_small((unsigned)i, t.E);
         // 16 bytes per lane (16 one-byte or 4 four-byte indices; the block starts on a multiple of 16 interactions): on
         // host-coherent memory every lane's access is a transaction of its own, so they had better be few and wide
         const int per = eps_index_bytes == 1 ? 16 : 4;
@@ -647,6 +675,17 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
     __syncthreads();
     const int l16 = threadIdx.x & 15;
     const bool implicit = flags & INVPREF_IMPLICIT;
+    // The tie-break terms are tiny (the reference's 1e-10, 1e-11, ...): added to a distance d >= 2^26 max|eps| (6.7e-3) they
+    // are below a quarter of d's last place and the sum rounds back to d, bit for bit.  An interaction whose SMALLEST
+    // distance is that large therefore needs no permutation row at all -- its three dependent LDS look-ups are skipped
+    // (most interactions; the others take the look-ups as before: same sums, same argmin).
+    float eps_thr = 0.f;
+    if (eps_packed || eps_index) {
+        float mx = 0.f;
+#pragma unroll
+        for (int k = 0; k < INVPREF_MAX_ENVS; k++) mx = (k < t.E) ? __builtin_fmaxf(mx, __builtin_fabsf(eps_base.v[k])) : mx;
+        eps_thr = mx * 67108864.f * 1.001f;
+    }
     for (int64_t s = s_begin + (threadIdx.x >> 4); s < s_end; s += rows_per_block) {
         const int64_t u = users[s], v = items[s];
         const float y = scores[s];
@@ -682,9 +721,15 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
         if (eps_rows && l16 < t.E) dist = dist + eps_rows[s * t.E + l16];
         // train.py:192-196 with the row's permutation unranked on the device: position l16 of permutation row idx[s] of
         // the tie-break vector is element (packed >> 4 l16) & 15 of it (eps_unrank_kernel)
-        if (eps_packed && l16 < t.E) dist = dist + sbase[(eps_packed[s] >> (4 * l16)) & 15ull];
-        if (eps_index && l16 < t.E)   // (E <= 7: the row looked up in the workgroup's LDS table)
-            dist = dist + sbase[(stab[min(sidx[s - s_begin], (unsigned)(eps_rows_n - 1))] >> (4 * l16)) & 15u];   // (clamped: see eps_unrank_kernel)
+        if (eps_packed || eps_index) {
+            // (NaN distances are ignored by the minimum and stay NaN under the add: nothing to look up for them either)
+            const bool need = row16_min(l16 < t.E ? dist : __builtin_inff()) < eps_thr;
+            if (need) {
+                if (eps_packed && l16 < t.E) dist = dist + sbase[(eps_packed[s] >> (4 * l16)) & 15ull];
+                if (eps_index && l16 < t.E)   // (E <= 7: the row looked up in the workgroup's LDS table)
+                    dist = dist + sbase[(stab[min(sidx[s - s_begin], (unsigned)(eps_rows_n - 1))] >> (4 * l16)) & 15u];   // (clamped: see eps_unrank_kernel)
+            }
+        }
         // argmin with the lowest index among equal minima (torch.argmin; the sequential `dist < best` scan)
         // A NaN distance wins, the first one if there are several (torch.argmin's LessOrNan; only reachable with
         // NaN parameters) -- row16_min ignores NaNs, so the lowest NaN lane is found separately.

@@ -212,8 +212,9 @@ def test_static_pop_manager_vs_reference():
     assert mgr.epochs == 4
 
 
+@pytest.mark.parametrize('scale', [1e-2, 1e-8])
 @pytest.mark.parametrize('E', [2, 4, 5, 8, 13])
-def test_estep_unranks_the_permutation_rows_on_the_device(E):
+def test_estep_unranks_the_permutation_rows_on_the_device(E, scale):
     """cluster_use_random_sort (train.py:86-92, :192-196) with only the drawn permutation INDEX on the device: the E-step's
     assignments, counts and weights equal, bit for bit, those of the E-step fed the gathered N x E rows of
     itertools.permutations order (built here with the manager's host-side unranking, pinned to itertools by a CPU test)."""
@@ -228,7 +229,9 @@ def test_estep_unranks_the_permutation_rows_on_the_device(E):
     # (the reference's own 1e-10 .. 1e-25 are below one ulp of the distances: SURVEY 7), so the tie-break decides every row
     for k in ('embed_user_env_aware.weight', 'embed_item_env_aware.weight', 'embed_env.weight'):
         tabs[k] = np.zeros_like(tabs[k])
-    base = np.array([1e-2 * (0.5 ** i) for i in range(E)], dtype=np.float32)
+    # (scale 1e-8: the kernel skips the permutation row of an interaction whose smallest distance is above 2^26 max|eps|
+    #  = 0.67 -- there the add is a no-op in fp32 -- and looks it up for the others: both kinds occur among these BCE distances)
+    base = np.array([scale * (0.5 ** i) for i in range(E)], dtype=np.float32)
     idx = rs.randint(0, math.factorial(E), N)
     dt = np.uint8 if E <= 5 else (np.int32 if E <= 12 else np.int64)
     P = [torch.from_numpy(tabs[k]).to(DEV) for k in ops.PARAM_NAMES]
@@ -242,7 +245,7 @@ def test_estep_unranks_the_permutation_rows_on_the_device(E):
         np.testing.assert_array_equal(x.cpu().numpy(), z.cpu().numpy())
     # the tie-break really decided rows: without it everything ties at environment 0
     plain = ops.estep(P, dev(u), dev(v), dev(y), True, old, ws)[0].cpu().numpy()
-    assert (plain == 0).all() and (a[0].cpu().numpy() != 0).any()
+    assert (plain == 0).all() and (scale < 1e-3 or (a[0].cpu().numpy() != 0).any())
 
 
 def test_estep_row_offsets_32_and_64_bit_agree():

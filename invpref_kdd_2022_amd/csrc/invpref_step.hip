@@ -1908,7 +1908,7 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     // INVPREF_WIDE_MM=0 (diagnostics / A-B): the per-interaction classifier of step_wide.hpp for full rows too
     // (default: rows on 32 lanes -- D = 256: launch 1 14.4 vs 18.1 ms at 2^24 interactions; rows on 16 lanes measured level
     //  or slower, profiles/r05/EXPERIMENTS.md; INVPREF_WIDE_MM=1 takes the form for every full-row wide instance)
-    static const char *mm_env = getenv("INVPREF_WIDE_MM");
+    const char *mm_env = getenv("INVPREF_WIDE_MM");   // (read per call: the tests switch forms inside one process)
     const bool mm_want = mm_env ? mm_env[0] == '1' : shp.lg == 32;
     const bool use_mm = mm_want && !pure && t.b != nullptr && (reinterpret_cast<uintptr_t>(t.W) & 15u) == 0;
     if (shp.wide && !defer) {

@@ -381,3 +381,50 @@ def test_step_scratch_and_plan_lists_stay_inside_their_bounds(U, I, E, D, B):
             assert np.isfinite(got).all(), k
             err, scale = np.abs(got - want.reshape(got.shape)).max(), max(np.abs(want).max(), 1e-4)
             assert err <= 1.5e-4 * scale, (k, push, float(err), float(scale))
+
+
+@pytest.mark.parametrize('D,E,mm', [(64, 8, '1'), (64, 16, '1'), (128, 8, '1'), (128, 16, '1'), (128, 5, '1'), (256, 16, '1'),
+                                    (256, 9, '1'), (256, 5, '1'), (256, 16, '0'), (256, 8, '0')])
+def test_mfma_classifier_form_of_launch_1(D, E, mm, monkeypatch):
+    """csrc/step_wide_mm.hpp (full wide rows: the classifier as MFMA products over the workgroup's interactions) forced on for
+    every instance it is compiled for -- it is the default only for rows on 32 lanes -- and forced off for those: gradient pass
+    against the oracle entry by entry, the fused pass, pull and push forms, run-to-run bitwise; and the two forms against
+    each other (float reordering only)."""
+    rs = np.random.RandomState(100 * D + E)
+    U, I, B = 700, 300, 9000
+    data = synth.interactions(77 + D + E, U, I, B, implicit=True, zipf=True)
+    u, v, y = data[:, 0], data[:, 1], data[:, 2].astype(np.float32)
+    e = rs.randint(0, E, B)
+    w = rs.uniform(0.1, 1, B).astype(np.float32)
+    tabs = synth.tables(D + E, U, I, E, D, std=0.2)
+    coefs = np.array(COEFS[:6], np.float64)
+    flags_o, flags = O.flags_of(True, True, True, False, True), ops.flags_of(True, True, True, False, True)
+    og, ol = O.mstep(O.Tables(tabs), u, v, e, y, w, coefs, flags_o)
+    P, ws = dev(tabs), ops.Workspace(DEV)
+    for push in ((False, True) if D <= 128 else (False,)):
+        dp = planlib.upload(planlib.build_row_plan(u, v, y, U, I, factor_num=D, env_num=E, push=push), DEV)
+        res = {}
+        for form in (mm, '0' if mm == '1' else '1'):
+            monkeypatch.setenv('INVPREF_WIDE_MM', form)
+            outs = []
+            for _ in range(2):
+                G = [torch.full_like(p, 7.0) for p in P]
+                losses = torch.zeros(6, device=DEV)
+                ops.mstep_rows_grad(P, G, dp, t64(e), t32(y), t32(w), B, coefs, flags, losses, ws)
+                outs.append(([g.cpu().numpy() for g in G], losses.cpu().numpy()))
+            np.testing.assert_allclose(outs[0][1], ol, rtol=3e-5, atol=1e-7)
+            np.testing.assert_array_equal(outs[0][1], outs[1][1])
+            for k, g, g2, want in zip(ops.PARAM_NAMES, outs[0][0], outs[1][0], og):
+                np.testing.assert_array_equal(g, g2, err_msg=k)
+                err, scale = np.abs(g - want.reshape(g.shape)).max(), max(np.abs(want).max(), 1e-4)
+                assert err <= 1.5e-4 * scale, (k, form, push, float(err), float(scale))
+            P2, M, V = ([torch.zeros_like(p) for p in P] for _ in range(3))
+            losses = torch.zeros(6, device=DEV)
+            ops.mstep_rows_adam(P, P2, M, V, dp, t64(e), t32(y), t32(w), B, coefs, flags, losses, 1, 0.01, ws)
+            np.testing.assert_allclose(losses.cpu().numpy(), ol, rtol=3e-5, atol=1e-7)
+            res[form] = (outs[0][0], [x.cpu().numpy() for x in P2 + M + V])
+        for k, a, b in zip(ops.PARAM_NAMES, res['0'][0], res['1'][0]):
+            scale = max(np.abs(a).max(), 1e-4)
+            assert np.abs(a - b).max() <= 2e-5 * scale, (k, push)
+        for a, b in zip(res['0'][1][len(P):], res['1'][1][len(P):]):   # the moments of the fused pass (first step: (1 - beta) g, g^2)
+            assert np.abs(a - b).max() <= 2e-5 * max(np.abs(a).max(), 1e-6)

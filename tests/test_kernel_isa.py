@@ -37,6 +37,11 @@ def test_full_row_instances_have_no_scratch_traffic(kernels):
     # of them inside the interaction loop (depth 2)
     for name in ('mstep_eval_wide_kernel<32, 2, true, 16, true>', 'mstep_eval_wide_kernel<32, 2, true, 8, true>'):
         assert ks[name]['scratch_ops'] <= 24, (name, ks[name])
+    # the MFMA-classifier form of launch 1 (csrc/step_wide_mm.hpp): the default instance (rows on 32 lanes) within a couple of
+    # loop-invariant spills -- a reload from scratch memory waits for every outstanding vector-memory operation of the wave, the
+    # gathers in flight included (profiles/r05/EXPERIMENTS.md) -- and its three products on the matrix cores
+    for name in ('mstep_eval_mm_kernel<32, 2, 16, true>', 'mstep_eval_mm_kernel<32, 2, 8, true>'):
+        assert ks[name]['scratch_ops'] <= 4 and ks[name]['mfma'] >= 40, (name, ks[name])
     # the latency-tuned Yahoo instance keeps three workgroups per CU: at most 168 registers
     assert ks['mstep_eval_kernel<16, true, 4, false, true>']['vgpr'] <= 168
     # the alternating one-launch-per-step kernels (csrc/step_alt.hpp): every instance free of scratch, three per CU

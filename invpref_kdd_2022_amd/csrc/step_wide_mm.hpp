@@ -155,6 +155,9 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
     float dB[4] = {0.f, 0.f, 0.f, 0.f};   // wave 0: sum of gz over the interactions n16 of every iteration, classes 4 kq + r
     float accLi = 0.f, accLe = 0.f, accLc = 0.f, accL2 = 0.f, accL1 = 0.f;
     float *slab = a.slabs + (int64_t)slab_index * G::SLAB;
+#ifdef WIDE_DIAG_TRACE
+    int wtrace_n = 0;   // (tools/wide_trace.py: shader-clock stamps of workgroup 40's first wave, -DWIDE_DIAG_TRACE builds only)
+#endif
     if (threadIdx.x < 64) sM[threadIdx.x] = 0.f;   // (interactions NG .. 15 of the padded products: scale 0 for good)
 
     for (int r = r0; r < r0 + nr; r++) {
@@ -225,6 +228,7 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
         auto step = [&](const Slot &q, bool has) {
             // ---- S1: the interaction's recommendation part on its lane group (an empty slot of the lock-step iteration
             // evaluates its stale -- finite -- rows with every gradient scalar forced to zero)
+            WTRACE(20);
             const int e = q.e;
             const float w_rec = rw_rec ? q.w : 1.f, w_cls = rw_cls ? q.w : 1.f;
             float g_p, g_q;
@@ -297,7 +301,9 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
                     rec_g[min(lg, 3)] = val;
                 }
             }
+            WTRACE(23);
             MM_BARRIER();
+            WTRACE(24);
             // ---- S2: partial logits of the iteration's interactions over the wave's columns
             {
                 // (two accumulator chains: a product does not wait for the one in front of it)
@@ -314,7 +320,9 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
                 *reinterpret_cast<float4 *>(sP + (wave * 16 + n16) * PS + 4 * kq) =
                     make_float4(z[0] + z1[0], z[1] + z1[1], z[2] + z1[2], z[3] + z1[3]);
             }
+            WTRACE(25);
             MM_BARRIER();
+            WTRACE(27);
             // ---- S3: softmax of every interaction in every wave (lane (n16, kq): classes 4 kq .. 4 kq + 3 of interaction n16)
             {
                 float z[4], gz[4];
@@ -356,6 +364,7 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
                 if (!push && (n16 & 3) == wave && n16 < NG && 4 * kq < EMAX)
                     *reinterpret_cast<float4 *>(a.records + (unsigned)psn * (unsigned)RS + 4 + 4 * kq) = gz4;
                 *reinterpret_cast<float4 *>(sZ + (wave * 16 + n16) * PS + 4 * kq) = gz4;
+                WTRACE(21);
                 // G[interaction][cols_w] = gz W: k runs over the classes 4 kq + r
                 f32x4 g[T];
 #pragma unroll
@@ -398,7 +407,9 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
                     }
                 }
             }
+            WTRACE(22);
             MM_BARRIER();
+            WTRACE(24);
             // ---- S5: the rows' gradients with gx = gz W from LDS
             {
                 float4 ev[NC];
@@ -423,8 +434,10 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
 #pragma unroll
             for (int j = 0; j < UE; j++) {
                 if (s + j < iters) step(sl[j], s + j < nsmp);
+                WTRACE(26);
                 gather(sl[j], idn[j]);
                 idn[j] = list_at(s + 2 * UE + j);
+                WTRACE(6);
             }
         }
         if (r == r0 + STAMP_ROUND) STAMP(4);

@@ -42,7 +42,7 @@ tag, t = (raw >> 56) & 0xff, raw & ((1 << 56) - 1)
 t = t - t[0]
 names = {1: 'entry', 2: 'rows arrived', 3: 'evaluated (gx done)', 4: 'updates/stores', 5: 'mfma issued', 6: 'refill issued',
          30: '  S1 rows in, x/qi out', 31: '  S1 row sums', 32: '  S1 loss chains', 33: '  S1 meta', 34: '  S1 ge/o/push/reports',
-         20: 'A: entry', 21: ' S3 softmax done', 22: ' S3 products + gx out', 23: ' S1 + refill issued', 24: 'barrier A', 25: ' S2 products + P out', 26: ' S5 done', 27: 'barrier B',
+         20: 'S1 entry', 21: ' S3 softmax done', 22: ' S3 products + gx out', 23: ' S1 done', 24: 'barrier', 25: ' S2 products + P out', 26: ' S5 done', 27: 'barrier',
          10: '  row sums', 11: '  loss chains', 12: '  class dots', 13: '  softmax, gz out', 14: '  gz back'}
 prev = 0
 for k, (g, x) in enumerate(zip(tag, t)):

@@ -641,37 +641,20 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
             if (threadIdx.x == k) sbase[k] = eps_base.v[k];
     }
     // A workgroup walks ONE contiguous block of interactions, 16 per pass (any split gives the same per-interaction results).
-    // That makes its permutation indices one contiguous byte range, fetched here in one burst -- the index array may be
-    // PINNED HOST memory (the managers hand their staging buffer over as it is: no copy engine, no copy node in the graph),
-    // and a burst of whole lines is what the link moves well.
     const int64_t rows_per_block = blockDim.x / kRow;
     const int64_t chunk = ((N + gridDim.x - 1) / gridDim.x + rows_per_block - 1) / rows_per_block * rows_per_block;
     const int64_t s_begin = blockIdx.x * chunk, s_end = min(N, s_begin + chunk);
-    unsigned *sidx = stab + eps_rows_n;   // [chunk] the block's permutation rows (E <= 7)
-    if (eps_index) {
+    // (E <= 7) the permutation INDEX of an interaction is fetched by its own lane group, one pass ahead of its use: a byte (or
+    // word) per interaction, adjacent for the wave's four groups -- from device memory or, as the managers hand it over, straight
+    // from PINNED HOST memory: the link's latency sits under a pass of arithmetic instead of in front of the workgroup's first
+    // (round 5: the staged form -- the workgroup's whole index range fetched and spread into LDS before the first pass -- cost
+    // 7 us of a 43 us kernel with device-resident indices and 12 us from pinned memory)
+    auto load_idx = [&](int64_t sx) -> unsigned {
+        return eps_index_bytes == 1 ? (unsigned)reinterpret_cast<const uint8_t *>(eps_index)[sx]
+                                    : (unsigned)reinterpret_cast<const int32_t *>(eps_index)[sx];
+    };
+    if (eps_index)
         for (int i = threadIdx.x; i < eps_rows_n; i += blockDim.x) stab[i] = unrank_packed_small((unsigned)i, t.E);
-        // 16 bytes per lane (16 one-byte or 4 four-byte indices; the block starts on a multiple of 16 interactions): on
-        // host-coherent memory every lane's access is a transaction of its own, so they had better be few and wide
-        const int per = eps_index_bytes == 1 ? 16 : 4;
-        const int64_t n_here = s_end - s_begin, n_vec = ((reinterpret_cast<uintptr_t>(eps_index) & 15) == 0) ? n_here / per : 0;
-        const char *base = reinterpret_cast<const char *>(eps_index) + s_begin * eps_index_bytes;
-        for (int64_t i = threadIdx.x; i < n_vec; i += blockDim.x) {
-            const uint4 v = reinterpret_cast<const uint4 *>(base)[i];
-            const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (eps_index_bytes == 1) {
-#pragma unroll
-                    for (int b = 0; b < 4; b++) sidx[i * 16 + k * 4 + b] = (w[k] >> (8 * b)) & 255u;
-                } else {
-                    sidx[i * 4 + k] = w[k];
-                }
-            }
-        }
-        for (int64_t i = n_vec * per + threadIdx.x; i < n_here; i += blockDim.x)   // (the block's tail / an unaligned array)
-            sidx[i] = eps_index_bytes == 1 ? (unsigned)reinterpret_cast<const uint8_t *>(eps_index)[s_begin + i]
-                                            : (unsigned)reinterpret_cast<const int32_t *>(eps_index)[s_begin + i];
-    }
     __syncthreads();
     const int l16 = threadIdx.x & 15;
     const bool implicit = flags & INVPREF_IMPLICIT;
@@ -686,7 +669,10 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
         for (int k = 0; k < INVPREF_MAX_ENVS; k++) mx = (k < t.E) ? __builtin_fmaxf(mx, __builtin_fabsf(eps_base.v[k])) : mx;
         eps_thr = mx * 67108864.f * 1.001f;
     }
-    for (int64_t s = s_begin + (threadIdx.x >> 4); s < s_end; s += rows_per_block) {
+    const int64_t s_first = s_begin + (threadIdx.x >> 4);
+    unsigned idx_cur = (eps_index && s_first < s_end) ? load_idx(s_first) : 0u;
+    for (int64_t s = s_first; s < s_end; s += rows_per_block) {
+        const unsigned idx_next = (eps_index && s + rows_per_block < s_end) ? load_idx(s + rows_per_block) : 0u;
         const int64_t u = users[s], v = items[s];
         const float y = scores[s];
         float4 pu[NC], qi[NC], pa[NC], qa[NC];
@@ -727,7 +713,7 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
             if (need) {
                 if (eps_packed && l16 < t.E) dist = dist + sbase[(eps_packed[s] >> (4 * l16)) & 15ull];
                 if (eps_index && l16 < t.E)   // (E <= 7: the row looked up in the workgroup's LDS table)
-                    dist = dist + sbase[(stab[min(sidx[s - s_begin], (unsigned)(eps_rows_n - 1))] >> (4 * l16)) & 15u];   // (clamped: see eps_unrank_kernel)
+                    dist = dist + sbase[(stab[min(idx_cur, (unsigned)(eps_rows_n - 1))] >> (4 * l16)) & 15u];   // (clamped: see eps_unrank_kernel)
             }
         }
         // argmin with the lowest index among equal minima (torch.argmin; the sequential `dist < best` scan)
@@ -745,6 +731,7 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
             atomicAdd(cnt + bi, 1);
             if (changed) atomicAdd(cnt + t.E, 1);
         }
+        idx_cur = idx_next;
     }
     __syncthreads();
     for (int i = threadIdx.x; i <= t.E; i += blockDim.x) slabs[(int64_t)blockIdx.x * (t.E + 1) + i] = cnt[i];
@@ -1250,12 +1237,11 @@ static int estep_launch(const InvPrefTables *tables, const int64_t *users, const
         if ((index_bytes == 1 && t.E > 5) || (index_bytes == 4 && t.E > 12)) return INVPREF_EINVAL;
         for (int k = 0; k < t.E; k++) eps_base.v[k] = eps_base_host[k];
     }
-    // the LDS-table form (up to seven environments) while the table and the workgroup's chunk of indices fit 64 KB of LDS;
-    // beyond that (about 2e7 interactions per call) the unrank-first form below takes over (it used to be an error)
+    // the LDS-table form (up to seven environments: the E! packed rows fit LDS at any interaction count -- the indices
+    // themselves are fetched pass by pass); otherwise the unrank-first form below
     bool table_form = perm_index && t.E <= kEpsTableMaxE && index_bytes != 8;
     if (table_form) {
-        const int64_t rpb = kEstepThreads / kRow, chunk = ((N + nb - 1) / nb + rpb - 1) / rpb * rpb;
-        lds_extra = sizeof(unsigned) * ((size_t)fac.f[t.E] + (size_t)chunk);
+        lds_extra = sizeof(unsigned) * (size_t)fac.f[t.E];
         if (lds + lds_extra > 64 * 1024) { table_form = false; lds_extra = 0; }
     }
     if (table_form) {

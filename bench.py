@@ -727,6 +727,18 @@ def main():
               'estep_timing': 'graph replay' if ms_estep_replay else 'eager cluster()',
               'estep_eager_ms': ms_estep_eager, 'estep_eager_interactions_per_s_per_gpu': n_local / (ms_estep_eager * 1e-3),
               'timed_seconds': dt}
+    if world > 1 and getattr(mgr, 'cluster_use_random_sort', False):
+        # every rank draws the permutation indices of the GLOBAL minibatches (the reference's numpy stream is sequential:
+        # a rank cannot skip to its share), so this host time grows with the rank count while the interval does not --
+        # printed so that a SCALE record explains itself
+        import time as _t
+        st_rng = np.random.get_state()
+        t0 = _t.perf_counter()
+        mgr._eps_index()
+        detail['host_draw_ms'] = (_t.perf_counter() - t0) * 1e3
+        np.random.set_state(st_rng)
+        detail['host_draw_note'] = ('np.random.randint over the global interaction count per E-step, on every rank; it overlaps the '
+                                    'interval only while the epochs are launched asynchronously')
     detail.update(eager_kernel_times(mgr))
 
     P = mgr.state.n

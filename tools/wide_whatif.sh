@@ -12,7 +12,8 @@ for shape in "$@"; do
     lib=$R/invpref_kdd_2022_amd/variants/${parts[0]}.so
     [ "${parts[0]}" = default ] && lib=$R/invpref_kdd_2022_amd/libinvpref_hip.so
     export INVPREF_LIB=$lib PROBE_EAGER=1 PROBE_SHAPE=$shape PROBE_STEPS=${PROBE_STEPS:-4}
-    unset INVPREF_WIDE_MM
+    for kv in "${prev_kv[@]}"; do unset "${kv%%=*}"; done   # (the previous spec's switches do not leak into this one)
+    prev_kv=("${parts[@]:1}")
     for kv in "${parts[@]:1}"; do export "$kv"; done
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$v-$shape -- python3 $R/tools/step_probe.py > $O/$v-$shape.log 2>&1
     f=$(ls $O/$v-$shape/*/*kernel_stats.csv 2>/dev/null | head -1)

@@ -759,11 +759,23 @@ __global__ __launch_bounds__(256) void stat_envs_kernel(const int64_t *__restric
     __shared__ float cw[INVPREF_MAX_ENVS];
     for (int i = threadIdx.x; i <= E; i += blockDim.x) tot[i] = 0;
     __syncthreads();
-    for (int c = 0; c <= E; c++) {
-        long long a = 0;
-        for (int s = threadIdx.x; s < nslabs; s += blockDim.x) a += slabs[(int64_t)s * (E + 1) + c];
-        for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&tot[c], (unsigned long long)a);
+    // (every count of a thread's slabs is requested before the first is summed: one round trip for the fold, not one per
+    //  class -- the per-class loop took 10.9 us of a 250 154-row call)
+    long long acc[INVPREF_MAX_ENVS + 1];
+#pragma unroll
+    for (int c = 0; c <= INVPREF_MAX_ENVS; c++) acc[c] = 0;
+    for (int s = threadIdx.x; s < nslabs; s += blockDim.x) {
+        const int *row = slabs + (int64_t)s * (E + 1);
+#pragma unroll
+        for (int c = 0; c <= INVPREF_MAX_ENVS; c++) acc[c] += (c <= E) ? row[min(c, E)] : 0;
+    }
+#pragma unroll
+    for (int c = 0; c <= INVPREF_MAX_ENVS; c++) {
+        if (c <= E) {   // (uniform)
+            long long a = acc[c];
+            for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+            if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&tot[c], (unsigned long long)a);
+        }
     }
     __syncthreads();
     if (threadIdx.x < E) {
@@ -778,9 +790,19 @@ __global__ __launch_bounds__(256) void stat_envs_kernel(const int64_t *__restric
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && diff) *diff = tot[E];
     __syncthreads();
-    if (sample_w)
-        for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < N; s += (int64_t)gridDim.x * blockDim.x)
-            sample_w[s] = cw[(int)envs[s]];
+    if (sample_w) {
+        // four consecutive rows per thread and pass, every load of the pass requested before the first look-up (a row per
+        // thread and pass left one dependent load -> store chain per iteration on four waves per CU)
+        const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+        for (int64_t s0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; s0 < N; s0 += stride) {
+            int e[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) e[k] = (int)envs[min(s0 + k, N - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (s0 + k < N) sample_w[s0 + k] = cw[e[k]];
+        }
+    }
 }
 
 // =====================================================================================
@@ -1272,8 +1294,11 @@ static int estep_launch(const InvPrefTables *tables, const int64_t *users, const
 #undef ECALL1
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return (int)err;
+    // every workgroup of stat_envs folds ALL the count slabs for itself before it gathers its share of the sample weights:
+    // at most 256 of them (one per CU, a grid-stride share of rows each) -- a thousand workgroups read 40 MB of slabs for
+    // 1 MB of weights (round 5: 10.9 us at the Yahoo shape)
     int64_t nb2 = (N + 255) / 256;
-    if (nb2 > kEstepMaxBlocks) nb2 = kEstepMaxBlocks;
+    if (nb2 > 256) nb2 = 256;
     hipLaunchKernelGGL(stat_envs_kernel, dim3((unsigned)nb2), dim3(256), 0, st, new_envs, N, t.E, slabs, nb, counts, diff,
                        class_weights, sample_weights);
     return (int)hipGetLastError();

@@ -226,6 +226,7 @@ class _BasicTrainManager(_InvPrefTrainManager):
             if (self.epoch_cnt % self.evaluate_interval) == 0 and self.epoch_cnt >= self.test_begin_epoch:
                 evaluate()
         self.sync_parameters()
+        self._check_alt_error()   # (PureMF launches wait for nothing inside a launch: the word can only be set by another user of the workspace)
         if defer and loss_result_list:
             loss_result_list = self.loss_dicts(torch.stack(loss_result_list))
         return (loss_result_list, train_epoch_index_list), (test_result_list, test_epoch_list)

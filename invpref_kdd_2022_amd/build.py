@@ -72,5 +72,37 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(name: str, extra_flags, sources=('invpref_step.hip',), force: bool = False) -> str:
+    """An A/B or test build of the HIP library under variants/<name>.so (git-ignored; shipped by gpurun): the listed
+    translation units recompiled with `extra_flags`, the others taken from the regular build's objects.  Select it with
+    INVPREF_LIB=<path> (read by _capi at import).  tests/test_alt_gpu.py builds its forced-time-out library this way."""
+    build()
+    vdir = os.path.join(PKG, 'variants')
+    out = os.path.join(vdir, name + '.so')
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.abspath(__file__)]
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
+        return out
+    odir = os.path.join(OBJDIR, 'variant_' + name)
+    os.makedirs(odir, exist_ok=True)
+    os.makedirs(vdir, exist_ok=True)
+    procs, objs = [], []
+    for src in SOURCES:
+        if src in sources:
+            obj = os.path.join(odir, os.path.splitext(src)[0] + '.o')
+            cmd = [_hipcc()] + FLAGS + list(extra_flags) + ['-c', os.path.join(CSRC, src), '-o', obj]
+            procs.append((cmd, subprocess.Popen(cmd)))
+        else:
+            obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + '.o')
+            if not os.path.exists(obj):   # (a library that came prebuilt without its objects)
+                cmd = [_hipcc()] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+                procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    subprocess.check_call([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out])
+    return out
+
+
 if __name__ == '__main__':
     print(build(force=True, verbose=True))

@@ -77,6 +77,10 @@ __device__ __forceinline__ void st_sc1(int *p, int v) {
 #ifndef ALT_POLL_MAX
 #define ALT_POLL_MAX (1 << 17)    // polls before a waiting workgroup gives up (sets the error word): ~30 ms
 #endif
+#ifndef ALT_TEST_BAD_TAG
+#define ALT_TEST_BAD_TAG 0        // (test builds only, tests/test_alt_gpu.py: the job workgroups wait for a tag nobody publishes,
+                                  //  so every wait times out -- with a small ALT_POLL_MAX -- and the managers must raise)
+#endif
 #ifndef ALT_STREAM_DELAY
 #define ALT_STREAM_DELAY 0        // s_sleep units of 64 clocks in front of a stream task (evaluating launches)
 #endif
@@ -138,6 +142,7 @@ __device__ __forceinline__ void alt_stage_finish(const AltArgs &a, AltStage &x, 
     const int lane = threadIdx.x & 63;
     bool on[4], onb;
     alt_stage_lanes(a, lane, on, onb);
+    if (ALT_TEST_BAD_TAG) gen ^= 0x40000000;
     const unsigned o0 = (unsigned)lane * 8u, ob = (unsigned)(2 * EDP + (onb ? lane : 0)) * 8u;
     // (the loaded registers pass THROUGH the wait: nothing the compiler schedules can read them before it)
     asm volatile("s_waitcnt vmcnt(0)"
@@ -146,6 +151,7 @@ __device__ __forceinline__ void alt_stage_finish(const AltArgs &a, AltStage &x, 
                  :
                  : "memory");
     int polls = 0;
+    bool timed_out = false;
     for (;;) {
         bool ok = !onb || (int)(x.g[8] >> 32) == gen;
 #pragma unroll
@@ -153,7 +159,11 @@ __device__ __forceinline__ void alt_stage_finish(const AltArgs &a, AltStage &x, 
             ok = ok && (!on[i] || ((int)(x.g[i] >> 32) == gen && (int)(x.g[4 + i] >> 32) == gen));
         if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
         if (++polls > ALT_POLL_MAX) {
+            // gave up: the error word is STICKY (only AltWorkspace.reset_error() clears it; the managers read it with every
+            // loss read-back and raise), and the tables staged below are poisoned with NaN instead of whatever stale granules
+            // the last poll returned -- a run that timed out cannot train on quietly on wrong small tables
             if (lane == 0) st_sc1(a.fold_flags + 63, 1);
+            timed_out = true;
             break;
         }
         __builtin_amdgcn_s_sleep(4);
@@ -162,6 +172,10 @@ __device__ __forceinline__ void alt_stage_finish(const AltArgs &a, AltStage &x, 
                        "=&v"(x.g[7]), "=&v"(x.g[8])
                      : "v"(o0), "v"(ob), "s"(a.pub)
                      : "memory");
+    }
+    if (timed_out) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) x.g[i] = 0x7fc00000ull;
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -886,10 +900,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 3 : 1) void mstep_alt_ker
     }
     const int b = (int)blockIdx.x;
     if (b < a.first_task_block) {
-        if (!(MODE & 1) && b == 0 && threadIdx.x < 64) {
+        if (!(MODE & 1) && b == 0 && threadIdx.x < 63) {
             // a run starts (no fold in this launch, nobody polls): every flag word back to zero, so that no stale flag of an
             // earlier run can look like one of this run's step numbers.  (In the kernel, not a hipMemsetAsync in front of
             // it: a captured memset node replayed garbage into these words on ROCm 7.0.2 -- tools/alt_soak.py)
+            // Word 63, the error word, is NOT touched: a time-out stays visible until the host has seen it.
             a.fold_flags[threadIdx.x] = 0;
         }
         if (!(MODE & 1) && b == 0) {

@@ -241,8 +241,12 @@ class AltWorkspace:
         self.err_off = lib().invpref_alt_error_offset(C.byref(t), self.n_cap, self.partials_cap)
 
     def error(self) -> int:
-        """1 if a job workgroup ever gave up waiting for the fold flags (host sync)"""
+        """1 if a job workgroup ever gave up waiting for the small tables of its step (host sync).  The word is sticky:
+        no launch clears it, only reset_error() does."""
         return int(self.buf[self.err_off:self.err_off + 4].view(torch.int32).item())
+
+    def reset_error(self) -> None:
+        self.buf[self.err_off:self.err_off + 4].zero_()
 
 
 def alt_supported(params) -> bool:

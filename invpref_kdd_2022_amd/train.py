@@ -571,9 +571,21 @@ class _InvPrefTrainManager:
         self._loss_slot = 0
 
     def alt_error(self) -> int:
-        """1 if a workgroup of an alternating launch ever gave up waiting for the fold flags (host sync; never in a healthy run)"""
+        """1 if a workgroup of an alternating launch ever gave up waiting for its step's small tables (host sync; never in a
+        healthy run).  Sticky on the device until _check_alt_error() has raised for it."""
         A = getattr(self, '_alt', None)
         return 0 if not A or A['ws'] is None else A['ws'].error()
+
+    def _check_alt_error(self) -> None:
+        """Called wherever the host reads results of a run back anyway (train_epochs(sync=True), loss_dicts of a deferred
+        run, the end of train()): a job workgroup that timed out staged NaN tables, so the run's numbers are void --
+        say so loudly instead of handing them back (csrc/step_alt.hpp: alt_stage_finish)."""
+        if self.alt_error():
+            self._alt['ws'].reset_error()
+            raise _capi.InvPrefError(
+                'alternating M-step: a job workgroup gave up waiting for the fold blocks of its launch (ALT_POLL_MAX polls); '
+                'the parameters of this run are invalid (NaN small tables were staged).  Re-create the manager; '
+                'INVPREF_ALT=0 selects the two-launch form, which has no in-launch dependency.')
 
     def _raw_step(self, k: int, alpha: float, stream=None, mid_event=None, sched=False):
         st = self.state
@@ -715,6 +727,8 @@ class _InvPrefTrainManager:
             dev.append(self._enqueue_epochs(left))
             left -= dev[-1].shape[0]
         out = torch.cat(dev) if dev else torch.zeros(0, 6, device=self.device)
+        if sync:
+            self._check_alt_error()
         return self.loss_dicts(out) if sync else out
 
     @staticmethod
@@ -1086,6 +1100,7 @@ class _InvPrefTrainManager:
                     print(transfer_loss_dict_to_line_str(envs_cnt))
 
         self.sync_parameters()  # (user-sharded runs: every rank ends with the complete model)
+        self._check_alt_error()
         if defer:  # one read-back for everything
             loss_result_list = [dict(zip(LOSS_KEYS, v)) for v in torch.stack(loss_result_list).tolist()] \
                 if loss_result_list else []

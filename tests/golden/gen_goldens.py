@@ -24,6 +24,7 @@ What each fixture pins:
   g13   MIND-shaped trajectory: E=16, D=256, B=262144, 3 steps + E-step (1 and 8 reference threads)
   g14   MovieLens at full size: 6040 x 3706, B=65536, 2 epochs + E-step (1 and 8 reference threads)
   g15   the reference's own 1-thread vs 8-thread spread on the g4 / g10 runs
+  g16   torch.manual_seed(s) -> state_dict of the reference's constructors (sha256 per tensor)  -> §8 a1
 """
 import sys
 import types
@@ -739,9 +740,36 @@ def gen_g15():
     np.savez_compressed(os.path.join(OUT, 'g15_reference_thread_spread.npz'), **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# g16: model initialisation (reference models.py:272-305, :414-446, :197-220): torch.manual_seed(s), then the
+# reference's constructor -- five nn.Embedding tables (default init, then normal_(std=0.01) in _init_weight's order), the
+# classifier's nn.Linear (default init, then xavier_uniform_ on the weight; the bias keeps nn.Linear's default).  Stored: the
+# sha256 of every state_dict entry + the first 8 values of each (a readable witness), for a Coat-, a Yahoo-driver- and a
+# BASELINE-configs[1]-sized model of both kinds.  The drop-in modules must draw the same numbers in the same order.
+def gen_g16():
+    out, cases = {}, []
+    for kind, cls in (('implicit', ref_models.InvPrefImplicit), ('explicit', ref_models.InvPrefExplicit)):
+        for (U, I, E, D, roe, ree, seed) in ((290, 300, 2, 30, True, False, 17373331), (15400, 1000, 2, 40, True, False, 17373331),
+                                             (15400, 1000, 4, 64, False, True, 17373522), (37, 11, 16, 256, False, True, 5)):
+            torch.manual_seed(seed)
+            m = cls(user_num=U, item_num=I, env_num=E, factor_num=D, reg_only_embed=roe, reg_env_embed=ree)
+            sd = m.state_dict()
+            assert list(sd.keys()) == PARAM_NAMES, list(sd.keys())
+            tag = f'{kind}_{U}x{I}_E{E}_D{D}_s{seed}'
+            cases.append((kind, U, I, E, D, int(roe), int(ree), seed))
+            for k in PARAM_NAMES:
+                a = sd[k].detach().numpy()
+                out[f'{tag}|{k}|sha256'] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(a, np.float32).tobytes()).digest(), np.uint8)
+                out[f'{tag}|{k}|head'] = a.reshape(-1)[:8].copy()
+                out[f'{tag}|{k}|shape'] = np.array(a.shape, np.int64)
+    out['cases'] = np.array([[0 if c[0] == 'implicit' else 1, *c[1:]] for c in cases], np.int64)
+    np.savez_compressed(os.path.join(OUT, 'g16_model_init.npz'), **out)
+    print('g16:', len(cases), 'seeded constructions')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9', 'g10', 'g11', 'g12', 'g13', 'g14',
-                             'g15']
+                             'g15', 'g16']
     torch.manual_seed(0)
     for name in which:
         globals()['gen_' + name]()

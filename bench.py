@@ -765,11 +765,11 @@ def main():
         what = 'the whole optimiser step: gradient pass + all-reduce + stand-alone Adam'
     achieved = nbytes / (ms_step_dev * 1e-3) / 1e9
     # the second byte model: what the step would have to move if user rows the minibatch does not touch
-    # were left alone (the exact deferred form exists -- INVPREF_DEFER=1, tests/test_deferred_gpu.py -- and measures
-    # SLOWER: profiles/r04/deferred_adam_ab.txt; the headline runs the dense form, so `frac` uses the dense bytes)
+    # were left alone (the exact deferred form was built in round 4 and measured SLOWER -- profiles/r04/deferred_adam_ab.txt,
+    # 25.3 vs 18.9 us per step -- and was removed in round 6; the run is the dense form, so `frac` uses the dense bytes)
     untouched = 0.0
-    if fused and getattr(mgr, '_plans', None):
-        untouched = sum(int(x) for dp in mgr._plans for x in dp.struct.defer_tail) / len(mgr._plans)
+    if fused and getattr(mgr, '_raw_batches', None):
+        untouched = sum(mgr.model.user_num - int(torch.unique(b[3]).numel()) for b in mgr._raw_batches) / len(mgr._raw_batches)
     nbytes_touched = nbytes - 24 * 2 * D * untouched
     traffic, traffic_stamp = pmc_traffic_bytes(knames) if world == 1 else (None, None)
     rocprof_ms = rocprof_avg_ms(knames) if world == 1 else None      # (the committed profiles are 1-GPU runs)
@@ -794,7 +794,7 @@ def main():
                 'touched_rows_model': {'bytes_per_launch': nbytes_touched, 'untouched_user_rows_per_step': untouched,
                                        'achieved': nbytes_touched / (ms_step_dev * 1e-3) / 1e9,
                                        'frac': nbytes_touched / (ms_step_dev * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                       'note': 'untouched user rows not counted (what deferred Adam would move); the run '
+                                       'note': 'untouched user rows not counted (what a lazy Adam would move); the run '
                                                'itself is the dense form'}}
     if alt:
         # the second byte model: what the ALTERNATING form itself has to move per step -- per interaction ids /

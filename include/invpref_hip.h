@@ -148,10 +148,6 @@ typedef struct InvPrefRowPlan {
      * must be of mode 7 (or 0) with [a, b) = the slice's slots.  One extra row write + read per interaction and table: for
      * minibatches whose rows are a small share of the step's bytes (plan.py decides). */
     const int32_t *push_slot;                 /* [n] */
-    /* deferred dense Adam (invpref_mstep_rows_adam_deferred_hip): of the rows class c streams in launch 1 / launch 2, the
-     * LAST defer_tail[c][0] / [c][1] entries are untouched rows of the USER tables -- a deferred step leaves them alone
-     * (their zero-gradient updates are replayed when the row is next touched, or by invpref_flush_deferred_hip). */
-    int32_t defer_tail[8][2];
 } InvPrefRowPlan;
 
 /* Scratch of one planned step: the records + the partial slabs.  It needs no initialisation (every word is stored
@@ -219,34 +215,6 @@ int invpref_mstep_rows_adam_sched_hip(const InvPrefTables *tables, const InvPref
                                       const float *sample_weights, int64_t batch_norm, const InvPrefCoefs *coefs,
                                       uint32_t flags, float *losses6, const InvPrefAdamSchedule *sched,
                                       void *workspace, size_t workspace_bytes, void *stream);
-
-/* ---- deferred dense Adam on untouched user rows (same results as the dense step, bit for bit).
- * torch.optim.Adam (train.py:41, :155-157) updates EVERY row at EVERY step; a user row the minibatch does not touch has a
- * gradient of exactly zero and nothing in the step reads it, so its update can be postponed: `last_step[u]` (device
- * int32[user_num]) is the step whose update row u has seen last.  invpref_mstep_rows_adam_deferred_hip is
- * invpref_mstep_rows_adam_sched_hip, except that
- *   * the untouched user rows of the plan (defer_tail) are not streamed;
- *   * a user job first replays its row's pending updates -- steps last_step[u] + 1 .. step - 1, gradient zero, each
- *     with ITS step's scalars from the schedule table, the same arithmetic as the streamed form -- then evaluates,
- *     updates the row with this step's gradient and sets last_step[u] = step;
- *   * the USER tables are updated in place: `tables` and `new_tables` must name the same two user tables (the item
- *     tables, embed_env and the classifier ping-pong as before).  Needs the push form of the plan (launch 2 must not
- *     gather user rows) and a shape invpref_rows_defer_supported() accepts.
- * invpref_flush_deferred_hip brings every user row up to date (pending updates through the step BEFORE the one in
- * sched->state's slot `sched->slot`), writes the rows of `home` (the tables the deferred steps used) into `dst` (may be
- * the same tables) and sets last_step[] to that step: call it before anything reads all rows (E-step, evaluation,
- * state_dict) and before the schedule table is rebased.  Before the first deferred step last_step[] must hold the
- * number of steps already taken. */
-int invpref_rows_defer_supported(const InvPrefTables *tables, const InvPrefRowPlan *plan);
-int invpref_mstep_rows_adam_deferred_hip(const InvPrefTables *tables, const InvPrefTables *new_tables,
-                                         const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
-                                         const InvPrefRowPlan *plan, const int64_t *envs, const float *scores,
-                                         const float *sample_weights, int64_t batch_norm, const InvPrefCoefs *coefs,
-                                         uint32_t flags, float *losses6, const InvPrefAdamSchedule *sched,
-                                         int32_t *last_step, void *workspace, size_t workspace_bytes, void *stream);
-int invpref_flush_deferred_hip(const InvPrefTables *home, const InvPrefTables *dst, const InvPrefTables *exp_avg,
-                               const InvPrefTables *exp_avg_sq, int32_t *last_step, const InvPrefAdamSchedule *sched,
-                               void *stream);
 
 /* ---- ONE launch per optimiser step: the evaluating side alternates (round 5).
  * The step's arithmetic is symmetric in users and items (models.py:307-326) and torch.optim.Adam (train.py:41, :155-157)

@@ -34,7 +34,7 @@ typedef struct InvPrefPlanParams {
 typedef struct InvPrefHostPlan InvPrefHostPlan;
 
 /* which: 0 user_desc [rounds][NG][8] | 1 item_desc | 2 user_round_iters | 3 user_list [n][4] | 4 item_list [n][2] |
- *        5 stream_rows | 6 push_slot (length 0 without push) | 7 cls [8][8] | 8 defer_tail [8][2] */
+ *        5 stream_rows | 6 push_slot (length 0 without push) | 7 cls [8][8] */
 InvPrefHostPlan *invpref_plan_build(const int64_t *users, const int64_t *items, const float *scores, int64_t n,
                                     int64_t user_num, int64_t item_num, const InvPrefPlanParams *params);
 int64_t invpref_plan_array(const InvPrefHostPlan *plan, int32_t which, const int32_t **data);

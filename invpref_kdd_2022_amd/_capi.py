@@ -24,8 +24,7 @@ EXPORTS = [
     'invpref_adam_schedule_fill', 'invpref_mstep_rows_adam_sched_hip', 'invpref_eval_topk_hip',
     'invpref_eval_error_sums_hip', 'invpref_mstep_rows_adam_profiled_hip', 'invpref_static_pop_workspace_bytes',
     'invpref_static_pop_hip', 'invpref_adam_ranges_hip', 'invpref_mstep_rows_grad_sched_hip',
-    'invpref_adam_ranges_sched_hip', 'invpref_rows_lanes_per_group', 'invpref_rows_defer_supported',
-    'invpref_mstep_rows_adam_deferred_hip', 'invpref_flush_deferred_hip', 'invpref_estep_perm_hip',
+    'invpref_adam_ranges_sched_hip', 'invpref_rows_lanes_per_group', 'invpref_estep_perm_hip',
     'invpref_pack_rows_hip', 'invpref_unpack_rows_hip', 'invpref_alt_workspace_bytes', 'invpref_alt_supported',
     'invpref_mstep_alt_hip', 'invpref_alt_error_offset',
 ]
@@ -101,12 +100,6 @@ def lib():
         L.invpref_mstep_rows_adam_sched_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), C.POINTER(Tables),
                                                         C.POINTER(Tables), vp, vp, vp, vp, i64, C.POINTER(Coefs), u32,
                                                         vp, C.POINTER(AdamSchedule), vp, C.c_size_t, vp]
-        L.invpref_mstep_rows_adam_deferred_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), C.POINTER(Tables),
-                                                           C.POINTER(Tables), vp, vp, vp, vp, i64, C.POINTER(Coefs), u32,
-                                                           vp, C.POINTER(AdamSchedule), vp, vp, C.c_size_t, vp]
-        L.invpref_rows_defer_supported.argtypes = [C.POINTER(Tables), vp]
-        L.invpref_flush_deferred_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), C.POINTER(Tables),
-                                                 C.POINTER(Tables), vp, C.POINTER(AdamSchedule), vp]
         L.invpref_eval_topk_hip.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp]
         L.invpref_eval_error_sums_hip.argtypes = [vp, vp, i64, vp, vp]
         L.invpref_mstep_rows_adam_profiled_hip.argtypes = L.invpref_mstep_rows_adam_hip.argtypes + [vp]

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(256) void adam_ranges_kernel(float *__restrict__ p,
 // sixteen 4-bit element numbers, which the E-step's lanes turn into their tie-break term.
 constexpr int kEpsTableMaxE = 7;
 struct EpsBase { float v[INVPREF_MAX_ENVS]; };
-struct Factorials { unsigned long long f[INVPREF_MAX_ENVS]; };   // f[k] = k!
+struct Factorials { unsigned long long f[INVPREF_MAX_ENVS + 1]; };   // f[k] = k!, k = 0 .. 16 (16! = 2.1e13 fits; eps_unrank_kernel clamps to f[E] - 1)
 __device__ __forceinline__ unsigned long long unrank_packed(unsigned long long r, int E, const Factorials &fac) {
     unsigned avail = (1u << E) - 1u;
     unsigned long long out = 0;
@@ -1249,7 +1249,7 @@ static int estep_launch(const InvPrefTables *tables, const int64_t *users, const
     EpsBase eps_base{};
     Factorials fac{};
     fac.f[0] = 1;
-    for (int k = 1; k < INVPREF_MAX_ENVS; k++) fac.f[k] = fac.f[k - 1] * (unsigned long long)k;
+    for (int k = 1; k <= INVPREF_MAX_ENVS; k++) fac.f[k] = fac.f[k - 1] * (unsigned long long)k;
     const void *eps_index = nullptr;   // E <= 7: looked up in the kernel's own LDS table
     int eps_rows_n = 0;
     size_t lds_extra = 0;

@@ -18,11 +18,11 @@
 #include <vector>
 
 struct InvPrefHostPlan {
-    std::vector<int32_t> arr[9];   // (alt plans use 0 .. 5)
+    std::vector<int32_t> arr[8];   // (alt plans use 0 .. 5)
     // the big arrays (lists, descriptors, push slots) live in UNINITIALISED storage: every element is written exactly once by
     // the builder, and zero-filling 0.5 GB first costs as much as the sort itself
-    std::unique_ptr<int32_t[]> big[9];
-    size_t big_n[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    std::unique_ptr<int32_t[]> big[8];
+    size_t big_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int32_t *alloc(int which, size_t n) {
         big[which].reset(new int32_t[n ? n : 1]);
         big_n[which] = n;
@@ -306,8 +306,6 @@ InvPrefHostPlan *build(const int64_t *users, const int64_t *items, const float *
     lap("rounds of the classes");
     int32_t cls[8][8];
     std::memset(cls, 0, sizeof(cls));
-    int32_t defer_tail[8][2];
-    std::memset(defer_tail, 0, sizeof(defer_tail));
     // untouched rows: streamed, no job
     std::vector<int32_t> stream_u, stream_i;
     for (int64_t r = 0; r < U; r++)
@@ -333,16 +331,14 @@ InvPrefHostPlan *build(const int64_t *users, const int64_t *items, const float *
             k = std::min<int64_t>((int64_t)rows.size(), std::max<int64_t>(k, room * p.rows_per_stream_task));
         }
         k = std::max<int64_t>(0, std::min<int64_t>(k, (int64_t)rows.size()));
-        // inside each launch's share: item rows first, USER rows last (InvPrefRowPlan.defer_tail)
+        // inside each launch's share: item rows first, user rows last
         for (int li = 0; li < 2; li++) {
             const int64_t a = li == 0 ? 0 : k, b = li == 0 ? k : (int64_t)rows.size();
             std::vector<int32_t> &dst = li == 0 ? s1[(size_t)c] : s2[(size_t)c];
-            int32_t nu = 0;
             for (int64_t q = a; q < b; q++)
                 if (rows[(size_t)q] & kItemBit) dst.push_back(rows[(size_t)q]);
             for (int64_t q = a; q < b; q++)
-                if (!(rows[(size_t)q] & kItemBit)) { dst.push_back(rows[(size_t)q]); nu++; }
-            defer_tail[c][li] = nu;
+                if (!(rows[(size_t)q] & kItemBit)) dst.push_back(rows[(size_t)q]);
         }
     }
     for (int c = 0; c < ncls; c++) {
@@ -366,7 +362,6 @@ InvPrefHostPlan *build(const int64_t *users, const int64_t *items, const float *
     for (int c = 0; c < ncls; c++) sr.insert(sr.end(), s2[(size_t)c].begin(), s2[(size_t)c].end());
     lap("concatenate + stream rows");
     hp->arr[7].assign(&cls[0][0], &cls[0][0] + 64);
-    hp->arr[8].assign(&defer_tail[0][0], &defer_tail[0][0] + 16);
     return hp;
 }
 
@@ -527,7 +522,7 @@ InvPrefHostPlan *invpref_plan_build(const int64_t *users, const int64_t *items, 
 }
 
 int64_t invpref_plan_array(const InvPrefHostPlan *plan, int32_t which, const int32_t **data) {
-    if (!plan || which < 0 || which > 8) return -1;
+    if (!plan || which < 0 || which > 7) return -1;
     if (plan->big[which]) {
         if (data) *data = plan->big[which].get();
         return (int64_t)plan->big_n[which];

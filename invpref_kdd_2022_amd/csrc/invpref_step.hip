@@ -41,7 +41,6 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kDeferWin = 64;   // deferred rows: steps whose Adam scalars a launch-1 workgroup keeps in LDS
 
 // one row of the device-side schedule (include/invpref_hip.h: InvPrefAdamSchedule)
 struct SchedRow {
@@ -242,8 +241,10 @@ struct StepArgs {
     float *slabs_ev;              // wide rows (step_wide.hpp, EVL2): [launch-2 item tasks][EMAX][DP] partial sums of embed_env's gradient
     int *sched_state;             // optional device int32[32]: two slots {step, base, SchedRow}, see InvPrefAdamSchedule
     int sched_slot;
-    int *last_step;               // deferred dense Adam (launch 1, DEFER instances): [U] step of a user row's last update
-    const float *sched_rows;      // ... and the schedule table (float[n][8]) the pending zero-gradient updates are replayed from
+    // (16 unused bytes keep the kernel-argument offsets of rounds 4-5: with the block two pointers shorter hipcc's scalar-register
+    //  allocation of mstep_eval_wide_kernel<16, 2, true, 8, false> -- the MovieLens instance, at 100 SGPRs -- spills nine of them
+    //  and the dispatch then sets up a private segment; tests/test_kernel_isa.py holds that instance to a segment size of 0)
+    void *reserved_[2];
     int stamps_nodrain;
     unsigned long long *stamps;   // diagnostic (INVPREF_STAMPS): [workgroup][8] s_memrealtime ticks
 };
@@ -451,7 +452,7 @@ struct USample {
 #ifndef STEP_ROW_ST
 #define STEP_ROW_ST 0   // (A/B knob: 1 = write-through stores for the rows the jobs finish)
 #endif
-template <int LG, bool VEC, int EMAX, bool DEFER, bool FULL>
+template <int LG, bool VEC, int EMAX, bool FULL>
 __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a, int r0, int nr, int slab_index, float *lds) {
     using G = Geo<LG, EMAX>;
     // (rows of more than 64 floats and more than four environments run step_wide.hpp; the branches of this function for
@@ -472,10 +473,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
     const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
     const bool pure = a.flags & INVPREF_PURE_MF;   // env-aware tables, embed_env, classifier absent: never touched
     // (E > 8: the LDS-DMA landing area holds the embed_env partial sums instead; the moments are loaded late)
-    // (DEFER: the moments are needed FIRST -- the row's pending zero-gradient updates are replayed in front of the
-    //  evaluation -- so they are ordinary loads, parked in the landing area afterwards)
-    const bool dma = VEC && a.fused && G::REG && !(STEP_NO_DMA && G::DIRECT) && !DEFER;
-    static_assert(!DEFER || (EvalLds<LG, EMAX>::ALIAS && VEC), "deferred rows: the aliased landing-area instances only");
+    const bool dma = VEC && a.fused && G::REG && !(STEP_NO_DMA && G::DIRECT);
     const bool push = a.push_slot != nullptr;
     float *sdE = lds + L::mv;   // E > 8: [EMAX][DP] embed_env partial sums of the workgroup, rows indexed by the environment
     StepScalars k = a.k;
@@ -493,18 +491,6 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
         stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
         stage_small(sW, t.W, t.E, t.D, EMAX, DP);
         if (threadIdx.x < EMAX) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
-    }
-    // DEFER: this step's number, and the Adam scalars of the kDeferWin steps before it staged in LDS
-    int tcur = 0, sbase = 0;
-    float2 *swin = reinterpret_cast<float2 *>(lds + L::total);
-    if (DEFER) {
-        const int *cur = a.sched_state + 16 * a.sched_slot;
-        tcur = cur[0]; sbase = cur[1];
-        if (threadIdx.x < kDeferWin) {
-            const int sx = tcur - kDeferWin + (int)threadIdx.x;
-            swin[threadIdx.x] = sx >= sbase ? *reinterpret_cast<const float2 *>(a.sched_rows + 8 * (sx - sbase))
-                                            : make_float2(0.f, 0.f);
-        }
     }
     if (!G::REG)
         for (int i = threadIdx.x; i < EMAX * DP; i += kThreads) sdE[i] = 0.f;
@@ -559,19 +545,10 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
         // everything that depends only on the descriptor is requested together: own rows, the Adam moments of the
         // row (needed last: LDS-DMA, no registers held across the loop) and the first interactions' rows / env / weight
         float4 oi = f4zero(), oe = f4zero(), gi = f4zero(), ge = f4zero();
-        float4 dmi = f4zero(), dvi = f4zero(), dme = f4zero(), dve = f4zero();   // DEFER: the row's moments, up front
-        int pend_from = 0x7fffffff;                                              // DEFER: first step the row has not seen yet
         {   // (an idle slot reads row 0 rather than branching around the loads)
             const int rowc = active ? row : 0;
             oi = row4<VEC, FULL>(t.Pu, rowc, t.D, lg);
             if (!pure) oe = row4<VEC, FULL>(t.Pa, rowc, t.D, lg);
-            if (DEFER) {
-                // every slice of the row replays for itself (it needs the up-to-date row for its evaluations)
-                const int ls = a.last_step[rowc];
-                if (active) pend_from = ls + 1;
-                dmi = row4<VEC, FULL>(a.m[0], rowc, t.D, lg); dvi = row4<VEC, FULL>(a.v[0], rowc, t.D, lg);
-                if (!pure) { dme = row4<VEC, FULL>(a.m[2], rowc, t.D, lg); dve = row4<VEC, FULL>(a.v[2], rowc, t.D, lg); }
-            }
         }
         // UE interactions in flight per group, each in a register slot of its own: the slot just consumed is refilled
         // at once (no register copies: a copy of a register that is still being loaded would wait for the load)
@@ -667,35 +644,6 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             }
             __syncthreads();   // staged tables visible (the gathers above are in flight)
             STAMP(3);
-        }
-        if (DEFER) {
-            // Deferred dense Adam: steps pend_from .. cur - 1 did not touch this row, so their updates -- gradient exactly
-            // zero, the step's own scalars from the schedule table -- were never applied.  They are replayed here, in
-            // registers, with the SAME adam1f the streamed form uses: bit for bit what the dense step would have left in
-            // memory.  (Under the partner gathers' round trip: those were requested above.  The scalars of the last
-            // kDeferWin steps were staged in LDS with the small tables -- a load that depended on the row's stamp would be
-            // one more round trip on the step's critical chain -- older ones come from the table itself.)
-            auto sched_at = [&](int sx) {
-                const int j = sx - (tcur - kDeferWin);
-                if (j >= 0) return swin[j];
-                return *reinterpret_cast<const float2 *>(a.sched_rows + 8 * (sx - sbase));
-            };
-            int s = pend_from;
-            float2 sc = make_float2(0.f, 0.f);
-            if (s < tcur) sc = sched_at(s);
-            while (s < tcur) {
-                float2 nsc = sc;   // (the next step's scalars fly under this step's arithmetic)
-                if (s + 1 < tcur) nsc = sched_at(s + 1);
-                AdamScalars as = ad;
-                as.step_size = sc.x; as.bc2_sqrt = sc.y;
-                adam4(oi, f4zero(), dmi, dvi, as);
-                if (!pure) adam4(oe, f4zero(), dme, dve, as);
-                sc = nsc;
-                s++;
-            }
-            // park the moments in the lane's own words of the wave's landing area: needed again when the row is finished
-            mv_wave[0 * 64 + lane] = dmi; mv_wave[1 * 64 + lane] = dvi;
-            if (!pure) { mv_wave[2 * 64 + lane] = dme; mv_wave[3 * 64 + lane] = dve; }
         }
         // one interaction: evaluate, accumulate the user rows' gradients, store the record, feed the E x D / loss sums
         auto step = [&](const Slot &q, bool has) {
@@ -897,8 +845,8 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             return L::ALIAS ? lds + L::mv + (g / GW) * (4 * 64 * 4) + (g % GW) * 2 * DP : slots + g * 2 * DP;
         };
         float4 mi = f4zero(), vi = f4zero(), me = f4zero(), ve = f4zero();
-        if (L::ALIAS && (dma || DEFER) && active && leader) {   // (the slices' partials overwrite the landing area next)
-            if (!DEFER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA pieces have landed
+        if (L::ALIAS && dma && active && leader) {   // (the slices' partials overwrite the landing area next)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA pieces have landed
             mi = mv_wave[0 * 64 + lane]; vi = mv_wave[1 * 64 + lane];
             if (!pure) { me = mv_wave[2 * 64 + lane]; ve = mv_wave[3 * 64 + lane]; }
         }
@@ -949,7 +897,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 put4<VEC, 0, FULL>(a.np[0], row, t.D, lg, gi);
                 if (!pure) put4<VEC, 0, FULL>(a.np[2], row, t.D, lg, ge);
             } else {
-                if ((dma || DEFER) && L::ALIAS) {   // (taken out of the landing area above)
+                if (dma && L::ALIAS) {   // (taken out of the landing area above)
                 } else if (dma) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA pieces have landed
                     mi = mv_wave[0 * 64 + lane]; vi = mv_wave[1 * 64 + lane];
@@ -968,7 +916,6 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                     put4<VEC, STEP_ROW_ST, FULL>(a.m[2], row, t.D, lg, me);
                     put4<VEC, STEP_ROW_ST, FULL>(a.v[2], row, t.D, lg, ve);
                 }
-                if (DEFER && lg == 0) a.last_step[row] = tcur;   // up to date as of this step
             }
         }
     }
@@ -1516,7 +1463,7 @@ __device__ __forceinline__ void class_row(const StepArgs &a, int c, int (&q)[4])
 #ifndef STEP_APPLY_WAVES
 #define STEP_APPLY_WAVES 4
 #endif
-template <int LG, bool VEC, int EMAX, bool DEFER = false, bool FULL = false>
+template <int LG, bool VEC, int EMAX, bool FULL = false>
 __global__ __launch_bounds__(kThreads, (LG == 16 && EMAX <= 4) ? STEP_EVAL_WAVES_SMALL : STEP_EVAL_WAVES) void mstep_eval_kernel(DevTables t, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // Workgroup b runs the tasks of class c = b % n_cls (XCD-affine order, InvPrefRowPlan), the j-th of them with
@@ -1530,7 +1477,7 @@ __global__ __launch_bounds__(kThreads, (LG == 16 && EMAX <= 4) ? STEP_EVAL_WAVES
     const int tj = (q[1] + rpt - 1) / rpt;
     if (j < tj) {
 #ifndef DBG_NO_JOBS
-        user_task<LG, VEC, EMAX, DEFER, FULL>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), q[0] / rpt + j, lds);
+        user_task<LG, VEC, EMAX, FULL>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), q[0] / rpt + j, lds);
 #endif
         return;
     }
@@ -1602,67 +1549,6 @@ __global__ __launch_bounds__(kThreads, FULL ? 3 : STEP_APPLY_WAVES) void mstep_a
     }
 }
 
-// Deferred dense Adam, the other half: brings EVERY user row up to date -- the pending zero-gradient updates of steps
-// last[row] + 1 .. t_done replayed with the schedule table's scalars, the same adam1f -- and moves the rows from the
-// tables the deferred steps kept them in (`home`) to the current parameter buffer (`dst`; may be the same memory).
-// One wavefront per row, so nobody else reads the row's `last` word while it is rewritten.
-struct FlushArgs {
-    const float *home[2];    // user tables the deferred steps updated in place (invariant, env-aware; [1] NULL: PureMF)
-    float *dst[2];           // the same two tables of the current parameter buffer
-    float *m[2], *v[2];
-    int *last_step;
-    const int *sched_state;  // the slot of the step that would run NEXT: {t_done + 1, base, ...}
-    int sched_slot;
-    const float *sched_rows;
-    int U, D;
-};
-__global__ __launch_bounds__(kThreads) void flush_deferred_kernel(FlushArgs f) {
-    const int lane = threadIdx.x & 63;
-    const int row = (int)blockIdx.x * kWaves + ((int)threadIdx.x >> 6);
-    if (row >= f.U) return;
-    const int *cur = f.sched_state + 16 * f.sched_slot;
-    const int t_done = cur[0] - 1, base = cur[1];
-    const int from = __builtin_amdgcn_readfirstlane(f.last_step[row]) + 1;
-    const bool moved = f.home[0] != f.dst[0];
-    if (from > t_done && !moved) return;
-    constexpr int NE = INVPREF_MAX_FACTORS / 64;   // elements per lane and table
-    float p[2][NE], m[2][NE], v[2][NE];
-    const unsigned off = (unsigned)row * (unsigned)f.D;
-#pragma unroll
-    for (int tb = 0; tb < 2; tb++) {
-#pragma unroll
-        for (int c = 0; c < NE; c++) {
-            const int d = lane + 64 * c;
-            const bool on = f.home[tb] && d < f.D;
-            p[tb][c] = on ? f.home[tb][off + d] : 0.f;
-            m[tb][c] = (on && from <= t_done) ? f.m[tb][off + d] : 0.f;
-            v[tb][c] = (on && from <= t_done) ? f.v[tb][off + d] : 0.f;
-        }
-    }
-    for (int s = from; s <= t_done; s++) {   // (wave-uniform)
-        const float *sr = f.sched_rows + 8 * (s - base);
-        AdamScalars as;
-        as.step_size = sr[0]; as.bc2_sqrt = sr[1]; as.w1 = sr[2]; as.b2 = sr[3]; as.w2 = sr[4]; as.eps = sr[5];
-#pragma unroll
-        for (int tb = 0; tb < 2; tb++) {
-#pragma unroll
-            for (int c = 0; c < NE; c++) adam1f(p[tb][c], 0.f, m[tb][c], v[tb][c], as);
-        }
-    }
-#pragma unroll
-    for (int tb = 0; tb < 2; tb++) {
-#pragma unroll
-        for (int c = 0; c < NE; c++) {
-            const int d = lane + 64 * c;
-            if (f.home[tb] && d < f.D) {
-                f.dst[tb][off + d] = p[tb][c];
-                if (from <= t_done) { f.m[tb][off + d] = m[tb][c]; f.v[tb][off + d] = v[tb][c]; }
-            }
-        }
-    }
-    if (lane == 0 && from <= t_done) f.last_step[row] = t_done;
-}
-
 #include "step_wide.hpp"
 #include "step_wide_mm.hpp"
 
@@ -1724,16 +1610,15 @@ inline size_t workspace_floats(const InvPrefRowPlan *plan, const Shape &s) {
            (s.evl2 ? (size_t)s.emax * s.dp * (ni > 0 ? ni : 1) : 0);
 }
 
-inline int plan_tasks(const InvPrefRowPlan *plan, int launch, int *task_wgs, bool defer = false) {
+inline int plan_tasks(const InvPrefRowPlan *plan, int launch, int *task_wgs) {
     // workgroups of one launch: the classes' task lists interleaved, padded to the longest
-    // (defer: the untouched USER rows at the tail of every class's stream list are not streamed)
     const int ncls = plan->n_classes > 0 ? plan->n_classes : 1;
     const int rpt = launch == 0 ? plan->user_rounds_per_task : plan->item_rounds_per_task;
     const int spt = (launch == 1 && plan->rows_per_stream_task2 > 0) ? plan->rows_per_stream_task2 : plan->rows_per_stream_task;
     int per_class = 0;
     for (int c = 0; c < ncls; c++) {
         const int32_t *q = plan->cls[c] + 4 * launch;
-        const int ns = q[3] - (defer ? plan->defer_tail[c][launch] : 0);
+        const int ns = q[3];
         const int tot = (q[1] + rpt - 1) / rpt + (ns + spt - 1) / spt;
         per_class = tot > per_class ? tot : per_class;
     }
@@ -1745,8 +1630,7 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
                 const float *weights, int64_t batch_norm, const InvPrefCoefs *coefs, uint32_t flags, float *losses6,
                 void *workspace, size_t workspace_bytes, hipStream_t st, int fused, const InvPrefTables *grads,
                 const InvPrefTables *new_tables, const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
-                const AdamScalars &ad, const InvPrefAdamSchedule *sched, void *profile_event,
-                int32_t *last_step = nullptr) {
+                const AdamScalars &ad, const InvPrefAdamSchedule *sched, void *profile_event) {
     const bool pure = flags & INVPREF_PURE_MF;
     int rc = check_tables(tables, pure);
     if (sched && (!sched->state || !sched->table || sched->n <= 0)) return INVPREF_EINVAL;
@@ -1790,22 +1674,9 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
         return INVPREF_EINVAL;
     const int ncls = plan->n_classes > 0 ? plan->n_classes : 1;
     if (ncls > 8) return INVPREF_EINVAL;
-    const bool defer = last_step != nullptr;
-    if (defer) {
-        // deferred dense Adam on untouched user rows: scalars of past steps come from the schedule table; the user tables
-        // are updated IN PLACE (launch 2 must not gather user rows: push form); compiled for the smallest instance
-        if (!fused || !sched || !plan->push_slot) return INVPREF_EINVAL;
-        if (tables->embed_user_invariant != new_tables->embed_user_invariant ||
-            tables->embed_user_env_aware != new_tables->embed_user_env_aware)
-            return INVPREF_EINVAL;
-        if (!vec || shp.wide) return INVPREF_EUNSUPPORTED;
-    }
     for (int c = 0; c < ncls; c++) {
         const int32_t *q = plan->cls[c];
         for (int i = 0; i < 8; i++) if (q[i] < 0) return INVPREF_EINVAL;
-        if (plan->defer_tail[c][0] < 0 || plan->defer_tail[c][1] < 0 || plan->defer_tail[c][0] > q[3] ||
-            plan->defer_tail[c][1] > q[7])
-            return INVPREF_EINVAL;
         if (q[0] + q[1] > plan->n_user_rounds || q[4] + q[5] > plan->n_item_rounds || q[2] + q[3] > plan->n_stream ||
             q[6] + q[7] > plan->n_stream || q[0] % plan->user_rounds_per_task || q[4] % plan->item_rounds_per_task)
             return INVPREF_EINVAL;
@@ -1828,15 +1699,13 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a.push_slot = plan->push_slot;
     a.sched_state = sched ? sched->state : nullptr;
     a.sched_slot = sched ? (sched->slot & 1) : 0;
-    a.last_step = last_step;
-    a.sched_rows = sched ? sched->table : nullptr;
     static const char *stamp_env = getenv("INVPREF_STAMPS");   // diagnostics: device pointer (hex) of a stamp buffer
     unsigned long long *stamps = stamp_env ? reinterpret_cast<unsigned long long *>(strtoull(stamp_env, nullptr, 16)) : nullptr;
     static const bool nodrain = getenv("INVPREF_STAMPS_NODRAIN") != nullptr;
     a.stamps_nodrain = nodrain;
     int wg1 = 0, wg2 = 0;
-    plan_tasks(plan, 0, &wg1, defer);
-    plan_tasks(plan, 1, &wg2, defer);
+    plan_tasks(plan, 0, &wg1);
+    plan_tasks(plan, 1, &wg2);
     const size_t lds1 = eval_lds_bytes(shp), lds2 = apply_lds_bytes(shp);
     if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return INVPREF_EUNSUPPORTED;
     // launch 1
@@ -1848,7 +1717,6 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a1.stream_rows = plan->stream_rows;
     a1.stamps = stamps;
     for (int c = 0; c < 8; c++) for (int i = 0; i < 4; i++) a1.cls[c][i] = c < ncls ? plan->cls[c][i] : 0;
-    if (defer) for (int c = 0; c < ncls; c++) a1.cls[c][3] -= plan->defer_tail[c][0];
     // launch 2
     StepArgs a2 = a;
     a2.desc = reinterpret_cast<const int4 *>(plan->item_desc);
@@ -1858,7 +1726,6 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a2.stream_rows = plan->stream_rows;
     a2.stamps = stamps ? stamps + 8192 * 8 : nullptr;   // (the stamp buffer's second half belongs to launch 2)
     for (int c = 0; c < 8; c++) for (int i = 0; i < 4; i++) a2.cls[c][i] = c < ncls ? plan->cls[c][4 + i] : 0;
-    if (defer) for (int c = 0; c < ncls; c++) a2.cls[c][3] -= plan->defer_tail[c][1];
     FoldArgs f{};
     if (!fused) {
         f.gEv = grads->embed_env; f.gW = grads->classifier_weight; f.gb = grads->classifier_bias;
@@ -1911,7 +1778,7 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     const char *mm_env = getenv("INVPREF_WIDE_MM");   // (read per call: the tests switch forms inside one process)
     const bool mm_want = mm_env ? mm_env[0] == '1' : shp.lg == 32;
     const bool use_mm = mm_want && !pure && t.b != nullptr && (reinterpret_cast<uintptr_t>(t.W) & 15u) == 0;
-    if (shp.wide && !defer) {
+    if (shp.wide) {
         // (the wide kernels' vector form is for FULL rows only -- factor_num 64 / 128 / 256: no clamps or selects behind a
         //  load; any other row length takes their element-wise form)
         if (vec && t.D == shp.dp) {
@@ -1936,19 +1803,11 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     // element-wise-guarded instances instead
     static const bool no_full = getenv("INVPREF_NO_FULL") != nullptr && getenv("INVPREF_NO_FULL")[0] == '1';
     const bool full = vec && t.D == 64 && !no_full;
-    if (defer) {
-        const size_t lds1d = lds1 + kDeferWin * sizeof(float2);
-        if ((rc = ensure_lds(mstep_eval_kernel<16, true, 4, true>, lds1d))) return rc;
-        if ((rc = ensure_lds(mstep_apply_kernel<16, true, 4>, lds2))) return rc;
-        if (wg1 > 0)
-            hipLaunchKernelGGL((mstep_eval_kernel<16, true, 4, true>), dim3(wg1), dim3(kThreads), lds1d, st, t, a1);
-        if (profile_event && hipEventRecord((hipEvent_t)profile_event, st) != hipSuccess) return INVPREF_EINVAL;
-        hipLaunchKernelGGL((mstep_apply_kernel<16, true, 4>), dim3(grid2), dim3(kThreads), lds2, st, t, a2, f);
-    } else if (full) {
-        if ((rc = ensure_lds(mstep_eval_kernel<16, true, 4, false, true>, lds1))) return rc;
+    if (full) {
+        if ((rc = ensure_lds(mstep_eval_kernel<16, true, 4, true>, lds1))) return rc;
         if ((rc = ensure_lds(mstep_apply_kernel<16, true, 4, true>, lds2))) return rc;
         if (wg1 > 0)
-            hipLaunchKernelGGL((mstep_eval_kernel<16, true, 4, false, true>), dim3(wg1), dim3(kThreads), lds1, st, t, a1);
+            hipLaunchKernelGGL((mstep_eval_kernel<16, true, 4, true>), dim3(wg1), dim3(kThreads), lds1, st, t, a1);
         if (profile_event && hipEventRecord((hipEvent_t)profile_event, st) != hipSuccess) return INVPREF_EINVAL;
         hipLaunchKernelGGL((mstep_apply_kernel<16, true, 4, true>), dim3(grid2), dim3(kThreads), lds2, st, t, a2, f);
     } else if (!vec) {
@@ -2091,54 +1950,12 @@ int invpref_mstep_rows_adam_sched_hip(const InvPrefTables *tables, const InvPref
                        sched, nullptr);
 }
 
-int invpref_mstep_rows_adam_deferred_hip(const InvPrefTables *tables, const InvPrefTables *new_tables,
-                                         const InvPrefTables *exp_avg, const InvPrefTables *exp_avg_sq,
-                                         const InvPrefRowPlan *plan, const int64_t *envs, const float *scores,
-                                         const float *sample_weights, int64_t batch_norm, const InvPrefCoefs *coefs,
-                                         uint32_t flags, float *losses6, const InvPrefAdamSchedule *sched,
-                                         int32_t *last_step, void *workspace, size_t workspace_bytes, void *stream) {
-    if (!sched || !last_step) return INVPREF_EINVAL;
-    return launch_step(tables, plan, envs, scores, sample_weights, batch_norm, coefs, flags, losses6, workspace,
-                       workspace_bytes, (hipStream_t)stream, 1, nullptr, new_tables, exp_avg, exp_avg_sq, AdamScalars{},
-                       sched, nullptr, last_step);
-}
-
-int invpref_rows_defer_supported(const InvPrefTables *tables, const InvPrefRowPlan *plan) {
-    if (!tables || !plan) return 0;
-    const bool pure = tables->embed_user_env_aware == nullptr;
-    if (check_tables(tables, pure)) return 0;
-    return plan->push_slot && vec_ok(tables) && !shape_of((int)tables->factor_num, (int)tables->env_num).wide;
-}
-
-int invpref_flush_deferred_hip(const InvPrefTables *home, const InvPrefTables *dst, const InvPrefTables *exp_avg,
-                               const InvPrefTables *exp_avg_sq, int32_t *last_step, const InvPrefAdamSchedule *sched,
-                               void *stream) {
-    if (!home || !dst || !exp_avg || !exp_avg_sq || !last_step || !sched || !sched->state || !sched->table)
-        return INVPREF_EINVAL;
-    const bool pure = home->embed_user_env_aware == nullptr;
-    int rc;
-    if ((rc = check_tables(home, pure)) || (rc = check_tables(dst, pure)) || (rc = check_tables(exp_avg, pure)) ||
-        (rc = check_tables(exp_avg_sq, pure)))
-        return rc;
-    if ((uint64_t)home->user_num * (uint64_t)home->factor_num * 4ull >= (1ull << 32)) return INVPREF_EUNSUPPORTED;
-    FlushArgs f{};
-    f.home[0] = home->embed_user_invariant; f.home[1] = pure ? nullptr : home->embed_user_env_aware;
-    f.dst[0] = dst->embed_user_invariant; f.dst[1] = pure ? nullptr : dst->embed_user_env_aware;
-    f.m[0] = exp_avg->embed_user_invariant; f.m[1] = pure ? nullptr : exp_avg->embed_user_env_aware;
-    f.v[0] = exp_avg_sq->embed_user_invariant; f.v[1] = pure ? nullptr : exp_avg_sq->embed_user_env_aware;
-    f.last_step = last_step; f.sched_state = sched->state; f.sched_slot = sched->slot & 1; f.sched_rows = sched->table;
-    f.U = (int)home->user_num; f.D = (int)home->factor_num;
-    const int blocks = (f.U + kWaves - 1) / kWaves;
-    hipLaunchKernelGGL(flush_deferred_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, f);
-    return (int)hipGetLastError();
-}
-
 }  // extern "C"
 
 // (diagnostic, not declared in the header) resident workgroups per CU of the smallest launch-1 instance
 extern "C" int invpref_debug_eval_occupancy(void) {
     int n = -1;
     const size_t lds = eval_lds_bytes(shape_of(64, 4));
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mstep_eval_kernel<16, true, 4, false, true>, kThreads, lds) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, mstep_eval_kernel<16, true, 4, true>, kThreads, lds) != hipSuccess) return -1;
     return n * 1000 + (int)(lds / 1024);
 }

@@ -199,13 +199,11 @@ def mstep_rows_grad(params, grads, dplan, envs, scores, sample_weights, batch_no
 def mstep_rows_adam(params, new_params, exp_avg, exp_avg_sq, dplan, envs, scores, sample_weights, batch_norm: int,
                     coefs, flags: int, losses6: torch.Tensor, step: int, lr: float, workspace: Workspace,
                     beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, pure: bool = False,
-                    sched=None, mid_event=None, last_step=None) -> None:
+                    sched=None, mid_event=None) -> None:
     """M-step + Adam in one pass: reads params, writes new_params, updates the moments in place.
     pure=True: PureMF step (INVPREF_PURE_MF): the table lists hold [user table, item table] only, envs /
     sample_weights may be None.  sched = (state int32[32], table fp32[n, 8], slot): per-step scalars from the
     device-side schedule (graph replay) instead of (step, lr, betas, eps).
-    last_step (int32[user_num], with sched): deferred dense Adam on the plan's untouched user rows -- params and
-    new_params must then hold the SAME user tables (updated in place); see flush_deferred().
     mid_event (profiling, bench.py): a torch.cuda.Event recorded on the stream BETWEEN the step's two launches; the call
     goes straight to the C ABI then (invpref_mstep_rows_adam_profiled_hip)."""
     if pure:
@@ -226,7 +224,7 @@ def mstep_rows_adam(params, new_params, exp_avg, exp_avg_sq, dplan, envs, scores
     _o().train_step_planned_adam_(list(params), list(new_params), list(exp_avg), list(exp_avg_sq), dplan.buf, dplan.meta,
                                   envs, scores, sample_weights, int(batch_norm), [float(c) for c in coefs[:6]],
                                   int(flags), losses6, int(step), float(lr), float(beta1), float(beta2), float(eps),
-                                  s_state, s_table, int(s_slot), ws, last_step)
+                                  s_state, s_table, int(s_slot), ws)
 
 
 class AltWorkspace:
@@ -268,19 +266,6 @@ def mstep_alt(params, exp_avg, exp_avg_sq, aplan, envs, sample_weights, batch_no
                          int(batch_norm), int(batch_norm_prev), [float(c) for c in coefs[:6]], int(flags), losses6_prev,
                          int(step), float(lr), float(beta1), float(beta2), float(eps), s_state, s_table, int(s_slot), aws.buf,
                          aws.n_cap, aws.partials_cap, int(parity))
-
-
-def defer_supported(params, dplan) -> bool:
-    """may this plan run with deferred dense Adam on its untouched user rows? (push form, smallest kernel instance)"""
-    t = (_capi.make_pure_tables if len(params) == 2 else make_tables)(params)
-    return bool(lib().invpref_rows_defer_supported(C.byref(t), C.byref(dplan.struct)))
-
-
-def flush_deferred(home, dst, exp_avg, exp_avg_sq, last_step, sched) -> None:
-    """every user row up to date (pending zero-gradient Adam updates replayed), rows of `home` written to `dst`.
-    sched = (state, table, slot of the step that would run next)."""
-    _o().flush_deferred_(list(home), list(dst), list(exp_avg), list(exp_avg_sq), last_step, sched[0], sched[1],
-                         int(sched[2]))
 
 
 POP_KEYS = ['users_cnt_weight_result', 'items_cnt_weight_result', 'users_normalize_cnt_weight_result',

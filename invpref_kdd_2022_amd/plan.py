@@ -38,8 +38,7 @@ class RowPlanStruct(C.Structure):
                 ('user_desc', C.c_void_p), ('item_desc', C.c_void_p), ('user_round_iters', C.c_void_p),
                 ('user_list', C.c_void_p), ('item_list', C.c_void_p), ('n_stream', C.c_int32),
                 ('rows_per_stream_task', C.c_int32), ('stream_rows', C.c_void_p), ('n_classes', C.c_int32),
-                ('rows_per_stream_task2', C.c_int32), ('cls', C.c_int32 * 64), ('push_slot', C.c_void_p),
-                ('defer_tail', C.c_int32 * 16)]
+                ('rows_per_stream_task2', C.c_int32), ('cls', C.c_int32 * 64), ('push_slot', C.c_void_p)]
 
 
 ARRAYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list', 'stream_rows', 'push_slot')
@@ -188,8 +187,7 @@ class AltPlanParamsStruct(C.Structure):
 
 
 _NATIVE = None
-_NATIVE_ARRAYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list', 'stream_rows', 'push_slot', 'cls',
-                  'defer_tail')
+_NATIVE_ARRAYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list', 'stream_rows', 'push_slot', 'cls')
 
 
 def _native_lib():
@@ -268,7 +266,7 @@ def _plan_from_handle(L, h, r: dict) -> dict:
                 push_slot=(out['push_slot'] if r['push'] else None), push=r['push'], stream_rows=out['stream_rows'], n_stream=sb,
                 rows_per_stream_task=r['rows_per_stream_task'], rows_per_stream_task2=r['rows_per_stream_task2'],
                 stream_split=(float(cls[:, 3].sum()) / sb if (r['fill_cap'] and sb) else r['stream_split']),
-                n_classes=r['n_classes'], cls=cls.copy(), defer_tail=out['defer_tail'].reshape(8, 2).copy())
+                n_classes=r['n_classes'], cls=cls.copy())
 
 
 def _native_build(users, items, scores, user_num, item_num, r: dict) -> dict:
@@ -494,7 +492,6 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     ucls, icls = row_class(np.arange(user_num), n_classes), row_class(np.arange(item_num), n_classes)
     du_parts, it_parts, di_parts, s1_parts, s2_parts = [], [], [], [], []
     cls = np.zeros((8, 8), np.int32)
-    defer_tail = np.zeros((8, 2), np.int32)
     for c in range(n_classes):
         d, it = _side_rounds(users[pu], ucols, user_num, ng, per_slice, rounds_per_task, 2,
                              skip=(ucnt == 0) | (ucls != c), snake=snake_user)
@@ -510,12 +507,10 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         if fill_cap:   # (per class: the grid is n_classes x the longest class)
             room = fill_cap // n_classes - -(-len(du_parts[-1]) // rounds_per_task)
             k = min(len(rows), max(k, room * rows_per_stream_task))
-        # inside each launch's share: item rows first, USER rows last -- a deferred step (InvPrefRowPlan.defer_tail)
-        # leaves that tail alone
+        # inside each launch's share: item rows first, user rows last
         for part, li in ((rows[:k], 0), (rows[k:], 1)):
             is_user = (part & ITEM_BIT) == 0
             part = np.concatenate([part[~is_user], part[is_user]])
-            defer_tail[c, li] = int(is_user.sum())
             (s1_parts if li == 0 else s2_parts).append(part)
     ub = ib = sb = 0
     for c in range(n_classes):
@@ -535,17 +530,15 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
                 stream_rows=np.concatenate(s1_parts + s2_parts).astype(np.int32), n_stream=sb,
                 rows_per_stream_task=rows_per_stream_task, rows_per_stream_task2=rows_per_stream_task2,
                 stream_split=(sum(len(x) for x in s1_parts) / sb if (fill_cap and sb) else stream_split),
-                n_classes=n_classes, cls=cls, defer_tail=defer_tail)
+                n_classes=n_classes, cls=cls)
 
 
-def launch_workgroups(plan: dict, launch: int, defer: bool = False) -> int:
-    """task workgroups of launch 0 / 1: the classes' task lists interleaved, padded to the longest
-    (defer: a deferred step does not stream the untouched user rows, InvPrefRowPlan.defer_tail)"""
+def launch_workgroups(plan: dict, launch: int) -> int:
+    """task workgroups of launch 0 / 1: the classes' task lists interleaved, padded to the longest"""
     ncls, cls = int(plan['n_classes']), np.asarray(plan['cls'])
-    tail = np.asarray(plan['defer_tail'])[:, launch] if defer else np.zeros(8, np.int32)
     rpt = plan['user_rounds_per_task'] if launch == 0 else plan['item_rounds_per_task']
     spt = plan['rows_per_stream_task'] if launch == 0 else plan.get('rows_per_stream_task2', plan['rows_per_stream_task'])
-    return ncls * max(-(-int(cls[c, 4 * launch + 1]) // rpt) + -(-(int(cls[c, 4 * launch + 3]) - int(tail[c])) // spt)
+    return ncls * max(-(-int(cls[c, 4 * launch + 1]) // rpt) + -(-int(cls[c, 4 * launch + 3]) // spt)
                       for c in range(ncls))
 
 
@@ -564,7 +557,7 @@ class DevicePlan:
     meta: torch.Tensor = None   # CPU int64[len(_fields_)]: struct fields in order, pointers as int32 offsets into buf
 
 
-_ARRAY_FIELDS = {'cls': 64, 'defer_tail': 16}
+_ARRAY_FIELDS = {'cls': 64}
 _META_LEN = sum(_ARRAY_FIELDS.get(name, 1) for name, _ in RowPlanStruct._fields_)
 
 
@@ -624,8 +617,7 @@ def upload(plan: dict, device) -> DevicePlan:
                        ptrs['user_round_iters'], ptrs['user_list'], ptrs['item_list'], plan['n_stream'],
                        plan['rows_per_stream_task'], ptrs['stream_rows'], int(plan['n_classes']),
                        int(plan.get('rows_per_stream_task2', 0)),
-                       (C.c_int32 * 64)(*cls.reshape(-1).tolist()), ptrs['push_slot'],
-                       (C.c_int32 * 16)(*np.asarray(plan.get('defer_tail', np.zeros((8, 2))), np.int32).reshape(-1).tolist()))
+                       (C.c_int32 * 64)(*cls.reshape(-1).tolist()), ptrs['push_slot'])
     meta = _meta_of(st, offs)
     return DevicePlan(st, [buf], plan_workgroups(plan), len(plan['user_desc']) + len(plan['item_desc']), buf,
                       torch.tensor(meta, dtype=torch.int64))
@@ -851,7 +843,21 @@ def build_alt_plans(users: np.ndarray, items: np.ndarray, scores: np.ndarray, sp
     def rng(r):
         return None if r is None else (users[r[0]:r[0] + r[1]], items[r[0]:r[0] + r[1]], scores[r[0]:r[0] + r[1]])
     L = _native_lib()
-    if L is None or os.environ.get('INVPREF_PLAN_NATIVE', '1') == '0' or per_slice_u != per_slice_i or slots_u != slots_i:
+    if L is not None and os.environ.get('INVPREF_PLAN_NATIVE', '1') != '0' and (per_slice_u != per_slice_i or slots_u != slots_i):
+        # the sides differ in slice length or slots per round (the Yahoo shape: rounds of 16 slots for the users' launches, of
+        # 32 for the items'): ONE threaded native call per side instead of one serial call per plan
+        out = [None] * len(specs)
+        for sd in (0, 1):
+            idx = [j for j, sp in enumerate(specs) if sp[2] == sd]
+            if idx:
+                ps, sl = (per_slice_i, slots_i) if sd else (per_slice_u, slots_u)
+                for j, pl in zip(idx, build_alt_plans(users, items, scores, [specs[j] for j in idx], user_num, item_num,
+                                                      factor_num=factor_num, per_slice_u=ps, per_slice_i=ps, n_classes=n_classes,
+                                                      rows_per_stream_task=rows_per_stream_task, threads=threads, slots_u=sl,
+                                                      slots_i=sl)):
+                    out[j] = pl
+        return out
+    if L is None or os.environ.get('INVPREF_PLAN_NATIVE', '1') == '0':
         return [build_alt_plan(rng(c), None if pv is None else rng(pv)[:2], side, user_num, item_num, factor_num=factor_num,
                                per_slice=per_slice_i if side else per_slice_u, n_classes=n_classes,
                                rows_per_stream_task=rows_per_stream_task, slots=slots_i if side else slots_u)

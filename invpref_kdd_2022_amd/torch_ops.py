@@ -12,9 +12,7 @@ What replaces what in the reference:
 ``train_step_fused``           forward + 3 losses + 2 regularisers + ``loss.backward()`` of ``train_a_batch``
                                (train.py:108-156; models.py:307-391; functions.py:4-16): ADDS into ``grads``/``losses6``
 ``train_step_planned_grad_``   the same on a row plan (plan.py): atomic-free, OVERWRITES every gradient row
-``train_step_planned_adam_``   the same + ``optimizer.step()`` in one pass (train.py:94-157 entire); with ``last_step``:
-                               dense Adam on untouched user rows deferred and replayed exactly (train.py:41, :155-157)
-``flush_deferred_``            brings every deferred user row up to date (before anything reads all rows)
+``train_step_planned_adam_``   the same + ``optimizer.step()`` in one pass (train.py:94-157 entire)
 ``train_step_alt_``            ONE launch of the alternating form: a whole ``train_a_batch`` step per launch, the evaluating
                                side (users / items) alternating; tables and moments in place (train.py:94-157, :41)
 ``adam_dense_``                ``optimizer.zero_grad()`` + ``torch.optim.Adam.step()`` (train.py:41, :155-157)
@@ -200,31 +198,18 @@ def _planned_grad_fake(tables, grads, plan_buf, plan_meta, envs, scores, sample_
 _define('train_step_planned_adam_(Tensor[] tables, Tensor(a!)[] new_tables, Tensor(b!)[] exp_avg, Tensor(c!)[] exp_avg_sq, '
         'Tensor plan_buf, Tensor plan_meta, Tensor? envs, Tensor scores, Tensor? sample_weights, int batch_norm, '
         'float[] coefs, int flags, Tensor(d!) losses6, int step, float lr, float beta1, float beta2, float eps, '
-        'Tensor(e!)? sched_state, Tensor? sched_table, int sched_slot, Tensor(f!) workspace, '
-        'Tensor(g!)? last_step=None) -> ()')
+        'Tensor(e!)? sched_state, Tensor? sched_table, int sched_slot, Tensor(f!) workspace) -> ()')
 
 
 @_impl('train_step_planned_adam_')
 def _planned_adam(tables, new_tables, exp_avg, exp_avg_sq, plan_buf, plan_meta, envs, scores, sample_weights,
                   batch_norm, coefs, flags, losses6, step, lr, beta1, beta2, eps, sched_state, sched_table, sched_slot,
-                  workspace, last_step=None):
+                  workspace):
     t, tn, tm, tv = _tables(tables), _tables(new_tables), _tables(exp_avg), _tables(exp_avg_sq)
     _f32(scores, 'scores'); _f32(sample_weights, 'sample_weights'); _f32(losses6, 'losses6')
     cf = _coefs(coefs)
     ps = _plan_struct(plan_buf, plan_meta)
     pe = ptr(None if envs is None else _ids(envs, 'envs'))
-    if last_step is not None:
-        # deferred dense Adam on untouched user rows (include/invpref_hip.h): user tables in place, schedule-driven
-        _capi._req(last_step, torch.int32, 'last_step')
-        if sched_state is None or last_step.numel() != t.user_num:
-            raise InvPrefError('last_step: int32[user_num], together with the device-side schedule')
-        sc = _sched_struct(sched_state, sched_table, sched_slot)
-        check(lib().invpref_mstep_rows_adam_deferred_hip(C.byref(t), C.byref(tn), C.byref(tm), C.byref(tv), C.byref(ps), pe,
-                                                         ptr(scores), ptr(sample_weights), int(batch_norm), C.byref(cf),
-                                                         int(flags), ptr(losses6), C.byref(sc), ptr(last_step),
-                                                         ptr(workspace), workspace.numel(), stream_ptr()),
-              'invpref_mstep_rows_adam_deferred_hip')
-        return
     if sched_state is not None:
         # Adam scalars (and a scheduled alpha) come from the device-side schedule: graph replay freezes arguments
         sc = _sched_struct(sched_state, sched_table, sched_slot)
@@ -244,7 +229,7 @@ def _planned_adam(tables, new_tables, exp_avg, exp_avg_sq, plan_buf, plan_meta, 
 @_fake('train_step_planned_adam_')
 def _planned_adam_fake(tables, new_tables, exp_avg, exp_avg_sq, plan_buf, plan_meta, envs, scores, sample_weights,
                        batch_norm, coefs, flags, losses6, step, lr, beta1, beta2, eps, sched_state, sched_table,
-                       sched_slot, workspace, last_step=None):
+                       sched_slot, workspace):
     return None
 
 
@@ -281,26 +266,6 @@ def _step_alt_fake(tables, exp_avg, exp_avg_sq, plan_buf, plan_meta, envs, sampl
     return None
 
 
-_define('flush_deferred_(Tensor[] home, Tensor(a!)[] dst, Tensor(b!)[] exp_avg, Tensor(c!)[] exp_avg_sq, '
-        'Tensor(d!) last_step, Tensor sched_state, Tensor sched_table, int sched_slot) -> ()')
-
-
-@_impl('flush_deferred_')
-def _flush_deferred(home, dst, exp_avg, exp_avg_sq, last_step, sched_state, sched_table, sched_slot):
-    # every user row brought up to date through the step before the one in the schedule's slot `sched_slot`; the rows of
-    # `home` land in `dst` (full table lists in state_dict order; only the user tables are touched)
-    th, td, tm, tv = _tables(home), _tables(dst), _tables(exp_avg), _tables(exp_avg_sq)
-    _capi._req(last_step, torch.int32, 'last_step')
-    if last_step.numel() != th.user_num:
-        raise InvPrefError('last_step: int32[user_num]')
-    sc = _sched_struct(sched_state, sched_table, sched_slot)
-    check(lib().invpref_flush_deferred_hip(C.byref(th), C.byref(td), C.byref(tm), C.byref(tv), ptr(last_step), C.byref(sc),
-                                           stream_ptr()), 'invpref_flush_deferred_hip')
-
-
-@_fake('flush_deferred_')
-def _flush_deferred_fake(home, dst, exp_avg, exp_avg_sq, last_step, sched_state, sched_table, sched_slot):
-    return None
 
 
 # ------------------------------------------------------------------------------------------------ Adam

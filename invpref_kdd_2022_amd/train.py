@@ -202,6 +202,7 @@ class _InvPrefTrainManager:
         self._unfused = self.use_plan and os.environ.get('INVPREF_UNFUSED', '') == '1'
         self._plans = None
         self._batch_plans, self.planned_batch_steps = {}, 0   # train_a_batch on caller tensors: see _cached_batch_plan
+        self._batch_plans_foreign = {}
         # runs of whole epochs as one HIP graph launch (single GPU, planned path); INVPREF_NO_GRAPH=1 disables
         self.use_graph = os.environ.get('INVPREF_NO_GRAPH', '0') != '1'
         # testing aid: run the multi-GPU step sequence (gradient pass -> all-reduce -> stand-alone Adam) on one rank
@@ -394,19 +395,29 @@ class _InvPrefTrainManager:
             pos = getattr(self, '_batch_pos', None)
             if pos is None or pos.numel() < n:
                 pos = self._batch_pos = torch.arange(max(n, 1 << 16), dtype=torch.int64, device=users.device) * 2654435761 + 1
-            mix = users.to(torch.int64) * 40503 + items.to(torch.int64) * 1000003 + \
-                scores.float().contiguous().view(torch.int32).to(torch.int64)
+            # (a multiplicative mix of the three words per interaction, xor-folded: not linear in (u, i) as u * a + i * b was)
+            mix = (users.to(torch.int64) * -7046029254386353131) ^ (items.to(torch.int64) * -4417276706812531889 + 0x2545F491) ^ \
+                (scores.float().contiguous().view(torch.int32).to(torch.int64) * 40503)
+            mix = mix ^ (mix >> 29)
             # (the content IS the key: addresses and version counters of foreign tensors say nothing)
             key = ('foreign', n, users.dtype, items.dtype, int((mix * pos[:n]).sum().item()))
-        hit = self._batch_plans.get(key)
+        # (foreign minibatches have a small cache of their own -- filling it never evicts the resident slices' plans -- and a
+        #  hit is trusted only after the ids and labels kept with the plan compare equal: the checksum is a filter, not an
+        #  identity -- ADVICE r05)
+        cache = self._batch_plans if resident else self._batch_plans_foreign
+        hit = cache.get(key)
+        if hit is not None and not resident and hit != 1:
+            hit, ku, ki, ky = hit
+            if not (torch.equal(ku, users) and torch.equal(ki, items) and torch.equal(ky, scores.float())):
+                hit = 1                         # a checksum collision: plan this content afresh, replacing the entry
         if hit is None:
-            if len(self._batch_plans) >= (self._BATCH_PLAN_CACHE_MAX if resident else self._BATCH_PLAN_CACHE_MAX_FOREIGN):
-                self._batch_plans.clear()
+            if len(cache) >= (self._BATCH_PLAN_CACHE_MAX if resident else self._BATCH_PLAN_CACHE_MAX_FOREIGN):
+                cache.clear()
             # first sighting: with the native builder a plan costs about a millisecond (and the ids' trip to the host), so it
             # is made at once -- INVPREF_BATCH_PLAN_AT=2 waits for the second sighting (a caller that never repeats a
             # minibatch pays nothing for plans it would not reuse) and runs the first one plan-free
             if os.environ.get('INVPREF_BATCH_PLAN_AT', '1') != '1' or planlib._native_lib() is None or not resident:
-                self._batch_plans[key] = 1
+                cache[key] = 1
                 return None
             hit = 1
         if hit == 1:                            # invert the scatter pattern once (host side)
@@ -415,7 +426,7 @@ class _InvPrefTrainManager:
                                                         self.model.item_num, factor_num=self.model.factor_num,
                                                         env_num=getattr(self.model, 'env_num', 0)),
                                  self.device)
-            self._batch_plans[key] = hit
+            cache[key] = hit if resident else (hit, users.clone(), items.clone(), scores.float().clone())
         return hit
 
     # ---- the epoch loop: every per-minibatch argument (views of the resident interaction arrays, the row plan,
@@ -460,22 +471,6 @@ class _InvPrefTrainManager:
                                               self.model.item_num, **kw) for lo, n, *_ in self._raw_batches]
             self._plans = [planlib.upload(pl, self.device) for pl in pls]
             self.plan_build_s = time.perf_counter() - t0     # host-side, once per run (reported by bench.py)
-        # Deferred dense Adam on untouched user rows (include/invpref_hip.h): inside a replayed run of
-        # epochs a user row the minibatch does not touch is left alone -- its zero-gradient updates are replayed, exactly,
-        # when it is next touched -- and a flush at the end of the run brings every row up to date.  Bit for bit the dense
-        # optimiser (tests/test_deferred_gpu.py), but OFF by default (INVPREF_DEFER=1 turns it on): measured at the Yahoo
-        # shape it is slower -- 25.3 us per step against 18.9 -- because the streamed rows were never on the step's
-        # critical chain while every replayed update is (about 0.45 us each, and rarely seen users are dozens of steps
-        # behind); with no update pending at all the step takes 19.40 us against 19.46 (profiles/r04/deferred_adam_ab.txt).
-        self._defer = False
-        if self.use_plan and self._plans and self.users_tensor.is_cuda and self._fused_seq() \
-                and os.environ.get('INVPREF_DEFER', '0') == '1':
-            self._defer = all(ops.defer_supported(st.p_views, dp) for dp in self._plans) \
-                and any(int(x) for dp in self._plans for x in dp.struct.defer_tail)
-        if self._defer and getattr(self, '_last_step', None) is None:
-            self._last_step = torch.zeros(self.model.user_num, dtype=torch.int32, device=self.device)
-            self._last_step_valid = None
-        self._defer_home = None
         self._alt_setup()
         if self.use_plan and self.users_tensor.is_cuda:
             # every plan shares ONE scratch (records + partial slabs; nothing carries over between steps): size it for
@@ -491,11 +486,11 @@ class _InvPrefTrainManager:
     # intermediate state; parameters and moments are updated in place (no buffer swap).
     def _alt_setup(self):
         st = self.state
-        self._alt = None
+        prev, self._alt = self._alt, None
         # (eagerly issued epochs run the same launches as captured ones: graph replay == eager launches, bit for bit;
         #  INVPREF_ALT_EAGER=0 keeps eagerly issued epochs on the two-launch form)
         self._alt_eager = os.environ.get('INVPREF_ALT_EAGER', '1') == '1'
-        if not (self.use_plan and self._plans and self.users_tensor.is_cuda and self._fused_seq() and not self._defer
+        if not (self.use_plan and self._plans and self.users_tensor.is_cuda and self._fused_seq()
                 and os.environ.get('INVPREF_ALT', '1') == '1' and ops.alt_supported(st.p_views)):
             return
         n_cap = max(b[1] for b in self._raw_batches)
@@ -505,6 +500,10 @@ class _InvPrefTrainManager:
                                      self.scores_tensor.cpu().numpy().astype(np.float32))
         self._alt = dict(plans={}, host_plans={}, n_cap=n_cap, partials_cap=n_cap // 4 + n_cap // 8 + 128, ws=None,
                          build_s=0.0)
+        if prev is not None and prev['n_cap'] == n_cap:
+            # (the plans depend on the ids and the minibatch bounds only -- not on the environment / weight arrays whose
+            #  re-homing brought us here: keep them, their slot choice and the workspace)
+            self._alt.update({k: prev[k] for k in ('plans', 'ws', 'slots') if k in prev})
 
     def _alt_keys(self, n: int):
         """(k_prev, k, side) of every launch of a run of n epochs, the flush (k = None) last"""
@@ -601,16 +600,9 @@ class _InvPrefTrainManager:
             # fused M-step + Adam: one pass, gradient never stored, parameters ping-pong
             st.step += 1
             sc = (self._sched['state'], self._sched['table'], st.step & 1) if sched else None
-            pv, pa, last = st.p_views, st.p_views_alt, None
-            if sched and self._defer_home is not None:
-                # deferred form: the user tables stay where the run found them and are updated in place
-                pv, pa, last = list(pv), list(pa), self._last_step
-                for i in self._user_tables:
-                    pv[i] = pa[i] = self._defer_home[i]
-            ops.mstep_rows_adam(pv, pa, st.m_views, st.v_views, self._plans[k], be, by, bw, bn,
+            ops.mstep_rows_adam(st.p_views, st.p_views_alt, st.m_views, st.v_views, self._plans[k], be, by, bw, bn,
                                 coefs, self._flags, lp, st.step, self.lr, self.workspace, pure=self._pure, sched=sc,
-                                mid_event=mid_event,   # (profiling: recorded between the step's two launches)
-                                last_step=last)
+                                mid_event=mid_event)   # (profiling: recorded between the step's two launches)
             st.swap()
             return
         st.step += 1
@@ -693,23 +685,10 @@ class _InvPrefTrainManager:
         if getattr(self, '_alt', None) is not None and (sched or self._alt_eager):
             self._issue_epochs_alt(sched, n)
             return
-        defer = bool(sched and getattr(self, '_defer', False))
-        self._defer_home = list(st.p_views) if defer else None
-        try:
-            for j in range(n):
-                self._loss_slot = j
-                for k in range(self.batch_num):
-                    self._raw_step(k, self._alpha_for(k), stream, sched=sched)
-            if defer:
-                # the run ends with every user row up to date in the CURRENT parameter buffer: nothing outside a replayed
-                # run ever sees a deferred row
-                home = list(st.p_views)
-                for i in self._user_tables:
-                    home[i] = self._defer_home[i]
-                ops.flush_deferred(home, st.p_views, st.m_views, st.v_views, self._last_step,
-                                   (self._sched['state'], self._sched['table'], (st.step + 1) & 1))
-        finally:
-            self._defer_home = None
+        for j in range(n):
+            self._loss_slot = j
+            for k in range(self.batch_num):
+                self._raw_step(k, self._alpha_for(k), stream, sched=sched)
         self._loss_slot = 0
 
     def train_a_epoch(self) -> dict:
@@ -776,11 +755,7 @@ class _InvPrefTrainManager:
                 self._graphs_agreed = None
                 self._loss_slot = 0
         if g is not None:
-            if getattr(self, '_defer', False) and self._last_step_valid != st.step:
-                self._last_step.fill_(st.step)     # (eager steps in between do not keep the row stamps)
             g.replay()
-            if getattr(self, '_defer', False):
-                self._last_step_valid = st.step + steps
             st.step += steps
             if steps % 2 and fused_seq and self._alt is None:   # (the alternating form updates in place)
                 st.swap()

@@ -28,11 +28,14 @@ def test_full_row_instances_have_no_scratch_traffic(kernels):
     assert len(ks) >= 25
     # the instances the bench configurations run: Yahoo (16 lanes x 1 float4, E <= 4, full rows), MovieLens (16 x 2, E = 8),
     # and every 16-lane wide instance on full rows
-    for name in ('mstep_eval_kernel<16, true, 4, false, true>', 'mstep_apply_kernel<16, true, 4, true>',
+    for name in ('mstep_eval_kernel<16, true, 4, true>', 'mstep_apply_kernel<16, true, 4, true>',
                  'mstep_eval_wide_kernel<16, 2, true, 8, false>', 'mstep_apply_wide_kernel<16, 2, true, 8, false>',
                  'mstep_eval_wide_kernel<16, 1, true, 8, false>', 'mstep_eval_wide_kernel<16, 1, true, 16, false>',
                  'mstep_eval_wide_kernel<16, 2, true, 16, false>', 'mstep_apply_wide_kernel<32, 2, true, 16, true>'):
         assert ks[name]['scratch_ops'] == 0, (name, ks[name])
+    # ... and the MovieLens instance without a private segment at all (at 100 scalar registers it is one kernel-argument
+    # layout away from spilling nine of them: csrc/invpref_step.hip, StepArgs.reserved_)
+    assert ks['mstep_eval_wide_kernel<16, 2, true, 8, false>']['scratch'] == 0
     # rows on 32 lanes (MIND: 256 accumulator + row registers): a handful of loop-invariant values may sit in scratch, none
     # of them inside the interaction loop (depth 2)
     for name in ('mstep_eval_wide_kernel<32, 2, true, 16, true>', 'mstep_eval_wide_kernel<32, 2, true, 8, true>'):
@@ -43,7 +46,7 @@ def test_full_row_instances_have_no_scratch_traffic(kernels):
     for name in ('mstep_eval_mm_kernel<32, 2, 16, true>', 'mstep_eval_mm_kernel<32, 2, 8, true>'):
         assert ks[name]['scratch_ops'] <= 4 and ks[name]['mfma'] >= 40, (name, ks[name])
     # the latency-tuned Yahoo instance keeps three workgroups per CU: at most 168 registers
-    assert ks['mstep_eval_kernel<16, true, 4, false, true>']['vgpr'] <= 168
+    assert ks['mstep_eval_kernel<16, true, 4, true>']['vgpr'] <= 168
     # the alternating one-launch-per-step kernels (csrc/step_alt.hpp): every instance free of scratch, three per CU
     alt = {name: k for name, k in ks.items() if name.startswith('mstep_alt_kernel')}
     assert len(alt) == 18     # {vector + full rows, vector, element-wise} x {first, steady, flush} x {256, 512 threads}

@@ -49,44 +49,12 @@ Pn = sum(p.numel() for p in P)
 nbytes = B * (32 + 16 * D) + 24 * Pn
 
 
-DEFER = os.environ.get('PROBE_DEFER') == '1'   # deferred dense Adam on untouched user rows (schedule-driven, in place)
-if DEFER:
-    import ctypes as C
-    from invpref_kdd_2022_amd import _capi
-    host = np.zeros((4096, 8), np.float32)
-    _capi.check(_capi.lib().invpref_adam_schedule_fill(host.ctypes.data, 1, 4096, 0.005, 0.9, 0.999, 1e-8), 'fill')
-    sched_table = torch.from_numpy(host).to(dev)
-    sched_state = torch.zeros(32, dtype=torch.int32, device=dev)
-    last_step = torch.zeros(U, dtype=torch.int32, device=dev)
-    FIRST = 5
-
-
-def sched_reset(step):
-    st32 = np.zeros(32, np.int32)
-    o = 16 * (step & 1)
-    st32[o:o + 2] = step, 1
-    st32[o + 2:o + 10] = host[step - 1].view(np.int32)
-    sched_state.copy_(torch.from_numpy(st32))
-    last_step.fill_(step - 1)
-
-
 def run_steps(first=0, last=None, flush=True, reset=True):
     a, b = P, P2
-    if DEFER and first == 0 and reset:
-        sched_reset(FIRST)
     for k in range(first, nb if last is None else last):
         sl = slice(k * B, (k + 1) * B)
-        if DEFER:
-            pa, pb = list(a), list(b)
-            pa[0] = pb[0] = P[0]; pa[2] = pb[2] = P[2]
-            ops.mstep_rows_adam(pa, pb, M, V, plans[k], e[sl], y[sl], w[sl], B, coefs, flags, losses, FIRST + k, 0.005, ws,
-                                sched=(sched_state, sched_table, (FIRST + k) & 1), last_step=last_step)
-        else:
-            ops.mstep_rows_adam(a, b, M, V, plans[k], e[sl], y[sl], w[sl], B, coefs, flags, losses, 5 + k, 0.005, ws)
+        ops.mstep_rows_adam(a, b, M, V, plans[k], e[sl], y[sl], w[sl], B, coefs, flags, losses, 5 + k, 0.005, ws)
         a, b = b, a
-    if DEFER and flush and last is None:
-        home = list(a); home[0], home[2] = P[0], P[2]
-        ops.flush_deferred(home, a, M, V, last_step, (sched_state, sched_table, (FIRST + nb) & 1))
     return nb
 
 
@@ -95,8 +63,6 @@ def graph_time(reps=20):
     with torch.cuda.stream(s):
         run_steps(); torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        if DEFER:
-            sched_reset(FIRST)
         with torch.cuda.graph(g, stream=s):
             n = run_steps(reset=False)
         g.replay(); torch.cuda.synchronize()
@@ -105,8 +71,6 @@ def graph_time(reps=20):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(reps):
-                if DEFER:
-                    sched_reset(FIRST)    # (a replay starts from the same step numbers: two tiny copies)
                 g.replay()
             b.record()
             torch.cuda.synchronize()
@@ -117,7 +81,7 @@ def graph_time(reps=20):
 p0 = pls[0]
 print(f'shape U={U} I={I} E={E} D={D} B={B}: lanes {p0["lanes_per_group"]}, per_slice {p0["per_slice"]}/{p0["item_per_slice"]}, '
       f'rounds/task {p0["user_rounds_per_task"]}/{p0["item_rounds_per_task"]}, stream rows/task {p0["rows_per_stream_task"]}, '
-      f'split {p0["stream_split"]:.2f}; workgroups launch 1 {planlib.launch_workgroups(p0, 0, DEFER)}, launch 2 {planlib.launch_workgroups(p0, 1, DEFER)}')
+      f'split {p0["stream_split"]:.2f}; workgroups launch 1 {planlib.launch_workgroups(p0, 0)}, launch 2 {planlib.launch_workgroups(p0, 1)}')
 if os.environ.get('PROBE_EAGER') == '1':   # (profiling passes: every launch issued eagerly, a few times)
     for _ in range(3):
         run_steps()
@@ -136,15 +100,7 @@ for rep in range(3):
     stamps.zero_()
     a, b = (P, P2) if ks % 2 == 0 else (P2, P)
     sl = slice(ks * B, (ks + 1) * B)
-    if DEFER:
-        pa, pb = list(a), list(b)
-        pa[0] = pb[0] = P[0]; pa[2] = pb[2] = P[2]
-        if os.environ.get('PROBE_DEFER_PEND'):   # (what-if: every row exactly this many steps behind)
-            last_step.fill_(FIRST + ks - 1 - int(os.environ['PROBE_DEFER_PEND']))
-        ops.mstep_rows_adam(pa, pb, M, V, plans[ks], e[sl], y[sl], w[sl], B, coefs, flags, losses, FIRST + ks, 0.005, ws,
-                            sched=(sched_state, sched_table, (FIRST + ks) & 1), last_step=last_step)
-    else:
-        ops.mstep_rows_adam(a, b, M, V, plans[ks], e[sl], y[sl], w[sl], B, coefs, flags, losses, 5 + ks, 0.005, ws)
+    ops.mstep_rows_adam(a, b, M, V, plans[ks], e[sl], y[sl], w[sl], B, coefs, flags, losses, 5 + ks, 0.005, ws)
 torch.cuda.synchronize()
 pl = pls[ks]
 ncls, cls = pl['n_classes'], np.asarray(pl['cls'])
@@ -153,14 +109,14 @@ t0 = None
 for launch, name in ((0, 'launch 1 (eval)'), (1, 'launch 2 (apply)')):
     rpt = pl['user_rounds_per_task'] if launch == 0 else pl['item_rounds_per_task']
     spt = pl['rows_per_stream_task'] if launch == 0 else pl['rows_per_stream_task2']
-    wg = planlib.launch_workgroups(pl, launch, DEFER)
+    wg = planlib.launch_workgroups(pl, launch)
     extra = 0 if launch == 0 else 64
     st = raw[launch * 8192: launch * 8192 + wg + extra]
     kind = np.full(len(st), 'pad', dtype=object)
     for bk in range(wg):
         c, j = bk % ncls, bk // ncls
         tj = -(-int(cls[c, 4 * launch + 1]) // rpt)
-        kind[bk] = 'job' if j < tj else ('stream' if (j - tj) * spt < cls[c, 4 * launch + 3] - (pl['defer_tail'][c][launch] if DEFER else 0) else 'pad')
+        kind[bk] = 'job' if j < tj else ('stream' if (j - tj) * spt < cls[c, 4 * launch + 3] else 'pad')
     kind[wg:] = 'fold'
     live = st[:, 0] > 0
     if t0 is None:

@@ -289,8 +289,9 @@ def timed_run(mgr, world, steps_req, warmup_req):
             out = mgr.train_epochs(left, sync=False)
             pending.append(out)
             left -= out.shape[0]
-        pending.append(mgr.cluster(sync=False))
-        pending.append(mgr.stat_envs(sync=False))
+        # train.py:329-330: cluster() and the stat_envs() that follows it -- ONE launch on one GPU (the kernel's epilogue folds
+        # counts, diff_num and class weights; results are views of the E-step ring, nothing is cloned behind the replay)
+        pending.extend(mgr.cluster_and_stat_envs(sync=False))
 
     def barrier():
         if world > 1:
@@ -358,14 +359,15 @@ def device_step_times(mgr, world):
     ms_step = min(a.elapsed_time(b) for a, b in zip(ev[:-1], ev[1:])) / (CLUSTER_INTERVAL * nb)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    mgr.cluster(sync=False); mgr.stat_envs(sync=False)
+    mgr.cluster_and_stat_envs(sync=False)
     e1.record()
     torch.cuda.synchronize()
     ms_eager = e0.elapsed_time(e1)     # (an eagerly issued cluster(): the host's permutation draws sit inside)
     # the E-step as the timed loop runs it: one replay of the captured graph (device time, HIP events around each replay)
     ms_replay = None
     if world == 1 and mgr.graphs_enabled() and not mgr._pure:
-        g, _, _ = mgr._estep_graph(mgr.cluster_use_random_sort)
+        fused = mgr._fused_estep_ok()
+        g, _, _ = mgr._estep_graph(mgr.cluster_use_random_sort, fused=fused, combined=True)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(12)]
         for i, (a, b) in enumerate(evs):
             a.record(); g.replay(); b.record()
@@ -539,7 +541,7 @@ def estep_random_sort_timing(dev, n=20):
         mgr = build_manager(dev, 0, 1, random_sort=rs)
         mgr.train_epochs(1)
         mgr.prepare_graphs([1])
-        g, eps_buf, _ = mgr._estep_graph(rs)
+        g, eps_buf, _ = mgr._estep_graph(rs, fused=mgr._fused_estep_ok(), combined=True)
         host_s = 0.0
         if rs:
             t0 = time.perf_counter()
@@ -567,7 +569,7 @@ def estep_random_sort_timing(dev, n=20):
         del mgr
         torch.cuda.empty_cache()
     out['ratio'] = out['estep_random_sort_ms'] / out['estep_plain_ms']
-    out['note'] = ('device time of one replay of the captured E-step (estep_assign_kernel + stat_envs_kernel), median of %d; '
+    out['note'] = ('device time of one replay of the captured E-step (ONE launch: estep_assign_kernel with the stat_envs fold as its epilogue), median of %d; '
                    'random sort = 1 byte of permutation index per interaction read from pinned host memory + the row looked up '
                    'in an LDS table; host draws = np.random.randint per minibatch, the reference\'s own numpy stream' % n)
     return out
@@ -632,9 +634,10 @@ def end_to_end(dev, env_num, factor_num, epochs=200):
     def graph_for(n):   # (time only the calls that capture)
         return cap_graph(n) if mgr._graph_key(n) in mgr._graphs else timed(cap_graph, 'graph_capture')(n)
 
-    def estep_graph(with_eps):
-        key = (mgr.state.p_views[0].data_ptr(), mgr.envs.data_ptr(), mgr.users_tensor.data_ptr(), with_eps)
-        return cap_estep(with_eps) if key in mgr._estep_graphs else timed(cap_estep, 'graph_capture')(with_eps)
+    def estep_graph(with_eps, fused=False, combined=True):
+        key = (mgr.state.p_views[0].data_ptr(), mgr.envs.data_ptr(), mgr.users_tensor.data_ptr(), with_eps, fused, combined)
+        return cap_estep(with_eps, fused, combined) if key in mgr._estep_graphs \
+            else timed(cap_estep, 'graph_capture')(with_eps, fused, combined)
     mgr._graph_for, mgr._estep_graph = graph_for, estep_graph
     t_ctor = time.perf_counter() - t0
     (losses, _), (tests, test_epochs), (diffs, _, cluster_epochs) = mgr.train(silent=True)

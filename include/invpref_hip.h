@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define INVPREF_ABI_VERSION 5
+#define INVPREF_ABI_VERSION 6
 
 /* error codes */
 #define INVPREF_OK 0
@@ -52,6 +52,13 @@ extern "C" {
                                      ignored and may be NULL in every table struct.  With coefficients
                                      (1, 0, 0, 2*L2_coe, 2*L1_coe, 0) the reported terms are
                                      losses6 = {score_loss, -, 0, L2_reg/2, L1_reg/2, loss} of train.py:399-404 */
+#define INVPREF_WEIGHTS_BY_ENV 256u /* planned M-step entry points (invpref_mstep_rows_*, invpref_mstep_alt_hip): the
+                                     `sample_weights` argument holds class_weights[env_num] -- the E floats stat_envs forms
+                                     (train.py:274-277) -- and an interaction's weight is class_weights[envs[i]], which IS
+                                     sample_weights[i] (train.py:278) as long as stat_envs() has run since the environments
+                                     last changed (train.py:329-330 calls them together).  Staged with the small tables: no
+                                     per-interaction weight load.  Without the flag sample_weights[i] is read as before
+                                     (train_a_batch on caller tensors, train.py:94-106). */
 
 /* The seven parameter tensors of InvPrefImplicit/InvPrefExplicit (models.py:283-291, :197-201),
  * in state_dict order.  Also used for gradients and Adam moments (same shapes). */
@@ -396,6 +403,31 @@ int invpref_estep_perm_hip(const InvPrefTables *tables, const int64_t *users, co
                            const int64_t *old_envs, int64_t *new_envs, int64_t *counts, int64_t *diff,
                            float *class_weights, float *sample_weights, void *workspace, size_t workspace_bytes,
                            void *stream);
+
+/* ---- cluster() + the stat_envs() that always follows it (train.py:235-259, :268-280, called together at train.py:329-330) as
+ * ONE launch (round 6): the assignment kernel's workgroups publish their count slabs and take a ticket, the
+ * last one folds them into counts[env_num], diff[1] (cluster()'s diff_num) and class_weights[env_num] =
+ * min(count + 1, N - 1) / N.  No N-length sample_weights array is produced: the planned M-step entry points form
+ * sample_weights[i] = class_weights[envs[i]] themselves under INVPREF_WEIGHTS_BY_ENV.
+ *   envs        in place: the old assignment of row i is read, the new one written, by the same lane;
+ *   perm_index  NULL: plain argmin (cluster_use_random_sort=False); else as invpref_estep_perm_hip, with
+ *   perm_table  (device, optional, env_num <= 7) the E! packed permutation rows made once by invpref_perm_table_fill -- the
+ *               workgroups then load the table instead of unranking it;
+ *   state       device int32[4] that must be ZERO before the first call and is left zero by every call ({ticket, ring position});
+ *   ring        optional int64[ring_cap][env_num + 1]: the call writes {counts, diff} to row (calls so far) % ring_cap and counts
+ *               the call in state[1] -- a captured launch's arguments are frozen, so a replayed E-step keeps its results apart
+ *               this way without a copy behind every replay;
+ *   counts / diff / class_weights  optional direct outputs (NULL: skipped).
+ * Single rank only (the class weights need the GLOBAL counts: a sharded rank uses invpref_estep_perm_hip / invpref_estep_hip,
+ * all-reduces the counts and calls invpref_sample_weights_hip). */
+int invpref_estep_fused_hip(const InvPrefTables *tables, const int64_t *users, const int64_t *items, const float *scores,
+                            int64_t N, uint32_t flags, const void *perm_index, int index_bytes, const float *eps_base,
+                            const uint32_t *perm_table, int64_t *envs, int32_t *state, int64_t *ring, int32_t ring_cap,
+                            int64_t *counts, int64_t *diff, float *class_weights, void *workspace, size_t workspace_bytes,
+                            void *stream);
+/* host helper: host_table[r] = permutation row r of train.py:86-92 (itertools.permutations order), 4 bits per position;
+ * env_num <= 7.  Returns the number of rows (env_num!) or INVPREF_EINVAL. */
+int invpref_perm_table_fill(int32_t env_num, uint32_t *host_table);
 
 /* ---- stat_envs alone (train.py:268-280), e.g. before the first epoch (train.py:297). */
 int invpref_stat_envs_hip(const int64_t *envs, int64_t N, int64_t env_num, int64_t *counts, float *class_weights,

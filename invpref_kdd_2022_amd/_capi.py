@@ -15,6 +15,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('INVPREF_LIB') or os.path.join(PKG, 'libinvpref_hip.so')  # INVPREF_LIB: kernel A/B builds
 
 IMPLICIT, REWEIGHT_REC, REWEIGHT_CLS, REG_ONLY_EMBED, REG_ENV_EMBED, DENSE_REG, NO_GRAD, PURE_MF = 1, 2, 4, 8, 16, 32, 64, 128
+WEIGHTS_BY_ENV = 256   # INVPREF_WEIGHTS_BY_ENV: `sample_weights` holds class_weights[env_num], weight of i = class_weights[envs[i]]
+ABI_VERSION = 6
 
 EXPORTS = [
     'invpref_abi_version', 'invpref_device_name', 'invpref_forward_hip', 'invpref_mstep_workspace_bytes',
@@ -26,7 +28,7 @@ EXPORTS = [
     'invpref_static_pop_hip', 'invpref_adam_ranges_hip', 'invpref_mstep_rows_grad_sched_hip',
     'invpref_adam_ranges_sched_hip', 'invpref_rows_lanes_per_group', 'invpref_estep_perm_hip',
     'invpref_pack_rows_hip', 'invpref_unpack_rows_hip', 'invpref_alt_workspace_bytes', 'invpref_alt_supported',
-    'invpref_mstep_alt_hip', 'invpref_alt_error_offset',
+    'invpref_mstep_alt_hip', 'invpref_alt_error_offset', 'invpref_estep_fused_hip', 'invpref_perm_table_fill',
 ]
 
 
@@ -116,7 +118,10 @@ def lib():
         L.invpref_mstep_alt_hip.argtypes = [C.POINTER(Tables), C.POINTER(Tables), C.POINTER(Tables), vp, vp, vp, i64, i64,
                                             C.POINTER(Coefs), u32, vp, i64, f64, f64, f64, f64, C.POINTER(AdamSchedule), vp,
                                             C.c_size_t, C.c_int32, C.c_int32, C.c_int32, vp]
-        if L.invpref_abi_version() != 5:
+        L.invpref_estep_fused_hip.argtypes = [C.POINTER(Tables), vp, vp, vp, i64, u32, vp, C.c_int, vp, vp, vp, vp, vp,
+                                              C.c_int32, vp, vp, vp, vp, C.c_size_t, vp]
+        L.invpref_perm_table_fill.argtypes = [C.c_int32, vp]
+        if L.invpref_abi_version() != ABI_VERSION:
             raise InvPrefError('libinvpref_hip.so ABI version mismatch')
         _lib = L
     return _lib

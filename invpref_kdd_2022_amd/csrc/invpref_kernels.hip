@@ -615,6 +615,24 @@ __global__ __launch_bounds__(256) void eps_unrank_kernel(const IT *__restrict__ 
 // NARROW: every big table is under 2^32 bytes (any reference configuration: MIND's are 51 MB), so a row's address is its
 // table's base + one 32-bit offset (id x D in a 32-bit multiply) instead of a 64-bit product per gathered row; the ids
 // arrive as the reference's int64 (LongTensor) either way.
+// The stat_envs half of an E-step (train.py:268-280: counts, class weights; + cluster()'s diff_num, train.py:255) as the
+// EPILOGUE of the assignment kernel (invpref_estep_fused_hip): every workgroup publishes its count slab with
+// write-through stores, drains them and takes a ticket; the workgroup whose ticket is the last one folds all the slabs.  The
+// hand-off is the guide's measured form (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the sc1 table): sc1
+// stores by ONE wave of the producer, its s_waitcnt vmcnt(0), an agent-scope atomic add by a lane of that wave, the adder
+// whose add came last reads everything with sc1 loads behind a workgroup barrier.
+struct EstepFin {
+    int *state;          // device int32[4], ZERO before the first call and left zero: {ticket, ring position, -, -}; NULL: no epilogue
+    int64_t *ring;       // [ring_cap][E + 1] {counts[0..E), diff} of E-step number `ring position` (mod ring_cap); may be NULL
+    int ring_cap;
+    int64_t *counts;     // [E] (may be NULL)
+    int64_t *diff;       // [1] (may be NULL)
+    float *class_w;      // [E] min(count + 1, N - 1) / N   (train.py:274-277; may be NULL)
+    const unsigned *perm_table;   // E <= 7: the E! packed permutation rows, built once (invpref_perm_table_fill); NULL: unranked here
+};
+__device__ __forceinline__ int ld_sc1_i(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1_i(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 template <int NC, bool VEC, bool NARROW>
 __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const int64_t *__restrict__ users,
                                                            const int64_t *__restrict__ items,
@@ -624,7 +642,7 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
                                                            const void *__restrict__ eps_index, int eps_index_bytes,
                                                            int eps_rows_n, Factorials fac,
                                                            const int64_t *old_envs, int64_t *new_envs,
-                                                           int *__restrict__ slabs) {
+                                                           int *slabs, EstepFin fin) {
     // (old_envs and new_envs may be the SAME buffer -- cluster() updates the assignments in place -- so neither
     //  is __restrict__; element s is read into a register before it is written)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -653,8 +671,14 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
         return eps_index_bytes == 1 ? (unsigned)reinterpret_cast<const uint8_t *>(eps_index)[sx]
                                     : (unsigned)reinterpret_cast<const int32_t *>(eps_index)[sx];
     };
-    if (eps_index)
-        for (int i = threadIdx.x; i < eps_rows_n; i += blockDim.x) stab[i] = unrank_packed_small((unsigned)i, t.E);
+    if (eps_index) {
+        // (the table is the same for every workgroup of every launch: handed over ready-made by the fused entry point -- one
+        //  coalesced load of 96 bytes at four environments instead of ~1 000 instructions on wave 0 while the others wait)
+        if (fin.perm_table)
+            for (int i = threadIdx.x; i < eps_rows_n; i += blockDim.x) stab[i] = fin.perm_table[i];
+        else
+            for (int i = threadIdx.x; i < eps_rows_n; i += blockDim.x) stab[i] = unrank_packed_small((unsigned)i, t.E);
+    }
     __syncthreads();
     const int l16 = threadIdx.x & 15;
     const bool implicit = flags & INVPREF_IMPLICIT;
@@ -734,7 +758,66 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
         idx_cur = idx_next;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i <= t.E; i += blockDim.x) slabs[(int64_t)blockIdx.x * (t.E + 1) + i] = cnt[i];
+    if (!fin.state) {
+        for (int i = threadIdx.x; i <= t.E; i += blockDim.x) slabs[(int64_t)blockIdx.x * (t.E + 1) + i] = cnt[i];
+        return;
+    }
+    // ---- fused epilogue (E + 1 <= 17: the slab is stored by lanes of wave 0 alone)
+    __shared__ int s_last;
+    __shared__ long long s_tot[INVPREF_MAX_ENVS + 1];
+    if (threadIdx.x < 64) {
+        if ((int)threadIdx.x <= t.E) st_sc1_i(slabs + (int64_t)blockIdx.x * (t.E + 1) + threadIdx.x, cnt[threadIdx.x]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(fin.state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == (int)gridDim.x - 1;
+        }
+    }
+    for (int i = threadIdx.x; i <= t.E; i += blockDim.x) s_tot[i] = 0;
+    __syncthreads();
+    if (!s_last) return;
+    {
+        const int E1 = t.E + 1, nsl = (int)gridDim.x;
+        long long acc[INVPREF_MAX_ENVS + 1];
+#pragma unroll
+        for (int c = 0; c <= INVPREF_MAX_ENVS; c++) acc[c] = 0;
+        // (every count of a thread's slabs requested before the first is summed; write-through stores -> cache-bypassing loads)
+        for (int sl = threadIdx.x; sl < nsl; sl += blockDim.x) {
+            const int *row = slabs + (int64_t)sl * E1;
+            int x[INVPREF_MAX_ENVS + 1];
+#pragma unroll
+            for (int c = 0; c <= INVPREF_MAX_ENVS; c++) x[c] = (c <= t.E) ? ld_sc1_i(row + min(c, t.E)) : 0;
+#pragma unroll
+            for (int c = 0; c <= INVPREF_MAX_ENVS; c++) acc[c] += x[c];
+        }
+#pragma unroll
+        for (int c = 0; c <= INVPREF_MAX_ENVS; c++) {
+            if (c <= t.E) {   // (uniform)
+                long long a = acc[c];
+                for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
+                if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&s_tot[c], (unsigned long long)a);
+            }
+        }
+        __syncthreads();
+        int64_t *row = nullptr;
+        if (fin.ring) row = fin.ring + (int64_t)((unsigned)fin.state[1] % (unsigned)fin.ring_cap) * E1;
+        if ((int)threadIdx.x < t.E) {
+            const long long c = s_tot[threadIdx.x];
+            const long long r = (c + 1 < N - 1) ? c + 1 : N - 1;
+            if (fin.counts) fin.counts[threadIdx.x] = c;
+            if (fin.class_w) fin.class_w[threadIdx.x] = (float)((double)r / (double)N);
+            if (row) row[threadIdx.x] = c;
+        }
+        if (threadIdx.x == 0) {
+            if (fin.diff) *fin.diff = s_tot[t.E];
+            if (row) row[t.E] = s_tot[t.E];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (fin.ring) fin.state[1] = fin.state[1] + 1;
+            st_sc1_i(fin.state, 0);   // the ticket is back at zero for the next launch (stream order: it starts after this one ends)
+        }
+    }
 }
 
 // per-workgroup env histogram (for stat_envs alone)
@@ -1233,10 +1316,11 @@ static int estep_launch(const InvPrefTables *tables, const int64_t *users, const
                         int64_t N, uint32_t flags, const float *eps_rows, const void *perm_index, int index_bytes,
                         const float *eps_base_host, const int64_t *old_envs, int64_t *new_envs, int64_t *counts,
                         int64_t *diff, float *class_weights, float *sample_weights, void *workspace,
-                        size_t workspace_bytes, void *stream) {
+                        size_t workspace_bytes, void *stream, const EstepFin *fused = nullptr) {
     int rc = check_tables(tables);
     if (rc) return rc;
-    if (N <= 0 || !users || !items || !scores || !new_envs || !counts || !diff || !workspace) return INVPREF_EINVAL;
+    if (N <= 0 || !users || !items || !scores || !new_envs || !workspace) return INVPREF_EINVAL;
+    if (!fused && (!counts || !diff)) return INVPREF_EINVAL;
     if (workspace_bytes < invpref_estep_workspace_bytes(tables, N)) return INVPREF_EWORKSPACE;
     const DevTables t = dev_tables(tables);
     const bool vec = vec_ok(tables);
@@ -1281,10 +1365,15 @@ static int estep_launch(const InvPrefTables *tables, const int64_t *users, const
         else
             hipLaunchKernelGGL(eps_unrank_kernel<int64_t>, dim3((unsigned)ub), dim3(256), 0, st, (const int64_t *)perm_index, N, t.E, fac, eps_packed);
     }
+    EstepFin fin{};
+    if (fused) {
+        fin = *fused;
+        if (!table_form) fin.perm_table = nullptr;
+    }
 #define ECALL1(NCV, VECV, NARV)                                                                                   \
     hipLaunchKernelGGL((estep_assign_kernel<NCV, VECV, NARV>), dim3(nb), dim3(kEstepThreads), lds + lds_extra, st, t, users, items, \
                        scores, N, flags, eps_rows, eps_packed, eps_base, eps_index, index_bytes, eps_rows_n, fac, old_envs, \
-                       new_envs, slabs)
+                       new_envs, slabs, fin)
 #define ECALL(NCV, VECV) do { if (narrow) ECALL1(NCV, VECV, true); else ECALL1(NCV, VECV, false); } while (0)
     // (INVPREF_ESTEP_OFFSETS64=1: the 64-bit form regardless -- the only way a test reaches it short of a 4 GB table)
     static const bool force64 = std::getenv("INVPREF_ESTEP_OFFSETS64") != nullptr && std::getenv("INVPREF_ESTEP_OFFSETS64")[0] == '1';
@@ -1294,6 +1383,7 @@ static int estep_launch(const InvPrefTables *tables, const int64_t *users, const
 #undef ECALL1
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return (int)err;
+    if (fused) return 0;   // (counts, diff and class weights came out of the kernel's epilogue; no sample-weight array)
     // every workgroup of stat_envs folds ALL the count slabs for itself before it gathers its share of the sample weights:
     // at most 256 of them (one per CU, a grid-stride share of rows each) -- a thousand workgroups read 40 MB of slabs for
     // 1 MB of weights (round 5: 10.9 us at the Yahoo shape)
@@ -1320,6 +1410,43 @@ int invpref_estep_perm_hip(const InvPrefTables *tables, const int64_t *users, co
     if (!perm_index) return INVPREF_EINVAL;
     return estep_launch(tables, users, items, scores, N, flags, nullptr, perm_index, index_bytes, eps_base, old_envs,
                         new_envs, counts, diff, class_weights, sample_weights, workspace, workspace_bytes, stream);
+}
+
+/* host helper: the E! packed permutation rows of train.py:86-92 in itertools.permutations order -- row r, position pos:
+ * element number (table[r] >> 4 pos) & 15 of the tie-break vector -- for up to seven environments (5 040 rows). */
+int invpref_perm_table_fill(int32_t env_num, uint32_t *host_table) {
+    if (!host_table || env_num < 1 || env_num > kEpsTableMaxE) return INVPREF_EINVAL;
+    int rows = 1;
+    for (int k = 2; k <= env_num; k++) rows *= k;
+    for (int r = 0; r < rows; r++) {
+        unsigned avail = (1u << env_num) - 1u, out = 0;
+        int rem = r, f = rows;
+        for (int pos = 0; pos < env_num; pos++) {
+            f /= (env_num - pos);
+            const int d = rem / f;
+            rem -= d * f;
+            int seen = 0, pick = 0;
+            for (int b = 0; b < env_num; b++)
+                if ((avail >> b) & 1u) { if (seen == d) pick = b; seen++; }
+            avail &= ~(1u << pick);
+            out |= (unsigned)pick << (4 * pos);
+        }
+        host_table[r] = out;
+    }
+    return rows;
+}
+
+int invpref_estep_fused_hip(const InvPrefTables *tables, const int64_t *users, const int64_t *items, const float *scores,
+                            int64_t N, uint32_t flags, const void *perm_index, int index_bytes, const float *eps_base,
+                            const uint32_t *perm_table, int64_t *envs, int32_t *state, int64_t *ring, int32_t ring_cap,
+                            int64_t *counts, int64_t *diff, float *class_weights, void *workspace, size_t workspace_bytes,
+                            void *stream) {
+    if (!state || !envs || (ring && ring_cap <= 0)) return INVPREF_EINVAL;
+    EstepFin fin{};
+    fin.state = state; fin.ring = ring; fin.ring_cap = ring_cap; fin.counts = counts; fin.diff = diff;
+    fin.class_w = class_weights; fin.perm_table = perm_table;
+    return estep_launch(tables, users, items, scores, N, flags, nullptr, perm_index, perm_index ? index_bytes : 0, eps_base, envs,
+                        envs, counts, diff, class_weights, nullptr, workspace, workspace_bytes, stream, &fin);
 }
 
 }  // extern "C"

@@ -305,7 +305,8 @@ struct EvalLds {
     // -- the leader takes the row's moments out of it first, same wave, program order -- which is what lets three
     // workgroups of the smallest instance share a CU's 160 KB
     static constexpr bool ALIAS = G::REG && STEP_SLOT_ALIAS;
-    static constexpr int slots = sb + EMAX;
+    static constexpr int scw = sb + EMAX;                           // [EMAX] class weights (INVPREF_WEIGHTS_BY_ENV; else ones)
+    static constexpr int slots = scw + EMAX;
     static constexpr int mv = slots + (ALIAS ? 0 : G::NG * 2 * G::DP);   // [4 waves][4][64] float4 LDS-DMA landing area
     static constexpr int red = mv + (STEP_NO_DMA && G::DIRECT ? 0 : kWaves * 4 * 64 * 4);            // REG: [4 waves][SLAB]; else [4 waves][8] loss sums
     static constexpr int rec = red + (G::REG ? G::RED * G::SLAB : kWaves * kLossSlots);   // E > 8: [2][NG][2][DP] x, o
@@ -463,13 +464,14 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
     constexpr int UE = !G::REG ? 1 : ((LG == 16 && EMAX <= 4 && STEP_EVAL_DEPTH > 2) ? 2 : STEP_EVAL_DEPTH);
     using L = EvalLds<LG, EMAX>;
     constexpr int NG = G::NG, DP = G::DP, RS = G::RS;
-    float *sEv = lds + L::sEv, *sW = lds + L::sW, *sb = lds + L::sb, *slots = lds + L::slots;
+    float *sEv = lds + L::sEv, *sW = lds + L::sW, *sb = lds + L::sb, *scw = lds + L::scw, *slots = lds + L::slots;
     float4 *mv = reinterpret_cast<float4 *>(lds + L::mv);
     float *red = lds + L::red;
     const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float4 *mv_wave = mv + wave * 4 * 64;
     const bool implicit = a.flags & INVPREF_IMPLICIT;
     const bool rw_rec = a.flags & INVPREF_REWEIGHT_REC, rw_cls = a.flags & INVPREF_REWEIGHT_CLS;
+    const bool by_env = a.flags & INVPREF_WEIGHTS_BY_ENV;   // weight = class_weights[env], staged with the small tables
     const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
     const bool pure = a.flags & INVPREF_PURE_MF;   // env-aware tables, embed_env, classifier absent: never touched
     // (E > 8: the LDS-DMA landing area holds the embed_env partial sums instead; the moments are loaded late)
@@ -491,6 +493,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
         stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
         stage_small(sW, t.W, t.E, t.D, EMAX, DP);
         if (threadIdx.x < EMAX) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
+        if (threadIdx.x < EMAX) scw[threadIdx.x] = (by_env && threadIdx.x < t.E) ? a.weights[threadIdx.x] : 1.f;
     }
     if (!G::REG)
         for (int i = threadIdx.x; i < EMAX * DP; i += kThreads) sdE[i] = 0.f;
@@ -569,7 +572,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                     q.qa = row4<VEC, FULL>(t.Qa, sm.oth, t.D, lg);
                     q.e = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.envs) + pso * 8u);   // low word of the int64 id
                 }
-                if (rw_rec || rw_cls) q.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + pso * 4u);
+                if ((rw_rec || rw_cls) && !by_env) q.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + pso * 4u);
                 if (push) q.cs = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.push_slot) + pso * 4u);
                 return;
             }
@@ -577,7 +580,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 q.qa = row4<VEC, FULL>(t.Qa, sm.oth, t.D, lg);
                 q.e = (int)a.envs[sm.ps];
             }
-            if (rw_rec || rw_cls) q.w = a.weights[sm.ps];
+            if ((rw_rec || rw_cls) && !by_env) q.w = a.weights[sm.ps];
             if (push) q.cs = a.push_slot[sm.ps];
         };
 #pragma unroll
@@ -641,6 +644,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
                 stage_small(sW, t.W, t.E, t.D, EMAX, DP);
                 if (threadIdx.x < EMAX) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
+                if (threadIdx.x < EMAX) scw[threadIdx.x] = (by_env && threadIdx.x < t.E) ? a.weights[threadIdx.x] : 1.f;
             }
             __syncthreads();   // staged tables visible (the gathers above are in flight)
             STAMP(3);
@@ -651,7 +655,8 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             if (EMAX > 4) gzs = lds + L::recs + ((it_total & 1) * NG + grp) * (EMAX + 4);
             const int e = q.e;
             if (has) {
-                const float w_rec = rw_rec ? q.w : 1.f, w_cls = rw_cls ? q.w : 1.f;
+                const float wq = by_env ? scw[e] : q.w;
+                const float w_rec = rw_rec ? wq : 1.f, w_cls = rw_cls ? wq : 1.f;
                 const float4 ev = *reinterpret_cast<const float4 *>(sEv + e * DP + lg * 4);
                 Eval<EMAX> o;
                 eval_interaction<LG, EMAX>(o, oi, q.qi, oe, q.qa, ev, sW, sb, gzs, t.E, e, q.sm.y, w_rec * k.invB,
@@ -1577,7 +1582,7 @@ inline size_t eval_lds_bytes(const Shape &s) {
     if (!s.wide) return sizeof(float) * EvalLds<16, 4>::total;
     // (the layout itself: WGeo / WGeo::Img in step_wide.hpp)
     const size_t ng = kThreads / s.lg;
-    const size_t live = (size_t)2 * s.emax * s.dp + 16 + ng * 2 * s.dp + 2 * ng * (s.emax + 4);
+    const size_t live = (size_t)2 * s.emax * s.dp + 32 + ng * 2 * s.dp + 2 * ng * (s.emax + 4);
     const size_t len = (size_t)(s.evl2 ? 1 : 2) * s.emax * s.dp;
     const size_t nimg = 4 * len <= 10240 ? 4 : (2 * len <= 10240 ? 2 : 1);
     const size_t tail = nimg * len > live ? nimg * len : live;
@@ -1639,6 +1644,7 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     (void)scores;   // (the labels travel inside the plan)
     if (pure && (flags & (INVPREF_REWEIGHT_CLS | INVPREF_REG_ENV_EMBED))) return INVPREF_EINVAL;
     if ((flags & (INVPREF_REWEIGHT_REC | INVPREF_REWEIGHT_CLS)) && !weights) return INVPREF_EINVAL;
+    if ((flags & INVPREF_WEIGHTS_BY_ENV) && pure) return INVPREF_EINVAL;
     const DevTables t = dev_tables(tables);
     // rows are addressed with 32-bit byte offsets (row4 / put4): every table must stay below 4 GiB
     if ((uint64_t)(t.U > t.I ? t.U : t.I) * (uint64_t)t.D * 4ull >= (1ull << 32)) return INVPREF_EUNSUPPORTED;
@@ -1744,18 +1750,18 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     if (shp.evl2) { f.slabs_ev = a.slabs_ev; f.n_partials_ev = plan->n_item_rounds / plan->item_rounds_per_task; }
     // wide rows / more than four environments (step_wide.hpp).  evl2: launch 2 = the item jobs alone (they produce embed_env's
     // partial slabs), launch 3 = the fold blocks alone
-#define CALL_W(LGV, NCV, VECV, EMAXV, EV2)                                                                        \
+#define CALL_W1(LGV, NCV, VECV, EMAXV, EV2, BYE)                                                                  \
     do {                                                                                                          \
         if ((rc = ensure_lds(mstep_apply_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>, lds2))) return rc;            \
         if (VECV && use_mm) {   /* full rows: the classifier as products over the workgroup's interactions (step_wide_mm.hpp) */ \
             const size_t ldsm = sizeof(float) * MGeo<LGV, NCV, EMAXV, EV2>::total;                                \
-            if ((rc = ensure_lds(mstep_eval_mm_kernel<LGV, NCV, EMAXV, EV2>, ldsm))) return rc;                  \
+            if ((rc = ensure_lds(mstep_eval_mm_kernel<LGV, NCV, EMAXV, EV2, BYE>, ldsm))) return rc;             \
             if (wg1 > 0)                                                                                          \
-                hipLaunchKernelGGL((mstep_eval_mm_kernel<LGV, NCV, EMAXV, EV2>), dim3(wg1), dim3(kThreads), ldsm, st, t, a1); \
+                hipLaunchKernelGGL((mstep_eval_mm_kernel<LGV, NCV, EMAXV, EV2, BYE>), dim3(wg1), dim3(kThreads), ldsm, st, t, a1); \
         } else {                                                                                                  \
-            if ((rc = ensure_lds(mstep_eval_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>, lds1))) return rc;         \
+            if ((rc = ensure_lds(mstep_eval_wide_kernel<LGV, NCV, VECV, EMAXV, EV2, BYE>, lds1))) return rc;    \
             if (wg1 > 0)                                                                                          \
-                hipLaunchKernelGGL((mstep_eval_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>), dim3(wg1), dim3(kThreads), lds1, st, t, a1); \
+                hipLaunchKernelGGL((mstep_eval_wide_kernel<LGV, NCV, VECV, EMAXV, EV2, BYE>), dim3(wg1), dim3(kThreads), lds1, st, t, a1); \
         }                                                                                                         \
         if (profile_event && hipEventRecord((hipEvent_t)profile_event, st) != hipSuccess) return INVPREF_EINVAL; \
         if (!EV2) {                                                                                               \
@@ -1767,6 +1773,11 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
             f3.n_task_wgs = 0;                                                                                    \
             hipLaunchKernelGGL((mstep_apply_wide_kernel<LGV, NCV, VECV, EMAXV, EV2>), dim3(f.fold_blocks + 1), dim3(kThreads), fold_lds_bytes(), st, t, a2, f3); \
         }                                                                                                         \
+    } while (0)
+    /* (INVPREF_WEIGHTS_BY_ENV is a compile-time property of the full-row instances: step_wide.hpp) */
+#define CALL_W(LGV, NCV, VECV, EMAXV, EV2)                                                                        \
+    do {                                                                                                          \
+        if (VECV && (flags & INVPREF_WEIGHTS_BY_ENV)) CALL_W1(LGV, NCV, VECV, EMAXV, EV2, (VECV)); else CALL_W1(LGV, NCV, VECV, EMAXV, EV2, false); \
     } while (0)
 #define CALL_WE(LGV, NCV, VECV, EV2)                                                               \
     do {                                                                                           \
@@ -1790,6 +1801,7 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     }
 #undef CALL_WE
 #undef CALL_W
+#undef CALL_W1
 #define CALL(LGV, VECV, EMAXV)                                                                                  \
     do {                                                                                                        \
         if ((rc = ensure_lds(mstep_eval_kernel<LGV, VECV, EMAXV>, lds1))) return rc;                            \

@@ -106,6 +106,7 @@ __device__ __forceinline__ void st_sc1(int *p, int v) {
 // one of this run's step numbers.
 struct AltStage {
     unsigned long long g[9];
+    float cw;   // INVPREF_WEIGHTS_BY_ENV: class weight of environment `lane` (lanes < env_num of wave 0), requested with the granules
 };
 __device__ __forceinline__ void alt_stage_lanes(const AltArgs &a, int lane, bool (&on)[4], bool &onb) {
     constexpr int DP = 64;
@@ -136,8 +137,10 @@ __device__ __forceinline__ void alt_stage_issue(const AltArgs &a, AltStage &x) {
                    "=&v"(x.g[7]), "=&v"(x.g[8])
                  : "v"(o0), "v"(ob), "s"(a.pub)
                  : "memory");
+    // (the class weights are final before the launch -- stat_envs runs between runs -- and ride in the same burst)
+    x.cw = ((a.flags & INVPREF_WEIGHTS_BY_ENV) && lane < a.E) ? a.weights[lane] : 1.f;
 }
-__device__ __forceinline__ void alt_stage_finish(const AltArgs &a, AltStage &x, int gen, float *sEv, float *sW, float *sb) {
+__device__ __forceinline__ void alt_stage_finish(const AltArgs &a, AltStage &x, int gen, float *sEv, float *sW, float *sb, float *scw) {
     constexpr int EMAX = 4, EDP = 4 * 64;
     const int lane = threadIdx.x & 63;
     bool on[4], onb;
@@ -183,9 +186,10 @@ __device__ __forceinline__ void alt_stage_finish(const AltArgs &a, AltStage &x, 
         sW[lane + 64 * i] = on[i] ? __builtin_bit_cast(float, (unsigned)x.g[4 + i]) : 0.f;
     }
     if (lane < EMAX) sb[lane] = onb ? __builtin_bit_cast(float, (unsigned)x.g[8]) : 0.f;
+    if (lane < EMAX) scw[lane] = x.cw;
 }
 // a run's first launch: the tables are final in memory (the previous run's flush launch ended before this one began)
-__device__ __forceinline__ void alt_stage_plain(const AltArgs &a, float *sEv, float *sW, float *sb, bool pure) {
+__device__ __forceinline__ void alt_stage_plain(const AltArgs &a, float *sEv, float *sW, float *sb, float *scw, bool pure) {
     constexpr int EMAX = 4, DP = 64;
     const int lane = threadIdx.x & 63;
     bool on[4], onb;
@@ -198,6 +202,7 @@ __device__ __forceinline__ void alt_stage_plain(const AltArgs &a, float *sEv, fl
         sW[idx] = o ? a.W[e * a.D + d] : 0.f;
     }
     if (lane < EMAX) sb[lane] = (onb && !pure) ? a.b[lane] : 0.f;
+    if (lane < EMAX) scw[lane] = ((a.flags & INVPREF_WEIGHTS_BY_ENV) && onb && !pure) ? a.weights[lane] : 1.f;
 }
 
 // geometry of a job workgroup of THREADS threads: THREADS / 16 group slots (16 or 32: a hot row's interactions spread over up
@@ -208,7 +213,8 @@ struct AltGeo {
     static constexpr int NG = THREADS / 16, WAVES = THREADS / 64, DP = 64, EMAX = 4;
     static constexpr int SLAB = 2 * EMAX * DP + EMAX + kLossSlots;
     static constexpr int sEv = 0, sW = sEv + EMAX * DP, sb = sW + EMAX * DP;
-    static constexpr int mv = sb + EMAX;                      // [WAVES][4][64] float4
+    static constexpr int scw = sb + EMAX;                     // [EMAX] class weights (INVPREF_WEIGHTS_BY_ENV; else ones)
+    static constexpr int mv = scw + EMAX;                     // [WAVES][4][64] float4
     static constexpr int red = mv + WAVES * 4 * 64 * 4;       // [NG][SLAB]
     static constexpr int total = red + NG * SLAB;
 };
@@ -230,13 +236,14 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
     using L = AltGeo<THREADS>;
     static_assert(STEP_LDS_DW && !STEP_NO_DMA && EvalLds<16, 4>::total == AltGeo<256>::total, "alt_task: the default smallest-instance layout");
     constexpr int NG = G::NG, DP = G::DP;
-    float *sEv = lds + L::sEv, *sW = lds + L::sW, *sb = lds + L::sb;
+    float *sEv = lds + L::sEv, *sW = lds + L::sW, *sb = lds + L::sb, *scw = lds + L::scw;
     float4 *mv = reinterpret_cast<float4 *>(lds + L::mv);
     float *red = lds + L::red;
     const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float4 *mv_wave = mv + wave * 4 * 64;
     const bool implicit = a.flags & INVPREF_IMPLICIT;
     const bool rw_rec = a.flags & INVPREF_REWEIGHT_REC, rw_cls = a.flags & INVPREF_REWEIGHT_CLS;
+    const bool by_env = a.flags & INVPREF_WEIGHTS_BY_ENV;   // weight = class_weights[env], staged in LDS: no per-interaction load
     const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
     const bool pure = a.flags & INVPREF_PURE_MF;
     const bool dense = (a.flags & INVPREF_DENSE_REG) && !(a.flags & INVPREF_REG_ONLY_EMBED) && !pure;
@@ -361,7 +368,7 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
                     q.qa = row4<VEC, FULL>(oth1, sm.oth, D, lg);
                     q.e = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.envs) + pso * 8u);
                 }
-                if (rw_rec || rw_cls) q.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + pso * 4u);
+                if ((rw_rec || rw_cls) && !by_env) q.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + pso * 4u);
                 q.cs = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.push_slot) + pso * 4u);
                 return;
             }
@@ -369,7 +376,7 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
                 q.qa = row4<VEC, FULL>(oth1, sm.oth, D, lg);
                 q.e = (int)a.envs[sm.ps];
             }
-            if (rw_rec || rw_cls) q.w = a.weights[sm.ps];
+            if ((rw_rec || rw_cls) && !by_env) q.w = a.weights[sm.ps];
             q.cs = a.push_slot[sm.ps];
         };
 #pragma unroll
@@ -415,6 +422,7 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
         AltStage stg;
 #pragma unroll
         for (int i = 0; i < 9; i++) stg.g[i] = 0ull;
+        stg.cw = 1.f;
 #if ALT_EARLY_STAGE
         if (has_cur && has_prev && !pure && wave == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -512,8 +520,8 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
 #if !ALT_EARLY_STAGE
                 if (has_prev && !pure) alt_stage_issue(a, stg);
 #endif
-                if (has_prev && !pure) alt_stage_finish(a, stg, gen, sEv, sW, sb);
-                else alt_stage_plain(a, sEv, sW, sb, pure);
+                if (has_prev && !pure) alt_stage_finish(a, stg, gen, sEv, sW, sb, scw);
+                else alt_stage_plain(a, sEv, sW, sb, scw, pure);
             }
             __syncthreads();
             ASTAMP(4);
@@ -523,7 +531,8 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
         auto step = [&](const Slot &q, bool has) {
             const int e = q.e;
             if (has) {
-                const float w_rec = rw_rec ? q.w : 1.f, w_cls = rw_cls ? q.w : 1.f;
+                const float wq = by_env ? scw[e] : q.w;
+                const float w_rec = rw_rec ? wq : 1.f, w_cls = rw_cls ? wq : 1.f;
                 const float4 ev = *reinterpret_cast<const float4 *>(sEv + e * DP + lg * 4);
                 Eval<EMAX> o;
                 eval_interaction<LG, EMAX>(o, oi, q.qi, oe, q.qa, ev, sW, sb, nullptr, a.E, e, q.sm.y, w_rec * k.invB,
@@ -988,6 +997,7 @@ int launch_alt(const InvPrefTables *tables, const InvPrefTables *exp_avg, const 
     if (!sched && step < 1) return INVPREF_EINVAL;
     if (pure && (flags & (INVPREF_REWEIGHT_CLS | INVPREF_REG_ENV_EMBED))) return INVPREF_EINVAL;
     if (has_cur && (flags & (INVPREF_REWEIGHT_REC | INVPREF_REWEIGHT_CLS)) && !weights) return INVPREF_EINVAL;
+    if ((flags & INVPREF_WEIGHTS_BY_ENV) && pure) return INVPREF_EINVAL;
     if ((uint64_t)(tables->user_num > tables->item_num ? tables->user_num : tables->item_num) * (uint64_t)D * 4ull >= (1ull << 32))
         return INVPREF_EUNSUPPORTED;
     if (plan->lanes_per_group != 16 || (plan->slots_per_round != 16 && plan->slots_per_round != 32) || plan->side < 0 || plan->side > 1 || plan->n < 0 || plan->n_prev < 0 ||

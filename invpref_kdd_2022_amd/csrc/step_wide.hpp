@@ -73,7 +73,7 @@ struct WGeo {
     static constexpr int HALVES = LG / 16;            // 16-lane pieces of a group = MFMA k slots a row spans
     static constexpr int TILES = NC * HALVES;         // column tiles of a table: 16 float4 columns x 16 classes each
     // LDS of launch 1 (floats)
-    static constexpr int sEv = 0, sW = EMAX * DP, sb = 2 * EMAX * DP, slots = sb + 16;
+    static constexpr int sEv = 0, sW = EMAX * DP, sb = 2 * EMAX * DP, scw = sb + 16, slots = scw + 16;   // scw: [16] class weights (INVPREF_WEIGHTS_BY_ENV)
     static constexpr int gzs = slots + NG * 2 * DP;                  // [2][NG][EMAX + 4] class gradients of a group
     static constexpr int live_end = gzs + 2 * NG * (EMAX + 4);
     // task end: the waves' accumulator tiles meet in NIMG LDS images laid over everything above (nobody reads it any
@@ -348,17 +348,21 @@ __device__ __forceinline__ void tiles_to_lds(float *img, const f32x4 (&acc)[NC *
 // =====================================================================================
 // launch 1: rounds of USER jobs
 // =====================================================================================
-template <int LG, int NC, bool VEC, int EMAX, bool EVL2>
+// BYENV (full-row instances): INVPREF_WEIGHTS_BY_ENV at COMPILE time -- the weight of an interaction is class_weights[env] from
+// LDS and a gather slot carries no weight register (at 250+ registers a run-time switch put loop-carried values into
+// scratch memory); the element-wise instances (VEC = false) take the flag at run time.
+template <int LG, int NC, bool VEC, int EMAX, bool EVL2, bool BYENV = false>
 __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArgs &a, int r0, int nr, int slab_index, float *lds) {
     using G = WGeo<LG, NC, EMAX>;
     constexpr int NG = G::NG, DP = G::DP, RS = G::RS, TILES = G::TILES;
     // interactions in flight per group: what the instance's register budget allows (WideCfg)
     constexpr int UE = WideCfg<LG, NC, EMAX>::UE;
     using IM = typename G::template Img<EVL2>;
-    float *sEv = lds + G::sEv, *sW = lds + G::sW, *sb = lds + G::sb, *slots = lds + G::slots, *tail = lds + IM::tail;
+    float *sEv = lds + G::sEv, *sW = lds + G::sW, *sb = lds + G::sb, *scw = lds + G::scw, *slots = lds + G::slots, *tail = lds + IM::tail;
     const int lg = threadIdx.x & (LG - 1), grp = threadIdx.x / LG, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool implicit = a.flags & INVPREF_IMPLICIT;
     const bool rw_rec = a.flags & INVPREF_REWEIGHT_REC, rw_cls = a.flags & INVPREF_REWEIGHT_CLS;
+    const bool by_env = BYENV || (!VEC && (a.flags & INVPREF_WEIGHTS_BY_ENV));   // weight = class_weights[env], staged with the small tables
     const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
     const bool pure = a.flags & INVPREF_PURE_MF;
     const bool push = a.push_slot != nullptr;
@@ -446,7 +450,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
                 load_row<LG, NC, VEC>(q.qa, t.Qa, oth, t.D, lg);
                 q.e = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.envs) + pso * 8u);   // low word of the int64 id
             }
-            if (rw_rec || rw_cls) q.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + pso * 4u);
+            if ((rw_rec || rw_cls) && !by_env) q.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + pso * 4u);
             if (push) q.cs = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.push_slot) + pso * 4u);
         };
         // the slice's FIRST interaction is in the descriptor's registers either way (inline form: words 2 .. 4, list form:
@@ -470,7 +474,11 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             // them would put the tables' round trip ahead of the rows' on the task's critical chain
             stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
             stage_small(sW, t.W, t.E, t.D, EMAX, DP);
-            if (threadIdx.x < 16) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
+            // (32-bit offsets from the scalar bases: a 64-bit address pair per table, formed at the top of the task and held
+            //  across the rounds, went to scratch memory at this register pressure)
+            const unsigned so = (threadIdx.x < (unsigned)t.E ? threadIdx.x : 0u) * 4u;
+            if (threadIdx.x < 16) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(t.b) + so) : 0.f;
+            if (threadIdx.x < 16) scw[threadIdx.x] = (by_env && threadIdx.x < t.E) ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + so) : 1.f;
             __syncthreads();
             if (LG == 16) bias_l = sb[lg & (EMAX - 1)];   // the lane's class bias, once: an LDS read per interaction sat on the softmax chain
         }
@@ -483,7 +491,8 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             float *gzs = lds + G::gzs + ((it_total & 1) * NG + grp) * (EMAX + 4);
             WTRACE(1);
             const int e = q.e;
-            const float w_rec = rw_rec ? q.w : 1.f, w_cls = rw_cls ? q.w : 1.f;
+            const float wq = by_env ? scw[e] : q.w;
+            const float w_rec = rw_rec ? wq : 1.f, w_cls = rw_cls ? wq : 1.f;
             float4 ev[NC];
             lds_row<LG, NC>(ev, sEv, e, lg);
 #ifdef WIDE_DIAG_TRACE
@@ -1080,7 +1089,7 @@ __device__ __forceinline__ void stream_task_wide(const DevTables &t, const StepA
 }
 
 // ---- the two kernels
-template <int LG, int NC, bool VEC, int EMAX, bool EVL2>
+template <int LG, int NC, bool VEC, int EMAX, bool EVL2, bool BYENV = false>
 __global__ __launch_bounds__(kThreads, (WideCfg<LG, NC, EMAX>::WAVES)) void mstep_eval_wide_kernel(DevTables t, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ncls = a.n_cls;
@@ -1091,7 +1100,7 @@ __global__ __launch_bounds__(kThreads, (WideCfg<LG, NC, EMAX>::WAVES)) void mste
     const int rpt = a.rounds_per_task, spt = a.rows_per_stream_task;
     const int tj = (q[1] + rpt - 1) / rpt;
     if (j < tj) {
-        user_task_wide<LG, NC, VEC, EMAX, EVL2>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), q[0] / rpt + j, lds);
+        user_task_wide<LG, NC, VEC, EMAX, EVL2, BYENV>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), q[0] / rpt + j, lds);
         return;
     }
     j -= tj;

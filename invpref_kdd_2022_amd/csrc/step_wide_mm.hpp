@@ -53,7 +53,8 @@ struct MGeo {
     static constexpr int P = GX + NG * XS;                   // [waves][16 interactions][PS] partial logits
     static constexpr int GZT = P + kWaves * 16 * PS;         // [waves][16 interactions][PS] a wave's private copy of gz
     static constexpr int META = GZT + kWaves * 16 * PS;      // [16 interactions][4]
-    static constexpr int tail = META + 64;                   // [waves][kLossSlots]
+    static constexpr int CW = META + 64;                     // [16] class weights (INVPREF_WEIGHTS_BY_ENV; else ones)
+    static constexpr int tail = CW + 16;                     // [waves][kLossSlots]
     static constexpr int total = tail + kWaves * kLossSlots;
 };
 
@@ -95,7 +96,7 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 #endif
 }
 
-template <int LG, int NC, int EMAX, bool EVL2>
+template <int LG, int NC, int EMAX, bool EVL2, bool BYENV = false>
 __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const StepArgs &a, int r0, int nr, int slab_index, float *lds) {
     using G = MGeo<LG, NC, EMAX, EVL2>;
     constexpr bool VEC = true;
@@ -108,6 +109,8 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
     const int n16 = lane & 15, kq = lane >> 4;
     const bool implicit = a.flags & INVPREF_IMPLICIT;
     const bool rw_rec = a.flags & INVPREF_REWEIGHT_REC, rw_cls = a.flags & INVPREF_REWEIGHT_CLS;
+    constexpr bool by_env = BYENV;   // (compile time, see step_wide.hpp) weight = class_weights[env], staged with embed_env
+    float *scw = lds + G::CW;
     const bool reg_env = a.flags & INVPREF_REG_ENV_EMBED;
     const bool push = a.push_slot != nullptr;
     const int E = t.E;
@@ -202,7 +205,7 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
             const unsigned pso = (unsigned)sm.ps;
             load_row<LG, NC, VEC>(q.qa, t.Qa, oth, t.D, lg);
             q.e = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.envs) + pso * 8u);   // low word of the int64 id
-            if (rw_rec || rw_cls) q.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + pso * 4u);
+            if ((rw_rec || rw_cls) && !by_env) q.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + pso * 4u);
             if (push) q.cs = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.push_slot) + pso * 4u);
         };
         const USample first = mode == 7 ? USample{dd2.x, dd2.y, __builtin_bit_cast(float, dd2.z)}
@@ -221,6 +224,8 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
         for (int j = 0; j < UE; j++) idn[j] = list_at(UE + j);
         if (r == r0) {   // embed_env's table is staged behind the first round's gathers (see step_wide.hpp)
             stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
+            if (threadIdx.x < 16)   // (a 32-bit offset from the scalar base, see step_wide.hpp)
+                scw[threadIdx.x] = (by_env && threadIdx.x < t.E) ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + (threadIdx.x & 15u) * 4u) : 1.f;
             __syncthreads();
         }
         if (r == r0 + STAMP_ROUND) STAMP(3);
@@ -230,7 +235,6 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
             // evaluates its stale -- finite -- rows with every gradient scalar forced to zero)
             WTRACE(20);
             const int e = q.e;
-            const float w_rec = rw_rec ? q.w : 1.f, w_cls = rw_cls ? q.w : 1.f;
             float g_p, g_q;
             {
                 float4 ev[NC], x[NC];
@@ -246,6 +250,10 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
                 }
                 const float p = group_sum<LG>(ps);
                 const float qq = group_sum<LG>(qs);
+                // (the class weight is read HERE, with the products above already on their way to LDS: at 256 registers a
+                //  value held across them went to scratch memory)
+                const float wq = by_env ? scw[e] : q.w;
+                const float w_rec = rw_rec ? wq : 1.f, w_cls = rw_cls ? wq : 1.f;
                 const float cw_rec = w_rec * k.invB;
                 float li, le;
                 if (implicit) {
@@ -557,7 +565,7 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
     STAMP(7);
 }
 
-template <int LG, int NC, int EMAX, bool EVL2>
+template <int LG, int NC, int EMAX, bool EVL2, bool BYENV = false>
 __global__ __launch_bounds__(kThreads, WIDE_MM_WAVES) void mstep_eval_mm_kernel(DevTables t, StepArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ncls = a.n_cls;
@@ -568,7 +576,7 @@ __global__ __launch_bounds__(kThreads, WIDE_MM_WAVES) void mstep_eval_mm_kernel(
     const int rpt = a.rounds_per_task, spt = a.rows_per_stream_task;
     const int tj = (q[1] + rpt - 1) / rpt;
     if (j < tj) {
-        user_task_wide_mm<LG, NC, EMAX, EVL2>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), q[0] / rpt + j, lds);
+        user_task_wide_mm<LG, NC, EMAX, EVL2, BYENV>(t, a, q[0] + j * rpt, min(rpt, q[1] - j * rpt), q[0] / rpt + j, lds);
         return;
     }
     j -= tj;

@@ -14,7 +14,7 @@ import torch
 
 from . import _capi
 from . import torch_ops  # noqa: F401  (registers torch.ops.invpref.*)
-from ._capi import (DENSE_REG, IMPLICIT, REG_ENV_EMBED, REG_ONLY_EMBED, REWEIGHT_CLS, REWEIGHT_REC, Coefs,
+from ._capi import (DENSE_REG, IMPLICIT, REG_ENV_EMBED, REG_ONLY_EMBED, REWEIGHT_CLS, REWEIGHT_REC, WEIGHTS_BY_ENV, Coefs,
                     InvPrefError, check, lib, make_tables, ptr, stream_ptr)
 
 PARAM_NAMES = [
@@ -150,6 +150,49 @@ def estep(params: Sequence[torch.Tensor], users, items, scores, implicit: bool, 
     if want_weights:
         cw, sw = _o().sample_weights(out, counts, users.numel(), t.env_num)
     return out, counts, diff, cw, sw
+
+
+class EstepState:
+    """what invpref_estep_fused_hip keeps between calls: the ticket / ring-position words (zero before the first call), the ring
+    of {counts, diff} rows the replayed E-steps write to, and the E! permutation rows of train.py:86-92 (built once)."""
+
+    def __init__(self, env_num: int, device, ring_cap: int = 256):
+        self.env_num, self.ring_cap = int(env_num), int(ring_cap)
+        self.state = torch.zeros(4, dtype=torch.int32, device=device)
+        self.ring = torch.zeros(ring_cap, env_num + 1, dtype=torch.int64, device=device)
+        self.issued = 0          # host mirror of state[1]: E-steps issued so far
+        self.perm_table = None
+        if env_num <= 7:
+            import numpy as np
+            rows = 1
+            for k in range(2, env_num + 1):
+                rows *= k
+            host = np.zeros(rows, np.uint32)
+            if lib().invpref_perm_table_fill(env_num, host.ctypes.data) != rows:
+                raise InvPrefError('invpref_perm_table_fill failed')
+            self.perm_table = torch.from_numpy(host.view(np.int32)).to(device)
+
+    def next_row(self) -> int:
+        """ring row the NEXT issued E-step writes (call when issuing / replaying one)"""
+        r = self.issued % self.ring_cap
+        self.issued += 1
+        return r
+
+
+def estep_fused(params: Sequence[torch.Tensor], users, items, scores, implicit: bool, envs: torch.Tensor, es: EstepState,
+                workspace: Workspace, perm_index: Optional[torch.Tensor] = None, eps_base=None,
+                counts: Optional[torch.Tensor] = None, diff: Optional[torch.Tensor] = None,
+                class_weights: Optional[torch.Tensor] = None, use_ring: bool = True) -> None:
+    """cluster() + stat_envs() (train.py:235-259, :268-280) as ONE launch over all given interactions, `envs` updated in
+    place; counts / diff / class weights come out of the kernel's epilogue (to the given tensors and / or the next row of
+    es.ring: the caller advances es.next_row() per issued or replayed call).  No N-length sample_weights: the planned M-step
+    looks class_weights[env] up itself (flags | WEIGHTS_BY_ENV)."""
+    _gpu(users, envs, *params)
+    t = make_tables(params)
+    ws = workspace.get(lib().invpref_estep_workspace_bytes(C.byref(t), users.numel()))
+    _o().estep_fused_(list(params), users, items, scores, envs, bool(implicit), perm_index,
+                      None if eps_base is None else [float(x) for x in eps_base], es.perm_table, es.state,
+                      es.ring if use_ring else None, counts, diff, class_weights, ws)
 
 
 def stat_envs(envs: torch.Tensor, env_num: int, workspace: Workspace, want_sample_weights: bool = True):

@@ -20,6 +20,7 @@ What replaces what in the reference:
 ``pack_rows_`` / ``unpack_``   the touched rows of the flat gradient into / out of one buffer (row-sharded ranks' exchange)
 ``estep_assign``               ``cluster_a_batch`` / ``cluster`` (train.py:169-202, :235-259), functional
 ``estep_assign_``              ``cluster()`` updating ``envs`` in place + the ``stat_envs()`` that follows (train.py:330)
+``estep_fused_``               the same as ONE launch: counts, ``diff_num`` and class weights from the kernel's epilogue
 ``stat_envs``                  ``stat_envs()`` (train.py:268-280)
 ``sample_weights``             its weight half from global counts (multi-GPU)
 ``forward`` / ``backward``     ``InvPref*.forward`` values (models.py:307-326, :448-467) and its backward
@@ -447,6 +448,47 @@ def _estep_assign_inplace_fake(tables, users, items, scores, envs, implicit, eps
     return (torch.empty(E, dtype=torch.int64, device=dev), torch.empty(1, dtype=torch.int64, device=dev),
             torch.empty(E if want_weights else 0, dtype=torch.float32, device=dev),
             torch.empty(N if want_weights else 0, dtype=torch.float32, device=dev))
+
+
+_define('estep_fused_(Tensor[] tables, Tensor users, Tensor items, Tensor scores, Tensor(a!) envs, bool implicit, '
+        'Tensor? perm_index, float[]? eps_base, Tensor? perm_table, Tensor(b!) state, Tensor(c!)? ring, Tensor(d!)? counts, '
+        'Tensor(e!)? diff, Tensor(f!)? class_weights, Tensor(g!) workspace) -> ()')
+
+
+@_impl('estep_fused_')
+def _estep_fused(tables, users, items, scores, envs, implicit, perm_index, eps_base, perm_table, state, ring, counts, diff,
+                 class_weights, workspace):
+    # cluster() + stat_envs() as ONE launch (include/invpref_hip.h: invpref_estep_fused_hip; train.py:235-259, :268-280)
+    t = _tables(tables)
+    N = users.numel()
+    _f32(scores, 'scores'); _f32(class_weights, 'class_weights')
+    _ids(envs, 'envs')
+    _capi._req(state, torch.int32, 'state')
+    for x, nm in ((ring, 'ring'), (counts, 'counts'), (diff, 'diff')):
+        _capi._req(x, torch.int64, nm)
+    if state.numel() < 4 or (ring is not None and (ring.dim() != 2 or ring.shape[1] != t.env_num + 1)) \
+            or (counts is not None and counts.numel() < t.env_num) or (class_weights is not None and class_weights.numel() < t.env_num):
+        raise InvPrefError('estep_fused_: state int32[4], ring int64[cap, env_num + 1], counts / class_weights [env_num]')
+    base, nbytes = None, 0
+    if perm_index is not None:
+        if eps_base is None or len(eps_base) != t.env_num or perm_index.dtype not in _PERM_BYTES or perm_index.numel() != N:
+            raise InvPrefError('perm_index: one uint8 / int32 / int64 permutation row per interaction + eps_base[env_num]')
+        if not (perm_index.is_cuda or (perm_index.is_pinned() and t.env_num <= 7)) or not perm_index.is_contiguous():
+            raise InvPrefError('perm_index: a contiguous device tensor, or (up to 7 environments) pinned host memory')
+        base, nbytes = (C.c_float * t.env_num)(*[float(x) for x in eps_base]), _PERM_BYTES[perm_index.dtype]
+    if perm_table is not None:
+        _capi._req(perm_table, torch.int32, 'perm_table')
+    check(lib().invpref_estep_fused_hip(C.byref(t), ptr(_ids(users, 'users')), ptr(_ids(items, 'items')), ptr(scores), N,
+                                        _capi.IMPLICIT if implicit else 0, ptr(perm_index), nbytes, base, ptr(perm_table),
+                                        ptr(envs), ptr(state), ptr(ring), 0 if ring is None else int(ring.shape[0]),
+                                        ptr(counts), ptr(diff), ptr(class_weights), ptr(workspace), workspace.numel(),
+                                        stream_ptr()), 'invpref_estep_fused_hip')
+
+
+@_fake('estep_fused_')
+def _estep_fused_fake(tables, users, items, scores, envs, implicit, perm_index, eps_base, perm_table, state, ring, counts, diff,
+                      class_weights, workspace):
+    return None
 
 
 _define('stat_envs(Tensor envs, int env_num, bool want_sample_weights, Tensor(a!) workspace) -> (Tensor, Tensor, Tensor)')

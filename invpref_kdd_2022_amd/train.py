@@ -164,7 +164,15 @@ class _InvPrefTrainManager:
             self.alpha, self.update_alpha = alpha, False
         self.use_class_re_weight = use_class_re_weight
         self.use_recommend_re_weight = use_recommend_re_weight
-        self.sample_weights = torch.zeros(self.users_tensor.shape[0], dtype=torch.float32, device=self.device)
+        # sample_weights[i] = class_weights[envs[i]] (train.py:274-278).  The N-length array is kept LAZILY on one GPU: stat_envs()
+        # refreshes class_weights and the planned M-step kernels look the weight up by environment (INVPREF_WEIGHTS_BY_ENV);
+        # the array is materialised when somebody reads the `sample_weights` attribute (property below).
+        self._sample_weights = torch.zeros(self.users_tensor.shape[0], dtype=torch.float32, device=self.device)
+        self._sw_lazy = False        # True: _sample_weights is behind (it equals class_weights[envs] once materialised)
+        self._by_env = False         # True: class_weights[envs] IS what the reference's sample_weights would hold right now
+        self._epoch_by_env = False   # what the epochs being issued / captured use (fixed per _enqueue_epochs call)
+        self._counts_dev = torch.zeros(self.envs_num, dtype=torch.int64, device=self.device)
+        self._es = None              # ops.EstepState of the fused E-step (one GPU)
         self.class_weights = torch.zeros(self.envs_num, dtype=torch.float32, device=self.device)
         self.test_begin_epoch = test_begin_epoch
         self.begin_cluster_epoch, self.stop_cluster_epoch = begin_cluster_epoch, stop_cluster_epoch
@@ -215,6 +223,39 @@ class _InvPrefTrainManager:
         self._sched = None
         self._sched_synced = False
         self._alt = None
+
+    # ------------------------------------------------------------------ sample weights (train.py:67, :274-278)
+    @property
+    def sample_weights(self) -> torch.Tensor:
+        """The reference's attribute.  Read from outside, the array is brought up to date first; and because the caller may
+        write into it (the reference's loop only slices it), the epochs fall back to reading it per interaction until the next
+        stat_envs() re-establishes sample_weights == class_weights[envs]."""
+        self._materialise_sample_weights()
+        self._by_env = False
+        return self._sample_weights
+
+    @sample_weights.setter
+    def sample_weights(self, value: torch.Tensor):
+        self._sample_weights, self._sw_lazy, self._by_env = value, False, False
+
+    def _materialise_sample_weights(self):
+        if self._sw_lazy:
+            _, sw = ops.sample_weights(self.envs, self._counts_dev, self.n_total, self.envs_num)   # class_weights[envs]
+            self._sample_weights.copy_(sw)
+            self._sw_lazy = False
+
+    def _step_weights(self, bw):
+        """(weights argument, flags) of one of the epochs' planned launches: the minibatch's slice of the sample-weight array, or
+        -- INVPREF_WEIGHTS_BY_ENV -- the E class weights the kernel indexes by environment"""
+        if bw is not None and self._epoch_by_env:
+            return self.class_weights, self._flags | _capi.WEIGHTS_BY_ENV
+        return bw, self._flags
+
+    def _weights_by_env(self) -> bool:
+        """may the epochs' launches take an interaction's weight as class_weights[env]? (one GPU, planned M-step, weights
+        consistent with the environments: stat_envs() ran since they last changed, nobody was handed the array since)"""
+        return bool(self._by_env and self.world_size == 1 and self.use_plan and not self._pure
+                    and os.environ.get('INVPREF_WEIGHTS_BY_ENV', '1') == '1')
 
     def _setup_ranges(self, model):
         """What one optimiser step exchanges and updates on this rank: `_ar_lo` = first float of the flat
@@ -441,11 +482,11 @@ class _InvPrefTrainManager:
         self._epoch_losses = torch.zeros(self._graph_epochs, self.batch_num, 6, dtype=torch.float32, device=self.device)
         self._loss_slot = 0
         self._raw_ptrs = (self.users_tensor.data_ptr(), self.items_tensor.data_ptr(), self.envs.data_ptr(),
-                          self.scores_tensor.data_ptr(), self.sample_weights.data_ptr())
+                          self.scores_tensor.data_ptr(), self._sample_weights.data_ptr())
         self._raw_batches = []
         for k in range(self.batch_num):
             lo, hi = self.shard.local_batch_bounds(k)
-            v = None if self._pure else (self.envs[lo:hi], self.sample_weights[lo:hi])
+            v = None if self._pure else (self.envs[lo:hi], self._sample_weights[lo:hi])
             self._raw_batches.append((lo, hi - lo, self.shard.global_batch_len(k), self.users_tensor[lo:hi],
                                       self.items_tensor[lo:hi], self.scores_tensor[lo:hi],
                                       None if self._pure else v[0], None if self._pure else v[1]))
@@ -556,8 +597,9 @@ class _InvPrefTrainManager:
             st.step += 1
             sc = (self._sched['state'], self._sched['table'], st.step & 1) if sched else None
             lp = self._epoch_losses[(i - 1) // bn, (i - 1) % bn] if i else None
-            ops.mstep_alt(st.p_views, st.m_views, st.v_views, dp, be, bw, bnorm,
-                          self._raw_batches[k_prev][2] if k_prev is not None else bnorm, self._coefs(alpha), self._flags, lp,
+            wts, flags = self._step_weights(bw)
+            ops.mstep_alt(st.p_views, st.m_views, st.v_views, dp, be, wts, bnorm,
+                          self._raw_batches[k_prev][2] if k_prev is not None else bnorm, self._coefs(alpha), flags, lp,
                           st.step, self.lr, A['ws'], i & 1, pure=self._pure, sched=sc)
             k_prev, tasks_prev = k, dp.n_tasks
         # the flush: the other side's rows take the last step's update, the last fold (in the LAST step's schedule slot)
@@ -600,8 +642,9 @@ class _InvPrefTrainManager:
             # fused M-step + Adam: one pass, gradient never stored, parameters ping-pong
             st.step += 1
             sc = (self._sched['state'], self._sched['table'], st.step & 1) if sched else None
-            ops.mstep_rows_adam(st.p_views, st.p_views_alt, st.m_views, st.v_views, self._plans[k], be, by, bw, bn,
-                                coefs, self._flags, lp, st.step, self.lr, self.workspace, pure=self._pure, sched=sc,
+            wts, flags = self._step_weights(bw)
+            ops.mstep_rows_adam(st.p_views, st.p_views_alt, st.m_views, st.v_views, self._plans[k], be, by, wts, bn,
+                                coefs, flags, lp, st.step, self.lr, self.workspace, pure=self._pure, sched=sc,
                                 mid_event=mid_event)   # (profiling: recorded between the step's two launches)
             st.swap()
             return
@@ -610,7 +653,8 @@ class _InvPrefTrainManager:
         # schedule, read by the gradient pass and moved on by the ranged Adam launch that ends the step
         sc = (self._sched['state'], self._sched['table'], st.step & 1) if sched else None
         if self.use_plan:
-            ops.mstep_rows_grad(st.p_views, st.g_views, self._plans[k], be, by, bw, bn, coefs, self._flags, lp,
+            wts, flags = self._step_weights(bw)
+            ops.mstep_rows_grad(st.p_views, st.g_views, self._plans[k], be, by, wts, bn, coefs, flags, lp,
                                 self.workspace, sched=sc)
         else:
             ops.mstep_grad(st.p_views, st.g_views, bu, bi, be, by, bw, bn, coefs, self._flags, lp, self.workspace)
@@ -721,11 +765,18 @@ class _InvPrefTrainManager:
         one launch per run instead of 2*batch_num per epoch."""
         self.model.train()
         if getattr(self, '_raw_ptrs', None) is None or self._raw_ptrs[2] != self.envs.data_ptr() \
-                or self._raw_ptrs[4] != self.sample_weights.data_ptr():
+                or self._raw_ptrs[4] != self._sample_weights.data_ptr():
+            if getattr(self, '_raw_ptrs', None) is not None and self._raw_ptrs[2] != self.envs.data_ptr():
+                self._by_env = False        # (somebody replaced the environments: weights by position until the next stat_envs())
             self._raw_setup()
             self._graphs.clear()
             self._estep_graphs.clear()
         st = self.state
+        # per-interaction weights: by environment from the E class weights, or from the N-length array (brought up to date
+        # HERE, outside any capture)
+        self._epoch_by_env = self._weights_by_env()
+        if not self._epoch_by_env:
+            self._materialise_sample_weights()
         # the fused single-GPU step, and the gradient-pass -> [all-reduce] -> ranged-Adam sequence of sharded runs and
         # wide rows (RCCL collectives record into a HIP graph like kernels do), are replayed as whole-epoch graphs
         fused_seq = self._fused_seq()
@@ -806,7 +857,7 @@ class _InvPrefTrainManager:
         return dist.get_backend(self.process_group) == 'nccl'
 
     def _graph_key(self, n: int):
-        return (self.state.p_views[0].data_ptr(), n, self.state.step & 1)
+        return (self.state.p_views[0].data_ptr(), n, self.state.step & 1, self._epoch_by_env)
 
     def _graph_for(self, n: int):
         """The HIP graph of n epochs starting from the current parameter buffer (captured on first use)."""
@@ -837,6 +888,9 @@ class _InvPrefTrainManager:
         if not self._graph_warm or getattr(self, '_raw_ptrs', None) is None:
             raise RuntimeError('prepare_graphs(): run one epoch first (train_epochs(1))')
         self._sched_prepare(self.batch_num)
+        self._epoch_by_env = self._weights_by_env()
+        if not self._epoch_by_env:
+            self._materialise_sample_weights()
         for n in sorted({min(max(1, int(x)), self._graph_epochs) for x in run_lengths}):
             step0 = self.state.step
             for _ in range(2):  # a fused step swaps the buffers and flips the schedule slot: both move together
@@ -848,7 +902,11 @@ class _InvPrefTrainManager:
         # the E-step graphs of both parameter buffers too (their capture warms up and synchronises the host)
         if self.users_tensor.is_cuda and self.world_size == 1 and not self._pure:
             for _ in range(2):
-                self._estep_graph(self.cluster_use_random_sort)
+                if self._fused_estep_ok():
+                    self._estep_state()
+                    self._estep_graph(self.cluster_use_random_sort, fused=True, combined=True)
+                else:
+                    self._estep_graph(self.cluster_use_random_sort)
                 if self._fused_seq():
                     self.state.swap()
 
@@ -900,10 +958,73 @@ class _InvPrefTrainManager:
             self._eps_stage_done.record()
         return out
 
-    def cluster(self, sync: bool = True):
-        """train.py:235-259 (+ the stat_envs that always follows it is fused in: train.py:330).
-        sync=False: no read-back, returns diff_num as a device int64[1] tensor."""
+    # ---- one GPU: cluster() + stat_envs() are ONE launch (include/invpref_hip.h: invpref_estep_fused_hip) -- the assignment
+    # kernel's epilogue folds the counts, cluster()'s diff_num and the class weights; nothing N-long is produced (the M-step
+    # looks class_weights[env] up itself) and nothing is cloned behind a replay (results land in a ring the kernel advances)
+    def _fused_estep_ok(self) -> bool:
+        return bool(self.world_size == 1 and self.envs.is_cuda and not self._pure and self.use_plan
+                    and os.environ.get('INVPREF_ESTEP_FUSED', '1') == '1')
+
+    def _estep_state(self):
+        if self._es is None:
+            self._es = ops.EstepState(self.envs_num, self.device)
+            self._pend_cw = torch.zeros(self.envs_num, dtype=torch.float32, device=self.device)
+            self._pend_counts = torch.zeros(self.envs_num, dtype=torch.int64, device=self.device)
+        return self._es
+
+    def _issue_fused_estep(self, eps_buf, combined: bool):
+        """enqueues (or records, under capture) the fused E-step.  combined: class weights and counts go straight into the
+        manager's own tensors (cluster() and stat_envs() called together, train.py:329-330); otherwise into the buffers a later
+        stat_envs() applies."""
+        es = self._estep_state()
+        ops.estep_fused(self.state.p_views, self.users_tensor, self.items_tensor, self.scores_tensor, self.implicit, self.envs,
+                        es, self.workspace, perm_index=eps_buf,
+                        eps_base=self._eps_base.tolist() if eps_buf is not None else None,
+                        counts=self._counts_dev if combined else self._pend_counts,
+                        class_weights=self.class_weights if combined else self._pend_cw)
+
+    def _run_fused_estep(self, combined: bool) -> int:
+        """one fused E-step on the current stream -- a graph replay where graphs are on -- and the ring row it writes"""
+        es = self._estep_state()
+        with_eps = self.cluster_use_random_sort
+        if self.use_graph and not torch.cuda.is_current_stream_capturing():
+            g, eps_buf, _ = self._estep_graph(with_eps, fused=True, combined=combined)
+            self._fill_eps(eps_buf)
+            g.replay()
+            self._eps_replayed(eps_buf)
+        else:
+            self._issue_fused_estep(self._eps_index_device() if with_eps else None, combined)
+        return es.next_row()
+
+    def cluster_and_stat_envs(self, sync: bool = True):
+        """cluster() followed by stat_envs() (train.py:329-330: the reference never calls one without the other inside
+        train()) -> (diff_num, {env: count}).  sync=False: no read-back; both come back as device views of the E-step ring
+        (valid until ops.EstepState.ring_cap further E-steps have run)."""
+        if not self._fused_estep_ok():
+            return self.cluster(sync=sync), self.stat_envs(sync=sync)
         self.model.eval()
+        row = self._run_fused_estep(combined=True)
+        self._pending_stat = None
+        self._sw_lazy, self._by_env = True, True      # sample_weights == class_weights[envs] from here on, not materialised
+        E, ring = self.envs_num, self._es.ring
+        if sync:
+            vals = ring[row].tolist()
+            return int(vals[E]), {env: int(c) for env, c in enumerate(vals[:E])}
+        return ring[row, E:E + 1], ring[row, :E]
+
+    def cluster(self, sync: bool = True):
+        """train.py:235-259.  sync=False: no read-back, returns diff_num as a device int64[1] tensor."""
+        self.model.eval()
+        if self._fused_estep_ok() and not torch.cuda.is_current_stream_capturing():
+            # cluster() WITHOUT the stat_envs() that follows it in train(): the reference's sample_weights keep their values BY
+            # POSITION (train.py:67, :278) while the environments move -- bring the array up to date with the old environments
+            # first, and read it per interaction until stat_envs() runs
+            self._materialise_sample_weights()
+            row = self._run_fused_estep(combined=False)
+            self._by_env = False
+            self._pending_stat = 'fused'
+            diff = self._es.ring[row, self.envs_num:self.envs_num + 1]
+            return int(diff.item()) if sync else diff
         if self.world_size == 1 and self.use_graph and self.envs.is_cuda and not torch.cuda.is_current_stream_capturing():
             # one HIP-graph replay instead of a handful of eager launches behind the Python operator layer (the
             # host-side cost of those was several times the 40 us the kernels take); the permutation indices of
@@ -925,12 +1046,12 @@ class _InvPrefTrainManager:
         self._pending_stat = (counts, cw, sw)
         return int(diff.item()) if sync else diff.clone()
 
-    def _estep_graph(self, with_eps: bool):
-        """The captured E-step (+ the count / weight half of stat_envs) for the CURRENT parameter buffer and interaction
-        arrays, captured on first use: (graph, eps staging buffer or None, output tensors in the graph's pool).
-        The capture needs a warm-up E-step and a host sync; prepare_graphs() does it ahead of time for both
-        parameter buffers, so that cluster(sync=False) inside a timed loop only replays."""
-        key = (self.state.p_views[0].data_ptr(), self.envs.data_ptr(), self.users_tensor.data_ptr(), with_eps)
+    def _estep_graph(self, with_eps: bool, fused: bool = False, combined: bool = True):
+        """The captured E-step for the CURRENT parameter buffer and interaction arrays, captured on first use: (graph, eps
+        staging buffer or None, output tensors in the graph's pool -- None for the fused form, whose outputs are the manager's
+        own tensors and the ring).  The capture needs a warm-up E-step and a host sync; prepare_graphs() does it ahead of time
+        for both parameter buffers, so that an E-step inside a timed loop only replays."""
+        key = (self.state.p_views[0].data_ptr(), self.envs.data_ptr(), self.users_tensor.data_ptr(), with_eps, fused, combined)
         ent = self._estep_graphs.get(key)
         if ent is None:
             # (the buffer the captured E-step reads its permutation indices from, 1 / 4 / 8 bytes per interaction: up to
@@ -945,15 +1066,24 @@ class _InvPrefTrainManager:
                     else torch.zeros(n_loc, dtype=dt, device=self.device)
 
             def run():
+                if fused:
+                    self._issue_fused_estep(eps_buf, combined)
+                    return None
                 _, counts, diff, cw, sw = ops.estep(self.state.p_views, self.users_tensor, self.items_tensor,
                                                     self.scores_tensor, self.implicit, self.envs, self.workspace,
                                                     new_envs=self.envs, want_weights=True, perm_index=eps_buf,
                                                     eps_base=self._eps_base.tolist() if with_eps else None)
                 return counts, diff, cw, sw
-            # sizes the workspace outside the capture (envs is restored: the warm-up is not an E-step)
+            # sizes the workspace outside the capture; the warm-up is not an E-step: the environments, the class weights, the
+            # counts and the ring position are put back
             keep = self.envs.clone()
+            keep_cw, keep_c = self.class_weights.clone(), self._counts_dev.clone()
             run()
             self.envs.copy_(keep)
+            if fused:
+                self.class_weights.copy_(keep_cw)
+                self._counts_dev.copy_(keep_c)
+                self._es.state[1] -= 1
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -961,21 +1091,27 @@ class _InvPrefTrainManager:
             ent = self._estep_graphs[key] = (g, eps_buf, outs)
         return ent
 
-    def _cluster_replay(self, with_eps: bool):
-        """One graph per parameter buffer (the fused M-step ping-pongs between two) and per interaction-array set."""
-        g, eps_buf, outs = self._estep_graph(with_eps)
+    def _fill_eps(self, eps_buf):
+        """this E-step's permutation indices (host numpy stream, like the reference) into the buffer the graph reads"""
         if eps_buf is not None and not eps_buf.is_cuda:
-            # this E-step's draws (host numpy stream, like the reference) straight into the pinned buffer the graph reads
             done = getattr(self, '_eps_read_done', None)
             if done is not None:
                 done.synchronize()                 # (the previous replay has read the buffer)
             eps_buf.numpy()[:] = self._eps_index()
         elif eps_buf is not None:
             self._eps_index_device(out=eps_buf)
-        g.replay()
+
+    def _eps_replayed(self, eps_buf):
         if eps_buf is not None and not eps_buf.is_cuda:
             self._eps_read_done = torch.cuda.Event()
             self._eps_read_done.record()
+
+    def _cluster_replay(self, with_eps: bool):
+        """One graph per parameter buffer (the fused M-step ping-pongs between two) and per interaction-array set."""
+        g, eps_buf, outs = self._estep_graph(with_eps)
+        self._fill_eps(eps_buf)
+        g.replay()
+        self._eps_replayed(eps_buf)
         return outs
 
     def cluster_a_batch(self, batch_users_tensor, batch_items_tensor, batch_scores_tensor) -> torch.Tensor:
@@ -993,18 +1129,31 @@ class _InvPrefTrainManager:
     def stat_envs(self, sync: bool = True):
         """train.py:268-280.  sync=False: no read-back, returns the per-env counts as a device tensor."""
         pend = getattr(self, '_pending_stat', None)
-        if pend is not None:
+        self._pending_stat = None
+        lazy_ok = self._fused_estep_ok()
+        if isinstance(pend, str):                  # a fused cluster() ran: its epilogue left counts and class weights behind
+            counts, cw, sw = self._pend_counts, self._pend_cw, None
+        elif pend is not None:
             counts, cw, sw = pend
-            self._pending_stat = None
         elif self.world_size == 1:
-            counts, cw, sw = ops.stat_envs(self.envs, self.envs_num, self.workspace)
+            counts, cw, sw = ops.stat_envs(self.envs, self.envs_num, self.workspace, want_sample_weights=not lazy_ok)
         else:
             counts, _, _ = ops.stat_envs(self.envs, self.envs_num, self.workspace, want_sample_weights=False)
             all_reduce_sum_(counts, self.process_group)
             cw, sw = ops.sample_weights(self.envs, counts, self.n_total, self.envs_num)
         # in place: the epoch loop (and a captured HIP graph of it) holds pointers into these buffers
         self.class_weights.copy_(cw)
-        self.sample_weights.copy_(sw)
+        if lazy_ok:
+            # one GPU: the planned M-step takes class_weights[env] (INVPREF_WEIGHTS_BY_ENV); the N-length array is
+            # materialised only if somebody asks for the attribute
+            self._counts_dev.copy_(counts)
+            self._sw_lazy, self._by_env = True, True
+        else:
+            if sw is None:
+                _, sw = ops.sample_weights(self.envs, counts, self.n_total, self.envs_num)
+            self._sample_weights.copy_(sw)
+            self._sw_lazy = False
+            self._by_env = True      # (consistent; whether launches USE it: _weights_by_env())
         return {env: int(c) for env, c in enumerate(counts.tolist())} if sync else counts.clone()
 
     def update_each_env_count(self):  # train.py:261-266
@@ -1062,11 +1211,15 @@ class _InvPrefTrainManager:
             if (self.epoch_cnt % self.cluster_interval) == 0:
                 if (self.begin_cluster_epoch is None or self.begin_cluster_epoch <= self.epoch_cnt) \
                         and (self.stop_cluster_epoch is None or self.stop_cluster_epoch > self.epoch_cnt):
-                    diff_num = self.cluster(sync=not defer)
+                    diff_num, envs_cnt = self.cluster_and_stat_envs(sync=not defer)   # train.py:329-330, one launch
                 else:
-                    diff_num = 0
+                    diff_num, envs_cnt = 0, self.stat_envs(sync=not defer)
                 cluster_diff_num_list.append(diff_num)
-                envs_cnt = self.stat_envs(sync=not defer)
+                if defer and self._es is not None and len(cluster_diff_num_list) % (self._es.ring_cap - 8) == 0:
+                    # (deferred results are views of the E-step ring: read them out before it wraps)
+                    cluster_diff_num_list = [int(d.item()) if torch.is_tensor(d) else d for d in cluster_diff_num_list]
+                    envs_cnt_list = [t.tolist() if torch.is_tensor(t) else t for t in envs_cnt_list]
+                    envs_cnt = envs_cnt.tolist()
                 cluster_epoch_list.append(self.epoch_cnt)
                 envs_cnt_list.append(envs_cnt)
                 if not defer:
@@ -1080,7 +1233,8 @@ class _InvPrefTrainManager:
             loss_result_list = [dict(zip(LOSS_KEYS, v)) for v in torch.stack(loss_result_list).tolist()] \
                 if loss_result_list else []
             cluster_diff_num_list = [int(d.item()) if torch.is_tensor(d) else d for d in cluster_diff_num_list]
-            envs_cnt_list = [{env: int(c) for env, c in enumerate(t.tolist())} for t in envs_cnt_list]
+            envs_cnt_list = [{env: int(c) for env, c in enumerate(t.tolist() if torch.is_tensor(t) else t)}
+                             for t in envs_cnt_list]
 
         return (loss_result_list, train_epoch_index_list), \
                (test_result_list, test_epoch_list), \

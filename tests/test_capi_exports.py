@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported(lib):
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/invpref_hip.h but not exported'
     assert set(_capi.EXPORTS) <= set(names)
-    assert lib.invpref_abi_version() == 5
+    assert lib.invpref_abi_version() == _capi.ABI_VERSION == 6
 
 
 def test_struct_layouts_match_header():

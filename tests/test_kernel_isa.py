@@ -28,22 +28,34 @@ def test_full_row_instances_have_no_scratch_traffic(kernels):
     assert len(ks) >= 25
     # the instances the bench configurations run: Yahoo (16 lanes x 1 float4, E <= 4, full rows), MovieLens (16 x 2, E = 8),
     # and every 16-lane wide instance on full rows
+    # (eval instances: <..., BYENV> -- the class-weight form of INVPREF_WEIGHTS_BY_ENV the managers' epochs run, and the
+    #  per-interaction-weight form of train_a_batch on caller tensors)
     for name in ('mstep_eval_kernel<16, true, 4, true>', 'mstep_apply_kernel<16, true, 4, true>',
-                 'mstep_eval_wide_kernel<16, 2, true, 8, false>', 'mstep_apply_wide_kernel<16, 2, true, 8, false>',
-                 'mstep_eval_wide_kernel<16, 1, true, 8, false>', 'mstep_eval_wide_kernel<16, 1, true, 16, false>',
-                 'mstep_eval_wide_kernel<16, 2, true, 16, false>', 'mstep_apply_wide_kernel<32, 2, true, 16, true>'):
+                 'mstep_eval_wide_kernel<16, 2, true, 8, false, true>', 'mstep_eval_wide_kernel<16, 2, true, 8, false, false>',
+                 'mstep_apply_wide_kernel<16, 2, true, 8, false>',
+                 'mstep_eval_wide_kernel<16, 1, true, 8, false, true>', 'mstep_eval_wide_kernel<16, 1, true, 16, false, true>',
+                 'mstep_eval_wide_kernel<16, 1, true, 8, false, false>', 'mstep_eval_wide_kernel<16, 1, true, 16, false, false>',
+                 'mstep_apply_wide_kernel<32, 2, true, 16, true>'):
         assert ks[name]['scratch_ops'] == 0, (name, ks[name])
     # ... and the MovieLens instance without a private segment at all (at 100 scalar registers it is one kernel-argument
     # layout away from spilling nine of them: csrc/invpref_step.hip, StepArgs.reserved_)
-    assert ks['mstep_eval_wide_kernel<16, 2, true, 8, false>']['scratch'] == 0
-    # rows on 32 lanes (MIND: 256 accumulator + row registers): a handful of loop-invariant values may sit in scratch, none
-    # of them inside the interaction loop (depth 2)
-    for name in ('mstep_eval_wide_kernel<32, 2, true, 16, true>', 'mstep_eval_wide_kernel<32, 2, true, 8, true>'):
+    assert ks['mstep_eval_wide_kernel<16, 2, true, 8, false, true>']['scratch'] == 0
+    assert ks['mstep_eval_wide_kernel<16, 2, true, 8, false, false>']['scratch'] == 0
+    # NO instance of the wide kernels touches scratch memory inside its lock-step interaction loop (loop depth >= 2: a reload
+    # there waits for every gather in flight); rows on 32 lanes (MIND: 256 accumulator + row registers) and the E = 16 / D = 128
+    # instance may keep a handful of once-per-round values there (addresses of the table staging)
+    for name, k in ks.items():
+        if name.startswith(('mstep_eval_wide_kernel', 'mstep_eval_mm_kernel', 'mstep_apply_wide_kernel')):
+            assert k['scratch_ops_in_loops'] == 0, (name, k)
+    for name in ('mstep_eval_wide_kernel<32, 2, true, 16, true, true>', 'mstep_eval_wide_kernel<32, 2, true, 8, true, true>',
+                 'mstep_eval_wide_kernel<32, 2, true, 16, true, false>', 'mstep_eval_wide_kernel<32, 2, true, 8, true, false>',
+                 'mstep_eval_wide_kernel<16, 2, true, 16, false, true>', 'mstep_eval_wide_kernel<16, 2, true, 16, false, false>'):
         assert ks[name]['scratch_ops'] <= 24, (name, ks[name])
-    # the MFMA-classifier form of launch 1 (csrc/step_wide_mm.hpp): the default instance (rows on 32 lanes) within a couple of
-    # loop-invariant spills -- a reload from scratch memory waits for every outstanding vector-memory operation of the wave, the
-    # gathers in flight included (profiles/r05/EXPERIMENTS.md) -- and its three products on the matrix cores
-    for name in ('mstep_eval_mm_kernel<32, 2, 16, true>', 'mstep_eval_mm_kernel<32, 2, 8, true>'):
+    # the MFMA-classifier form of launch 1 (csrc/step_wide_mm.hpp): the default instance (rows on 32 lanes) free of scratch
+    # traffic -- a reload from scratch memory waits for every outstanding vector-memory operation of the wave, the gathers in
+    # flight included (profiles/r05/EXPERIMENTS.md) -- and its three products on the matrix cores
+    for name in ('mstep_eval_mm_kernel<32, 2, 16, true, true>', 'mstep_eval_mm_kernel<32, 2, 8, true, true>',
+                 'mstep_eval_mm_kernel<32, 2, 16, true, false>', 'mstep_eval_mm_kernel<32, 2, 8, true, false>'):
         assert ks[name]['scratch_ops'] <= 4 and ks[name]['mfma'] >= 40, (name, ks[name])
     # the latency-tuned Yahoo instance keeps three workgroups per CU: at most 168 registers
     assert ks['mstep_eval_kernel<16, true, 4, true>']['vgpr'] <= 168

@@ -39,8 +39,7 @@ for alt in os.environ.get('SOAK_ALTS', '1,0').split(','):
     tr, diffs = [], []
     for it in range(NI):
         out = mgr.train_epochs(5, sync=False)
-        d = mgr.cluster(sync=False)
-        mgr.stat_envs(sync=False)
+        d, _ = mgr.cluster_and_stat_envs(sync=False)
         tr.append(out.cpu().numpy())
         if os.environ.get('SOAK_FLAGS') and mgr._alt is not None:
             ws = mgr._alt['ws']

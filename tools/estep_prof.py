@@ -12,7 +12,6 @@ for rs in (False, True):
     mgr = bench.build_manager(dev, 0, 1, random_sort=rs)
     mgr.train_epochs(1)
     for _ in range(40):
-        mgr.cluster(sync=False)
-        mgr.stat_envs(sync=False)
+        mgr.cluster_and_stat_envs(sync=False)
     torch.cuda.synchronize()
     print('random_sort', rs, 'done')

@@ -20,6 +20,21 @@ def listing(path=None):
     return open(out).read()
 
 
+def _deep_scratch_ops(code: str, min_depth: int = 2) -> int:
+    """scratch loads / stores in basic blocks at loop depth >= min_depth (the assembler's block comments: `in Loop: Header=BBx_y
+    Depth=d`).  Depth 1 of a task function is its loop over ROUNDS -- a spill there (e.g. an address of the once-per-task table
+    staging) runs once per round; depth 2 and deeper is the lock-step interaction loop, where a reload drains the gathers."""
+    depth, n = 0, 0
+    for line in code.split('\n'):
+        m = re.match(r'\s*;\s*%bb\.\d+:|\.LBB\d+_\d+:', line)
+        if m:
+            d = re.search(r'Depth=(\d+)', line)
+            depth = int(d.group(1)) if d else 0
+        if re.search(r'scratch_(load|store)', line) and depth >= min_depth:
+            n += 1
+    return n
+
+
 def kernels(s):
     res = []
     for m in re.finditer(r'\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel', s, re.S):
@@ -32,6 +47,7 @@ def kernels(s):
         short = re.sub(r'\(anonymous namespace\)::|void |\(.*', '', dem)
         res.append(dict(name=short, vgpr=g('next_free_vgpr'), accum=g('accum_offset'), sgpr=g('next_free_sgpr'),
                         scratch=g('private_segment_fixed_size'), scratch_ops=len(re.findall(r'scratch_(load|store)', code)),
+                        scratch_ops_in_loops=_deep_scratch_ops(code),
                         mfma=code.count('v_mfma'), lines=code.count('\n')))
     return res
 

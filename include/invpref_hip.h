@@ -413,13 +413,16 @@ int invpref_estep_perm_hip(const InvPrefTables *tables, const int64_t *users, co
  *   perm_index  NULL: plain argmin (cluster_use_random_sort=False); else as invpref_estep_perm_hip, with
  *   perm_table  (device, optional, env_num <= 7) the E! packed permutation rows made once by invpref_perm_table_fill -- the
  *               workgroups then load the table instead of unranking it;
- *   state       device int32[4] that must be ZERO before the first call and is left zero by every call ({ticket, ring position});
+ *   state       device int32[INVPREF_ESTEP_STATE_INTS] that must be ZERO before the first call and is left as the next call
+ *               needs it ([0] top ticket, [1] E-steps so far = ring position, [32 + 32 s] the ticket of shard s: 2 048
+ *               workgroups finishing together would queue ~25 us on ONE word);
  *   ring        optional int64[ring_cap][env_num + 1]: the call writes {counts, diff} to row (calls so far) % ring_cap and counts
  *               the call in state[1] -- a captured launch's arguments are frozen, so a replayed E-step keeps its results apart
  *               this way without a copy behind every replay;
  *   counts / diff / class_weights  optional direct outputs (NULL: skipped).
  * Single rank only (the class weights need the GLOBAL counts: a sharded rank uses invpref_estep_perm_hip / invpref_estep_hip,
  * all-reduces the counts and calls invpref_sample_weights_hip). */
+#define INVPREF_ESTEP_STATE_INTS (32 + 32 * 32)
 int invpref_estep_fused_hip(const InvPrefTables *tables, const int64_t *users, const int64_t *items, const float *scores,
                             int64_t N, uint32_t flags, const void *perm_index, int index_bytes, const float *eps_base,
                             const uint32_t *perm_table, int64_t *envs, int32_t *state, int64_t *ring, int32_t ring_cap,

@@ -621,8 +621,13 @@ __global__ __launch_bounds__(256) void eps_unrank_kernel(const IT *__restrict__ 
 // hand-off is the guide's measured form (MI355X_MICROARCH.md, inter-workgroup visibility, first row of the sc1 table): sc1
 // stores by ONE wave of the producer, its s_waitcnt vmcnt(0), an agent-scope atomic add by a lane of that wave, the adder
 // whose add came last reads everything with sc1 loads behind a workgroup barrier.
+// The ticket is SHARDED: 2 048 workgroups that finish together would queue on one word for ~25 us (one address takes ~88
+// returning atomics per microsecond); workgroup b takes a ticket of shard b % kTicketShards (each on a 128-byte line of its own),
+// the workgroup that completes a shard takes a ticket of the top word, the one that completes that folds.
+constexpr int kTicketShards = 32;   // (INVPREF_ESTEP_STATE_INTS = 32 + 32 * kTicketShards)
 struct EstepFin {
-    int *state;          // device int32[4], ZERO before the first call and left zero: {ticket, ring position, -, -}; NULL: no epilogue
+    int *state;          // device int32[kEstepStateInts], ZERO before the first call and left zero: [0] top ticket, [1] ring
+                         // position, [32 + 32 s] ticket of shard s; NULL: no epilogue
     int64_t *ring;       // [ring_cap][E + 1] {counts[0..E), diff} of E-step number `ring position` (mod ring_cap); may be NULL
     int ring_cap;
     int64_t *counts;     // [E] (may be NULL)
@@ -769,8 +774,15 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
         if ((int)threadIdx.x <= t.E) st_sc1_i(slabs + (int64_t)blockIdx.x * (t.E + 1) + threadIdx.x, cnt[threadIdx.x]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0) {
-            const int old = __hip_atomic_fetch_add(fin.state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = old == (int)gridDim.x - 1;
+            const int S = min(kTicketShards, (int)gridDim.x), sh = (int)blockIdx.x % S;
+            const int members = ((int)gridDim.x - sh + S - 1) / S;          // workgroups b with b % S == sh
+            int *tk = fin.state + 32 + 32 * sh;
+            int last = 0;
+            if (__hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+                st_sc1_i(tk, 0);                                            // (this launch is through with the shard)
+                last = __hip_atomic_fetch_add(fin.state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1;
+            }
+            s_last = last;
         }
     }
     for (int i = threadIdx.x; i <= t.E; i += blockDim.x) s_tot[i] = 0;
@@ -778,25 +790,13 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
     if (!s_last) return;
     {
         const int E1 = t.E + 1, nsl = (int)gridDim.x;
-        long long acc[INVPREF_MAX_ENVS + 1];
-#pragma unroll
-        for (int c = 0; c <= INVPREF_MAX_ENVS; c++) acc[c] = 0;
-        // (every count of a thread's slabs requested before the first is summed; write-through stores -> cache-bypassing loads)
+        // (write-through stores -> cache-bypassing loads; summed through LDS atomics with a handful of registers: the fold runs in
+        //  ONE workgroup per launch, and a register-hungry epilogue costs every workgroup of the launch its occupancy -- with
+        //  per-thread accumulators the Yahoo instance went from 57 to 74 registers, 8 -> 6 waves per SIMD, 44 -> 54 us)
         for (int sl = threadIdx.x; sl < nsl; sl += blockDim.x) {
             const int *row = slabs + (int64_t)sl * E1;
-            int x[INVPREF_MAX_ENVS + 1];
-#pragma unroll
-            for (int c = 0; c <= INVPREF_MAX_ENVS; c++) x[c] = (c <= t.E) ? ld_sc1_i(row + min(c, t.E)) : 0;
-#pragma unroll
-            for (int c = 0; c <= INVPREF_MAX_ENVS; c++) acc[c] += x[c];
-        }
-#pragma unroll
-        for (int c = 0; c <= INVPREF_MAX_ENVS; c++) {
-            if (c <= t.E) {   // (uniform)
-                long long a = acc[c];
-                for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64);
-                if ((threadIdx.x & 63) == 0) atomicAdd((unsigned long long *)&s_tot[c], (unsigned long long)a);
-            }
+#pragma nounroll
+            for (int c = 0; c < E1; c++) atomicAdd((unsigned long long *)&s_tot[c], (unsigned long long)ld_sc1_i(row + c));
         }
         __syncthreads();
         int64_t *row = nullptr;
@@ -951,7 +951,9 @@ inline int mstep_blocks(int64_t B) {
 }
 inline int estep_blocks(int64_t N) {
     int64_t nb = (N + (kEstepThreads / kRow) - 1) / (kEstepThreads / kRow);
-    return (int)(nb < 1 ? 1 : (nb > kEstepMaxBlocks ? kEstepMaxBlocks : nb));
+    static const int cap_env = std::getenv("INVPREF_ESTEP_BLOCKS") ? atoi(std::getenv("INVPREF_ESTEP_BLOCKS")) : 0;   // (A/B knob)
+    const int cap = cap_env > 0 && cap_env < kEstepMaxBlocks ? cap_env : kEstepMaxBlocks;
+    return (int)(nb < 1 ? 1 : (nb > cap ? cap : nb));
 }
 
 // dispatch over (NC, VEC, EMAX): VEC=false only exists at NC=4 (any D <= 256)
@@ -1441,7 +1443,7 @@ int invpref_estep_fused_hip(const InvPrefTables *tables, const int64_t *users, c
                             const uint32_t *perm_table, int64_t *envs, int32_t *state, int64_t *ring, int32_t ring_cap,
                             int64_t *counts, int64_t *diff, float *class_weights, void *workspace, size_t workspace_bytes,
                             void *stream) {
-    if (!state || !envs || (ring && ring_cap <= 0)) return INVPREF_EINVAL;
+    if (!state || !envs || (ring && ring_cap <= 0)) return INVPREF_EINVAL;   // (state: INVPREF_ESTEP_STATE_INTS int32, zeroed once)
     EstepFin fin{};
     fin.state = state; fin.ring = ring; fin.ring_cap = ring_cap; fin.counts = counts; fin.diff = diff;
     fin.class_w = class_weights; fin.perm_table = perm_table;

@@ -210,6 +210,19 @@ __device__ __forceinline__ void put4(float *__restrict__ base, int row, int D, i
         if (i0 + 3 < D) p[i0 + 3] = r.w;
     }
 }
+// MODE 1: write-through (sc1): the line is on its way to the memory side during the kernel instead of in the end-of-kernel
+// write-back of the XCD's L2 -- what a kernel boundary costs grows with the dirty bytes its predecessor leaves (MI355X guide,
+// price list "boundary": + B / 6 TB/s)
+template <int MODE>
+__device__ __forceinline__ void store4(float *dst, float4 r) {
+    if (MODE == 0) { *reinterpret_cast<float4 *>(dst) = r; return; }
+    v4f val = {r.x, r.y, r.z, r.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(val) : "memory");
+}
+
+#ifndef STEP_PUSH_ST
+#define STEP_PUSH_ST 0   // (A/B knob, two-launch forms: 1 = launch 1's contribution rows leave as write-through stores)
+#endif
 __device__ __forceinline__ void adam4(float4 &p, float4 g, float4 &m, float4 &v, const AdamScalars &ad) {
     adam1f(p.x, g.x, m.x, v.x, ad); adam1f(p.y, g.y, m.y, v.y, ad);
     adam1f(p.z, g.z, m.z, v.z, ad); adam1f(p.w, g.w, m.w, v.w, ad);
@@ -451,7 +464,9 @@ struct USample {
 #define STEP_EVAL_DEPTH 3
 #endif
 #ifndef STEP_ROW_ST
-#define STEP_ROW_ST 0   // (A/B knob: 1 = write-through stores for the rows the jobs finish)
+#define STEP_ROW_ST 1   // write-through stores for the rows the two-launch jobs finish (p', m', v': nothing of them is read again before
+                        // the next step; left dirty in L2 they lengthen the kernel boundary).  Round 6, same box: 2^24 interactions at
+                        // D = 64 4.95 -> 4.59 ms (0.487 -> 0.524), Yahoo B = N 92.2 -> 90.7 us, MovieLens- / MIND-shaped level (0: plain)
 #endif
 template <int LG, bool VEC, int EMAX, bool FULL>
 __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a, int r0, int nr, int slab_index, float *lds) {
@@ -670,8 +685,8 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                     // push form: the interaction's two contribution rows to its ITEM's gradient, stored at the item-sorted
                     // slot -- launch 2 then sums contiguous rows, no gathers, no classifier
                     float *cr = a.records + (unsigned)q.cs * (unsigned)(2 * DP) + lg * 4;
-                    *reinterpret_cast<float4 *>(cr) = f4mul(gip, oi);
-                    *reinterpret_cast<float4 *>(cr + DP) = f4scale(o.g_q, f4mul(oe, ev));
+                    store4<STEP_PUSH_ST>(cr, f4mul(gip, oi));
+                    store4<STEP_PUSH_ST>(cr + DP, f4scale(o.g_q, f4mul(oe, ev)));
                 } else {
                     // pull form: the record the item side consumes
                     float *rec_g = a.records + (unsigned)q.sm.ps * (unsigned)RS;

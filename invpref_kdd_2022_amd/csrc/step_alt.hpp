@@ -92,6 +92,18 @@ __device__ __forceinline__ void st_sc1(int *p, int v) {
 #define ALT_EARLY_STAGE 0         // (A/B knob: 1 = the small tables' granules requested in front of the previous step's update;
                                   //  18 registers across that phase: needs ALT_PEND_DEPTH 2 to stay free of scratch)
 #endif
+#ifndef ALT_PUSH_ST
+#define ALT_PUSH_ST 1             // the contribution rows pushed for the other side leave as write-through stores (0: plain) -- they are
+                                  // read by the NEXT launch on other XCDs, and dirty bytes left in L2 lengthen the kernel boundary
+                                  // (round 6, same box: 14.69 -> 14.33 us per launch; write-through rows p / m / v: 14.9, slower)
+#endif
+#ifndef ALT_SLAB_ST
+#define ALT_SLAB_ST 1             // the partial slab of a job workgroup too (read by the next launch's fold blocks)
+#endif
+#ifndef ALT_ROW_ST
+#define ALT_ROW_ST 0              // (A/B knob) 1: the rows a job finishes (p, m, v) leave as write-through stores -- measured SLOWER
+                                  // here (14.9 vs 14.7 us per launch): the other side gathers them in the very next launch
+#endif
 #ifndef ALT_PEND_DEPTH
 #define ALT_PEND_DEPTH 4          // pending contribution-row pairs in flight per group (two register sets)
 #endif
@@ -543,8 +555,8 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
                 f4add(gi, f4mul(gip, q.qi));
                 f4fma(ge, o.g_q, f4mul(q.qa, ev));
                 float *cr = a.push_rows + (unsigned)q.cs * (unsigned)(2 * DP) + lg * 4;
-                *reinterpret_cast<float4 *>(cr) = f4mul(gip, oi);
-                *reinterpret_cast<float4 *>(cr + DP) = f4scale(o.g_q, f4mul(oe, ev));
+                store4<ALT_PUSH_ST>(cr, f4mul(gip, oi));
+                store4<ALT_PUSH_ST>(cr + DP, f4scale(o.g_q, f4mul(oe, ev)));
                 float4 oo = f4scale(o.g_q, f4mul(oe, q.qa));
                 if (reg_env) f4add(oo, reg_term(ev, 2.f * k.r2, 2.f * k.r1));
                 float *mine = red + grp * G::SLAB;
@@ -643,7 +655,7 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
 #pragma unroll
                     for (int j = (q0 == 0 ? 1 : 0); j < 8; j++) f4add(sum, x[j]);
                 }
-                *reinterpret_cast<float4 *>(slab + threadIdx.x * 4) = sum;
+                store4<ALT_SLAB_ST>(slab + threadIdx.x * 4, sum);
             }
         }
         if (slices > 1) {
@@ -696,14 +708,14 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
                 f4fma(ge, cnt, reg_term(oe, k.r2, k.r1));
             }
             adam4(oi, gi, mi, vi, ad_cur);
-            put4<VEC, STEP_ROW_ST, FULL>(own0, row, D, lg, oi);
-            put4<VEC, STEP_ROW_ST, FULL>(a.own_m[0], row, D, lg, mi);
-            put4<VEC, STEP_ROW_ST, FULL>(a.own_v[0], row, D, lg, vi);
+            put4<VEC, ALT_ROW_ST, FULL>(own0, row, D, lg, oi);
+            put4<VEC, ALT_ROW_ST, FULL>(a.own_m[0], row, D, lg, mi);
+            put4<VEC, ALT_ROW_ST, FULL>(a.own_v[0], row, D, lg, vi);
             if (!pure) {
                 adam4(oe, ge, me, ve, ad_cur);
-                put4<VEC, STEP_ROW_ST, FULL>(own1, row, D, lg, oe);
-                put4<VEC, STEP_ROW_ST, FULL>(a.own_m[1], row, D, lg, me);
-                put4<VEC, STEP_ROW_ST, FULL>(a.own_v[1], row, D, lg, ve);
+                put4<VEC, ALT_ROW_ST, FULL>(own1, row, D, lg, oe);
+                put4<VEC, ALT_ROW_ST, FULL>(a.own_m[1], row, D, lg, me);
+                put4<VEC, ALT_ROW_ST, FULL>(a.own_v[1], row, D, lg, ve);
             }
         }
     }

@@ -525,8 +525,8 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
 #else
                 if (push) {   // the interaction's two contribution rows to its ITEM's gradient, at the item-sorted slot
 #endif
-                    *reinterpret_cast<float4 *>(cr + 4 * (lg + LG * j)) = f4mul(gip, oi[j]);
-                    *reinterpret_cast<float4 *>(cr + DP + 4 * (lg + LG * j)) = f4scale(o.g_q, f4mul(oe[j], ev[j]));
+                    store4<STEP_PUSH_ST>(cr + 4 * (lg + LG * j), f4mul(gip, oi[j]));
+                    store4<STEP_PUSH_ST>(cr + DP + 4 * (lg + LG * j), f4scale(o.g_q, f4mul(oe[j], ev[j])));
                 }
                 if constexpr (!EVL2) {
                     // o = g_q Pa*Qa (+ env regulariser): the interaction's term of embed_env's gradient

@@ -432,8 +432,8 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
                     f4add(gi[j], f4mul(gip, q.qi[j]));
                     f4fma(ge[j], g_q, f4mul(q.qa[j], ev[j]));
                     if (push) {   // the interaction's two contribution rows to its ITEM's gradient, at the item-sorted slot
-                        *reinterpret_cast<float4 *>(cr + 4 * (lg + LG * j)) = f4mul(gip, oi[j]);
-                        *reinterpret_cast<float4 *>(cr + DP + 4 * (lg + LG * j)) = f4scale(g_q, f4mul(oe[j], ev[j]));
+                        store4<STEP_PUSH_ST>(cr + 4 * (lg + LG * j), f4mul(gip, oi[j]));
+                        store4<STEP_PUSH_ST>(cr + DP + 4 * (lg + LG * j), f4scale(g_q, f4mul(oe[j], ev[j])));
                     }
                 }
             }

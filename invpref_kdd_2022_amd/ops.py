@@ -158,7 +158,7 @@ class EstepState:
 
     def __init__(self, env_num: int, device, ring_cap: int = 256):
         self.env_num, self.ring_cap = int(env_num), int(ring_cap)
-        self.state = torch.zeros(4, dtype=torch.int32, device=device)
+        self.state = torch.zeros(32 + 32 * 32, dtype=torch.int32, device=device)   # INVPREF_ESTEP_STATE_INTS
         self.ring = torch.zeros(ring_cap, env_num + 1, dtype=torch.int64, device=device)
         self.issued = 0          # host mirror of state[1]: E-steps issued so far
         self.perm_table = None

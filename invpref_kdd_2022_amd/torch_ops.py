@@ -466,9 +466,9 @@ def _estep_fused(tables, users, items, scores, envs, implicit, perm_index, eps_b
     _capi._req(state, torch.int32, 'state')
     for x, nm in ((ring, 'ring'), (counts, 'counts'), (diff, 'diff')):
         _capi._req(x, torch.int64, nm)
-    if state.numel() < 4 or (ring is not None and (ring.dim() != 2 or ring.shape[1] != t.env_num + 1)) \
+    if state.numel() < 32 + 32 * 32 or (ring is not None and (ring.dim() != 2 or ring.shape[1] != t.env_num + 1)) \
             or (counts is not None and counts.numel() < t.env_num) or (class_weights is not None and class_weights.numel() < t.env_num):
-        raise InvPrefError('estep_fused_: state int32[4], ring int64[cap, env_num + 1], counts / class_weights [env_num]')
+        raise InvPrefError('estep_fused_: state int32[INVPREF_ESTEP_STATE_INTS], ring int64[cap, env_num + 1], counts / class_weights [env_num]')
     base, nbytes = None, 0
     if perm_index is not None:
         if eps_base is None or len(eps_base) != t.env_num or perm_index.dtype not in _PERM_BYTES or perm_index.numel() != N:

@@ -1029,10 +1029,14 @@ class _InvPrefTrainManager:
             # one HIP-graph replay instead of a handful of eager launches behind the Python operator layer (the
             # host-side cost of those was several times the 40 us the kernels take); the permutation indices of
             # train.py:192-196 are host random numbers: they are copied into the buffer the graph reads
+            self._materialise_sample_weights()
             counts, diff, cw, sw = self._cluster_replay(self.cluster_use_random_sort)
             self._pending_stat = (counts, cw, sw)
+            self._by_env = False
             return int(diff.item()) if sync else diff.clone()
         perm = self._eps_index_device() if self.cluster_use_random_sort else None
+        self._materialise_sample_weights()
+        self._by_env = False
         # new assignments overwrite self.envs in place (the kernel reads old_envs[i] before writing i)
         new, counts, diff, cw, sw = ops.estep(self.state.p_views, self.users_tensor, self.items_tensor,
                                               self.scores_tensor, self.implicit, self.envs, self.workspace,

@@ -298,6 +298,20 @@ def test_yahoo_shaped_epochs_world_4_and_8(tmp_path, world, mode):
         np.testing.assert_array_equal(r[0]['losses'], x['losses'])
         assert int(r[0]['diff']) == int(x['diff'])
     P = 2 * (YU + YI) * YD + 2 * YE * YD + YE
+    if mode.startswith('rows'):
+        # BASELINE configs[3] / SURVEY 8(d)-4 as written: every GLOBAL minibatch of 8 192 rows cut `world` ways -- 1 024 rows per
+        # rank at eight ranks -- and the ragged last minibatch (250 154 - 30 x 8 192 = 4 394 rows) 549 / 550 per rank
+        per = YB // world
+        for i, x in enumerate(r):
+            rows = np.sort(x['rows'])
+            for k in (0, 17, 29):
+                assert int(((rows >= k * YB) & (rows < (k + 1) * YB)).sum()) == per
+                assert rows[(rows >= k * YB)][0] == k * YB + i * per        # contiguous slices, rank order (utils.py:12-19)
+            last = int((rows >= 30 * YB).sum())
+            assert last in ((YN - 30 * YB) // world, (YN - 30 * YB) // world + 1)
+        assert sum(int((x['rows'] >= 30 * YB).sum()) for x in r) == YN - 30 * YB == 4394
+        if world == 8:
+            assert per == 1024 and {int((x['rows'] >= 30 * YB).sum()) for x in r} == {549, 550}
     if mode == 'rows-packed':
         # one all-reduce per step over the rows the GLOBAL minibatch touches + the small tables: at this split (8 192
         # interactions per global minibatch over 15 400 users) well under half of the flat gradient

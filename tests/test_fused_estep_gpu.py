@@ -75,7 +75,7 @@ def test_fused_estep_equals_oracle_and_two_launch_form(U, I, E, D, N, implicit, 
         np.testing.assert_array_equal(ring[:E], oc)
         assert int(ring[E]) == od and row == call % 4
         st = es.state.cpu().numpy()
-        assert st[0] == 0 and st[1] == call + 1          # ticket reset; E-steps counted
+        assert st[0] == 0 and not st[32::32].any() and st[1] == call + 1    # every ticket back at zero; E-steps counted
         # the two-launch entry points on the same input: the same assignments
         new2, c2, d2, cw2, _ = ops.estep(P, u, v, y, implicit, _t(cur, np.int64), ws, perm_index=perm,
                                          eps_base=eps_base.tolist() if random_sort else None)

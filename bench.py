@@ -5,17 +5,26 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1] at N = 1, configs[3] at N > 1): Yahoo!R3-implicit-shaped
-synthetic data, U=15 400, I=1 000, 250 154 interactions PER GPU, E=4, D=64, minibatch 8 192 rows PER GPU (weak
-scaling: the global minibatch is 8 192*N rows), reference Yahoo hyper-parameters (Yahoo_InvPref_Implicit.py:17-41).
-N > 1 runs the configuration BASELINE.json names -- interactions ROW-sharded, one RCCL all-reduce of the flat
-gradient buffer per optimiser step -- and reports the user-sharded layout beside it in `detail`.
+synthetic data, U=15 400, I=1 000, 250 154 interactions, E=4, D=64, minibatch 8 192 rows, reference Yahoo
+hyper-parameters (Yahoo_InvPref_Implicit.py:17-41).  --scaling strong (the default): the SAME problem at every N, as
+BASELINE.json configs[3] / SURVEY 8(d)-4 word it -- 250 154 interactions in total, every global minibatch of 8 192 rows
+(the reference's own, Yahoo_InvPref_Implicit.py:25; contiguous unshuffled slices, utils.py:12-19) cut N ways (1 024 rows
+per rank at N = 8), interactions ROW-sharded, one RCCL all-reduce of the flat gradient buffer per optimiser step; the
+B = N variant (one step per epoch), the other exchanges, the user-sharded layout and the weak-scaling
+figures of rounds 1-5 (250 154 interactions and 8 192 rows PER GPU: --scaling weak) are in `detail`.
 
 A "step" is one optimiser step of the M-step (fused gradient kernel + dense Adam) on one minibatch; every 155 steps
 (= cluster_interval 5 epochs x 31 minibatches) the E-step (+ stat_envs) over all interactions runs inside the
 timed region, as in the reference loop.  The timed region is always WHOLE cluster intervals (so the replayed HIP
 graphs and the E-step are inside it) and at least MIN_TIMED_S long: --steps / --warmup are rounded up accordingly
 and the line reports both (`steps_requested`, `steps` = timed).  Inputs are resident in HBM before the timed region;
-nothing is read back inside it.  value = interactions processed by all ranks / max-over-ranks time.
+nothing is read back inside it.  value = interactions processed by all ranks / max-over-ranks time (EXACT: whole epochs of
+n interactions each -- the ragged last minibatch counts its 4 394 rows, not 8 192).
+
+Parity gate: before the line is printed, one epoch + one E-step from a seeded state run through the timed
+path (alternating launches, fused E-step with the reference's default tie-break) and through the CPU oracle; the line carries
+`parity_gate` and NO `value` when the six loss terms differ by more than 1e-5 relative or a single environment assignment
+differs on the same tables.
 """
 from __future__ import annotations
 
@@ -165,6 +174,57 @@ def large_profile_figures():
     return tot, dur, os.path.relpath(dirs[-1], ROOT)
 
 
+GATE_LOSS_TOL = 1e-5     # north_star: "within 1e-5 relative on fp32 loss"
+
+
+def parity_gate(dev):
+    """BASELINE.md §3.2 -- "parity gate before timing counts".  From ONE seeded state (the bench's own tables, interactions and
+    initial environments) the timed path -- stat_envs, one epoch of alternating launches (train.py:204-233, :94-157), then the
+    fused E-step with the reference's default tie-break (train.py:235-259, :192-196, :268-280) -- and the CPU oracle
+    (oracle/invpref_oracle.c, pinned by the goldens recorded from the reference) run the same thing:
+      * the epoch's six loss terms (train.py:159-166; the mean over its 31 minibatches) within GATE_LOSS_TOL relative;
+      * the E-step on the SAME tables (the device's, after that epoch): every one of the 250 154 assignments, the counts, diff_num
+        and the class weights equal, bit for bit (north_star: "bit-exact on integer env assignments").
+    The oracle is the checker here, never what is timed.  Returns the `parity_gate` object of the line."""
+    import math
+    import numpy as np
+    from invpref_kdd_2022_amd import synth
+    from invpref_kdd_2022_amd.train import LOSS_KEYS, _unrank_permutations
+    from oracle import oracle as O
+    mgr = build_manager(dev, 0, 1, random_sort=True, scaling='strong')     # (seeds numpy, draws env0, runs stat_envs)
+    data = synth.interactions(SEED, U, I, N_PER_GPU, implicit=True)
+    tabs = synth.tables(SEED + 7, U, I, E, D)
+    env0 = mgr.envs.cpu().numpy().copy()
+    cf = [YAHOO[k] for k in ('invariant_coe', 'env_aware_coe', 'env_coe', 'L2_coe', 'L1_coe', 'alpha')]
+    got = np.array([[d[k] for k in LOSS_KEYS] for d in mgr.train_epochs(1)], np.float64)
+    one_launch = getattr(mgr, '_alt', None) is not None
+    th = max(1, min(O.omp_max_threads(), len(os.sched_getaffinity(0)), 16))
+    tr = O.ParallelTrainer(tabs, data, env0, implicit=True, batch_size=B_PER_GPU, coefs=cf, lr=YAHOO['lr'], reweight_rec=False,
+                           reweight_cls=True, reg_only_embed=True, reg_env_embed=False, threads=th)
+    tr.stat_envs()
+    want = np.array([tr.train_a_epoch()], np.float64)
+    loss_err = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-30)))
+    # the E-step: same tables on both sides, the same numpy draws of the permutation rows
+    tab = O.Tables({k: p.detach().cpu().numpy() for k, p in zip(O.PARAM_NAMES, mgr.state.p_views)})
+    st = np.random.get_state()
+    diff, cnt = mgr.cluster_and_stat_envs()
+    np.random.set_state(st)
+    idx = np.concatenate([np.random.randint(0, math.factorial(E), mgr.shard.global_batch_len(k)) for k in range(mgr.batch_num)])
+    rows = _unrank_permutations(idx, mgr._eps_base)
+    on, oc, od, _ = O.estep(tab, data[:, 0], data[:, 1], data[:, 2], True, old_envs=env0, eps_rows=rows)
+    _, ocw, _ = O.stat_envs(on, E)
+    mism = int((mgr.envs.cpu().numpy() != on).sum())
+    counts_ok = [cnt[e] for e in range(E)] == [int(c) for c in oc] and int(diff) == int(od) \
+        and bool((mgr.class_weights.cpu().numpy() == ocw).all())
+    ok = bool(loss_err <= GATE_LOSS_TOL and mism == 0 and counts_ok and mgr.alt_error() == 0 and np.isfinite(got).all())
+    return {'pass': ok, 'loss_rel_err': loss_err, 'loss_tol': GATE_LOSS_TOL, 'envs_mismatch': mism,
+            'counts_diff_class_weights_equal': bool(counts_ok), 'interactions': int(len(on)), 'epoch_steps': int(mgr.batch_num),
+            'losses_device': got[0].tolist(), 'losses_oracle': want[0].tolist(), 'loss_keys': list(LOSS_KEYS),
+            'path': ('one alternating launch per optimiser step (mstep_alt_kernel)' if one_launch else 'two-launch planned step')
+                    + ' + fused E-step (estep_assign_kernel with the stat_envs epilogue), default tie-break',
+            'oracle': f'oracle/invpref_oracle.c, {th} threads (M-step epoch), serial E-step with the same permutation rows'}
+
+
 def cpu_baseline():
     """The oracle's all-core (OpenMP) loops on the same Yahoo-shaped workload on this box's host cores: M-step
     (gradient + dense Adam) epochs and the E-step, all cores and one core, min of N (SURVEY.md §8(d);
@@ -233,7 +293,16 @@ def cpu_baseline():
             'value_one_core': CLUSTER_INTERVAL * N_PER_GPU / (CLUSTER_INTERVAL * tm1 + te1)}
 
 
-def build_manager(dev, rank, world, shard_mode=None, random_sort=True):
+SCALING = 'strong'           # set from --scaling in main(): 'strong' = the same 250 154 x 8 192 problem at every N
+
+
+def problem_size(world, scaling=None, batch=None):
+    """(total interactions, global minibatch) of a run on `world` ranks"""
+    weak = (scaling or SCALING) == 'weak'
+    return N_PER_GPU * (world if weak else 1), (batch if batch else B_PER_GPU * (world if weak else 1))
+
+
+def build_manager(dev, rank, world, shard_mode=None, random_sort=True, scaling=None, batch=None):
     """random_sort: the reference's DEFAULT E-step path (cluster_use_random_sort=True, train.py:24, :192-196): every E-step
     draws a permutation index per interaction on the host (the reference's own numpy stream) and the device unranks it."""
     import numpy as np
@@ -243,14 +312,15 @@ def build_manager(dev, rank, world, shard_mode=None, random_sort=True):
     from invpref_kdd_2022_amd.train import ImplicitTrainManager
     if shard_mode is not None:
         os.environ['INVPREF_SHARD'] = shard_mode
-    data = synth.interactions(SEED, U, I, N_PER_GPU * world, implicit=True)
+    n_total, gbatch = problem_size(world, scaling, batch)
+    data = synth.interactions(SEED, U, I, n_total, implicit=True)
     tabs = synth.tables(SEED + 7, U, I, E, D)
     model = InvPrefImplicit(U, I, E, D, reg_only_embed=True, reg_env_embed=False)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in tabs.items()})
     np.random.seed(SEED)
     mgr = ImplicitTrainManager(
         model=model, evaluator=StubEvaluator(), device=dev, training_data=torch.from_numpy(data).to(dev),
-        batch_size=B_PER_GPU * world, epochs=10 ** 9, cluster_interval=CLUSTER_INTERVAL, evaluate_interval=10 ** 9,
+        batch_size=gbatch, epochs=10 ** 9, cluster_interval=CLUSTER_INTERVAL, evaluate_interval=10 ** 9,
         use_class_re_weight=True, use_recommend_re_weight=False, cluster_use_random_sort=random_sort,
         rank=rank, world_size=world, **YAHOO)
     mgr.stat_envs()
@@ -684,7 +754,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=1550)
     ap.add_argument('--warmup', type=int, default=155)
+    ap.add_argument('--scaling', choices=('strong', 'weak'), default='strong',
+                    help='strong (default): 250 154 interactions and the 8 192-row global minibatch at every N (BASELINE configs[3]); '
+                         'weak: 250 154 interactions and 8 192 rows PER GPU (rounds 1-5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity-gate', action='store_true', help='profiling runs only: the line then says so')
     ap.add_argument('--no-extras', action='store_true', help='skip roofline_large / eval timing (profiling runs)')
     ap.add_argument('--spawn', action='store_true', help='launch the ranks as child processes even for --gpus 1 (checks the launcher path)')
     args = ap.parse_args()
@@ -695,6 +769,8 @@ def main():
     import numpy as np  # noqa: F401
     import torch
     from invpref_kdd_2022_amd import parallel
+    global SCALING
+    SCALING = args.scaling
 
     # (INVPREF_BENCH_BACKEND=gloo INVPREF_BENCH_SAME_DEVICE=1: a rehearsal of the N-rank flow on a ONE-GPU box -- every
     #  rank on cuda:0, collectives through gloo, so no captured collectives; never what a measurement uses)
@@ -716,14 +792,28 @@ def main():
         torch.cuda.synchronize()
         rccl_ranks = int(probe.item()) if torch.distributed.get_backend() == 'nccl' else 0
         assert int(probe.item()) == torch.distributed.get_world_size() == world
+    def rate(m, steps_, dt_):
+        """interactions per second, exactly: whole epochs of m.n_total interactions (the ragged last minibatch is shorter)"""
+        return steps_ / m.batch_num * m.n_total / dt_
+
+    # the parity gate first: a path that does not reproduce the oracle is not timed (BASELINE.md §3.2)
+    gate = None
+    if world == 1 and not args.no_parity_gate:
+        gate = parity_gate(dev) if rank == 0 else None
+        if gate is not None and not gate['pass']:
+            print(json.dumps({'metric': 'training interactions/sec, Yahoo-implicit InvPref', 'value': None, 'unit': 'interactions/s',
+                              'n_gpus': world, 'error': 'parity gate failed: no value is reported', 'parity_gate': gate}))
+            sys.exit(4)
+        torch.cuda.empty_cache()
     mgr = build_manager(dev, rank, world, 'rows' if world > 1 else None)
+    n_total, gbatch = problem_size(world)
+    b_loc = gbatch // world                      # rows of a full minibatch on one rank (the byte models below are per rank)
     dt, steps, warm_steps, graphs = timed_run(mgr, world, args.steps, args.warmup)
-    inter = steps * B_PER_GPU * world
-    value = inter / dt
+    value = rate(mgr, steps, dt)
     ms_step_dev, ms_estep_eager, ms_estep_replay = device_step_times(mgr, world)
     n_local = mgr.users_tensor.shape[0]
     ms_estep = ms_estep_replay if ms_estep_replay else ms_estep_eager
-    detail = {'mstep_interactions_per_s_per_gpu': B_PER_GPU / (ms_step_dev * 1e-3),
+    detail = {'mstep_interactions_per_s_per_gpu': b_loc / (ms_step_dev * 1e-3),
               # the E-step rate from ONE REPLAY of the captured E-step (what the timed loop runs); the eagerly issued cluster()
               # -- the host's numpy permutation draws inside the interval -- beside it
               'estep_interactions_per_s_per_gpu': n_local / (ms_estep * 1e-3), 'estep_ms': ms_estep,
@@ -749,10 +839,10 @@ def main():
     # Algorithmic bytes.  SURVEY §8(d) prices the un-fused pair: M-step B*(32+32D) (ids/labels,
     # 4 row reads, 4 gradient-row adds) + Adam 32P (28 B/param + 4 B zeroing).  The fused owner pass never
     # stores the gradient, so it is priced at what it must move: B*(32+16D) + 24P (p,m,v read; p',m',v' written).
-    bytes_survey = B_PER_GPU * (32 + 32 * D) + 32 * P
+    bytes_survey = b_loc * (32 + 32 * D) + 32 * P
     alt = fused and getattr(mgr, '_alt', None) is not None     # ONE launch per step, the evaluating side alternating
     if fused:
-        nbytes = B_PER_GPU * (32 + 16 * D) + 24 * P
+        nbytes = b_loc * (32 + 16 * D) + 24 * P
         kname, knames = 'mstep_eval_kernel', ['mstep_eval_kernel', 'mstep_apply_kernel']
         what = 'the whole optimiser step: mstep_eval_kernel (user jobs: evaluation, records, fused Adam) + mstep_apply_kernel (item jobs, fold, fused Adam)'
         if alt:
@@ -804,7 +894,7 @@ def main():
         # labels / weights, 2 partner rows gathered, 2 contribution rows written and read back; the big tables' p, m, v read
         # and written once per TWO steps; the small tables every step -- so that the gain cannot hide in the denominator
         p_small = 2 * E * D + E
-        alt_bytes = B_PER_GPU * (32 + 24 * D) + 12 * (P - p_small) + 24 * p_small
+        alt_bytes = b_loc * (32 + 24 * D) + 12 * (P - p_small) + 24 * p_small
         roofline['alt_byte_model'] = {'bytes_per_launch': alt_bytes, 'achieved': alt_bytes / (ms_step_dev * 1e-3) / 1e9,
                                       'frac': alt_bytes / (ms_step_dev * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       'note': 'B(32 + 24 D) + 12 P_big + 24 P_small: the alternating form streams a side\'s rows '
@@ -815,9 +905,12 @@ def main():
         'metric': 'training interactions/sec, Yahoo-implicit InvPref', 'value': value, 'unit': 'interactions/s',
         'n_gpus': world, 'steps': steps, 'steps_requested': args.steps, 'warmup': warm_steps,
         'warmup_requested': args.warmup, 'ms_per_step': dt / steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': SCALING, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'yahoo_r3_implicit_shaped', 'users': U, 'items': I, 'envs': E, 'factor_num': D,
-                   'interactions_per_gpu': N_PER_GPU, 'batch_per_gpu': B_PER_GPU, 'global_batch': B_PER_GPU * world,
+                   'scaling': SCALING, 'interactions_total': n_total, 'global_batch': gbatch,
+                   'interactions_per_gpu': n_total // world, 'batch_per_gpu': b_loc,
+                   'interactions_counted': 'exact: steps / minibatches-per-epoch x interactions_total (the last minibatch of an '
+                                           'epoch has 4 394 rows, not 8 192: rounds 1-5 counted steps x 8 192, +1.5 %)',
                    'estep_every_steps': CLUSTER_INTERVAL * mgr.batch_num,
                    'parallelism': (f'{mgr.shard_mode}-sharded x{world}, 1 all-reduce/step '
                                    f'({4 * (mgr.state.n + 8 - mgr._ar_lo)} B)' if world > 1 else 'single GPU')},
@@ -825,6 +918,8 @@ def main():
         'roofline': roofline, 'detail': detail,
     }
     out['rccl_ranks'] = rccl_ranks    # ranks that took part in an RCCL all-reduce in front of the run (None: single GPU)
+    out['parity_gate'] = gate if gate is not None else {
+        'pass': None, 'note': 'not run (' + ('--no-parity-gate' if args.no_parity_gate else 'N > 1: the gate is the 1-GPU run') + ')'}
     if world > 1:
         # the headline is the literal form BASELINE.json configs[3] names (rows + one all-reduce); beside it: the same
         # split with the exchange as reduce-scatter -> Adam on the rank's slice -> all-gather, and the xGMI-first
@@ -836,7 +931,7 @@ def main():
         os.environ['INVPREF_EXCHANGE'] = 'scatter'
         mgr_a = build_manager(dev, rank, world, 'rows')
         dt_a, steps_a, _, _ = timed_run(mgr_a, world, args.steps, args.warmup)
-        out['detail']['rows_scatter'] = {'value': steps_a * B_PER_GPU * world / dt_a, 'ms_per_step': dt_a / steps_a * 1e3,
+        out['detail']['rows_scatter'] = {'value': rate(mgr_a, steps_a, dt_a), 'ms_per_step': dt_a / steps_a * 1e3,
                                          'steps': steps_a, 'exchange': 'reduce-scatter(grad) + all-gather(param)',
                                          'flat_buffer_bytes': 4 * mgr_a.state.cap}
         del mgr_a
@@ -845,7 +940,7 @@ def main():
         os.environ['INVPREF_EXCHANGE'] = 'packed'
         mgr_p = build_manager(dev, rank, world, 'rows')
         dt_p, steps_p, _, _ = timed_run(mgr_p, world, args.steps, args.warmup)
-        out['detail']['rows_packed'] = {'value': steps_p * B_PER_GPU * world / dt_p, 'ms_per_step': dt_p / steps_p * 1e3,
+        out['detail']['rows_packed'] = {'value': rate(mgr_p, steps_p, dt_p), 'ms_per_step': dt_p / steps_p * 1e3,
                                         'steps': steps_p, 'exchange': 'pack touched rows -> 1 all-reduce -> unpack',
                                         'all_reduce_bytes_mean': 4 * sum(mgr_p.packed_floats) / len(mgr_p.packed_floats),
                                         'flat_gradient_bytes': 4 * mgr_p.state.n}
@@ -854,8 +949,25 @@ def main():
         os.environ.pop('INVPREF_EXCHANGE', None)
         mgr_u = build_manager(dev, rank, world, 'users')
         dt_u, steps_u, _, _ = timed_run(mgr_u, world, args.steps, args.warmup)
-        out['detail']['user_sharded'] = {'value': steps_u * B_PER_GPU * world / dt_u, 'ms_per_step': dt_u / steps_u * 1e3,
+        out['detail']['user_sharded'] = {'value': rate(mgr_u, steps_u, dt_u), 'ms_per_step': dt_u / steps_u * 1e3,
                                          'steps': steps_u, 'all_reduce_bytes': 4 * (mgr_u.state.n + 8 - mgr_u._ar_lo)}
+        del mgr_u
+        torch.cuda.empty_cache()
+        # SURVEY 8(d)-4's large-batch variant: B = N, one optimiser step per epoch (the exchange amortised over 250 154 rows)
+        os.environ['INVPREF_EXCHANGE'] = 'allreduce'
+        mgr_b = build_manager(dev, rank, world, 'rows', batch=n_total)
+        dt_b, steps_b, _, _ = timed_run(mgr_b, world, args.steps, args.warmup)
+        out['detail']['large_batch'] = {'value': rate(mgr_b, steps_b, dt_b), 'ms_per_step': dt_b / steps_b * 1e3, 'steps': steps_b,
+                                        'global_batch': n_total, 'exchange': 'allreduce'}
+        del mgr_b
+        torch.cuda.empty_cache()
+        # ... and the other scaling mode, same exchange (strong run: the weak figures of rounds 1-5, and vice versa)
+        other = 'weak' if SCALING == 'strong' else 'strong'
+        mgr_w = build_manager(dev, rank, world, 'rows', scaling=other)
+        dt_w, steps_w, _, _ = timed_run(mgr_w, world, args.steps, args.warmup)
+        out['detail'][other] = {'value': rate(mgr_w, steps_w, dt_w), 'ms_per_step': dt_w / steps_w * 1e3, 'steps': steps_w,
+                                'interactions_total': mgr_w.n_total, 'global_batch': mgr_w.batch_size, 'exchange': 'allreduce'}
+        os.environ.pop('INVPREF_EXCHANGE', None)
     if rank == 0 and world == 1 and not args.no_extras:
         del mgr
         torch.cuda.empty_cache()

@@ -638,8 +638,13 @@ struct EstepFin {
 __device__ __forceinline__ int ld_sc1_i(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1_i(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+#ifndef ESTEP_NUM_SGPR
+#define ESTEP_NUM_SGPR 80   // 256-thread workgroups per CU are also capped by the scalar registers: <= 80 -> 8, 82-96 -> 7, 98+ -> 6
+                            // (MI355X guide, residency); left alone the compiler takes 100 and a quarter of the 2 048 workgroups
+                            // of a Yahoo-sized E-step waits for a second residency
+#endif
 template <int NC, bool VEC, bool NARROW>
-__global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const int64_t *__restrict__ users,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(ESTEP_NUM_SGPR))) void estep_assign_kernel(DevTables t, const int64_t *__restrict__ users,
                                                            const int64_t *__restrict__ items,
                                                            const float *__restrict__ scores, int64_t N, uint32_t flags,
                                                            const float *__restrict__ eps_rows,
@@ -790,13 +795,26 @@ __global__ __launch_bounds__(256) void estep_assign_kernel(DevTables t, const in
     if (!s_last) return;
     {
         const int E1 = t.E + 1, nsl = (int)gridDim.x;
-        // (write-through stores -> cache-bypassing loads; summed through LDS atomics with a handful of registers: the fold runs in
-        //  ONE workgroup per launch, and a register-hungry epilogue costs every workgroup of the launch its occupancy -- with
-        //  per-thread accumulators the Yahoo instance went from 57 to 74 registers, 8 -> 6 waves per SIMD, 44 -> 54 us)
-        for (int sl = threadIdx.x; sl < nsl; sl += blockDim.x) {
-            const int *row = slabs + (int64_t)sl * E1;
-#pragma nounroll
-            for (int c = 0; c < E1; c++) atomicAdd((unsigned long long *)&s_tot[c], (unsigned long long)ld_sc1_i(row + c));
+        // (write-through stores -> cache-bypassing loads.  The slabs are ONE contiguous int array [workgroups][E + 1]: thread t of
+        //  the first `per` = 256 - 256 % (E + 1) threads reads elements t, t + per, ... -- coalesced, and all of ONE class, t %
+        //  (E + 1) -- twenty loads in flight, one accumulator; then one LDS atomic per thread.  The fold runs in one workgroup per
+        //  launch but its registers are every workgroup's: with 17 per-thread 64-bit accumulators the Yahoo instance went from
+        //  57 to 74 registers, 8 -> 6 waves per SIMD; every thread adding every count through LDS atomics on the same five words
+        //  took 138 us; one class at a time (a round trip each) 53 us)
+        const int per = (int)blockDim.x - (int)blockDim.x % E1, total = nsl * E1;
+        if ((int)threadIdx.x < per) {
+            long long a = 0;
+            for (int i0 = threadIdx.x; i0 < total; i0 += 20 * per) {
+                int x[20];
+#pragma unroll
+                for (int k = 0; k < 20; k++) {
+                    const int i = i0 + k * per;
+                    x[k] = i < total ? ld_sc1_i(slabs + i) : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 20; k++) a += x[k];
+            }
+            atomicAdd((unsigned long long *)&s_tot[(int)threadIdx.x % E1], (unsigned long long)a);
         }
         __syncthreads();
         int64_t *row = nullptr;
@@ -886,6 +904,47 @@ __global__ __launch_bounds__(256) void stat_envs_kernel(const int64_t *__restric
                 if (s0 + k < N) sample_w[s0 + k] = cw[e[k]];
         }
     }
+}
+
+// The same fold as estep_assign_kernel's epilogue, as ONE workgroup of its own behind the assignment kernel (INVPREF_ESTEP_FOLD=kernel:
+// a kernel boundary + two round trips of one workgroup, against the epilogue's chain of store drain -> shard ticket -> top
+// ticket -> fold on the assignment kernel's own tail; measured per E-step in profiles/r06).
+__global__ __launch_bounds__(256) void estep_fold_kernel(const int *__restrict__ slabs, int nslabs, int E, int64_t N, EstepFin fin) {
+    __shared__ long long s_tot[INVPREF_MAX_ENVS + 1];
+    const int E1 = E + 1, total = nslabs * E1;
+    for (int i = threadIdx.x; i <= E; i += blockDim.x) s_tot[i] = 0;
+    __syncthreads();
+    const int per = (int)blockDim.x - (int)blockDim.x % E1;
+    if ((int)threadIdx.x < per) {
+        long long a = 0;
+        for (int i0 = threadIdx.x; i0 < total; i0 += 20 * per) {
+            int x[20];
+#pragma unroll
+            for (int k = 0; k < 20; k++) {
+                const int i = i0 + k * per;
+                x[k] = i < total ? slabs[i] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 20; k++) a += x[k];
+        }
+        atomicAdd((unsigned long long *)&s_tot[(int)threadIdx.x % E1], (unsigned long long)a);
+    }
+    __syncthreads();
+    int64_t *row = nullptr;
+    if (fin.ring) row = fin.ring + (int64_t)((unsigned)fin.state[1] % (unsigned)fin.ring_cap) * E1;
+    if ((int)threadIdx.x < E) {
+        const long long c = s_tot[threadIdx.x];
+        const long long r = (c + 1 < N - 1) ? c + 1 : N - 1;
+        if (fin.counts) fin.counts[threadIdx.x] = c;
+        if (fin.class_w) fin.class_w[threadIdx.x] = (float)((double)r / (double)N);
+        if (row) row[threadIdx.x] = c;
+    }
+    if (threadIdx.x == 0) {
+        if (fin.diff) *fin.diff = s_tot[E];
+        if (row) row[E] = s_tot[E];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && fin.ring) fin.state[1] = fin.state[1] + 1;
 }
 
 // =====================================================================================
@@ -1368,9 +1427,12 @@ static int estep_launch(const InvPrefTables *tables, const int64_t *users, const
             hipLaunchKernelGGL(eps_unrank_kernel<int64_t>, dim3((unsigned)ub), dim3(256), 0, st, (const int64_t *)perm_index, N, t.E, fac, eps_packed);
     }
     EstepFin fin{};
+    // INVPREF_ESTEP_FOLD=epilogue (default) | kernel: where the fused entry point folds the count slabs (see estep_fold_kernel)
+    static const bool fold_kernel = std::getenv("INVPREF_ESTEP_FOLD") != nullptr && std::getenv("INVPREF_ESTEP_FOLD")[0] == 'k';
     if (fused) {
         fin = *fused;
         if (!table_form) fin.perm_table = nullptr;
+        if (fold_kernel) fin.state = nullptr;          // (the assignment kernel stores plain slabs and takes no ticket)
     }
 #define ECALL1(NCV, VECV, NARV)                                                                                   \
     hipLaunchKernelGGL((estep_assign_kernel<NCV, VECV, NARV>), dim3(nb), dim3(kEstepThreads), lds + lds_extra, st, t, users, items, \
@@ -1385,6 +1447,10 @@ static int estep_launch(const InvPrefTables *tables, const int64_t *users, const
 #undef ECALL1
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return (int)err;
+    if (fused && fold_kernel) {
+        hipLaunchKernelGGL(estep_fold_kernel, dim3(1), dim3(256), 0, st, slabs, nb, t.E, N, *fused);
+        return (int)hipGetLastError();
+    }
     if (fused) return 0;   // (counts, diff and class weights came out of the kernel's epilogue; no sample-weight array)
     // every workgroup of stat_envs folds ALL the count slabs for itself before it gathers its share of the sample weights:
     // at most 256 of them (one per CU, a grid-stride share of rows each) -- a thousand workgroups read 40 MB of slabs for

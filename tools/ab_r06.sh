@@ -6,6 +6,7 @@ mkdir -p gpurun_out
 for v in "$@"; do
   lib=invpref_kdd_2022_amd/variants/$v.so
   [ "$v" = default ] && lib=invpref_kdd_2022_amd/libinvpref_hip.so
+  [ "$v" = foldkernel ] && lib=invpref_kdd_2022_amd/libinvpref_hip.so && export INVPREF_ESTEP_FOLD=kernel
   for rep in 1 2; do
     INVPREF_LIB=$PWD/$lib timeout 300 python bench.py --no-extras --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
@@ -13,4 +14,5 @@ d=json.loads(sys.stdin.read().strip().split('\n')[-1])
 print('$v rep $rep: ms_per_step %.5f  launch %.5f  estep %.4f  value %.1f M/s' % (d['ms_per_step'], d['roofline']['avg_launch_ms'], d['detail']['estep_ms'], d['value']/1e6))
 "
   done
+  unset INVPREF_ESTEP_FOLD
 done | tee -a gpurun_out/ab_r06.txt

@@ -5,16 +5,18 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/estep_ab6; rm -rf $O; mkdir -p $O
-for fused in 1 0; do
+for fused in 1 k 0; do
   export INVPREF_ESTEP_FUSED=$fused
+  unset INVPREF_ESTEP_FOLD
+  [ $fused = k ] && export INVPREF_ESTEP_FUSED=1 INVPREF_ESTEP_FOLD=kernel
   timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/f$fused -- python3 $R/tools/estep_prof.py > $O/f$fused.log 2>&1
   f=$(ls $O/f$fused/*/*kernel_trace.csv 2>/dev/null | head -1)
-  echo "== INVPREF_ESTEP_FUSED=$fused" >> $O/summary.txt
+  echo "== INVPREF_ESTEP_FUSED=$fused (k: fused entry point, the fold as a second one-workgroup kernel)" >> $O/summary.txt
   [ -n "$f" ] && python3 - "$f" >> $O/summary.txt <<'PY'
 import csv, sys, statistics
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-for kn in ('estep_assign_kernel', 'stat_envs_kernel', 'sample_weights_kernel'):
+for kn in ('estep_assign_kernel', 'estep_fold_kernel', 'stat_envs_kernel', 'sample_weights_kernel'):
     d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in rows if kn in r['Kernel_Name']]
     if not d:
         continue
@@ -24,5 +26,5 @@ for kn in ('estep_assign_kernel', 'stat_envs_kernel', 'sample_weights_kernel'):
 PY
   rm -rf $O/f$fused
 done
-unset INVPREF_ESTEP_FUSED
+unset INVPREF_ESTEP_FUSED INVPREF_ESTEP_FOLD
 cat $O/summary.txt

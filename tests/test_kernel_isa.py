@@ -63,7 +63,10 @@ def test_full_row_instances_have_no_scratch_traffic(kernels):
     alt = {name: k for name, k in ks.items() if name.startswith('mstep_alt_kernel')}
     assert len(alt) == 18     # {vector + full rows, vector, element-wise} x {first, steady, flush} x {256, 512 threads}
     for name, k in alt.items():
-        assert k['scratch_ops'] == 0 and k['scratch'] == 0 and k['mfma'] == 0 and k['vgpr'] <= 168, (name, k)
+        # (256-thread workgroups run three per CU: 168 registers; the 512-thread ones -- a hot side's rounds of 32 slots -- one
+        #  per CU, two waves per SIMD: the whole file)
+        cap = 168 if name.endswith(', 256>') else 256
+        assert k['scratch_ops'] == 0 and k['scratch'] == 0 and k['mfma'] == 0 and k['vgpr'] <= cap, (name, k)
 
 
 def test_wide_instances_run_their_outer_products_on_mfma(kernels):

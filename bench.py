@@ -645,14 +645,15 @@ def estep_random_sort_timing(dev, n=20):
     return out
 
 
-def yahoo_test_loader():
-    """a data-loader stand-in of the Yahoo test shape: 5 400 test users x 1 000 items, 1 .. 32 train items to mask and 10
-    ground-truth items per user (Yahoo_InvPref_Implicit.py:43-48 evaluates top-k 3/5/7 in test batches of 1 024)"""
+def test_loader(n_users=U, n_items=I, n_test=5400, mask_max=32, n_truth=10, seed=11):
+    """a data-loader stand-in of a test shape: n_test test users x n_items items, 1 .. mask_max train items to mask and n_truth
+    ground-truth items per user (default: the Yahoo test shape, Yahoo_InvPref_Implicit.py:43-48 evaluates top-k 3/5/7 in test
+    batches of 1 024)"""
     import numpy as np
-    rs = np.random.RandomState(11)
-    users = sorted(rs.choice(U, 5400, replace=False).tolist())
-    mask = {u: set(rs.choice(I, rs.randint(1, 33), replace=False).tolist()) for u in users}
-    truth = {u: set(rs.choice(I, 10, replace=False).tolist()) for u in users}
+    rs = np.random.RandomState(seed)
+    users = sorted(rs.choice(n_users, n_test, replace=False).tolist())
+    mask = {u: set(rs.choice(n_items, rs.randint(1, mask_max + 1), replace=False).tolist()) for u in users}
+    truth = {u: set(rs.choice(n_items, n_truth, replace=False).tolist()) for u in users}
 
     class Loader:
         all_test_users_by_sorted_list = users
@@ -662,6 +663,10 @@ def yahoo_test_loader():
         def user_mask_items(u):
             return mask[u]
     return Loader()
+
+
+def yahoo_test_loader():
+    return test_loader()
 
 
 def end_to_end(dev, env_num, factor_num, epochs=200):
@@ -727,26 +732,52 @@ def end_to_end(dev, env_num, factor_num, epochs=200):
 
 
 def eval_timing(dev):
-    """ImplicitTestManager.evaluate() on the Yahoo test shape (5 400 test users x 1 000 items,
-    top-k 3/5/7, test batch 1 024: Yahoo_InvPref_Implicit.py:43-48); the reference's CPU path took 4.8 s per call in
-    the survey container."""
+    """ImplicitTestManager.evaluate() (models.py:393-407, evaluate.py:76-135) at the test shapes of the three
+    implicit BASELINE configurations -- Yahoo (5 400 test users x 1 000 items, top-k 3/5/7, test batch 1 024:
+    Yahoo_InvPref_Implicit.py:43-48; the reference's CPU path took 4.8 s per call in the survey container),
+    MovieLens (6 040 x 3 706, D = 128, top-k 10/20/30, test batch 2 048: MovieLens_InvPref.py:45-46) and MIND (50 000 test users
+    x 51 283 items, D = 256, top-k 5/10/20/40, test batch 256: MIND_InvPref.py:45-46) -- wall seconds per call, min of 3, and
+    the device time of predict_kernel alone over all the call's batches (the score matrix is the call's bulk:
+    n_test x items x (2 D flops, 4 bytes written))."""
     import torch
     from invpref_kdd_2022_amd.evaluate import ImplicitTestManager
     from invpref_kdd_2022_amd.models import InvPrefImplicit
-    loader = yahoo_test_loader()
-    users = loader.all_test_users_by_sorted_list
-    model = InvPrefImplicit(U, I, E, D).to(dev)
-    tm = ImplicitTestManager(model, loader, test_batch_size=1024, top_k_list=[3, 5, 7], use_item_pool=False)
-    tm.evaluate()                       # builds the CSR arrays from the python sets once
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        res = tm.evaluate()
-        ts.append(time.perf_counter() - t0)
-    assert 0.0 <= res['ndcg'][5] <= 1.0
-    return {'evaluate_s': min(ts), 'test_users': len(users), 'items': I, 'top_k': [3, 5, 7],
-            'reference_cpu_s_survey_container': 4.8}
+    out = {}
+    for name, (nu, ni, ne, nd, n_test, tb, topk, mask_max, n_truth) in dict(
+            yahoo=(U, I, E, D, 5400, 1024, [3, 5, 7], 32, 10),
+            movielens=(6040, 3706, 8, 128, 6040, 2048, [10, 20, 30], 300, 20),
+            mind=(50000, 51283, 16, 256, 50000, 256, [5, 10, 20, 40], 60, 10)).items():
+        loader = test_loader(nu, ni, n_test, mask_max, n_truth)
+        model = InvPrefImplicit(nu, ni, ne, nd).to(dev)
+        tm = ImplicitTestManager(model, loader, test_batch_size=tb, top_k_list=list(topk), use_item_pool=False)
+        tm.evaluate()                       # builds the CSR arrays from the python sets once
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = tm.evaluate()
+            ts.append(time.perf_counter() - t0)
+        assert 0.0 <= res['ndcg'][topk[1]] <= 1.0
+        # predict alone, device time: every test batch's score matrix
+        users = tm._users
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for lo in range(0, n_test, tb):
+            r = model.predict(users[lo:lo + tb].contiguous())
+        e1.record()
+        torch.cuda.synchronize()
+        pred_ms = e0.elapsed_time(e1)
+        flops, byts = 2.0 * n_test * ni * nd, 4.0 * n_test * ni
+        out[name] = {'evaluate_s': min(ts), 'test_users': n_test, 'items': ni, 'factor_num': nd, 'top_k': topk, 'test_batch': tb,
+                     'predict_ms': pred_ms, 'predict_tflops': flops / (pred_ms * 1e-3) / 1e12,
+                     'predict_score_matrix_GBs_written': byts / (pred_ms * 1e-3) / 1e9}
+        del model, tm, loader, r
+        torch.cuda.empty_cache()
+    out['yahoo']['reference_cpu_s_survey_container'] = 4.8
+    # (kept flat for continuity with rounds 1-5: the Yahoo figure)
+    out.update({k: out['yahoo'][k] for k in ('evaluate_s', 'test_users', 'items', 'top_k')})
+    out['reference_cpu_s_survey_container'] = 4.8
+    return out
 
 
 def main():

@@ -120,6 +120,132 @@ __global__ __launch_bounds__(256) void topk_mask_big_kernel(const float *__restr
     }
 }
 
+// The same selection for large item counts WITHOUT k passes over the row (round 6: MIND's 51 283 items x top-40 was 40 sweeps
+// of a 205 KB row per test user -- 0.58 s of a 0.60 s evaluate()): a RADIX SELECT finds the k-th best (value, id) pair in three
+// histogram passes over the row -- 11 + 11 + 10 bits of the value's order-preserving key -- plus, only when more items tie with
+// the k-th value than are needed, two passes over the ids of the tied items; one more pass collects the k winners, which one
+// wave ranks by (value descending, id ascending) -- exactly the order of k argmax passes with the lowest id first among equal
+// scores -- and looks up in the ground-truth list.  Same masking arithmetic as above: -1024 for a train item, += 1024 for
+// an item of the pool.
+__device__ __forceinline__ unsigned order_key(float v) {
+    v = v + 0.0f;                                   // -0 -> +0: equal values, equal keys
+    if (v != v) return 0u;                          // a NaN score is never picked (`v > best` is false for it above)
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__global__ __launch_bounds__(256) void topk_select_kernel(const float *__restrict__ ratings, int64_t n_users, int n_items,
+                                                          const int *__restrict__ mask_ptr, const int *__restrict__ mask_items,
+                                                          const int *__restrict__ hl_ptr, const int *__restrict__ hl_items,
+                                                          const int *__restrict__ gt_ptr, const int *__restrict__ gt_items,
+                                                          int K, int *__restrict__ out_items, float *__restrict__ out_hits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned bits[];
+    __shared__ int hist[2048];
+    __shared__ unsigned s_sel;
+    __shared__ int s_need, s_n;
+    __shared__ unsigned ckey[kMaxK];
+    __shared__ int cid[kMaxK];
+    const int words = (n_items + 31) >> 5;
+    unsigned *bm = bits, *bh = bits + words;
+    const int64_t u = blockIdx.x;
+    for (int i = threadIdx.x; i < 2 * words; i += blockDim.x) bits[i] = 0u;
+    if (threadIdx.x == 0) { s_need = K; s_n = 0; }
+    __syncthreads();
+    for (int j = mask_ptr[u] + threadIdx.x; j < mask_ptr[u + 1]; j += blockDim.x)
+        atomicOr(bm + (mask_items[j] >> 5), 1u << (mask_items[j] & 31));
+    if (hl_ptr)
+        for (int j = hl_ptr[u] + threadIdx.x; j < hl_ptr[u + 1]; j += blockDim.x)
+            atomicOr(bh + (hl_items[j] >> 5), 1u << (hl_items[j] & 31));
+    __syncthreads();
+    const float *src = ratings + u * (int64_t)n_items;
+    auto key_of = [&](int i) {
+        const unsigned w = (unsigned)i >> 5, b = 1u << (i & 31);
+        float v = (bm[w] & b) ? -1024.0f : src[i];
+        if (bh[w] & b) v += 1024.0f;
+        return order_key(v);
+    };
+    // one radix pass: among the items `live` accepts, the histogram of digit(i); thread 0 then walks the bins from the top
+    // (descending = true) or the bottom until the s_need-th item falls into a bin: s_sel = that bin, s_need = its rank inside
+    auto pass = [&](int nbins, bool descending, auto live, auto digit) {
+        for (int b = threadIdx.x; b < nbins; b += blockDim.x) hist[b] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_items; i += blockDim.x) {
+            const unsigned k = key_of(i);
+            if (live(i, k)) atomicAdd(&hist[digit(i, k)], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            // (one wave: lane l owns nbins / 64 consecutive bins in walk order; a prefix over the lanes finds the lane, the lane
+            //  its bin)
+            const int per = nbins / 64, lane = threadIdx.x;
+            int mine = 0;
+            for (int j = 0; j < per; j++) {
+                const int pos = lane * per + j;
+                mine += hist[descending ? nbins - 1 - pos : pos];
+            }
+            int incl = mine;
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+            const int before = incl - mine, need = s_need;
+            if (before < need && need <= incl) {
+                int cum = before;
+                for (int j = 0; j < per; j++) {
+                    const int pos = lane * per + j, b = descending ? nbins - 1 - pos : pos, h = hist[b];
+                    if (cum + h >= need) { s_sel = (unsigned)b; s_need = need - cum; s_n = h; break; }
+                    cum += h;
+                }
+            }
+        }
+        __syncthreads();
+    };
+    unsigned pre = 0;      // the key's bits fixed so far
+    pass(2048, true, [&](int, unsigned) { return true; }, [&](int, unsigned k) { return k >> 21; });
+    pre = s_sel << 21;
+    __syncthreads();
+    pass(2048, true, [&](int, unsigned k) { return (k >> 21) == (pre >> 21); }, [&](int, unsigned k) { return (k >> 10) & 2047u; });
+    pre |= s_sel << 10;
+    __syncthreads();
+    pass(1024, true, [&](int, unsigned k) { return (k >> 10) == (pre >> 10); }, [&](int, unsigned k) { return k & 1023u; });
+    const unsigned T = pre | s_sel;     // the k-th best value's key; s_need of the s_n items that carry it are taken
+    int id_T = 0x7fffffff;              // ... the ones with id <= id_T
+    const bool tie = s_need < s_n;
+    __syncthreads();
+    if (tie) {                          // (workgroup-uniform) the s_need LOWEST ids among the tied items: 10 + 10 bits of the id
+        pass(1024, false, [&](int, unsigned k) { return k == T; }, [&](int i, unsigned) { return (unsigned)i >> 10; });
+        const unsigned hi = s_sel;
+        __syncthreads();
+        pass(1024, false, [&](int i, unsigned k) { return k == T && ((unsigned)i >> 10) == hi; }, [&](int i, unsigned) { return (unsigned)i & 1023u; });
+        id_T = (int)((hi << 10) | s_sel);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_items; i += blockDim.x) {
+        const unsigned k = key_of(i);
+        if (k > T || (k == T && i <= id_T)) {
+            const int at = atomicAdd(&s_n, 1);
+            if (at < kMaxK) { ckey[at] = k; cid[at] = i; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {             // rank the K winners: (key descending, id ascending)
+        const int lane = threadIdx.x, n = min(s_n, K);
+        const unsigned mk = lane < n ? ckey[lane] : 0u;
+        const int mi = lane < n ? cid[lane] : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < n; j++) {
+            const unsigned ok = ckey[j];
+            const int oi = cid[j];
+            rank += (ok > mk || (ok == mk && oi < mi)) ? 1 : 0;
+        }
+        if (lane < n) {
+            const int g0 = gt_ptr[u], g1 = gt_ptr[u + 1];
+            int lo = g0, hi = g1;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (gt_items[mid] < mi) lo = mid + 1; else hi = mid; }
+            out_items[u * K + rank] = mi;
+            out_hits[u * K + rank] = (lo < g1 && gt_items[lo] == mi) ? 1.0f : 0.0f;
+        }
+    }
+}
+
 // sum (a-b)^2 and sum |a-b| in double (evaluate.py:199-203: nn.MSELoss / nn.L1Loss over all test pairs)
 __global__ __launch_bounds__(256) void err_sums_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t n,
                                                        double *__restrict__ out2) {
@@ -254,6 +380,21 @@ int invpref_eval_topk_hip(const float *ratings, int64_t n_users, int64_t n_items
     if (k > kMaxK || k > n_items || n_items > 400000) return INVPREF_EUNSUPPORTED;
     if (n_users == 0) return 0;
     const size_t lds = sizeof(float) * 4 * (size_t)n_items;
+    // INVPREF_TOPK_SELECT=0: the k-pass kernels for every size (A/B, tests); default: the radix select beyond 4 096 items
+    static const bool sel_off = getenv("INVPREF_TOPK_SELECT") != nullptr && getenv("INVPREF_TOPK_SELECT")[0] == '0';
+    static const bool sel_all = getenv("INVPREF_TOPK_SELECT") != nullptr && getenv("INVPREF_TOPK_SELECT")[0] == '2';
+    if (!sel_off && (n_items > 4096 || sel_all) && n_items <= (1 << 20)) {
+        const size_t lds_sel = sizeof(unsigned) * 2 * (((size_t)n_items + 31) / 32);
+        if (lds_sel > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(topk_select_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sel);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)n_users), dim3(256), lds_sel, (hipStream_t)stream, ratings, n_users,
+                           (int)n_items, mask_ptr, mask_items, highlight_ptr, highlight_items, truth_ptr, truth_items, (int)k,
+                           out_items, out_hits);
+        return (int)hipGetLastError();
+    }
     if (lds > 160 * 1024) {   // the four staged rows exceed the CU's LDS: bit-set form, one workgroup per user
         const size_t lds_bits = sizeof(unsigned) * 3 * (((size_t)n_items + 31) / 32);
         if (lds_bits > 64 * 1024) {

@@ -956,15 +956,15 @@ __global__ __launch_bounds__(256) void estep_fold_kernel(const int *__restrict__
 template <int NC, bool VEC>
 __global__ __launch_bounds__(256) void predict_kernel(const float *__restrict__ Pu, const float *__restrict__ Qi,
                                                       const int64_t *__restrict__ users, int64_t n, int I, int D,
-                                                      int apply_sigmoid, float *__restrict__ out) {
+                                                      int apply_sigmoid, float *__restrict__ out, int per_slice) {
     const int l16 = threadIdx.x & 15;
     const int64_t row = blockIdx.x * (int64_t)(blockDim.x / kRow) + (threadIdx.x >> 4);
     if (row >= n) return;
     float4 pu[NC];
     load_row<NC, VEC>(Pu, users[row], D, l16, pu);
     float *o = out + row * (int64_t)I;
-    const int i_lo = blockIdx.y * (int)((I + gridDim.y - 1) / gridDim.y);
-    int i_hi = i_lo + (int)((I + gridDim.y - 1) / gridDim.y);
+    const int i_lo = blockIdx.y * per_slice;       // (a multiple of 16: the 64-byte result segments stay aligned)
+    int i_hi = i_lo + per_slice;
     i_hi = i_hi < I ? i_hi : I;
     for (int i0 = i_lo; i0 < i_hi; i0 += 16) {
         float res = 0.f;
@@ -980,6 +980,96 @@ __global__ __launch_bounds__(256) void predict_kernel(const float *__restrict__ 
             }
         }
         if (i0 + l16 < i_hi) o[i0 + l16] = res;
+    }
+}
+
+// The same score matrix on the MATRIX CORES ("the one genuinely dense contraction"; models.py:393-407,
+// evaluate.py:88-92) for rows of 64 / 128 / 256 floats -- bit for bit the values of predict_kernel, forward() and the oracle:
+// the canonical dot product gives element i to slot (i >> 2) & 15, runs ONE fma chain per slot over its elements in
+// increasing i and sums the 16 slots pairwise (xor 1, 2, 4, 8).  v_mfma_f32_16x16x4_f32 accumulates its four k terms as an fmaf
+// chain in k order, so ONE MFMA per (64-float chunk c, slot s) with k = the four consecutive elements 64 c + 4 s + k, chained
+// over c in the slot's own accumulator tile, IS the slot's chain -- for 16 users x 16 items at a time -- and the 16 slot tiles are
+// then added pairwise in the butterfly's order.  A workgroup = 64 users (one 16-user tile per wave, its rows held as MFMA A
+// operands for the whole sweep: 16 DC registers) x a range of items; a 16-item tile is staged in LDS once for the four waves
+// (row stride 64 DC + 4 floats: the B operand's lanes -- item n, k -- fall on 64 different banks), double-buffered, one barrier
+// per tile.  Lane l of a wave then holds C[4 (l >> 4) + r][l & 15]: users 4 (l >> 4) + r, item l & 15 -- 64-byte row segments.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <int DC>
+__global__ __launch_bounds__(256, 2) void predict_mm_kernel(const float *__restrict__ Pu, const float *__restrict__ Qi,
+                                                            const int64_t *__restrict__ users, int64_t n, int I,
+                                                            int apply_sigmoid, float *__restrict__ out, int steps_per) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int D = 64 * DC, RS = D + 4, TILE = 16 * RS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = lane & 15, k = lane >> 4;
+    // ---- A operands: user tile of this wave, a[c][s] = Pu[user m][64 c + 4 s + k]
+    const int64_t urow = (int64_t)blockIdx.x * 64 + wave * 16 + m;
+    const int64_t uid = users[urow < n ? urow : n - 1];
+    const float *pu = Pu + uid * (int64_t)D + k;
+    float a[DC][16];
+#pragma unroll
+    for (int c = 0; c < DC; c++)
+#pragma unroll
+        for (int s = 0; s < 16; s++) a[c][s] = pu[64 * c + 4 * s];
+    // ---- item tiles [t0, t1) of 16 items each
+    const int tiles = (I + 15) / 16;
+    const int t0 = (int)blockIdx.y * steps_per, t1 = min(tiles, t0 + steps_per);
+    if (t0 >= t1) return;
+    // staging: 16 rows x D floats = 4 D float4; thread th moves float4 number th + 256 j: row (th + 256 j) / (D / 4)
+    constexpr int F4 = D / 4, PER = 16 * F4 / 256;   // float4 per thread and tile: DC
+    static_assert(PER == DC, "staging: DC float4 per thread");
+    // (thread th moves float4 number th + 256 j of a tile: row r_j, float4 q_j of the row -- fixed per thread)
+    int src_off[PER], dst_off[PER], rr[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const int f = threadIdx.x + 256 * j;
+        rr[j] = f / F4;
+        src_off[j] = 4 * (f - rr[j] * F4);
+        dst_off[j] = rr[j] * RS + src_off[j];
+    }
+    float4 st[PER];
+    // every load and LDS store of the loop is unconditional (a load under a branch is waited for at the join, and a register
+    // array written under a branch goes to scratch memory): the tile after the last is the last one again
+#pragma unroll
+    for (int j = 0; j < PER; j++)
+        st[j] = *reinterpret_cast<const float4 *>(Qi + (int64_t)min(t0 * 16 + rr[j], I - 1) * D + src_off[j]);
+#pragma unroll
+    for (int j = 0; j < PER; j++) *reinterpret_cast<float4 *>(lds + dst_off[j]) = st[j];
+    __syncthreads();
+    for (int t = t0; t < t1; t++) {
+        const int buf = (t - t0) & 1;
+        const int tn = min(t + 1, t1 - 1);
+#pragma unroll
+        for (int j = 0; j < PER; j++)
+            st[j] = *reinterpret_cast<const float4 *>(Qi + (int64_t)min(tn * 16 + rr[j], I - 1) * D + src_off[j]);
+        const float *bt = lds + buf * TILE + m * RS + k;      // B[k][n = m]: item m of the tile, element 64 c + 4 s + k
+        f32x4_t acc[16];
+#pragma unroll
+        for (int s = 0; s < 16; s++) acc[s] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < DC; c++)
+#pragma unroll
+            for (int s = 0; s < 16; s++)
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][s], bt[64 * c + 4 * s], acc[s], 0, 0, 0);
+        // the 16 slots, pairwise in the butterfly's order (xor 1, 2, 4, 8)
+#pragma unroll
+        for (int s = 0; s < 16; s += 2) acc[s] = acc[s] + acc[s + 1];
+#pragma unroll
+        for (int s = 0; s < 16; s += 4) acc[s] = acc[s] + acc[s + 2];
+#pragma unroll
+        for (int s = 0; s < 16; s += 8) acc[s] = acc[s] + acc[s + 4];
+        acc[0] = acc[0] + acc[8];
+        const int item = t * 16 + m;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float p = acc[0][r];
+            if (apply_sigmoid) p = c_sigmoid(p);
+            const int64_t row = (int64_t)blockIdx.x * 64 + wave * 16 + 4 * k + r;
+            if (row < n && item < I) out[row * (int64_t)I + item] = p;
+        }
+#pragma unroll
+        for (int j = 0; j < PER; j++) *reinterpret_cast<float4 *>(lds + (buf ^ 1) * TILE + dst_off[j]) = st[j];
+        __syncthreads();
     }
 }
 
@@ -1238,13 +1328,38 @@ int invpref_predict_hip(const float *user_table, const float *item_table, const 
     const unsigned gx = (unsigned)((n_users + rows_per_block - 1) / rows_per_block);
     unsigned gy = 1;  // split the item sweep when there are few users, to fill the chip
     while ((int64_t)gx * gy < 1024 && gy * 64 < (unsigned)item_num) gy *= 2;
-    // item slices must start on multiples of 16 for the 64-byte result segments: enforced by rounding
-    const int per = (int)((item_num + gy - 1) / gy);
-    if (per % 16 != 0) gy = 1;
+    // item slices start on multiples of 16 for the 64-byte result segments: the slice length is rounded UP to one (round 6:
+    // it used to fall back to ONE slice whenever I / gy was not a multiple of 16 -- MIND's 51 283 items with 256 test users per
+    // call ran on 16 workgroups, 4.9 s per evaluate())
+    int per = (int)((item_num + gy - 1) / gy);
+    per = (per + 15) / 16 * 16;
+    gy = (unsigned)((item_num + per - 1) / per);
     hipStream_t st = (hipStream_t)stream;
+    // full 64-float chunks (factor_num 64 / 128 / 256) on 16-byte-aligned tables: the dense contraction on the matrix cores
+    // (predict_mm_kernel: fp32 MFMA, the canonical summation order); INVPREF_PREDICT_MM=0 keeps the vector-ALU sweep
+    static const bool mm_off = std::getenv("INVPREF_PREDICT_MM") != nullptr && std::getenv("INVPREF_PREDICT_MM")[0] == '0';
+    if (vec && !mm_off && (factor_num == 64 || factor_num == 128 || factor_num == 256) && n_users >= 16 && item_num >= 16) {
+        const unsigned ux = (unsigned)((n_users + 63) / 64);
+        // item groups: enough workgroups for two per CU, at least eight 16-item steps each
+        unsigned ig = (unsigned)((512 + ux - 1) / ux);
+        const unsigned steps_total = (unsigned)((item_num + 15) / 16);
+        if (ig > (steps_total + 7) / 8) ig = (steps_total + 7) / 8;
+        if (ig < 1) ig = 1;
+        const int steps_per = (int)((steps_total + ig - 1) / ig);
+        ig = (steps_total + steps_per - 1) / steps_per;
+#define MCALL(DCV)                                                                                                   \
+        do {                                                                                                         \
+            const size_t lds = sizeof(float) * 2 * 16 * (64 * DCV + 4);                                              \
+            hipLaunchKernelGGL((predict_mm_kernel<DCV>), dim3(ux, ig), dim3(256), lds, st, user_table, item_table, users, n_users, \
+                               (int)item_num, apply_sigmoid, out, steps_per);                                        \
+        } while (0)
+        if (factor_num == 64) MCALL(1); else if (factor_num == 128) MCALL(2); else MCALL(4);
+#undef MCALL
+        return (int)hipGetLastError();
+    }
 #define PCALL(NCV, VECV)                                                                                   \
     hipLaunchKernelGGL((predict_kernel<NCV, VECV>), dim3(gx, gy), dim3(256), 0, st, user_table, item_table, users, \
-                       n_users, (int)item_num, (int)factor_num, apply_sigmoid, out)
+                       n_users, (int)item_num, (int)factor_num, apply_sigmoid, out, per)
     if (!vec) { PCALL(4, false); } else if (nc == 1) { PCALL(1, true); } else if (nc == 2) { PCALL(2, true); } else { PCALL(4, true); }
 #undef PCALL
     return (int)hipGetLastError();

@@ -104,6 +104,10 @@ __device__ __forceinline__ void st_sc1(int *p, int v) {
 #define ALT_ROW_ST 0              // (A/B knob) 1: the rows a job finishes (p, m, v) leave as write-through stores -- measured SLOWER
                                   // here (14.9 vs 14.7 us per launch): the other side gathers them in the very next launch
 #endif
+#ifndef ALT_MV_ST
+#define ALT_MV_ST ALT_ROW_ST      // (A/B knob) 1: the Adam moments of the rows a job finishes leave as write-through stores (nobody
+                                  // reads them before the row's own job two launches on)
+#endif
 #ifndef ALT_PEND_DEPTH
 #define ALT_PEND_DEPTH 4          // pending contribution-row pairs in flight per group (two register sets)
 #endif
@@ -709,13 +713,13 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
             }
             adam4(oi, gi, mi, vi, ad_cur);
             put4<VEC, ALT_ROW_ST, FULL>(own0, row, D, lg, oi);
-            put4<VEC, ALT_ROW_ST, FULL>(a.own_m[0], row, D, lg, mi);
-            put4<VEC, ALT_ROW_ST, FULL>(a.own_v[0], row, D, lg, vi);
+            put4<VEC, ALT_MV_ST, FULL>(a.own_m[0], row, D, lg, mi);
+            put4<VEC, ALT_MV_ST, FULL>(a.own_v[0], row, D, lg, vi);
             if (!pure) {
                 adam4(oe, ge, me, ve, ad_cur);
                 put4<VEC, ALT_ROW_ST, FULL>(own1, row, D, lg, oe);
-                put4<VEC, ALT_ROW_ST, FULL>(a.own_m[1], row, D, lg, me);
-                put4<VEC, ALT_ROW_ST, FULL>(a.own_v[1], row, D, lg, ve);
+                put4<VEC, ALT_MV_ST, FULL>(a.own_m[1], row, D, lg, me);
+                put4<VEC, ALT_MV_ST, FULL>(a.own_v[1], row, D, lg, ve);
             }
         }
     }

@@ -103,8 +103,13 @@ class ImplicitTestManager:
             self._prepare(device)
         n_users = self._users.shape[0]
         sums = {m: np.zeros(len(self.top_k_list)) for m in ('ndcg', 'recall', 'precision')}
-        for lo in range(0, n_users, self.batch_size):
-            hi = min(lo + self.batch_size, n_users)
+        # test_batch_size bounds the reference's [n * I, D] temporary (models.py:393-407); here a batch is one score matrix of
+        # n x I floats and three launches, and the metrics are sums over users -- the same whatever the batch -- so small
+        # batches are merged up to a 1 GiB score matrix (MIND's 256-user batches: 196 launches + read-backs -> 10)
+        n_items = int(self.model.item_num) if hasattr(self.model, 'item_num') else 1
+        step = max(int(self.batch_size), min(n_users, (1 << 28) // max(1, n_items)))
+        for lo in range(0, n_users, step):
+            hi = min(lo + step, n_users)
             _, hits = self.topk(lo, hi)
             h = hits.cpu().numpy()
             for i, k in enumerate(self.top_k_list):

@@ -287,3 +287,108 @@ def test_cluster_without_stat_envs_keeps_the_weights_by_position():
     assert outs[0][0] == outs[1][0] and outs[0][3] == outs[1][3]
     assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
     np.testing.assert_array_equal(outs[0][4], outs[1][4])
+
+
+# ---------------------------------------------------------------------------------------------- predict on the matrix cores
+@pytest.mark.parametrize('U,I,D,n', [
+    (300, 1000, 64, 77),          # fewer users than a workgroup's 64; items not a multiple of 16
+    (500, 3706, 128, 2048),       # MovieLens' items, its test batch
+    (700, 5003, 256, 256),        # MIND's row length and test batch; a ragged last item tile
+    (64, 16, 64, 16), (65, 17, 128, 65), (1000, 51283, 256, 33),
+    (300, 1000, 40, 77), (120, 333, 30, 50),     # the reference drivers' factor_num 40 / Coat's 30: the vector-ALU sweep
+])
+@pytest.mark.parametrize('sigmoid', [True, False])
+def test_predict_mfma_is_the_canonical_dot_product_bit_for_bit(U, I, D, n, sigmoid):
+    """InvPrefImplicit.predict (models.py:393-407): the whole [n, item_num] score matrix.  Rows of 64 / 128 / 256 floats run
+    predict_mm_kernel -- v_mfma_f32_16x16x4_f32, one MFMA per (chunk, slot), slot tiles added in the butterfly's order -- and
+    must equal the oracle's forward() on every (user, item) pair BIT FOR BIT, exactly like the vector-ALU kernel
+    (INVPREF_PREDICT_MM=0, in a child process) does."""
+    tabs = synth.tables(21 + D, U, I, 2, D, std=0.3)
+    users = np.random.RandomState(n).randint(0, U, n).astype(np.int64)
+    got = ops.predict(_t(tabs[ops.PARAM_NAMES[0]], np.float32), _t(tabs[ops.PARAM_NAMES[1]], np.float32), _t(users, np.int64), sigmoid)
+    assert got.shape == (n, I)
+    rows = np.random.RandomState(1).choice(n, min(n, 24), replace=False)        # (every item of a sample of the users: oracle time)
+    rows = np.unique(np.concatenate([rows, [0, n - 1]]))
+    uu, ii = users[rows].repeat(I), np.tile(np.arange(I, dtype=np.int64), len(rows))
+    inv, _, _ = O.forward(O.Tables(tabs), uu, ii, np.zeros_like(uu), sigmoid)
+    if not sigmoid:        # (explicit forward's invariant score IS the dot product)
+        pass
+    np.testing.assert_array_equal(got.cpu().numpy()[rows].reshape(-1), inv)
+    assert np.isfinite(got.cpu().numpy()).all()
+
+
+def test_predict_mfma_equals_vector_alu_kernel_everywhere(tmp_path):
+    import subprocess
+    import sys
+    script = tmp_path / 'pred.py'
+    script.write_text('''
+import sys, numpy as np, torch
+from invpref_kdd_2022_amd import ops, synth
+dev = torch.device('cuda:0')
+out = {}
+for (U, I, D, n) in ((900, 3706, 128, 513), (400, 5003, 256, 130), (300, 999, 64, 200)):
+    tabs = synth.tables(5, U, I, 2, D, std=0.3)
+    users = torch.from_numpy(np.random.RandomState(2).randint(0, U, n).astype(np.int64)).to(dev)
+    P = [torch.from_numpy(tabs[k]).to(dev) for k in ops.PARAM_NAMES[:2]]
+    out[f'{D}'] = ops.predict(P[0], P[1], users, True).cpu().numpy()
+np.savez(sys.argv[1], **out)
+''')
+    res = []
+    for mm in ('1', '0'):
+        f = tmp_path / f'p{mm}.npz'
+        env = dict(os.environ, INVPREF_PREDICT_MM=mm, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        r = subprocess.run([sys.executable, str(script), str(f)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        res.append(np.load(f))
+    for k in res[0].files:
+        np.testing.assert_array_equal(res[0][k], res[1][k])
+
+
+# ---------------------------------------------------------------------------------------------- top-k by radix select
+@pytest.mark.parametrize('n_items,k,kind', [
+    (51283, 40, 'uniform'), (51283, 40, 'quantised'), (51283, 64, 'equal'), (5000, 30, 'quantised'), (4097, 1, 'uniform'),
+    (100000, 20, 'quantised'), (399999, 5, 'two-level'), (6000, 64, 'negative'),
+])
+def test_topk_radix_select_is_k_argmax_passes(n_items, k, kind):
+    """evaluate.py:88-120 for large item counts: the radix select (three histogram passes over the value's key, two over the
+    ids when more items tie with the k-th value than fit) must pick exactly what k argmax passes with the lowest id first
+    among equal scores pick -- numpy's stable argsort of the masked / highlighted row -- on rows FULL of ties."""
+    from invpref_kdd_2022_amd._capi import check, lib, ptr, stream_ptr
+    rs = np.random.RandomState(n_items + k)
+    n = 6
+    r = rs.rand(n, n_items).astype(np.float32)
+    if kind == 'quantised':
+        r = np.round(r * 8) / 8              # nine distinct values: thousands of ties at the k-th place
+    elif kind == 'equal':
+        r[:] = 0.5
+    elif kind == 'two-level':
+        r = (r > 0.99999).astype(np.float32)
+    elif kind == 'negative':
+        r = -r
+        r[:, ::5] = 0.0
+        r[:, 1::5] = -0.0
+    r = r.astype(np.float32)
+    mask = [np.sort(rs.choice(n_items, rs.randint(0, 500), replace=False)) for _ in range(n)]
+    pool = [np.sort(rs.choice(n_items, rs.randint(1, 3 * k), replace=False)) for _ in range(n)]
+    truth = [np.sort(rs.choice(n_items, rs.randint(1, 50), replace=False)) for _ in range(n)]
+
+    def csr(lists):
+        p = np.zeros(len(lists) + 1, np.int32)
+        p[1:] = np.cumsum([len(a) for a in lists])
+        return torch.from_numpy(p).to(DEV), torch.from_numpy(np.concatenate(lists).astype(np.int32)).to(DEV)
+    (mp, mi), (hp, hi), (tp, ti) = csr(mask), csr(pool), csr(truth)
+    rd = torch.from_numpy(r).to(DEV)
+    for use_pool in (False, True):
+        items = torch.full((n, k), -1, dtype=torch.int32, device=DEV)
+        hits = torch.full((n, k), -1, dtype=torch.float32, device=DEV)
+        check(lib().invpref_eval_topk_hip(ptr(rd), n, n_items, ptr(mp), ptr(mi), ptr(hp) if use_pool else None,
+                                          ptr(hi) if use_pool else None, ptr(tp), ptr(ti), k, ptr(items), ptr(hits),
+                                          stream_ptr()), 'invpref_eval_topk_hip')
+        for j in range(n):
+            row = r[j].copy()
+            row[mask[j]] = -1024.0
+            if use_pool:
+                row[pool[j]] += 1024.0
+            order = np.argsort(-(row + 0.0), kind='stable')[:k]
+            np.testing.assert_array_equal(items[j].cpu().numpy(), order, err_msg=f'user {j} pool {use_pool}')
+            np.testing.assert_array_equal(hits[j].cpu().numpy(), np.isin(order, truth[j]).astype(np.float32))

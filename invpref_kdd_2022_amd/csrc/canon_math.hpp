@@ -93,6 +93,20 @@ __device__ __forceinline__ float c_bce(float s, float y) {
     return (y - 1.0f) * a - y * b;
 }
 
+// The same value for labels that are exactly 0 or 1 (the implicit path's data, train.py:130-135) with ONE logarithm: for y = 1 the
+// definition is (0 * a) - b = -b, for y = 0 it is -a - (0 * b) = -a -- a and b are finite after their clamps (a NaN logarithm
+// clamps to -100), so the dropped product is a signed zero and the result is the same float (up to the sign of a zero result,
+// which no comparison or sum can see).  The caller checks the labels (a wave-uniform test) and keeps c_bce for anything else.
+__device__ __forceinline__ float c_bce_binary(float s, float y) {
+    const float x = -s, u = 1.0f + x;
+    const bool one = y == 1.0f;
+    float l = c_log(one ? s : u);
+    const float l1p = (u == 1.0f) ? x : l * (x / (u - 1.0f));     // c_log1p(-s) from log(1 - s)
+    l = one ? l : l1p;
+    l = l > -100.0f ? l : -100.0f;
+    return -l;
+}
+
 // aten binary_cross_entropy_backward: (s-y)/max((1-s)*s, 1e-12)
 __device__ __forceinline__ float c_dbce(float s, float y) {
     float d = (1.0f - s) * s;
@@ -117,6 +131,12 @@ __device__ __forceinline__ float f_bce(float s, float y) {
     float b = f_log(s);
     b = b > -100.0f ? b : -100.0f;
     return (y - 1.0f) * a - y * b;
+}
+// (labels exactly 0 or 1: one logarithm, see c_bce_binary)
+__device__ __forceinline__ float f_bce_binary(float s, float y) {
+    float l = f_log(y == 1.0f ? s : 1.0f - s);
+    l = l > -100.0f ? l : -100.0f;
+    return -l;
 }
 __device__ __forceinline__ float f_dbce(float s, float y) {
     float d = (1.0f - s) * s;

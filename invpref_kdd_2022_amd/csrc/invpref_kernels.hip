@@ -736,8 +736,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(ESTEP_NUM_SGPR)
             qmine = (l16 == c) ? q : qmine;
         }
         float dist;
-        if (implicit) dist = c_bce(sp * c_sigmoid(qmine), y);
-        else { const float r = (p + qmine) - y; dist = r * r; }
+        if (implicit) {
+            // labels of the implicit data are 0 or 1: ONE canonical logarithm per distance instead of two (same float, see
+            // canon_math.hpp: c_bce_binary); a wave that meets any other label takes the definition
+            const float sv = sp * c_sigmoid(qmine);
+            const bool binary = __builtin_amdgcn_ballot_w64(!(y == 0.0f || y == 1.0f)) == 0;
+            dist = binary ? c_bce_binary(sv, y) : c_bce(sv, y);
+        } else { const float r = (p + qmine) - y; dist = r * r; }
         if (eps_rows && l16 < t.E) dist = dist + eps_rows[s * t.E + l16];
         // train.py:192-196 with the row's permutation unranked on the device: position l16 of permutation row idx[s] of
         // the tie-break vector is element (packed >> 4 l16) & 15 of it (eps_unrank_kernel)

@@ -351,8 +351,13 @@ __device__ __forceinline__ void eval_interaction(Eval<EMAX> &o, float4 pu, float
     const float q = group_sum<LG>(dot4(f4mul(pa, qa), ev));
     if (implicit) {
         const float sp = f_sigmoid(p), sq = f_sigmoid(q), sv = sp * sq;
-        o.li = f_bce(sp, y);
-        o.le = f_bce(sv, y);
+        // (labels exactly 0 or 1 -- the implicit data, train.py:130-135 -- need one logarithm per loss; wave-uniform test)
+        o.li = f_bce_binary(sp, y);
+        o.le = f_bce_binary(sv, y);
+        if (__builtin_amdgcn_ballot_w64(!(y == 0.0f || y == 1.0f)) != 0) {   // (never with the reference's implicit data)
+            o.li = f_bce(sp, y);
+            o.le = f_bce(sv, y);
+        }
         const float d_inv = k.ca * cw_rec * f_dbce(sp, y);
         const float d_env = k.cb * cw_rec * f_dbce(sv, y);
         o.g_p = (d_inv + d_env * sq) * (sp * (1.f - sp));
@@ -508,7 +513,8 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
         stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
         stage_small(sW, t.W, t.E, t.D, EMAX, DP);
         if (threadIdx.x < EMAX) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
-        if (threadIdx.x < EMAX) scw[threadIdx.x] = (by_env && threadIdx.x < t.E) ? a.weights[threadIdx.x] : 1.f;
+        if (threadIdx.x < EMAX)   // (a 32-bit offset from the scalar base: an address pair held across the rounds went to scratch memory)
+                    scw[threadIdx.x] = (by_env && threadIdx.x < t.E) ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + (threadIdx.x & (EMAX - 1)) * 4u) : 1.f;
     }
     if (!G::REG)
         for (int i = threadIdx.x; i < EMAX * DP; i += kThreads) sdE[i] = 0.f;
@@ -659,7 +665,8 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 stage_small(sEv, t.Ev, t.E, t.D, EMAX, DP);
                 stage_small(sW, t.W, t.E, t.D, EMAX, DP);
                 if (threadIdx.x < EMAX) sb[threadIdx.x] = (threadIdx.x < t.E && t.b) ? t.b[threadIdx.x] : 0.f;
-                if (threadIdx.x < EMAX) scw[threadIdx.x] = (by_env && threadIdx.x < t.E) ? a.weights[threadIdx.x] : 1.f;
+                if (threadIdx.x < EMAX)   // (a 32-bit offset from the scalar base: an address pair held across the rounds went to scratch memory)
+                    scw[threadIdx.x] = (by_env && threadIdx.x < t.E) ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + (threadIdx.x & (EMAX - 1)) * 4u) : 1.f;
             }
             __syncthreads();   // staged tables visible (the gathers above are in flight)
             STAMP(3);

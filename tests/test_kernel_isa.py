@@ -30,7 +30,11 @@ def test_full_row_instances_have_no_scratch_traffic(kernels):
     # and every 16-lane wide instance on full rows
     # (eval instances: <..., BYENV> -- the class-weight form of INVPREF_WEIGHTS_BY_ENV the managers' epochs run, and the
     #  per-interaction-weight form of train_a_batch on caller tensors)
-    for name in ('mstep_eval_kernel<16, true, 4, true>', 'mstep_apply_kernel<16, true, 4, true>',
+    # (the Yahoo two-launch instance keeps ONE address pair of its once-per-task table staging in scratch memory -- loop depth
+    #  1, the rounds; nothing inside the interaction loop)
+    k0 = ks['mstep_eval_kernel<16, true, 4, true>']
+    assert k0['scratch_ops_in_loops'] == 0 and k0['scratch_ops'] <= 2, k0
+    for name in ('mstep_apply_kernel<16, true, 4, true>',
                  'mstep_eval_wide_kernel<16, 2, true, 8, false, true>', 'mstep_eval_wide_kernel<16, 2, true, 8, false, false>',
                  'mstep_apply_wide_kernel<16, 2, true, 8, false>',
                  'mstep_eval_wide_kernel<16, 1, true, 8, false, true>', 'mstep_eval_wide_kernel<16, 1, true, 16, false, true>',

@@ -127,7 +127,7 @@ class _BasicTrainManager(_InvPrefTrainManager):
         self.n_total, self.batch_size = n_total, batch_size
         self.batch_num = math.ceil(n_total / batch_size)
         forced = os.environ.get('INVPREF_FORCE_SHARDED_PATH', '0') == '1'
-        self.shard_mode = os.environ.get('INVPREF_SHARD', 'users') if (self.world_size > 1 or forced) else 'rows'
+        self.shard_mode = os.environ.get('INVPREF_SHARD', 'rows') if (self.world_size > 1 or forced) else 'rows'
         if self.shard_mode == 'users':
             self.shard = UserShard(training_data[:, 0].cpu().numpy(), n_total, batch_size, model.user_num, self.rank,
                                    self.world_size)
@@ -150,7 +150,7 @@ class _BasicTrainManager(_InvPrefTrainManager):
         self.cluster_interval = 1 << 62
         self.model.to(self.device)
         # (row-sharded: reduce-scatter / slice Adam / all-gather exchange like the InvPref managers, train.py)
-        self.exchange = os.environ.get('INVPREF_EXCHANGE', 'scatter') if self.shard_mode == 'rows' else 'allreduce'
+        self.exchange = os.environ.get('INVPREF_EXCHANGE', 'allreduce') if self.shard_mode == 'rows' else 'allreduce'
         self.state = FlatState(model.tables(), self.device,     # [user table | item table]: the shared part is last
                                chunks=self.world_size if self.exchange == 'scatter' else 1)
         self._setup_ranges(model)

@@ -12,8 +12,10 @@ the work inside is re-designed for MI355X:
 * no per-batch host syncs: ``train_a_epoch`` reads the loss terms back once per epoch.
 
 Sharding (parallel.py): with ``world_size`` G > 1 every rank keeps only its share of
-every minibatch ``[kB,(k+1)B)`` -- by default the interactions of the users it owns (only the item-side
-gradient is all-reduced), with INVPREF_SHARD=rows a contiguous row slice (everything all-reduced).
+every minibatch ``[kB,(k+1)B)`` -- by default (round 6: what BASELINE.json's north_star names) a contiguous row
+slice, parameters replicated, ONE all-reduce of the flat gradient per optimiser step (INVPREF_EXCHANGE=scatter |
+packed: the same sums as reduce-scatter + all-gather / over the touched rows only); with INVPREF_SHARD=users the
+interactions of the users it owns (only the item-side gradient is all-reduced).
 Every mean() keeps the GLOBAL batch length as denominator, so summing the per-rank gradient
 buffers reproduces the single-GPU gradient.
 """
@@ -129,11 +131,11 @@ class _InvPrefTrainManager:
         self.n_total = n_total
         self.batch_size = batch_size
         self.batch_num = math.ceil(n_total / batch_size)
-        # multi-GPU: users are partitioned by default (parallel.UserShard: only the item-side gradient is
-        # all-reduced); INVPREF_SHARD=rows selects the literal row split with fully replicated parameters
+        # multi-GPU: the literal row split of SURVEY 8(e) / north_star by default (parallel.RowShard, parameters replicated);
+        # INVPREF_SHARD=users partitions the users instead (parallel.UserShard: only the item-side gradient is all-reduced)
         # (testing aid INVPREF_FORCE_SHARDED_PATH=1: the sharded step sequence, either layout, on one rank)
         forced = os.environ.get('INVPREF_FORCE_SHARDED_PATH', '0') == '1'
-        self.shard_mode = os.environ.get('INVPREF_SHARD', 'users') if (self.world_size > 1 or forced) else 'rows'
+        self.shard_mode = os.environ.get('INVPREF_SHARD', 'rows') if (self.world_size > 1 or forced) else 'rows'
         if self.shard_mode not in ('users', 'rows'):
             raise ValueError('INVPREF_SHARD must be "users" or "rows"')
         if self.shard_mode == 'users':
@@ -188,7 +190,7 @@ class _InvPrefTrainManager:
         # Adam stream cut G-fold); "allreduce" = SURVEY 8(e) as written: every rank reduces and updates everything; "packed" =
         # the all-reduce over the rows the GLOBAL minibatch touches only (+ the small tables): every other gradient row is
         # zero on every rank, so nothing else needs the wire (_setup_packed)
-        self.exchange = os.environ.get('INVPREF_EXCHANGE', 'scatter') if self.shard_mode == 'rows' else 'allreduce'
+        self.exchange = os.environ.get('INVPREF_EXCHANGE', 'allreduce') if self.shard_mode == 'rows' else 'allreduce'
         if self.exchange not in ('scatter', 'allreduce', 'packed'):
             raise ValueError('INVPREF_EXCHANGE must be "scatter", "allreduce" or "packed"')
         self.state = FlatState(model.tables(), self.device,
@@ -539,6 +541,16 @@ class _InvPrefTrainManager:
         if host is None:
             host = self._alt_host = (self.users_tensor.cpu().numpy(), self.items_tensor.cpu().numpy(),
                                      self.scores_tensor.cpu().numpy().astype(np.float32))
+        # The alternating form EVALUATES from the items' side every other step: a row's interactions are spread over at most 32
+        # slices and each slice evaluates its share one after the other (~1.3 us each).  With 8 192-row Yahoo minibatches the
+        # hottest item has 60-77 interactions -- three per slice; with one minibatch per epoch (SURVEY 8(d)-4's B = N variant:
+        # 250 interactions per item on average) the chains are tens of evaluations long and the two-launch form, whose item
+        # side only SUMS contribution rows, is twice as fast (measured: 199 vs 101 us per step).  Decided on the first
+        # minibatch's heaviest row; INVPREF_ALT_MAX_CHAIN overrides the bound.
+        lo0, n0 = self._raw_batches[0][0], self._raw_batches[0][1]
+        heavy = max(int(np.bincount(host[0][lo0:lo0 + n0]).max(initial=0)), int(np.bincount(host[1][lo0:lo0 + n0]).max(initial=0)))
+        if -(-heavy // 32) > int(os.environ.get('INVPREF_ALT_MAX_CHAIN', '6')):
+            return
         self._alt = dict(plans={}, host_plans={}, n_cap=n_cap, partials_cap=n_cap // 4 + n_cap // 8 + 128, ws=None,
                          build_s=0.0)
         if prev is not None and prev['n_cap'] == n_cap:

@@ -318,7 +318,7 @@ def test_managers_raise_when_an_alternating_launch_times_out(tmp_path):
     lib = build.build_variant('alt_timeout', ['-DALT_TEST_BAD_TAG=1', '-DALT_POLL_MAX=8'])
     script = tmp_path / 'timeout_case.py'
     script.write_text(_TIMEOUT_SCRIPT)
-    env = dict(os.environ, INVPREF_LIB=lib, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, INVPREF_LIB=lib, INVPREF_ALT_MAX_CHAIN='1000000', PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'RAISED train_epochs:' in out.stdout and 'RAISED train:' in out.stdout, out.stdout + out.stderr

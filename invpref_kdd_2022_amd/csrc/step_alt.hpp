@@ -82,7 +82,9 @@ __device__ __forceinline__ void st_sc1(int *p, int v) {
                                   //  so every wait times out -- with a small ALT_POLL_MAX -- and the managers must raise)
 #endif
 #ifndef ALT_STREAM_DELAY
-#define ALT_STREAM_DELAY 0        // s_sleep units of 64 clocks in front of a stream task (evaluating launches)
+#define ALT_STREAM_DELAY 40       // s_sleep units of 64 clocks in front of a stream task (evaluating launches): ~1 us.  Round 5 measured
+                                  // no gain from it (16.0 vs 15.95 us); with the pushes written through and two pending pairs in flight
+                                  // (round 6) the rows without a job DO queue in front of the jobs' first burst: 14.08 -> 13.97 us
 #endif
 #ifndef ALT_PEND_COND
 #define ALT_PEND_COND 0           // (A/B knob: 1 = the first pending-row loads only for waves that have pending rows -- measured
@@ -109,7 +111,9 @@ __device__ __forceinline__ void st_sc1(int *p, int v) {
                                   // reads them before the row's own job two launches on)
 #endif
 #ifndef ALT_PEND_DEPTH
-#define ALT_PEND_DEPTH 4          // pending contribution-row pairs in flight per group (two register sets)
+#define ALT_PEND_DEPTH 2          // pending contribution-row pairs in flight per group (two register sets).  Round 5: 4 (16.26 vs 16.43
+                                  // us); round 6, the pushed rows now written through (they come from the Infinity Cache, not from a
+                                  // neighbour's L2) and the first burst the launch's bottleneck: 2 is faster, 14.23 -> 14.08 us
 #endif
 
 // The small tables travel from the fold blocks to the job workgroups of the SAME launch as data-tagged granules: the fold

@@ -75,3 +75,8 @@ if fs:
                 f.write(f'D64,"{tag_of(r["Name"])}",{r["Calls"]},{float(r["AverageNs"])/1e3:.2f}\n')
 PY
 ls $OUT | head -80
+# the raw rocprofv3 output directories stay on the box (gpurun merges at most 64 MiB back): the summaries above are what is kept
+for d in stats stats_eager stats_two_launch pmc_fetch pmc_write large24_pmc_fetch_D64 large24_pmc_write_D64 large24_stats_D64 estep_stats; do rm -rf $OUT/$d; done
+rm -rf $OUT/extra_*/ 2>/dev/null
+(cd $R && git rev-parse HEAD 2>/dev/null || true) > /dev/null
+du -sh $OUT

@@ -504,17 +504,20 @@ def step_bench(dev, Us, Is, Es, Ds, Bs, n_steps, zipf=False, seed=5, note=''):
     del host_plans
     e = torch.from_numpy(rs.randint(0, Es, n_steps * Bs).astype(np.int64)).to(dev)
     yt = torch.from_numpy(data[:, 2].astype(np.float32)).to(dev)
-    w = torch.rand(n_steps * Bs, device=dev)
+    # sample weights as the managers' epochs take them since round 6: class_weights[env] formed in the kernel from the E class
+    # weights (train.py:274-278; INVPREF_WEIGHTS_BY_ENV) -- no N-length array read per interaction
+    from invpref_kdd_2022_amd import _capi
+    _, cw, _ = ops.stat_envs(e, Es, ops.Workspace(dev), want_sample_weights=False)
     ws = ops.Workspace(dev)
     losses = torch.zeros(6, device=dev)
     cf = [YAHOO[k] for k in ('invariant_coe', 'env_aware_coe', 'env_coe', 'L2_coe', 'L1_coe', 'alpha')]
-    flags = ops.flags_of(True, False, True, True, False)
+    flags = ops.flags_of(True, False, True, True, False) | _capi.WEIGHTS_BY_ENV
 
     def run():
         a, b = P, P2
         for k in range(n_steps):
             sl = slice(k * Bs, (k + 1) * Bs)
-            ops.mstep_rows_adam(a, b, M, V, plans[k], e[sl], yt[sl], w[sl], Bs, cf, flags, losses, k + 1, 0.005, ws)
+            ops.mstep_rows_adam(a, b, M, V, plans[k], e[sl], yt[sl], cw, Bs, cf, flags, losses, k + 1, 0.005, ws)
             a, b = b, a
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):

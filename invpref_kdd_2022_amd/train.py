@@ -1077,7 +1077,13 @@ class _InvPrefTrainManager:
             if with_eps:
                 dt = torch.from_numpy(np.zeros(0, self._perm_index_dtype())).dtype
                 n_loc = self.users_tensor.shape[0]
-                pinned = self.envs_num <= 7 and os.environ.get('INVPREF_EPS_PINNED', '1') != '0'   # (0: A/B, copy first)
+                # INVPREF_EPS_PINNED: 1 (default) = the kernel reads PINNED HOST memory in place (up to seven environments), 0 = a
+                # device buffer filled by a copy in front of the replay, "ahead" = a device buffer filled by a copy on a SIDE stream
+                # while the epochs enqueued before the E-step still run (_fill_eps).  Round 6 measured "ahead": the kernel 61.9 ->
+                # 54.8 us, the replay 69.9 -> 63.8 us -- and the bench's interval 80 us LONGER (15.15 vs 14.63 us per step): the copy's
+                # blit kernel and the cross-stream waits sit among launches that fill the chip exactly
+                mode = os.environ.get('INVPREF_EPS_PINNED', '1')
+                pinned = self.envs_num <= 7 and mode == '1'
                 eps_buf = torch.zeros(n_loc, dtype=dt, pin_memory=True) if pinned \
                     else torch.zeros(n_loc, dtype=dt, device=self.device)
 
@@ -1114,11 +1120,34 @@ class _InvPrefTrainManager:
             if done is not None:
                 done.synchronize()                 # (the previous replay has read the buffer)
             eps_buf.numpy()[:] = self._eps_index()
+        elif eps_buf is not None and os.environ.get('INVPREF_EPS_PINNED', '1') == 'ahead':
+            # the draws are host work that overlaps the epochs the GPU is still running; so does their copy: on a side stream,
+            # behind the previous replay's read of the buffer, in front of this replay (one event each way)
+            idx = self._eps_index()
+            stage = getattr(self, '_eps_stage', None)
+            if stage is None or stage.numel() != len(idx) or stage.dtype != eps_buf.dtype:
+                stage = self._eps_stage = torch.empty(len(idx), dtype=eps_buf.dtype, pin_memory=True)
+                self._eps_stage_done = None
+            if self._eps_stage_done is not None:
+                self._eps_stage_done.synchronize()      # (the previous copy has left the staging buffer)
+            stage.numpy()[:] = idx
+            side = getattr(self, '_eps_stream', None)
+            if side is None:
+                side = self._eps_stream = torch.cuda.Stream(device=self.device)
+            done = getattr(self, '_eps_read_done', None)
+            if done is not None:
+                side.wait_event(done)                   # (the previous replay has read the device buffer)
+            with torch.cuda.stream(side):
+                eps_buf.copy_(stage, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            torch.cuda.current_stream().wait_event(ev)
+            self._eps_stage_done = ev
         elif eps_buf is not None:
             self._eps_index_device(out=eps_buf)
 
     def _eps_replayed(self, eps_buf):
-        if eps_buf is not None and not eps_buf.is_cuda:
+        if eps_buf is not None and (not eps_buf.is_cuda or os.environ.get('INVPREF_EPS_PINNED', '1') == 'ahead'):
             self._eps_read_done = torch.cuda.Event()
             self._eps_read_done.record()
 

@@ -38,10 +38,19 @@ N = nb * B
 y = torch.from_numpy(data[:N, 2].astype(np.float32)).to(dev)
 e = torch.from_numpy(np.random.RandomState(3).randint(0, E, N).astype(np.int64)).to(dev)
 w = torch.rand(N, device=dev)
+BY_ENV = os.environ.get('PROBE_BY_ENV', '1') == '1'   # weights as the managers' epochs take them: class_weights[env] in the kernel
 ws = ops.Workspace(dev)
 losses = torch.zeros(6, device=dev)
 coefs = (3.35, 9.99, 9.06, 3.13, 0.49, 1.9)
 flags = ops.flags_of(True, False, True, True, False)
+if BY_ENV:
+    from invpref_kdd_2022_amd import _capi
+    flags |= _capi.WEIGHTS_BY_ENV
+    _, cw_env, _ = ops.stat_envs(e, E, ops.Workspace(dev), want_sample_weights=False)
+
+
+def wts(sl):
+    return cw_env if BY_ENV else w[sl]
 pls = [planlib.build_row_plan(data[k * B:(k + 1) * B, 0], data[k * B:(k + 1) * B, 1], data[k * B:(k + 1) * B, 2], U, I,
                               factor_num=D, env_num=E) for k in range(nb)]
 plans = [planlib.upload(p, dev) for p in pls]
@@ -53,7 +62,7 @@ def run_steps(first=0, last=None, flush=True, reset=True):
     a, b = P, P2
     for k in range(first, nb if last is None else last):
         sl = slice(k * B, (k + 1) * B)
-        ops.mstep_rows_adam(a, b, M, V, plans[k], e[sl], y[sl], w[sl], B, coefs, flags, losses, 5 + k, 0.005, ws)
+        ops.mstep_rows_adam(a, b, M, V, plans[k], e[sl], y[sl], wts(sl), B, coefs, flags, losses, 5 + k, 0.005, ws)
         a, b = b, a
     return nb
 
@@ -100,7 +109,7 @@ for rep in range(3):
     stamps.zero_()
     a, b = (P, P2) if ks % 2 == 0 else (P2, P)
     sl = slice(ks * B, (ks + 1) * B)
-    ops.mstep_rows_adam(a, b, M, V, plans[ks], e[sl], y[sl], w[sl], B, coefs, flags, losses, 5 + ks, 0.005, ws)
+    ops.mstep_rows_adam(a, b, M, V, plans[ks], e[sl], y[sl], wts(sl), B, coefs, flags, losses, 5 + ks, 0.005, ws)
 torch.cuda.synchronize()
 pl = pls[ks]
 ncls, cls = pl['n_classes'], np.asarray(pl['cls'])

@@ -124,9 +124,10 @@ int invpref_mstep_grad_hip(const InvPrefTables *tables, const InvPrefTables *gra
  *   meta = leader | slices << 1 | mode << 6 | row_count << 9       (idle slots carry slices too)
  *   user side: mode 0 / 1 / 2 = that many interactions inline as (item row, position, label bits) = (a, b, c),
  *              (d, e, f); mode 7: interactions [a, b) of user_list;
- *   item side: mode 0 .. 3 = that many interactions inline as (user row, position) = (a, b), (c, d), (e, f);
+ *   item side: mode 0 .. 3 = that many interactions inline as (user row, slot) = (a, b), (c, d), (e, f);
  *              mode 7: interactions [a, b) of item_list.
- * `position` indexes the minibatch slices of envs / sample_weights and the record array.  Every row of every
+ * `position` indexes the minibatch slices of envs / sample_weights; `slot` = rec_slot[position] = the interaction's
+ * index in item_list order indexes the record array.  Every row of every
  * table appears exactly once: in a job or in the stream list (rows the minibatch does not touch: they get the
  * dense-Adam step with a zero gradient, rows_per_stream_task rows per workgroup, in either launch). */
 typedef struct InvPrefRowPlan {
@@ -135,8 +136,8 @@ typedef struct InvPrefRowPlan {
     const int32_t *user_desc;                 /* [n_user_rounds][NG][8] */
     const int32_t *item_desc;                 /* [n_item_rounds][NG][8] */
     const int32_t *user_round_iters;          /* [n_user_rounds] interactions of the round's longest slice */
-    const int32_t *user_list;                 /* [n][4] {item row, position, label bits, 0}, sorted by user row */
-    const int32_t *item_list;                 /* [n][2] {user row, position}, sorted by item row */
+    const int32_t *user_list;                 /* [n][4] {item row, position, label bits, slot}, sorted by user row */
+    const int32_t *item_list;                 /* [n][2] {user row, slot}, sorted by item row (entry s has slot s) */
     int32_t n_stream, rows_per_stream_task;
     const int32_t *stream_rows;               /* [n_stream] row id; bit 30 set: a row of the item tables */
     /* XCD-affine task order (speed only; any order gives the same results).  n_classes = 8 (the XCDs of an MI355X), or
@@ -155,6 +156,11 @@ typedef struct InvPrefRowPlan {
      * must be of mode 7 (or 0) with [a, b) = the slice's slots.  One extra row write + read per interaction and table: for
      * minibatches whose rows are a small share of the step's bytes (plan.py decides). */
     const int32_t *push_slot;                 /* [n] */
+    /* required: rec_slot[position] = the interaction's index in item_list order (its "slot").  Launch 1 stores the record
+     * launch 2 consumes (pull form) at THAT index of the workspace, so that an item job's slice of records is contiguous
+     * and read front to back; user_list's word 3 and the second word of every item-side id pair (item_list, inline
+     * descriptors) hold the slot as well.  In push form push_slot is this same array. */
+    const int32_t *rec_slot;                  /* [n] */
 } InvPrefRowPlan;
 
 /* Scratch of one planned step: the records + the partial slabs.  It needs no initialisation (every word is stored

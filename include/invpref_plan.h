@@ -23,7 +23,7 @@ typedef struct InvPrefPlanParams {
     int32_t rounds_per_task, item_rounds_per_task;
     int32_t n_classes;                /* 1 .. 8 */
     int32_t rows_per_stream_task;
-    int32_t push;                     /* item side in push form: no inline interactions, push_slot produced */
+    int32_t push;                     /* item side in push form: no inline interactions (rec_slot serves as push_slot) */
     int32_t user_lo, user_hi;         /* untouched user rows outside [user_lo, user_hi) are not streamed; (0, user_num) = all */
     int32_t fill_cap;                 /* launch-1 residency the stream split fills (0: plain split) */
     int32_t snake_user;               /* > 0: launch 1's rounds of a class heaviest first, every other row of this many reversed
@@ -33,8 +33,9 @@ typedef struct InvPrefPlanParams {
 
 typedef struct InvPrefHostPlan InvPrefHostPlan;
 
-/* which: 0 user_desc [rounds][NG][8] | 1 item_desc | 2 user_round_iters | 3 user_list [n][4] | 4 item_list [n][2] |
- *        5 stream_rows | 6 push_slot (length 0 without push) | 7 cls [8][8] */
+/* which: 0 user_desc [rounds][NG][8] | 1 item_desc | 2 user_round_iters | 3 user_list [n][4] = (item, position, label
+ *        bits, slot) | 4 item_list [n][2] = (user, slot) | 5 stream_rows | 6 rec_slot [n] (position -> slot = index in the
+ *        item order; InvPrefRowPlan.rec_slot, and .push_slot in push form) | 7 cls [8][8] */
 InvPrefHostPlan *invpref_plan_build(const int64_t *users, const int64_t *items, const float *scores, int64_t n,
                                     int64_t user_num, int64_t item_num, const InvPrefPlanParams *params);
 int64_t invpref_plan_array(const InvPrefHostPlan *plan, int32_t which, const int32_t **data);

@@ -256,9 +256,9 @@ InvPrefHostPlan *build(const int64_t *users, const int64_t *items, const float *
     InvPrefHostPlan *hp = new InvPrefHostPlan();
     std::vector<int32_t> &uit = hp->arr[2], &sr = hp->arr[5];
     // the sorted lists are written where the sort places each interaction: user_list [n][4] = (item, position, label bits,
-    // 0), item_list [n][2] = (user, position); push_slot[position] = the interaction's slot in the item order
+    // slot), item_list [n][2] = (user, slot); rec_slot[position] = the interaction's slot = its index in the item order
     int32_t *const ul = hp->alloc(3, (size_t)n * 4), *const il = hp->alloc(4, (size_t)n * 2);
-    int32_t *const ps = p.push ? hp->alloc(6, (size_t)n) : nullptr;
+    int32_t *const ps = hp->alloc(6, (size_t)n);
     lap("allocate lists");
     Side us, is;
     const int half = std::max(1, nt / 2);
@@ -270,15 +270,14 @@ InvPrefHostPlan *build(const int64_t *users, const int64_t *items, const float *
                 int32_t *d = L + (size_t)j * 4;
                 d[0] = (int32_t)items[i];
                 d[1] = (int32_t)i;
-                std::memcpy(d + 2, scores + i, 4);
-                d[3] = 0;
+                std::memcpy(d + 2, scores + i, 4);   // (word 3, the slot: below, once the item side has sorted)
             });
         } else {
             int32_t *L = il, *P = ps;
             ok[1] = sort_side(items, n, I, is, half, [&](int64_t i, int64_t j) {
                 L[(size_t)j * 2] = (int32_t)users[i];
-                L[(size_t)j * 2 + 1] = (int32_t)i;
-                if (P) P[(size_t)i] = (int32_t)j;
+                L[(size_t)j * 2 + 1] = (int32_t)j;
+                P[(size_t)i] = (int32_t)j;
             });
         }
     });
@@ -287,6 +286,14 @@ InvPrefHostPlan *build(const int64_t *users, const int64_t *items, const float *
         return nullptr;
     }
     lap("sort both sides");
+    {   // the slot of every entry of the user list (the item side's sort has placed them all by now)
+        const int chunks = nt > 1 ? nt * 4 : 1;
+        parallel_for(chunks, nt, [&](int c) {
+            const int64_t lo = n * c / chunks, hi = n * (c + 1) / chunks;
+            for (int64_t k = lo; k < hi; k++) ul[(size_t)k * 4 + 3] = ps[(size_t)ul[(size_t)k * 4 + 1]];
+        });
+    }
+    lap("slots into the user list");
     // touched rows of every class, in increasing order
     std::vector<std::vector<int32_t>> urows((size_t)ncls), irows((size_t)ncls);
     for (int64_t r = 0; r < U; r++)

@@ -232,8 +232,8 @@ __device__ __forceinline__ void adam4(float4 &p, float4 g, float4 &m, float4 &v,
 struct StepArgs {
     const int4 *desc;             // [rounds][NG][2]: see InvPrefRowPlan in include/invpref_hip.h
     const int *round_iters;       // launch 1: [rounds] longest slice of the round (E > 4 instances: uniform loop count)
-    const int4 *ulist;            // launch 1: [n] {item row, position, label bits, 0} sorted by user row
-    const int2 *ilist;            // launch 2: [n] {user row, position} sorted by item row
+    const int4 *ulist;            // launch 1: [n] {item row, position, label bits, slot} sorted by user row
+    const int2 *ilist;            // launch 2: [n] {user row, slot} sorted by item row
     const int64_t *envs;          // minibatch base pointers, indexed by position
     const float *weights;
     StepScalars k;
@@ -257,7 +257,9 @@ struct StepArgs {
     // (16 unused bytes keep the kernel-argument offsets of rounds 4-5: with the block two pointers shorter hipcc's scalar-register
     //  allocation of mstep_eval_wide_kernel<16, 2, true, 8, false> -- the MovieLens instance, at 100 SGPRs -- spills nine of them
     //  and the dispatch then sets up a private segment; tests/test_kernel_isa.py holds that instance to a segment size of 0)
-    void *reserved_[2];
+    const int *rec_slot;          // [n] position -> slot (index in item order): where launch 1 leaves the interaction's record /
+                                  // contribution rows (InvPrefRowPlan::rec_slot; push form: the same array as push_slot)
+    void *reserved_[1];
     int stamps_nodrain;
     unsigned long long *stamps;   // diagnostic (INVPREF_STAMPS): [workgroup][8] s_memrealtime ticks
 };
@@ -468,6 +470,9 @@ struct USample {
 #ifndef STEP_EVAL_DEPTH
 #define STEP_EVAL_DEPTH 3
 #endif
+#ifndef STEP_SLOT_FROM_LIST
+#define STEP_SLOT_FROM_LIST 1   // launch 1 takes an interaction's slot from its list entry (0: always from rec_slot[position], a random read)
+#endif
 #ifndef STEP_ROW_ST
 #define STEP_ROW_ST 1   // write-through stores for the rows the two-launch jobs finish (p', m', v': nothing of them is read again before
                         // the next step; left dirty in L2 they lengthen the kernel boundary).  Round 6, same box: 2^24 interactions at
@@ -584,7 +589,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
         };
         Slot sl[UE];
         USample idn[UE];   // (list form: the ids run UE interactions ahead of the rows)
-        auto gather = [&](Slot &q, const USample &sm) {
+        auto gather = [&](Slot &q, const USample &sm, int sidx) {
             q.sm = sm;
             q.qi = row4<VEC, FULL>(t.Qi, sm.oth, t.D, lg);
             if (FULL) {   // (32-bit offsets: one address register each, nothing to copy a loaded index into)
@@ -594,7 +599,11 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                     q.e = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.envs) + pso * 8u);   // low word of the int64 id
                 }
                 if ((rw_rec || rw_cls) && !by_env) q.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + pso * 4u);
-                if (push) q.cs = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.push_slot) + pso * 4u);
+                // the slot: word 3 of the list entry the ids came from (a line that was just read) or, inline form, rec_slot[position]
+                // -- one load from a selected address again
+                const int *sp = mode == 7 ? reinterpret_cast<const int *>(a.ulist + min(s_lo + sidx, s_hi1)) + 3
+                                          : reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.rec_slot) + pso * 4u);
+                q.cs = STEP_SLOT_FROM_LIST ? *sp : *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.rec_slot) + pso * 4u);
                 return;
             }
             if (!pure) {
@@ -602,7 +611,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 q.e = (int)a.envs[sm.ps];
             }
             if ((rw_rec || rw_cls) && !by_env) q.w = a.weights[sm.ps];
-            if (push) q.cs = a.push_slot[sm.ps];
+            q.cs = a.rec_slot[sm.ps];
         };
 #pragma unroll
         for (int j = 0; j < UE; j++) {
@@ -632,13 +641,13 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
             for (int j = 0; j < UE; j++) {
                 USample sm = ls[j];
                 if (mode != 7) sm = j == 0 ? USample{dd.z, dd.w, __builtin_bit_cast(float, dd1.x)} : USample{dd1.y, dd1.z, __builtin_bit_cast(float, dd1.w)};
-                gather(sl[j], sm);
+                gather(sl[j], sm, j);
                 idn[j] = ls[UE + j];
             }
         } else {
 #pragma unroll
             for (int j = 0; j < UE; j++)
-                if (j < nsmp) gather(sl[j], sample_at(j));
+                if (j < nsmp) gather(sl[j], sample_at(j), j);
 #pragma unroll
             for (int j = 0; j < UE; j++)
                 if (UE + j < nsmp) idn[j] = sample_at(UE + j);
@@ -695,8 +704,8 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                     store4<STEP_PUSH_ST>(cr, f4mul(gip, oi));
                     store4<STEP_PUSH_ST>(cr + DP, f4scale(o.g_q, f4mul(oe, ev)));
                 } else {
-                    // pull form: the record the item side consumes
-                    float *rec_g = a.records + (unsigned)q.sm.ps * (unsigned)RS;
+                    // pull form: the record the item side consumes, at the interaction's slot in the item order
+                    float *rec_g = a.records + (unsigned)q.cs * (unsigned)RS;
                     if (lg == 0)
                         *reinterpret_cast<float4 *>(rec_g) = make_float4(o.g_p, o.g_q, __builtin_bit_cast(float, e), 0.f);
                     if (EMAX <= 4) {
@@ -790,7 +799,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
 #pragma unroll
             for (int j = 0; j < UE; j++) {
                 if (s + j < iters) step(sl[j], s + j < nsmp);   // (E > 8: `iters` is uniform, the barrier inside is too)
-                if (FULL || s + UE + j < nsmp) gather(sl[j], idn[j]);
+                if (FULL || s + UE + j < nsmp) gather(sl[j], idn[j], s + UE + j);
                 if (FULL || s + 2 * UE + j < nsmp) idn[j] = sample_at(s + 2 * UE + j);
             }
         }
@@ -1697,7 +1706,7 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
         plan->item_rounds_per_task <= 0 || plan->n_user_rounds % plan->user_rounds_per_task != 0 ||
         plan->n_item_rounds % plan->item_rounds_per_task != 0 || plan->rows_per_stream_task <= 0 || plan->n_stream < 0 ||
         (plan->n_user_rounds > 0 && (!plan->user_desc || !plan->user_round_iters)) ||
-        (plan->n_item_rounds > 0 && !plan->item_desc) || (plan->n > 0 && (!plan->user_list || !plan->item_list)) ||
+        (plan->n_item_rounds > 0 && !plan->item_desc) || (plan->n > 0 && (!plan->user_list || !plan->item_list || !plan->rec_slot)) ||
         (plan->n_stream > 0 && !plan->stream_rows))
         return INVPREF_EINVAL;
     const int ncls = plan->n_classes > 0 ? plan->n_classes : 1;
@@ -1725,6 +1734,7 @@ int launch_step(const InvPrefTables *tables, const InvPrefRowPlan *plan, const i
     a.slabs_ev = a.slabs + slab * (size_t)(n_partials > 0 ? n_partials : 1);
     a.n_rec = plan->n;
     a.push_slot = plan->push_slot;
+    a.rec_slot = plan->push_slot ? plan->push_slot : plan->rec_slot;
     a.sched_state = sched ? sched->state : nullptr;
     a.sched_slot = sched ? (sched->slot & 1) : 0;
     static const char *stamp_env = getenv("INVPREF_STAMPS");   // diagnostics: device pointer (hex) of a stamp buffer

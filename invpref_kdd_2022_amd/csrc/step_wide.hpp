@@ -431,13 +431,12 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
         }
         struct Slot {
             float4 qi[NC], qa[NC];
-            int ps, e, cs;
+            int e, cs;   // cs: the interaction's slot in the item order (where its record / contribution rows go)
             float y, w;
         };
         Slot sl[UE];
         USample idn[UE];
-        auto gather = [&](Slot &q, const USample &sm) {
-            q.ps = sm.ps;
+        auto gather = [&](Slot &q, const USample &sm, int sidx) {
             q.y = sm.y;
 #ifdef WIDE_DIAG_HOT   // (what-if build: every gather hits the same few rows -- what the launch costs without gather latency)
             const int oth = sm.oth & 15;
@@ -451,7 +450,10 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
                 q.e = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.envs) + pso * 8u);   // low word of the int64 id
             }
             if ((rw_rec || rw_cls) && !by_env) q.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + pso * 4u);
-            if (push) q.cs = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.push_slot) + pso * 4u);
+            // the slot: word 3 of the list entry the ids came from or, inline form, rec_slot[position] -- one load, selected address
+            const int *sp = mode == 7 ? reinterpret_cast<const int *>(a.ulist + min(lo + sidx, hi1)) + 3
+                                      : reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.rec_slot) + pso * 4u);
+            q.cs = STEP_SLOT_FROM_LIST ? *sp : *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.rec_slot) + pso * 4u);
         };
         // the slice's FIRST interaction is in the descriptor's registers either way (inline form: words 2 .. 4, list form:
         // words 4 .. 6), so its gather leaves as soon as the descriptor is here -- not one list round trip later
@@ -461,11 +463,11 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
         for (int j = 0; j < UE; j++) {
 #pragma unroll
             for (int c = 0; c < NC; c++) sl[j].qi[c] = sl[j].qa[c] = f4zero();
-            sl[j].ps = sl[j].e = sl[j].cs = 0;
+            sl[j].e = sl[j].cs = 0;
             sl[j].y = 0.f;
             sl[j].w = 1.f;
-            if (WIDE_FIRST_FROM_DESC && LG == 16 && j == 0) gather(sl[j], first);
-            else gather(sl[j], list_at(j));
+            if (WIDE_FIRST_FROM_DESC && LG == 16 && j == 0) gather(sl[j], first, 0);
+            else gather(sl[j], list_at(j), j);
         }
 #pragma unroll
         for (int j = 0; j < UE; j++) idn[j] = list_at(UE + j);
@@ -544,7 +546,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
             if (!push) {
                 // pull form: the record {g_p, g_q, env, 0, gz[EMAX]} the item side consumes -- one word per lane, every lane
                 // (lanes beyond the record repeat its last word), so that the store is one unconditional wave instruction
-                float *rec_g = a.records + (unsigned)(has ? q.ps : a.n_rec) * (unsigned)RS;
+                float *rec_g = a.records + (unsigned)(has ? q.cs : a.n_rec) * (unsigned)RS;
                 // (gz of this interaction was written by the evaluation above: LDS operations of one wave execute in order.  No
                 //  asm fence here: its memory clobber made the compiler split the record's store -- +15 % fabric writes)
                 const float gzw = pure ? 0.f : gzs[min(max(lg - 4, 0), EMAX - 1)];
@@ -580,7 +582,7 @@ __device__ __forceinline__ void user_task_wide(const DevTables &t, const StepArg
 #pragma unroll
             for (int j = 0; j < UE; j++) {
                 if (s + j < iters) step(sl[j], s + j < nsmp);
-                gather(sl[j], idn[j]);
+                gather(sl[j], idn[j], s + UE + j);
                 idn[j] = list_at(s + 2 * UE + j);
                 WTRACE(6);
             }

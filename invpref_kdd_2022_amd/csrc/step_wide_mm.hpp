@@ -188,13 +188,12 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
         }
         struct Slot {
             float4 qi[NC], qa[NC];
-            int ps, e, cs;
+            int e, cs;   // cs: the interaction's slot in the item order (where its record / contribution rows go)
             float y, w;
         };
         Slot sl[UE];
         USample idn[UE];
-        auto gather = [&](Slot &q, const USample &sm) {
-            q.ps = sm.ps;
+        auto gather = [&](Slot &q, const USample &sm, int sidx) {
             q.y = sm.y;
 #ifdef MM_DIAG_HOT
             const int oth = sm.oth & 15;
@@ -206,7 +205,10 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
             load_row<LG, NC, VEC>(q.qa, t.Qa, oth, t.D, lg);
             q.e = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.envs) + pso * 8u);   // low word of the int64 id
             if ((rw_rec || rw_cls) && !by_env) q.w = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.weights) + pso * 4u);
-            if (push) q.cs = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.push_slot) + pso * 4u);
+            // the slot: word 3 of the list entry the ids came from or, inline form, rec_slot[position] -- one load, selected address
+            const int *sp = mode == 7 ? reinterpret_cast<const int *>(a.ulist + min(lo + sidx, hi1)) + 3
+                                      : reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.rec_slot) + pso * 4u);
+            q.cs = STEP_SLOT_FROM_LIST ? *sp : *reinterpret_cast<const int *>(reinterpret_cast<const char *>(a.rec_slot) + pso * 4u);
         };
         const USample first = mode == 7 ? USample{dd2.x, dd2.y, __builtin_bit_cast(float, dd2.z)}
                                         : USample{dd.z, dd.w, __builtin_bit_cast(float, dd2.x)};
@@ -214,11 +216,11 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
         for (int j = 0; j < UE; j++) {
 #pragma unroll
             for (int c = 0; c < NC; c++) sl[j].qi[c] = sl[j].qa[c] = f4zero();
-            sl[j].ps = sl[j].e = sl[j].cs = 0;
+            sl[j].e = sl[j].cs = 0;
             sl[j].y = 0.f;
             sl[j].w = 1.f;
-            if (WIDE_FIRST_FROM_DESC && LG == 16 && j == 0) gather(sl[j], first);
-            else gather(sl[j], list_at(j));
+            if (WIDE_FIRST_FROM_DESC && LG == 16 && j == 0) gather(sl[j], first, 0);
+            else gather(sl[j], list_at(j), j);
         }
 #pragma unroll
         for (int j = 0; j < UE; j++) idn[j] = list_at(UE + j);
@@ -281,7 +283,7 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
                     float4 m4;
                     m4.x = has ? k.cc * (w_cls * k.invB) : 0.f;
                     m4.y = __builtin_bit_cast(float, has ? e : -100);
-                    m4.z = __builtin_bit_cast(float, has ? q.ps : a.n_rec);
+                    m4.z = __builtin_bit_cast(float, has ? q.cs : a.n_rec);
                     m4.w = has ? w_cls : 0.f;
                     *reinterpret_cast<float4 *>(sM + 4 * grp) = m4;
                 }
@@ -304,7 +306,7 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
                 accL1 += has ? s1 : 0.f;
                 if (!push) {
                     // pull form: the head {g_p, g_q, env, 0} of the record the item side consumes (the waves add gz[EMAX] below)
-                    float *rec_g = a.records + (unsigned)(has ? q.ps : a.n_rec) * (unsigned)RS;
+                    float *rec_g = a.records + (unsigned)(has ? q.cs : a.n_rec) * (unsigned)RS;
                     const float val = lg == 0 ? g_p : (lg == 1 ? g_q : (lg == 2 ? __builtin_bit_cast(float, e) : 0.f));
                     rec_g[min(lg, 3)] = val;
                 }
@@ -443,7 +445,7 @@ __device__ __forceinline__ void user_task_wide_mm(const DevTables &t, const Step
             for (int j = 0; j < UE; j++) {
                 if (s + j < iters) step(sl[j], s + j < nsmp);
                 WTRACE(26);
-                gather(sl[j], idn[j]);
+                gather(sl[j], idn[j], s + UE + j);
                 idn[j] = list_at(s + 2 * UE + j);
                 WTRACE(6);
             }

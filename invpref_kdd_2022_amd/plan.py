@@ -38,11 +38,15 @@ class RowPlanStruct(C.Structure):
                 ('user_desc', C.c_void_p), ('item_desc', C.c_void_p), ('user_round_iters', C.c_void_p),
                 ('user_list', C.c_void_p), ('item_list', C.c_void_p), ('n_stream', C.c_int32),
                 ('rows_per_stream_task', C.c_int32), ('stream_rows', C.c_void_p), ('n_classes', C.c_int32),
-                ('rows_per_stream_task2', C.c_int32), ('cls', C.c_int32 * 64), ('push_slot', C.c_void_p)]
+                ('rows_per_stream_task2', C.c_int32), ('cls', C.c_int32 * 64), ('push_slot', C.c_void_p),
+                ('rec_slot', C.c_void_p)]
 
 
-ARRAYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list', 'stream_rows', 'push_slot')
+ARRAYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list', 'stream_rows', 'rec_slot', 'push_slot')
 OPTIONAL_ARRAYS = ('push_slot',)   # may be absent (plan[k] is None; meta offset -1; NULL in the struct)
+# rec_slot[position] = the interaction's index in item_list order ("slot"): launch 1 stores what it hands to launch 2 THERE --
+# the record (pull form) or the two contribution rows (push form: push_slot is the same array) -- so that launch 2's item
+# jobs read their slices of the workspace front to back; user_list's word 3 and item_list's word 1 carry the slot too.
 
 N_CLASSES = 8          # XCDs of an MI355X: blocks b and b + 8 of a launch share one (round-robin placement)
 CUS_PER_XCD = 32       # ... and inside an XCD tasks j, j + 32, j + 64 of a class share a CU (tools/probes/cu_map.hip)
@@ -73,7 +77,7 @@ def row_class(rows: np.ndarray, n_classes: int) -> np.ndarray:
 def _side_rounds(own, cols, n_rows: int, ng: int, per_slice: int, pad_to: int, inline: int, skip, snake: int = 0):
     """(desc [n_rounds, ng, 8] int32, iters [n_rounds]) for one side.  own: the side's row of every interaction in the
     side's sorted order; cols: the int32 columns of the sorted list (user side: partner, position, label bits; item
-    side: partner, position) -- `inline` interactions of a slice travel inside the descriptor, longer slices as a range
+    side: partner, slot) -- `inline` interactions of a slice travel inside the descriptor, longer slices as a range
     of the list.  skip: rows that get no job."""
     w = len(cols)
     cnt = np.bincount(own, minlength=n_rows).astype(np.int64)
@@ -187,7 +191,7 @@ class AltPlanParamsStruct(C.Structure):
 
 
 _NATIVE = None
-_NATIVE_ARRAYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list', 'stream_rows', 'push_slot', 'cls')
+_NATIVE_ARRAYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list', 'stream_rows', 'rec_slot', 'cls')
 
 
 def _native_lib():
@@ -263,7 +267,8 @@ def _plan_from_handle(L, h, r: dict) -> dict:
                 item_rounds_per_task=r['item_rounds_per_task'], user_desc=out['user_desc'].reshape(-1, ng, 8),
                 item_desc=out['item_desc'].reshape(-1, ng, 8), user_round_iters=out['user_round_iters'],
                 user_list=out['user_list'], item_list=out['item_list'],
-                push_slot=(out['push_slot'] if r['push'] else None), push=r['push'], stream_rows=out['stream_rows'], n_stream=sb,
+                rec_slot=out['rec_slot'], push_slot=(out['rec_slot'] if r['push'] else None), push=r['push'],
+                stream_rows=out['stream_rows'], n_stream=sb,
                 rows_per_stream_task=r['rows_per_stream_task'], rows_per_stream_task2=r['rows_per_stream_task2'],
                 stream_split=(float(cls[:, 3].sum()) / sb if (r['fill_cap'] and sb) else r['stream_split']),
                 n_classes=r['n_classes'], cls=cls.copy())
@@ -487,8 +492,10 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     pu = np.argsort(users, kind='stable')
     pi = np.argsort(items, kind='stable')
     ybits = scores.view(np.int32)
+    slot = np.empty(n, np.int32)            # position -> index in the item order
+    slot[pi] = np.arange(n, dtype=np.int32)
     ucols = (items[pu].astype(np.int32), pu.astype(np.int32), ybits[pu])
-    icols = (users[pi].astype(np.int32), pi.astype(np.int32))
+    icols = (users[pi].astype(np.int32), np.arange(n, dtype=np.int32))
     ucls, icls = row_class(np.arange(user_num), n_classes), row_class(np.arange(item_num), n_classes)
     du_parts, it_parts, di_parts, s1_parts, s2_parts = [], [], [], [], []
     cls = np.zeros((8, 8), np.int32)
@@ -524,9 +531,9 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
                 user_rounds_per_task=rounds_per_task, item_rounds_per_task=item_rounds_per_task,
                 user_desc=np.concatenate(du_parts), item_desc=np.concatenate(di_parts),
                 user_round_iters=np.concatenate(it_parts),
-                user_list=np.stack([ucols[0], ucols[1], ucols[2], np.zeros(n, np.int32)], axis=1).reshape(-1),
+                user_list=np.stack([ucols[0], ucols[1], ucols[2], slot[pu]], axis=1).reshape(-1),
                 item_list=np.stack([icols[0], icols[1]], axis=1).reshape(-1),
-                push_slot=(np.argsort(pi, kind='stable').astype(np.int32) if push else None), push=bool(push),
+                rec_slot=slot, push_slot=(slot if push else None), push=bool(push),
                 stream_rows=np.concatenate(s1_parts + s2_parts).astype(np.int32), n_stream=sb,
                 rows_per_stream_task=rows_per_stream_task, rows_per_stream_task2=rows_per_stream_task2,
                 stream_split=(sum(len(x) for x in s1_parts) / sb if (fill_cap and sb) else stream_split),
@@ -595,6 +602,9 @@ def upload(plan: dict, device) -> DevicePlan:
         if k in OPTIONAL_ARRAYS and plan.get(k) is None:
             offs[k] = -1
             continue
+        if k == 'push_slot' and plan[k] is plan['rec_slot']:   # (the same array: one copy on the device)
+            offs[k] = offs['rec_slot']
+            continue
         a = np.ascontiguousarray(plan[k], np.int32).reshape(-1)
         parts.append((off, a))
         offs[k] = off
@@ -617,7 +627,7 @@ def upload(plan: dict, device) -> DevicePlan:
                        ptrs['user_round_iters'], ptrs['user_list'], ptrs['item_list'], plan['n_stream'],
                        plan['rows_per_stream_task'], ptrs['stream_rows'], int(plan['n_classes']),
                        int(plan.get('rows_per_stream_task2', 0)),
-                       (C.c_int32 * 64)(*cls.reshape(-1).tolist()), ptrs['push_slot'])
+                       (C.c_int32 * 64)(*cls.reshape(-1).tolist()), ptrs['push_slot'], ptrs['rec_slot'])
     meta = _meta_of(st, offs)
     return DevicePlan(st, [buf], plan_workgroups(plan), len(plan['user_desc']) + len(plan['item_desc']), buf,
                       torch.tensor(meta, dtype=torch.int64))

@@ -38,8 +38,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_capi.Tables) == 4 * 8 + 7 * 8
     assert C.sizeof(_capi.Coefs) == 24
     assert C.sizeof(_capi.AdamSchedule) == 24
-    # InvPrefRowPlan: 6 int32, 5 ptr, 2 int32, 1 ptr, 2 int32, int32[8][8], 1 ptr
-    assert C.sizeof(planlib.RowPlanStruct) == 24 + 5 * 8 + 8 + 8 + 8 + 64 * 4 + 8
+    # InvPrefRowPlan: 6 int32, 5 ptr, 2 int32, 1 ptr, 2 int32, int32[8][8], 2 ptr
+    assert C.sizeof(planlib.RowPlanStruct) == 24 + 5 * 8 + 8 + 8 + 8 + 64 * 4 + 16
     fields = re.search(r'typedef struct InvPrefRowPlan \{(.*?)\} InvPrefRowPlan;', HEADER, re.S).group(1)
     fields = re.sub(r'/\*.*?\*/', '', fields, flags=re.S)
     fields = re.sub(r'\[\d+\]', '', fields)

@@ -366,12 +366,12 @@ def _pure_worker(rank, world, port, out_dir, mode):
             names = [f for f, _ in planlib.RowPlanStruct._fields_]
             meta = dict(zip(names, dplan.meta.tolist()))
             buf, n = dplan.buf.numpy(), meta['n']
-            # the minibatch in its own order, from the two sorted lists of the plan: {partner, position, ...}
+            # the minibatch in its own order, from the two sorted lists of the plan: {item, position, label, slot}, {user, slot}
             ul = buf[meta['user_list']:meta['user_list'] + 4 * n].reshape(n, 4)
             il = buf[meta['item_list']:meta['item_list'] + 2 * n].reshape(n, 2)
             u, v = np.zeros(n, np.int64), np.zeros(n, np.int64)
             v[ul[:, 1]] = ul[:, 0]
-            u[il[:, 1]] = il[:, 0]
+            u[ul[:, 1]] = il[ul[:, 3], 0]
             tab = O.Tables(O.pure_mf_params(params[0].detach().numpy(), params[1].detach().numpy()))
             g, l = O.mstep(tab, u, v, np.zeros(n, np.int64), scores.numpy(), None, np.asarray(coefs, np.float64),
                            O.flags_of(bool(flags & 1), False, False, True, False), bnorm=batch_norm, include_dense_reg=False)

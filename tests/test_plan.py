@@ -18,11 +18,19 @@ def check_plan(users, items, U, I, D=64, **kw):
     assert len(p['user_round_iters']) == len(ud)
     ulist, ilist = p['user_list'].reshape(-1, 4), p['item_list'].reshape(-1, 2)
     assert len(ulist) == n and len(ilist) == n
-    assert sorted(ulist[:, 1].tolist()) == list(range(n)) and sorted(ilist[:, 1].tolist()) == list(range(n))
-    assert (np.diff(users[ulist[:, 1]]) >= 0).all() and (np.diff(items[ilist[:, 1]]) >= 0).all()   # sorted by own row
+    # rec_slot: position -> slot = the interaction's index in the item order; the item side names interactions by slot, the user
+    # list carries both (word 1 the position, word 3 the slot)
+    rec_slot = p['rec_slot']
+    assert sorted(rec_slot.tolist()) == list(range(n))
+    pos_of_slot = np.empty(n, np.int64)
+    pos_of_slot[rec_slot] = np.arange(n)
+    np.testing.assert_array_equal(ilist[:, 1], np.arange(n))
+    np.testing.assert_array_equal(ulist[:, 3], rec_slot[ulist[:, 1]])
+    assert sorted(ulist[:, 1].tolist()) == list(range(n))
+    assert (np.diff(users[ulist[:, 1]]) >= 0).all() and (np.diff(items[pos_of_slot]) >= 0).all()   # sorted by own row
     np.testing.assert_array_equal(ulist[:, 0], items[ulist[:, 1]])
     np.testing.assert_array_equal(ulist[:, 2].view(np.float32), y[ulist[:, 1]])
-    np.testing.assert_array_equal(ilist[:, 0], users[ilist[:, 1]])
+    np.testing.assert_array_equal(ilist[:, 0], users[pos_of_slot])
     # streamed rows: every untouched row exactly once, in launch 1 or launch 2, grouped by class
     sr = p['stream_rows']
     assert len(sr) == p['n_stream']
@@ -54,8 +62,8 @@ def check_plan(users, items, U, I, D=64, **kw):
             assert len(si) <= 512 or (planlib.row_class(iseg, ncls) == c).all()
             sb += cnt_
     assert sb == p['n_stream']
-    if p['push']:   # push form: a position's contribution slot is its index in the item-sorted list; item slices are ranges
-        np.testing.assert_array_equal(ilist[p['push_slot'], 1], np.arange(n))
+    if p['push']:   # push form: the contribution rows go to the same slots; item slices are ranges
+        assert p['push_slot'] is rec_slot or np.array_equal(p['push_slot'], rec_slot)
     else:
         assert p['push_slot'] is None
     for side, (own, oth, R, lst, desc, inline, w) in enumerate((
@@ -74,17 +82,18 @@ def check_plan(users, items, U, I, D=64, **kw):
             if mode == planlib.MODE_LIST:
                 a, b = slot[2], slot[3]
                 assert b - a > inline
-                js = lst[a:b, 1]
+                js = lst[a:b, 1] if side == 0 else pos_of_slot[lst[a:b, 1]]
                 assert (own[js] == row).all()
                 seen[js] += 1
             else:
                 assert mode <= inline
                 for q in range(mode):
                     f = slot[2 + q * w: 2 + (q + 1) * w]
-                    assert own[f[1]] == row and oth[f[1]] == f[0]     # inline copy of the interaction
+                    pos = f[1] if side == 0 else pos_of_slot[f[1]]
+                    assert own[pos] == row and oth[pos] == f[0]       # inline copy of the interaction
                     if side == 0:
-                        assert np.int32(f[2]).view(np.float32) == y[f[1]]
-                    seen[f[1]] += 1
+                        assert np.int32(f[2]).view(np.float32) == y[pos]
+                    seen[pos] += 1
         assert (seen == 1).all()                                      # each interaction in exactly one slice per side
         for ri, rd in enumerate(desc):                                # slot layout inside a round
             g = (rd[0, 1] >> 1) & 31

@@ -6,7 +6,7 @@ import pytest
 
 from invpref_kdd_2022_amd import build, plan as planlib, synth
 
-KEYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list', 'stream_rows', 'push_slot', 'cls')
+KEYS = ('user_desc', 'item_desc', 'user_round_iters', 'user_list', 'item_list', 'stream_rows', 'rec_slot', 'push_slot', 'cls')
 SCALARS = ('n', 'lanes_per_group', 'per_slice', 'item_per_slice', 'user_rounds_per_task', 'item_rounds_per_task', 'n_stream',
            'rows_per_stream_task', 'rows_per_stream_task2', 'n_classes', 'push', 'stream_split')
 

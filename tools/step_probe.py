@@ -29,6 +29,13 @@ if os.environ.get('PROBE_SHAPE'):
     data = synth.interactions(1, U, I, nb * B, implicit=True, zipf=os.environ.get('PROBE_ZIPF') == '1')
 else:
     data = synth.yahoo_like()[:nb * B]
+# what-if orders of a minibatch's interactions (stable sorts): PROBE_USORT=1 by user -- launch 1's position-indexed accesses
+# (environment, weight, record store) become sequential along the user list; PROBE_ISORT=1 by item -- launch 2's record reads do
+for key, col in (('PROBE_USORT', 0), ('PROBE_ISORT', 1)):
+    if os.environ.get(key) == '1':
+        for k in range(nb):
+            blk = data[k * B:(k + 1) * B]
+            data[k * B:(k + 1) * B] = blk[np.argsort(blk[:, col], kind='stable')]
 tabs = synth.tables(2, U, I, E, D)
 P = [torch.from_numpy(tabs[k]).to(dev) for k in ops.PARAM_NAMES]
 P2 = [p.clone() for p in P]

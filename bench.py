@@ -24,7 +24,8 @@ n interactions each -- the ragged last minibatch counts its 4 394 rows, not 8 19
 Parity gate: before the line is printed, one epoch + one E-step from a seeded state run through the timed
 path (alternating launches, fused E-step with the reference's default tie-break) and through the CPU oracle; the line carries
 `parity_gate` and NO `value` when the six loss terms differ by more than 1e-5 relative or a single environment assignment
-differs on the same tables.
+differs on the same tables.  An N-rank run gates ITS path the same way (sharded_parity_gate: the row-sharded epoch and E-step of
+all ranks against the oracle on the whole problem, plus bit-equal parameter replicas).
 """
 from __future__ import annotations
 
@@ -223,6 +224,73 @@ def parity_gate(dev):
             'path': ('one alternating launch per optimiser step (mstep_alt_kernel)' if one_launch else 'two-launch planned step')
                     + ' + fused E-step (estep_assign_kernel with the stat_envs epilogue), default tie-break',
             'oracle': f'oracle/invpref_oracle.c, {th} threads (M-step epoch), serial E-step with the same permutation rows'}
+
+
+def sharded_parity_gate(dev, rank, world):
+    """The gate of an N-rank run: the SHARDED path the line times -- interactions row-sharded, one all-reduce of the flat gradient
+    per optimiser step, dense Adam on every rank, the E-step on each rank's rows with its counts all-reduced -- against the same
+    oracle run on the WHOLE problem (strong scaling: the 1-GPU problem; weak: N times the interactions):
+      * the epoch's six loss terms (already summed over the ranks by the step's all-reduce) within GATE_LOSS_TOL relative;
+      * the parameter replicas bit for bit equal on every rank after that epoch;
+      * the E-step on those tables: every assignment of every rank's rows, the all-reduced counts, diff_num and the class weights
+        equal to the oracle's, bit for bit.
+    Every rank runs it (collectives inside); rank 0 holds the oracle and the verdict."""
+    import math
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from invpref_kdd_2022_amd import synth
+    from invpref_kdd_2022_amd.train import LOSS_KEYS, _unrank_permutations
+    mgr = build_manager(dev, rank, world, 'rows', random_sort=True)     # (seeds numpy: the same draws on every rank)
+    n_total, gbatch = problem_size(world)
+    rows = mgr.shard.local_rows().to(dev)
+
+    def whole(local):            # a per-interaction array of the whole problem from the ranks' shards (disjoint rows: a sum)
+        full = torch.zeros(n_total, dtype=torch.int64, device=dev)
+        full[rows] = local.to(torch.int64)
+        dist.all_reduce(full, group=mgr.process_group)
+        return full.cpu().numpy()
+    env0 = whole(mgr.envs)
+    got = np.array([[d[k] for k in LOSS_KEYS] for d in mgr.train_epochs(1)], np.float64)
+    mgr.sync_parameters()
+    # replicas: the extremes over the ranks of every parameter's bit pattern must coincide
+    bits = torch.cat([p.detach().reshape(-1).view(torch.int32) for p in mgr.state.p_views]).to(torch.int64)
+    hi, lo = bits.clone(), bits.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=mgr.process_group)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=mgr.process_group)
+    replicas_differ = int((hi != lo).sum().item())
+    st = np.random.get_state()
+    diff, cnt = mgr.cluster_and_stat_envs()
+    new_envs = whole(mgr.envs)
+    if rank != 0:
+        return None
+    from oracle import oracle as O
+    data = synth.interactions(SEED, U, I, n_total, implicit=True)
+    tabs = synth.tables(SEED + 7, U, I, E, D)
+    cf = [YAHOO[k] for k in ('invariant_coe', 'env_aware_coe', 'env_coe', 'L2_coe', 'L1_coe', 'alpha')]
+    th = max(1, min(O.omp_max_threads(), len(os.sched_getaffinity(0)) // max(1, world), 16))
+    tr = O.ParallelTrainer(tabs, data, env0, implicit=True, batch_size=gbatch, coefs=cf, lr=YAHOO['lr'], reweight_rec=False,
+                           reweight_cls=True, reg_only_embed=True, reg_env_embed=False, threads=th)
+    tr.stat_envs()
+    want = np.array([tr.train_a_epoch()], np.float64)
+    loss_err = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-30)))
+    tab = O.Tables({k: p.detach().cpu().numpy() for k, p in zip(O.PARAM_NAMES, mgr.state.p_views)})
+    np.random.set_state(st)
+    idx = np.concatenate([np.random.randint(0, math.factorial(E), mgr.shard.global_batch_len(k)) for k in range(mgr.batch_num)])
+    perm_rows = _unrank_permutations(idx, mgr._eps_base)
+    on, oc, od, _ = O.estep(tab, data[:, 0], data[:, 1], data[:, 2], True, old_envs=env0, eps_rows=perm_rows)
+    _, ocw, _ = O.stat_envs(on, E)
+    mism = int((new_envs != on).sum())
+    counts_ok = [int(cnt[e]) for e in range(E)] == [int(c) for c in oc] and int(diff) == int(od) \
+        and bool((mgr.class_weights.cpu().numpy() == ocw).all())
+    ok = bool(loss_err <= GATE_LOSS_TOL and mism == 0 and counts_ok and replicas_differ == 0 and np.isfinite(got).all())
+    return {'pass': ok, 'ranks': world, 'loss_rel_err': loss_err, 'loss_tol': GATE_LOSS_TOL, 'envs_mismatch': mism,
+            'counts_diff_class_weights_equal': bool(counts_ok), 'replica_words_that_differ': replicas_differ,
+            'interactions': int(n_total), 'epoch_steps': int(mgr.batch_num), 'global_batch': int(gbatch),
+            'losses_device': got[0].tolist(), 'losses_oracle': want[0].tolist(), 'loss_keys': list(LOSS_KEYS),
+            'path': f'row-sharded x{world}: planned gradient pass + one all-reduce + dense Adam per step; E-step per shard, counts '
+                    'all-reduced; default tie-break',
+            'oracle': f'oracle/invpref_oracle.c, {th} threads, the whole problem on rank 0'}
 
 
 def cpu_baseline():
@@ -832,11 +900,20 @@ def main():
 
     # the parity gate first: a path that does not reproduce the oracle is not timed
     gate = None
-    if world == 1 and not args.no_parity_gate:
-        gate = parity_gate(dev) if rank == 0 else None
-        if gate is not None and not gate['pass']:
-            print(json.dumps({'metric': 'training interactions/sec, Yahoo-implicit InvPref', 'value': None, 'unit': 'interactions/s',
-                              'n_gpus': world, 'error': 'parity gate failed: no value is reported', 'parity_gate': gate}))
+    if not args.no_parity_gate:
+        if world == 1:
+            gate = parity_gate(dev)
+            failed = not gate['pass']
+        else:
+            gate = sharded_parity_gate(dev, rank, world)
+            verdict = torch.tensor([0 if (gate is None or gate['pass']) else 1], device=dev)
+            torch.distributed.all_reduce(verdict)          # (every rank leaves together)
+            failed = bool(verdict.item())
+        if failed:
+            if rank == 0:
+                print(json.dumps({'metric': 'training interactions/sec, Yahoo-implicit InvPref', 'value': None,
+                                  'unit': 'interactions/s', 'n_gpus': world, 'error': 'parity gate failed: no value is reported',
+                                  'parity_gate': gate}))
             sys.exit(4)
         torch.cuda.empty_cache()
     mgr = build_manager(dev, rank, world, 'rows' if world > 1 else None)
@@ -953,7 +1030,7 @@ def main():
     }
     out['rccl_ranks'] = rccl_ranks    # ranks that took part in an RCCL all-reduce in front of the run (None: single GPU)
     out['parity_gate'] = gate if gate is not None else {
-        'pass': None, 'note': 'not run (' + ('--no-parity-gate' if args.no_parity_gate else 'N > 1: the gate is the 1-GPU run') + ')'}
+        'pass': None, 'note': 'not run (--no-parity-gate)'}
     if world > 1:
         # the headline is the literal form BASELINE.json configs[3] names (rows + one all-reduce); beside it: the same
         # split with the exchange as reduce-scatter -> Adam on the rank's slice -> all-gather, and the xGMI-first

@@ -749,6 +749,9 @@ __device__ __forceinline__ void alt_stream(const AltArgs &a, const int4 *rows, i
             const int idx = grp + (it * R + q) * NG;
             on[q] = idx < n;
             e[q] = rows[on[q] ? idx : 0];
+#ifdef ALT_DIAG_SKIP_UNTOUCHED   // (what-if build, WRONG results: rows without pending pairs cost nothing -- the bound of a deferred Adam)
+            if (on[q] && e[q].z - e[q].y <= 0) { on[q] = false; e[q] = rows[0]; }
+#endif
         }
         float4 p[2 * R], m[2 * R], v[2 * R], ci[R][H], ce[R][H];
         int npend[R];

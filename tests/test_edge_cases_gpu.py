@@ -428,3 +428,38 @@ def test_mfma_classifier_form_of_launch_1(D, E, mm, monkeypatch):
             assert np.abs(a - b).max() <= 2e-5 * scale, (k, push)
         for a, b in zip(res['0'][1][len(P):], res['1'][1][len(P):]):   # the moments of the fused pass (first step: (1 - beta) g, g^2)
             assert np.abs(a - b).max() <= 2e-5 * max(np.abs(a).max(), 1e-6)
+
+
+def test_row_plan_without_record_slots_is_refused():
+    """InvPrefRowPlan.rec_slot (round 6: records and contribution rows live at the interaction's slot in the item order) is a
+    required array: a plan that travels without it is refused on both sides of the boundary -- the meta form by plan.py, the
+    struct by the C entry point (INVPREF_EINVAL) -- instead of writing records to slot garbage."""
+    import ctypes as C
+    from invpref_kdd_2022_amd import _capi
+    rs = np.random.RandomState(5)
+    U, I, E, D, B = 40, 30, 4, 64, 300
+    tabs = synth.tables(3, U, I, E, D, std=0.3)
+    u, v, e = rs.randint(0, U, B), rs.randint(0, I, B), rs.randint(0, E, B)
+    y = rs.randint(0, 2, B).astype(np.float32)
+    P = dev(tabs)
+    pl = planlib.build_row_plan(u, v, y, U, I, factor_num=D, env_num=E, push=False)
+    np.testing.assert_array_equal(pl['user_list'].reshape(-1, 4)[:, 3], pl['rec_slot'][pl['user_list'].reshape(-1, 4)[:, 1]])
+    dp = planlib.upload(pl, DEV)
+    names = [f for f, _ in planlib.RowPlanStruct._fields_]
+    k = sum(planlib._ARRAY_FIELDS.get(f, 1) for f in names[:names.index('rec_slot')])
+    meta = dp.meta.clone()
+    meta[k] = -1
+    with pytest.raises(ValueError):
+        planlib.struct_from_meta(dp.buf, meta)
+    st = planlib.RowPlanStruct.from_buffer_copy(bytes(dp.struct))
+    st.rec_slot = None
+    G = [torch.zeros_like(p) for p in P]
+    losses = torch.zeros(6, device=DEV)
+    ws = torch.empty(1 << 22, dtype=torch.float32, device=DEV)
+    t, g = ops.make_tables(P), ops.make_tables(G)
+    cf = _capi.Coefs(*[float(c) for c in COEFS])
+    rc = _capi.lib().invpref_mstep_rows_grad_hip(C.byref(t), C.byref(g), C.byref(st), _capi.ptr(t64(e)), _capi.ptr(t32(y)), None, B,
+                                                 C.byref(cf), ops.flags_of(True, False, False, False, True), _capi.ptr(losses),
+                                                 _capi.ptr(ws), ws.numel() * 4, _capi.stream_ptr())
+    assert rc == -1     # INVPREF_EINVAL
+    torch.cuda.synchronize()

@@ -251,7 +251,9 @@ def sharded_parity_gate(dev, rank, world):
         dist.all_reduce(full, group=mgr.process_group)
         return full.cpu().numpy()
     env0 = whole(mgr.envs)
-    got = np.array([[d[k] for k in LOSS_KEYS] for d in mgr.train_epochs(1)], np.float64)
+    out = mgr.train_epochs(1, sync=False)
+    sync_or_die(world)                     # (a collective that never completes ends the run with an error, not a hang)
+    got = np.array([[d[k] for k in LOSS_KEYS] for d in mgr.loss_dicts(out)], np.float64)
     mgr.sync_parameters()
     # replicas: the extremes over the ranks of every parameter's bit pattern must coincide
     bits = torch.cat([p.detach().reshape(-1).view(torch.int32) for p in mgr.state.p_views]).to(torch.int64)
@@ -260,7 +262,9 @@ def sharded_parity_gate(dev, rank, world):
     dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=mgr.process_group)
     replicas_differ = int((hi != lo).sum().item())
     st = np.random.get_state()
-    diff, cnt = mgr.cluster_and_stat_envs()
+    diff, cnt = mgr.cluster_and_stat_envs(sync=False)
+    sync_or_die(world)
+    diff, cnt = int(diff.reshape(-1)[0].item()), [int(c) for c in cnt.reshape(-1).tolist()]
     new_envs = whole(mgr.envs)
     if rank != 0:
         return None

@@ -283,6 +283,9 @@ struct StepArgs {
 #ifndef STEP_SLOT_ALIAS
 #define STEP_SLOT_ALIAS 1
 #endif
+#ifndef STEP_CLS_QUADS
+#define STEP_CLS_QUADS 0   // the four-class classifier of the 16-lane kernels with one class per QUAD of the group (see eval_interaction)
+#endif
 #ifndef STEP_LDS_DW
 #define STEP_LDS_DW 1   // (A/B knob: smallest instance, classifier partial sums accumulated in LDS rows too)
 #endif
@@ -330,10 +333,14 @@ struct EvalLds {
 };
 
 // ---- forward + analytic backward of ONE interaction on a lane group (M-step arithmetic: hardware exp/log/rcp).
+template <int LG, int EMAX>
+constexpr bool kClsQuads = LG == 16 && EMAX == 4 && STEP_CLS_QUADS;
 template <int EMAX>
 struct Eval {
     float g_p, g_q, li, le, lcls;
-    float gz[EMAX <= 4 ? EMAX : 1];   // E <= 4: every lane holds all classes
+    float gz[EMAX <= 4 ? EMAX : 1];   // E <= 4: every lane holds all classes -- gz[c] of class c, or (STEP_CLS_QUADS, kClsQuads) gz[j] of
+                                      // class (lg >> 2) ^ j: the lanes of quad 0 hold them in class order; lcls is then non-zero in
+                                      // the quad of the interaction's environment only
     float gz_lane;                    // E > 4: lane lg of the group holds class lg (0 beyond E)
     float4 x, gx;                     // x = Pu*Qi ; gx = sum_c gz_c W_c
 };
@@ -380,6 +387,45 @@ __device__ __forceinline__ void eval_interaction(Eval<EMAX> &o, float4 pu, float
         for (int c = 0; c < (EMAX <= 4 ? EMAX : 1); c++) o.gz[c] = 0.f;
     }
     if (pure) return;   // PureMF: no classifier
+    if constexpr (LG == 16 && EMAX == 4 && STEP_CLS_QUADS) {
+        // One class per QUAD of the 16-lane group.  The four partial dot products are reduce-scattered over the quads -- step 1
+        // with the quad q ^ 1 (row_half_mirror), step 2 with q ^ 2 (row_ror:8): three exchanged values instead of four full
+        // butterflies -- and summed inside the quad; quad q then holds logit q in all four lanes.  Max and sum of the softmax
+        // are two exchanges each over the same partners (every lane ends with the same bits: fp addition commutes and the
+        // association (e_q + e_q^1) + (e_q^2 + e_q^3) is the same set of pairs in every quad); ONE exponential, reciprocal and
+        // logarithm per lane instead of four + 1 + 1.  The class gradients come back by three moves: gz[j] = class q ^ j.
+        const int qd = lg >> 2;
+        float d[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) d[c] = dot4(o.x, *reinterpret_cast<const float4 *>(sW + c * DP + lg * 4));
+        const bool odd = qd & 1, hi = qd & 2;
+        float ka = odd ? d[1] : d[0], kb = odd ? d[3] : d[2];
+        const float ga = odd ? d[0] : d[1], gb = odd ? d[2] : d[3];
+        ka += dpp_move<0x141>(ga);
+        kb += dpp_move<0x141>(gb);
+        float zq = hi ? kb : ka;
+        const float gq = hi ? ka : kb;
+        zq += dpp_move<0x128>(gq);
+        zq += dpp_move<0xB1>(zq);
+        zq += dpp_move<0x4E>(zq);
+        zq = qd < E ? zq + sb[qd] : -__builtin_inff();
+        float mx = __builtin_fmaxf(zq, dpp_move<0x141>(zq));
+        mx = __builtin_fmaxf(mx, dpp_move<0x128>(mx));
+        const float dz = zq - mx;
+        const float ez = f_exp(dz);   // exp(-inf) = 0
+        float se = ez + dpp_move<0x141>(ez);
+        se += dpp_move<0x128>(se);
+        const float rse = f_rcp(se);
+        // NLL of log_softmax as the reference forms it (see below); the quad of the interaction's environment reports it
+        o.lcls = qd == e ? f_log(se) - dz : 0.f;
+        const float g0 = qd < E ? k.cc * cw_cls * (ez * rse - (qd == e ? 1.f : 0.f)) : 0.f;
+        const float g1 = dpp_move<0x141>(g0), g2 = dpp_move<0x128>(g0), g3 = dpp_move<0x128>(g1);
+        o.gz[0] = g0; o.gz[1] = g1; o.gz[2] = g2; o.gz[3] = g3;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            f4fma(o.gx, o.gz[j], *reinterpret_cast<const float4 *>(sW + ((qd ^ j) * DP + lg * 4)));
+        return;
+    }
     if (EMAX <= 4) {
         // the W rows are read from LDS ONCE, unconditionally and back to back (rows c >= E are staged as zeros);
         // everything after is selects and arithmetic
@@ -484,6 +530,7 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
     // (rows of more than 64 floats and more than four environments run step_wide.hpp; the branches of this function for
     //  other layouts are compile-time dead)
     static_assert(LG == 16 && EMAX == 4, "user_task: the 16-lane, four-environment instances only");
+    static_assert(!kClsQuads<LG, EMAX> || (G::DIRECT && STEP_LDS_DW), "class-per-quad gradients need the classifier's LDS rows");
     // interactions in flight per group (measured: 2 for the D <= 64, E <= 4 instances -- a third slot only costs registers
     // there -- and for E > 8, whose per-interaction barrier paces the groups anyway; 3 for the other larger rows)
     constexpr int UE = !G::REG ? 1 : ((LG == 16 && EMAX <= 4 && STEP_EVAL_DEPTH > 2) ? 2 : STEP_EVAL_DEPTH);
@@ -738,7 +785,8 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                         float *mine = red + grp * G::SLAB;
 #pragma unroll
                         for (int c = 0; c < (G::REG ? EMAX : 1); c++) {
-                            float4 *wr = reinterpret_cast<float4 *>(mine + EMAX * DP + c * DP + lg * 4);
+                            // (kClsQuads: gzv[c] belongs to class (lg >> 2) ^ c -- every lane still visits all four rows)
+                            float4 *wr = reinterpret_cast<float4 *>(mine + EMAX * DP + (kClsQuads<LG, EMAX> ? ((lg >> 2) ^ c) : c) * DP + lg * 4);
                             float4 cur = *wr;
                             f4fma(cur, gzv[c], o.x);
                             *wr = cur;
@@ -774,7 +822,8 @@ __device__ __forceinline__ void user_task(const DevTables &t, const StepArgs &a,
                 if (reg_env) { s2 += 2.f * f4sq(ev); s1 += 2.f * f4abs(ev); }
                 accL2 += s2;
                 accL1 += s1;
-                if (lg == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; accLc += o.lcls * w_cls; }
+                if (lg == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; }
+                if (kClsQuads<LG, EMAX> ? (lg & 3) == 0 : lg == 0) accLc += o.lcls * w_cls;
             }
             if (EMAX > 4) it_total++;
         };

@@ -570,7 +570,7 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
                 float *mine = red + grp * G::SLAB;
 #pragma unroll
                 for (int c = 0; c < EMAX; c++) {
-                    float4 *wr = reinterpret_cast<float4 *>(mine + EMAX * DP + c * DP + lg * 4);
+                    float4 *wr = reinterpret_cast<float4 *>(mine + EMAX * DP + (kClsQuads<LG, EMAX> ? ((lg >> 2) ^ c) : c) * DP + lg * 4);
                     float4 cur = *wr;
                     f4fma(cur, o.gz[c], o.x);
                     *wr = cur;
@@ -592,7 +592,8 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
                 if (reg_env) { s2 += 2.f * f4sq(ev); s1 += 2.f * f4abs(ev); }
                 accL2 += s2;
                 accL1 += s1;
-                if (lg == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; accLc += o.lcls * w_cls; }
+                if (lg == 0) { accLi += o.li * w_rec; accLe += o.le * w_rec; }
+                if (kClsQuads<LG, EMAX> ? (lg & 3) == 0 : lg == 0) accLc += o.lcls * w_cls;
             }
         };
         // (Tried in round 5: the slice's interactions evaluated two at a time in one basic block at two workgroups per CU, so

@@ -391,6 +391,14 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
             # the slices again (measured at that size, D = 64 / 128 / 256: +3 % each over 16; 20, 28 and 32 are behind)
             if per_slice == 16 and rounds_for(ucnt0, 24) <= 0.75 * r16:
                 per_slice = 24
+                # Round 6, with the records at the interaction's slot (launch 2 reads them front to back, launch 1 no longer pays
+                # a random slot read per interaction): the shortest slice that leaves (nearly) every row in ONE slice -- no slice
+                # meet, half the descriptors -- wins on launches of many residencies.  2^24 interactions, 42 per user row, same
+                # box: D = 64 4 173 us at 24 per slice, 3 989 at 48, 3 909-3 919 at 56 / 64, 3 887 at 96 (with 4 rounds per task);
+                # D = 128 9 004 / 8 506 / 8 371-8 456 / 8 475; D = 256 22.6 ms at 24, 21.8 at 48 (tools/ab_plan24b.sh).
+                if r16 > 6 * resident:
+                    fewest = rounds_for(ucnt0, 96)
+                    per_slice = next((ps for ps in (24, 32, 40, 48, 56, 64) if rounds_for(ucnt0, ps) <= 1.05 * fewest), 96)
             if r16 <= 6 * resident and os.environ.get('INVPREF_PLAN_SIMULATE', '1') == '1':
                 # a launch of a few residencies: where its last workgroup ends depends on how the task lengths pack
                 # into the resident slots.  Estimate that for each slice length (list scheduling of the tasks in launch
@@ -429,7 +437,8 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
     if rounds_per_task is None:
         # (at most 8 rounds per task for rows on 16 lanes -- measured on cache-exceeding launches of 2^20 .. 2^24 interactions:
         #  D = 64 +4 %, D = 128 +2 .. +5 % over 16 -- and 16 for rows on 32 lanes, whose tasks stage 32 KB of tables first: -3 % at 8)
-        cap = 16 if lanes == 32 else 8
+        # (long slices, round 6: about 200 interactions per group and task -- 4 rounds at 48-56 per slice: +2-3 % over 8 at 2^24)
+        cap = 16 if lanes == 32 else min(8, max(2, 224 // max(per_slice, 1)))
         # (rows on 32 lanes: about 800 tasks -- not quite two residencies of 512 -- instead of 1 536: measured at MIND's tables
         #  with minibatches of 32 768 .. 262 144, best at 4 / 6 / 6 / 4-8 rounds per task: +5 % at the rank share of eight GPUs)
         tgt = target * 800 // TARGET_WORKGROUPS if lanes == 32 else target

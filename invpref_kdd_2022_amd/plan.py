@@ -422,12 +422,10 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
             total = n * (32 + 16 * factor_num) + 24 * p_floats       # algorithmic bytes of the step
             resident = 20 * p_floats + contrib // 2 <= 200e6       # p, p', m, v, g-free: five flat buffers + the rows
             push = n > 0 and (resident or contrib <= 0.2 * total)
-            # Round 6: the pull records sit at the interaction's slot in the item order (launch 2 reads them front to back, 32 B per
-            # interaction against two contribution rows written and read), so on cache-resident tables of rows <= 64 floats the
-            # pull form overtakes push once the minibatch is large -- Yahoo tables, tools/ab_pushpull.sh: 32 768 interactions
-            # push 32.6 vs pull 34.1 us, 65 536 43.0 vs 42.5, 131 072 59.7 vs 57.4, B = N = 250 154 87.3 vs 82.5
-            if push and resident and small and n >= 100_000 and contrib > 0.2 * total:
-                push = False
+            # (Round 6, records at the interaction's slot: on UNIFORM ids at the Yahoo tables the pull form overtakes push from
+            #  65 536 interactions on -- B = N 82.5 vs 87.3 us -- but on skewed ids, Zipf or the Yahoo-like popularity, push stays
+            #  12-21 % ahead at every size (B = N 100-103 vs 118-125 us): its hot items sum contiguous rows.  The rule stands;
+            #  tools/ab_pushpull.sh, ab_pushpull2.sh)
     if lanes == 32:
         # rows of more than 128 floats: embed_env's outer product runs in launch 2's item jobs, which need the partner
         # rows and the records -- the pull form (csrc/step_wide.hpp, EVL2)

@@ -28,6 +28,9 @@ if os.environ.get('PROBE_SHAPE'):
     nb = min(nb, int(os.environ.get('PROBE_STEPS', '4')))
     data = synth.interactions(1, U, I, nb * B, implicit=True, zipf=os.environ.get('PROBE_ZIPF') == '1')
 else:
+    if os.environ.get('PROBE_B'):          # the Yahoo-like data (its own popularity skew) at another minibatch size
+        B = int(os.environ['PROBE_B'])
+        nb = max(1, min(nb, len(synth.yahoo_like()) // B))
     data = synth.yahoo_like()[:nb * B]
 # what-if orders of a minibatch's interactions (stable sorts): PROBE_USORT=1 by user -- launch 1's position-indexed accesses
 # (environment, weight, record store) become sequential along the user list; PROBE_ISORT=1 by item -- launch 2's record reads do

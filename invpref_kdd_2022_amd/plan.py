@@ -442,7 +442,8 @@ def build_row_plan(users: np.ndarray, items: np.ndarray, scores: np.ndarray, use
         # (at most 8 rounds per task for rows on 16 lanes -- measured on cache-exceeding launches of 2^20 .. 2^24 interactions:
         #  D = 64 +4 %, D = 128 +2 .. +5 % over 16 -- and 16 for rows on 32 lanes, whose tasks stage 32 KB of tables first: -3 % at 8)
         # (long slices, round 6: about 200 interactions per group and task -- 4 rounds at 48-56 per slice: +2-3 % over 8 at 2^24)
-        cap = 16 if lanes == 32 else min(8, max(2, 224 // max(per_slice, 1)))
+        #  (rows on 32 lanes, 56 per slice at 2^24: 4 rounds 20.6 ms, 8 20.8, 16 21.1, 2 21.0 -- tools/ab_plan24c.sh)
+        cap = (16 if per_slice < 40 else 4) if lanes == 32 else min(8, max(2, 224 // max(per_slice, 1)))
         # (rows on 32 lanes: about 800 tasks -- not quite two residencies of 512 -- instead of 1 536: measured at MIND's tables
         #  with minibatches of 32 768 .. 262 144, best at 4 / 6 / 6 / 4-8 rounds per task: +5 % at the rank share of eight GPUs)
         tgt = target * 800 // TARGET_WORKGROUPS if lanes == 32 else target

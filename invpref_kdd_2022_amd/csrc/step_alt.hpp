@@ -760,9 +760,21 @@ __device__ __forceinline__ void alt_stream(const AltArgs &a, const int4 *rows, i
         for (int q = 0; q < 2 * R; q++) {
             p[q] = m[q] = v[q] = f4zero();
             if (!(pure && (q & 1))) {
+#if defined(ALT_STREAM_NT)   // (A/B knob: the streamed rows are read once per two launches -- non-temporal loads)
+                if (FULL) {
+                    typedef float nt4 __attribute__((ext_vector_type(4)));
+                    const unsigned off = (unsigned)e[q >> 1].x * 256u + (unsigned)lg * 16u;
+                    const nt4 pp = __builtin_nontemporal_load(reinterpret_cast<const nt4 *>(reinterpret_cast<const char *>(a.own_p[q & 1]) + off));
+                    const nt4 mm = __builtin_nontemporal_load(reinterpret_cast<const nt4 *>(reinterpret_cast<const char *>(a.own_m[q & 1]) + off));
+                    const nt4 vv = __builtin_nontemporal_load(reinterpret_cast<const nt4 *>(reinterpret_cast<const char *>(a.own_v[q & 1]) + off));
+                    p[q] = make_float4(pp.x, pp.y, pp.z, pp.w); m[q] = make_float4(mm.x, mm.y, mm.z, mm.w); v[q] = make_float4(vv.x, vv.y, vv.z, vv.w);
+                } else
+#endif
+                {
                 p[q] = row4<VEC, FULL>(a.own_p[q & 1], e[q >> 1].x, D, lg);
                 m[q] = row4<VEC, FULL>(a.own_m[q & 1], e[q >> 1].x, D, lg);
                 v[q] = row4<VEC, FULL>(a.own_v[q & 1], e[q >> 1].x, D, lg);
+                }
             }
         }
 #pragma unroll

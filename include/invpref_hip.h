@@ -421,7 +421,8 @@ int invpref_estep_perm_hip(const InvPrefTables *tables, const int64_t *users, co
  *               workgroups then load the table instead of unranking it;
  *   state       device int32[INVPREF_ESTEP_STATE_INTS] that must be ZERO before the first call and is left as the next call
  *               needs it ([0] top ticket, [1] E-steps so far = ring position, [32 + 32 s] the ticket of shard s: 2 048
- *               workgroups finishing together would queue ~25 us on ONE word);
+ *               workgroups finishing together would queue ~25 us on ONE word; [33 + 32 s .. 33 + 32 s + env_num] the shard's
+ *               counts and diff, added by its workgroups with integer atomics and read -- then zeroed -- by the launch's last one);
  *   ring        optional int64[ring_cap][env_num + 1]: the call writes {counts, diff} to row (calls so far) % ring_cap and counts
  *               the call in state[1] -- a captured launch's arguments are frozen, so a replayed E-step keeps its results apart
  *               this way without a copy behind every replay;

@@ -624,6 +624,10 @@ __global__ __launch_bounds__(256) void eps_unrank_kernel(const IT *__restrict__ 
 // The ticket is SHARDED: 2 048 workgroups that finish together would queue on one word for ~25 us (one address takes ~88
 // returning atomics per microsecond); workgroup b takes a ticket of shard b % kTicketShards (each on a 128-byte line of its own),
 // the workgroup that completes a shard takes a ticket of the top word, the one that completes that folds.
+#ifndef ESTEP_SHARD_COUNTERS
+#define ESTEP_SHARD_COUNTERS 1   // the fused epilogue's counts: 1 = integer atomics into the shard's counters (round 6, late: the fused kernel
+                                 // 51.5 -> 42.2 us plain, 62.7 -> 51.7 with the tie-break, same box); 0 = a slab per workgroup, folded by the last one
+#endif
 constexpr int kTicketShards = 32;   // (INVPREF_ESTEP_STATE_INTS = 32 + 32 * kTicketShards)
 struct EstepFin {
     int *state;          // device int32[kEstepStateInts], ZERO before the first call and left zero: [0] top ticket, [1] ring
@@ -781,7 +785,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(ESTEP_NUM_SGPR)
     __shared__ int s_last;
     __shared__ long long s_tot[INVPREF_MAX_ENVS + 1];
     if (threadIdx.x < 64) {
+#if ESTEP_SHARD_COUNTERS
+        // (the workgroup's counts are ADDED into its shard's counters, words 1 .. E + 1 of the shard's 128-byte line, in front of its ticket)
+        if ((int)threadIdx.x <= t.E) {
+            const int S0 = min(kTicketShards, (int)gridDim.x);
+            __hip_atomic_fetch_add(fin.state + 32 + 32 * ((int)blockIdx.x % S0) + 1 + (int)threadIdx.x, cnt[threadIdx.x], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+#else
         if ((int)threadIdx.x <= t.E) st_sc1_i(slabs + (int64_t)blockIdx.x * (t.E + 1) + threadIdx.x, cnt[threadIdx.x]);
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0) {
             const int S = min(kTicketShards, (int)gridDim.x), sh = (int)blockIdx.x % S;
@@ -807,6 +820,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(ESTEP_NUM_SGPR)
         //  57 to 74 registers, 8 -> 6 waves per SIMD; every thread adding every count through LDS atomics on the same five words
         //  took 138 us; one class at a time (a round trip each) 53 us)
         const int per = (int)blockDim.x - (int)blockDim.x % E1, total = nsl * E1;
+#if ESTEP_SHARD_COUNTERS
+        // (every workgroup has ADDED its counts to its shard's counters -- integer atomics: order-free, exact -- in front of its
+        //  ticket: shards x (E + 1) words, ONE round trip of cache-bypassing loads, instead of every workgroup's slab in passes of
+        //  twenty loads.  The words go back to zero for the next launch)
+        (void)per; (void)total;
+        const int S0 = min(kTicketShards, nsl);
+        for (int i = threadIdx.x; i < S0 * E1; i += blockDim.x) {
+            int *w = fin.state + 32 + 32 * (i / E1) + 1 + i % E1;
+            const int x = ld_sc1_i(w);
+            st_sc1_i(w, 0);
+            atomicAdd((unsigned long long *)&s_tot[i % E1], (unsigned long long)(long long)x);
+        }
+#else
         if ((int)threadIdx.x < per) {
             long long a = 0;
             for (int i0 = threadIdx.x; i0 < total; i0 += 20 * per) {
@@ -821,6 +847,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(ESTEP_NUM_SGPR)
             }
             atomicAdd((unsigned long long *)&s_tot[(int)threadIdx.x % E1], (unsigned long long)a);
         }
+#endif
         __syncthreads();
         int64_t *row = nullptr;
         if (fin.ring) row = fin.ring + (int64_t)((unsigned)fin.state[1] % (unsigned)fin.ring_cap) * E1;

@@ -624,6 +624,9 @@ __global__ __launch_bounds__(256) void eps_unrank_kernel(const IT *__restrict__ 
 // The ticket is SHARDED: 2 048 workgroups that finish together would queue on one word for ~25 us (one address takes ~88
 // returning atomics per microsecond); workgroup b takes a ticket of shard b % kTicketShards (each on a 128-byte line of its own),
 // the workgroup that completes a shard takes a ticket of the top word, the one that completes that folds.
+#ifndef ESTEP_IDX_BULK
+#define ESTEP_IDX_BULK 1
+#endif
 #ifndef ESTEP_SHARD_COUNTERS
 #define ESTEP_SHARD_COUNTERS 1   // the fused epilogue's counts: 1 = integer atomics into the shard's counters (round 6, late: the fused kernel
                                  // 51.5 -> 42.2 us plain, 62.7 -> 51.7 with the tie-break, same box); 0 = a slab per workgroup, folded by the last one
@@ -708,9 +711,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(ESTEP_NUM_SGPR)
         eps_thr = mx * 67108864.f * 1.001f;
     }
     const int64_t s_first = s_begin + (threadIdx.x >> 4);
-    unsigned idx_cur = (eps_index && s_first < s_end) ? load_idx(s_first) : 0u;
-    for (int64_t s = s_first; s < s_end; s += rows_per_block) {
-        const unsigned idx_next = (eps_index && s + rows_per_block < s_end) ? load_idx(s + rows_per_block) : 0u;
+    // One-byte indices (E <= 5, the managers' form), ESTEP_IDX_BULK: a WAVE fetches the bytes of its four groups for sixteen passes
+    // with ONE load -- lane 4 k + g holds the byte of group g in pass k: four 64-byte lines instead of sixteen requests of four
+    // useful bytes each -- and a group picks its pass's byte out of the wave's registers (v_readlane: indifferent to lanes that
+    // have left the loop).  From pinned host memory the kernel is bound by the NUMBER of link reads, not by their latency.
+    const bool idx_bulk = ESTEP_IDX_BULK && eps_index && eps_index_bytes == 1;
+    const int lane64 = threadIdx.x & 63, grp_w = lane64 >> 4;
+    auto load_bulk = [&](int blk) -> unsigned {
+        const int64_t sx = s_begin + ((threadIdx.x >> 6) * 4 + (lane64 & 3)) + rows_per_block * ((int64_t)blk * 16 + (lane64 >> 2));
+        return sx < s_end ? (unsigned)reinterpret_cast<const uint8_t *>(eps_index)[sx] : 0u;
+    };
+    unsigned bulk_cur = idx_bulk ? load_bulk(0) : 0u, bulk_next = 0u;
+    unsigned idx_cur = (eps_index && !idx_bulk && s_first < s_end) ? load_idx(s_first) : 0u;
+    int pass = 0;
+    for (int64_t s = s_first; s < s_end; s += rows_per_block, pass++) {
+        unsigned idx_next = 0u;
+        if (idx_bulk) {
+            const int pk = __builtin_amdgcn_readfirstlane(pass);
+            if ((pk & 15) == 0) {
+                if (pk) bulk_cur = bulk_next;
+                bulk_next = load_bulk((pk >> 4) + 1);
+            }
+            const int src = (pk & 15) * 4;
+            const unsigned i0 = __builtin_amdgcn_readlane(bulk_cur, src), i1 = __builtin_amdgcn_readlane(bulk_cur, src + 1);
+            const unsigned i2 = __builtin_amdgcn_readlane(bulk_cur, src + 2), i3 = __builtin_amdgcn_readlane(bulk_cur, src + 3);
+            idx_cur = grp_w == 0 ? i0 : (grp_w == 1 ? i1 : (grp_w == 2 ? i2 : i3));
+        } else if (eps_index && s + rows_per_block < s_end) {
+            idx_next = load_idx(s + rows_per_block);
+        }
         const int64_t u = users[s], v = items[s];
         const float y = scores[s];
         float4 pu[NC], qi[NC], pa[NC], qa[NC];
@@ -774,7 +802,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(ESTEP_NUM_SGPR)
             atomicAdd(cnt + bi, 1);
             if (changed) atomicAdd(cnt + t.E, 1);
         }
-        idx_cur = idx_next;
+        if (!idx_bulk) idx_cur = idx_next;
     }
     __syncthreads();
     if (!fin.state) {

@@ -363,7 +363,10 @@ __device__ __forceinline__ void eval_interaction(Eval<EMAX> &o, float4 pu, float
         // (labels exactly 0 or 1 -- the implicit data, train.py:130-135 -- need one logarithm per loss; wave-uniform test)
         o.li = f_bce_binary(sp, y);
         o.le = f_bce_binary(sv, y);
-        if (__builtin_amdgcn_ballot_w64(!(y == 0.0f || y == 1.0f)) != 0) {   // (never with the reference's implicit data)
+#ifndef STEP_ASSUME_BINARY
+#define STEP_ASSUME_BINARY 0   // (what-if knob, WRONG for labels other than 0 / 1)
+#endif
+        if (!STEP_ASSUME_BINARY && __builtin_amdgcn_ballot_w64(!(y == 0.0f || y == 1.0f)) != 0) {   // (never with the reference's implicit data)
             o.li = f_bce(sp, y);
             o.le = f_bce(sv, y);
         }

@@ -555,7 +555,10 @@ __device__ __forceinline__ void alt_task(const AltArgs &a, int r0, int slab_inde
                 const float w_rec = rw_rec ? wq : 1.f, w_cls = rw_cls ? wq : 1.f;
                 const float4 ev = *reinterpret_cast<const float4 *>(sEv + e * DP + lg * 4);
                 Eval<EMAX> o;
-                eval_interaction<LG, EMAX>(o, oi, q.qi, oe, q.qa, ev, sW, sb, nullptr, a.E, e, q.sm.y, w_rec * k.invB,
+#ifndef ALT_EVAL_KIND
+#define ALT_EVAL_KIND -1   // (what-if knob: 1 = the implicit InvPref evaluation fixed at compile time -- one basic block)
+#endif
+                eval_interaction<LG, EMAX, ALT_EVAL_KIND>(o, oi, q.qi, oe, q.qa, ev, sW, sb, nullptr, a.E, e, q.sm.y, w_rec * k.invB,
                                            w_cls * k.invB, k, implicit, pure, lg);
                 float4 gip;
                 gip.x = o.g_p - k.alpha * o.gx.x; gip.y = o.g_p - k.alpha * o.gx.y;
